@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — CIGAR ops/s of the SV-signature hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (a1+a2: CIGAR walk → indel signatures)
+over one batch of synthetic haplotype-vs-reference alignments that is already resident in
+HBM.  The default workload is BASELINE config 2 (haploid, ~3.1 Gbp, ~5 k alignments,
+~1.5 M CIGAR ops per sample) batched as a cohort of `--samples` samples per GPU so that one
+step streams more than the 256 MiB Infinity Cache; `--samples 1` gives the single-sample
+latency.  Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and
+the max-over-ranks reduction; the data path has no collective — alignments shard by sample
+and contig), weak scaling: every rank processes its own cohort.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=64, help="haplotype samples per GPU per step")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic samples (replicated to --samples)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5), help="BASELINE config: 2 (mean M run 4000) or 5 (400)")
+    ap.add_argument("--min-sv-size", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--layout", default="packed", choices=("packed", "soa"))
+    return ap.parse_args()
+
+
+def build_batch(args, rank):
+    from svim_asm_amd import synth
+    mean_m = 4000 if args.config == 2 else 400
+    distinct = max(1, min(args.distinct, args.samples))
+    base = [synth.synth_cigar_batch(seed=1000 * (rank + 1) + args.config * 100 + i, mean_m=mean_m)
+            for i in range(distinct)]
+    reps = [base[i % distinct] for i in range(args.samples)]
+    return synth.concat_batches(reps)
+
+
+def cpu_baseline(batch, args):
+    """C restatement of the reference loop (oracle, kind=port) on 1 core, bounded sample."""
+    from oracle import orc
+    cig, off, rs = batch["cigar"], batch["aln_off"], batch["ref_start"]
+    # bound the sample to ~cpu_seconds: time one pass, then repeat
+    max_ops = min(len(cig), 200_000_000)
+    a_hi = int(np.searchsorted(off, max_ops, side="right")) - 1
+    a_hi = max(a_hi, 1)
+    n_ops = int(off[a_hi])
+    sub_c, sub_o, sub_r = cig[:n_ops], off[:a_hi + 1], rs[:a_hi]
+    t0 = time.perf_counter()
+    orc.cigar_extract(sub_c, sub_o, sub_r, args.min_sv_size)
+    one = time.perf_counter() - t0
+    reps = int(max(1, min(200, args.cpu_seconds / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.cigar_extract(sub_c, sub_o, sub_r, args.min_sv_size)
+    dt = time.perf_counter() - t0
+    out = {"value": n_ops * reps / dt, "unit": "CIGAR ops/s", "cores": 1, "kind": "port",
+           "sample": "%d passes over %d ops / %d alignments of the bench batch (C restatement of "
+                     "SVIM_intra.analyze_cigar_indel, gcc -O2, 1 thread, %.1f s)" % (reps, n_ops, a_hi, dt)}
+    # CPython restatement of the same loop (what the reference actually executes), small sample
+    try:
+        from oracle import svim_oracle
+        m = min(n_ops, 1_500_000)
+        a2 = max(1, int(np.searchsorted(off, m, side="right")) - 1)
+        tuples = [[(int(w) & 15, int(w) >> 4) for w in cig[int(off[a]):int(off[a + 1])]] for a in range(a2)]
+        t0 = time.perf_counter()
+        for tp in tuples:
+            svim_oracle.analyze_cigar_indel(tp, args.min_sv_size)
+        dtp = time.perf_counter() - t0
+        out["cpython_value"] = int(off[a2]) / dtp
+        out["cpython_sample"] = "%d ops, pure-Python restatement, tuples pre-materialised" % int(off[a2])
+    except Exception as e:  # the C figure above is the baseline; this one is informative only
+        out["cpython_error"] = repr(e)
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from svim_asm_amd import _lib
+    batch = build_batch(args, rank)
+    n_ops = int(batch["aln_off"][-1])
+    n_aln = len(batch["aln_off"]) - 1
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = _lib.Context(local_rank, stream=stream.cuda_stream)
+
+    cig_np = batch["cigar"]
+    d_off = torch.from_numpy(batch["aln_off"].astype(np.int64)).to(dev)
+    d_rs = torch.from_numpy(batch["ref_start"]).to(dev)
+    if args.layout == "packed":
+        d_cig = torch.from_numpy(cig_np.view(np.int32)).to(dev)
+        d_op = None
+    else:
+        d_cig = torch.from_numpy((cig_np >> 4).astype(np.uint32).view(np.int32)).to(dev)
+        d_op = torch.from_numpy((cig_np & 15).astype(np.uint8)).to(dev)
+    cap = max(1024, n_ops // 16)
+    o_aln = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_ref = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_read = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_len = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_type = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int64, device=dev)
+    outs = (o_aln.data_ptr(), o_ref.data_ptr(), o_read.data_ptr(), o_len.data_ptr(), o_type.data_ptr())
+
+    def step():
+        ctx.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
+                              args.min_sv_size, outs, cap, d_n.data_ptr(),
+                              d_op=None if d_op is None else d_op.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_sig = int(d_n.item())
+    if n_sig > cap:
+        raise SystemExit("output capacity too small: %d > %d" % (n_sig, cap))
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([n_ops], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_ops = int(tot.item())
+    else:
+        total_ops = n_ops
+
+    # ---- roofline of the dominant kernel (k_cigar_tiles), HIP events on the launch stream ----
+    ctx.set_timing(True)
+    k_ms, p_ms = [], []
+    for _ in range(max(5, min(20, args.steps))):
+        step()
+        ctx.sync()
+        tot_ms, dom_ms = ctx.last_kernel_ms()
+        k_ms.append(dom_ms)
+        p_ms.append(tot_ms)
+    ctx.set_timing(False)
+    k_avg = float(np.mean(k_ms)) * 1e-3
+    p_avg = float(np.mean(p_ms)) * 1e-3
+    algo_bytes = 4 * n_ops + 16 * n_aln + 17 * n_sig
+    achieved = algo_bytes / k_avg / 1e9
+
+    # correctness spot-check of what the timed loop produced (oracle = checker only)
+    if rank == 0:
+        from oracle import orc
+        a_chk = min(n_aln, 2000)
+        exp = orc.cigar_extract(cig_np[:int(batch["aln_off"][a_chk])], batch["aln_off"][:a_chk + 1],
+                                batch["ref_start"][:a_chk], args.min_sv_size)
+        k = len(exp["aln"])
+        ok = (np.array_equal(o_ref[:k].cpu().numpy().view(np.uint32), exp["ref_pos"]) and
+              np.array_equal(o_read[:k].cpu().numpy().view(np.uint32), exp["read_pos"]) and
+              np.array_equal(o_aln[:k].cpu().numpy().view(np.uint32), exp["aln"]) and
+              np.array_equal(o_type[:k].cpu().numpy(), exp["type"]))
+        if not ok:
+            raise SystemExit("bench output differs from the oracle on the checked prefix")
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        wl_key = "config%d_x%d_%s" % (args.config, args.samples, args.layout)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(wl_key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "CIGAR ops/sec (SV-signature extraction, human genome-genome alignment)",
+            "value": total_ops * args.steps / elapsed,
+            "unit": "CIGAR ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config %d (%s, GRCh38-sized, ~5k alignments/sample) x %d samples per GPU "
+                            "resident in HBM, %s layout" % (args.config, "haploid 3 Gbp" if args.config == 2 else
+                                                            "10x indel density", args.samples, args.layout),
+                "ops_per_step_per_gpu": n_ops, "alignments_per_step_per_gpu": n_aln,
+                "signatures_per_step_per_gpu": n_sig, "min_sv_size": args.min_sv_size,
+                "parallelism": "sample/contig shards x%d, no data-path collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_cigar_tiles<STAGE>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_avg * 1e3,
+                "path_ms": p_avg * 1e3, "path_achieved": algo_bytes / p_avg / 1e9,
+            },
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(batch, args)
+            res["speedup_vs_cpu_port"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

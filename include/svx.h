@@ -1,0 +1,250 @@
+/*
+ * svx.h — C-ABI of libsvx.so: the MI355X (gfx950) hot path of SVIM-asm.
+ *
+ * The reference (eldariont/svim-asm v1.0.3) is pure Python and has no FFI layer;
+ * the boundary a maintainer would bind is the set of Python function seams listed
+ * in SURVEY.md §8(b).  Each entry point below names the reference function
+ * (file:line under /root/reference/src/svim_asm) whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes stub that binds them from the reference side.
+ *
+ * Conventions
+ *   - every function returns int: SVX_OK (0) or a negative svx_status; nothing
+ *     throws, aborts or keeps hidden global state;
+ *   - a context (svx_ctx) = one device + one HIP stream + a growable HBM
+ *     workspace.  One thread uses a context at a time; contexts are independent
+ *     (8 contexts for the 8 GPUs of a node);
+ *   - functions without a suffix take HOST pointers (the library stages them to
+ *     HBM, runs the kernels and copies the results back, then synchronises);
+ *     functions ending in _dev take DEVICE pointers, enqueue on the context's
+ *     stream and do not synchronise (the caller owns the buffers, e.g. torch
+ *     tensors, and synchronises the stream it handed in);
+ *   - all outputs are written in the reference's deterministic order (prefix-sum
+ *     compaction and stable sorts; no atomically-ordered appends).
+ *   - there is NO CPU fallback inside this library: without a usable HIP device
+ *     svx_ctx_create fails with SVX_E_NODEVICE.
+ */
+#ifndef SVX_H_
+#define SVX_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svx_ctx svx_ctx;
+
+typedef enum svx_status {
+    SVX_OK = 0,
+    SVX_E_INVALID = -1,   /* bad argument (null pointer, non-monotone offsets, ...) */
+    SVX_E_CAPACITY = -2,  /* output buffer too small; *n_out holds the needed count */
+    SVX_E_HIP = -3,       /* a HIP runtime call failed; see svx_last_error          */
+    SVX_E_NOMEM = -4,     /* HBM / host allocation failed                           */
+    SVX_E_TOO_LARGE = -5, /* batch exceeds a documented limit (e.g. >= 2^32 ops)    */
+    SVX_E_NODEVICE = -6   /* no HIP device / device index out of range              */
+} svx_status;
+
+/* ---------------------------------------------------------------- context -- */
+
+/* Create a context on HIP device `device` with its own non-blocking stream. */
+int svx_ctx_create(int device, svx_ctx** out);
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch's current stream:
+ * torch.cuda.current_stream().cuda_stream).  Pass NULL for the default stream. */
+int svx_ctx_create_on_stream(int device, void* hip_stream, svx_ctx** out);
+void svx_ctx_destroy(svx_ctx* ctx);
+/* Block until everything enqueued on the context's stream has finished. */
+int svx_ctx_sync(svx_ctx* ctx);
+/* Last error text for this context (never NULL; "" when no error). */
+const char* svx_last_error(const svx_ctx* ctx);
+const char* svx_version(void);
+/* Number of visible HIP devices (0 when none / no driver). Never fails. */
+int svx_device_count(void);
+
+/* Kernel timing with HIP events on the context's stream.  When enabled, every
+ * *_dev entry point brackets its kernels with events; after svx_ctx_sync the
+ * elapsed GPU time of the last call is returned in milliseconds. */
+int svx_ctx_set_timing(svx_ctx* ctx, int enabled);
+int svx_ctx_last_kernel_ms(svx_ctx* ctx, float* ms_total, float* ms_dominant);
+
+/* ------------------------------------------------------------ a1 + a2 ------ */
+/*
+ * CIGAR walk → indel signatures.
+ * Replaces analyze_cigar_indel (SVIM_intra.py:8-30) over a whole batch of
+ * alignments, fused with the `ref_start + pos_ref` of analyze_alignment_indel
+ * (SVIM_intra.py:36-43).  The batch boundary is the per-contig loop of
+ * analyze_alignment_file_coordsorted (SVIM_COLLECT.py:61-83).
+ *
+ *   cigar      BAM-native packed ops, `len << 4 | op`, all alignments back to back
+ *              (pysam cigartuples (op,len) == (w & 15, w >> 4)); n_ops = aln_off[n_aln]
+ *   aln_off    n_aln + 1 non-decreasing offsets into `cigar` (empty alignments allowed)
+ *   ref_start  per-alignment reference_start added to pos_ref, or NULL for the
+ *              raw analyze_cigar_indel result (pos_ref relative to the alignment)
+ *   min_len    options.min_sv_size; an I/D op emits when len >= min_len
+ *
+ * Output (SoA, 17 B per signature, in (alignment, op) order):
+ *   aln        index of the alignment the op belongs to
+ *   ref_pos    ref_start[aln] + running reference offset BEFORE the op
+ *   read_pos   running query offset BEFORE the op (counts leading soft clips)
+ *   len        op length
+ *   type       SVX_SIG_INS (op 1) or SVX_SIG_DEL (op 2)
+ *
+ * Ops 0(M),7(=),8(X) advance both cursors, 1(I),4(S) the query, 2(D) the
+ * reference; 3(N),5(H),6(P),9(B) and codes 10-15 advance nothing
+ * (SVIM_intra.py:14-29 has no branch for them).
+ *
+ * If more than `cap` signatures exist, nothing beyond `cap` is written, *n_out
+ * receives the exact count and SVX_E_CAPACITY is returned.
+ * Limits: n_ops < 2^32 per call; per-alignment cursor sums < 2^32.
+ */
+#define SVX_SIG_INS 0
+#define SVX_SIG_DEL 1
+
+typedef struct svx_sig_soa {
+    uint32_t* aln;
+    uint32_t* ref_pos;
+    uint32_t* read_pos;
+    uint32_t* len;
+    uint8_t* type;
+} svx_sig_soa;
+
+int svx_cigar_extract(svx_ctx* ctx, const uint32_t* cigar, const uint64_t* aln_off,
+                      uint32_t n_aln, const int32_t* ref_start, uint32_t min_len,
+                      svx_sig_soa out, uint64_t cap, uint64_t* n_out);
+
+/* SoA input variant named by the north star: op codes and lengths in two arrays
+ * (pysam cigartuples flattened as u8 op[], u32 len[]). Same output contract. */
+int svx_cigar_extract_soa(svx_ctx* ctx, const uint8_t* op, const uint32_t* len,
+                          const uint64_t* aln_off, uint32_t n_aln, const int32_t* ref_start,
+                          uint32_t min_len, svx_sig_soa out, uint64_t cap, uint64_t* n_out);
+
+/* Device-pointer variants.  n_ops must equal aln_off[n_aln] (the caller knows it;
+ * the device copy is not read back).  d_n_out: one uint64 in device memory.
+ * Exactly min(count, cap) signatures are written. Asynchronous on the ctx stream. */
+int svx_cigar_extract_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint64_t n_ops,
+                          const uint64_t* d_aln_off, uint32_t n_aln, const int32_t* d_ref_start,
+                          uint32_t min_len, svx_sig_soa d_out, uint64_t cap, uint64_t* d_n_out);
+int svx_cigar_extract_soa_dev(svx_ctx* ctx, const uint8_t* d_op, const uint32_t* d_len,
+                              uint64_t n_ops, const uint64_t* d_aln_off, uint32_t n_aln,
+                              const int32_t* d_ref_start, uint32_t min_len, svx_sig_soa d_out,
+                              uint64_t cap, uint64_t* d_n_out);
+
+/* Per-alignment CIGAR statistics in the same pass family (pysam/htslib
+ * definitions used by SVIM_inter.py:68-79 and SVIM_COLLECT.py:11):
+ *   ref_len    Σ len over {M,D,N,=,X}   (reference_end - reference_start, htslib bam_endpos)
+ *   q_start    Σ leading S ops (skipping H)        = query_alignment_start
+ *   q_end      q_start + Σ len over {M,I,=,X}      = query_alignment_end
+ *   read_len   Σ len over {M,I,S,=,X,H}            = infer_read_length()
+ *   n_hard     Σ len over H                        = get_cigar_stats()[0][5]
+ * Each output array has n_aln entries (any may be NULL to skip). Host pointers. */
+typedef struct svx_aln_stats {
+    uint32_t* ref_len;
+    uint32_t* q_start;
+    uint32_t* q_end;
+    uint32_t* read_len;
+    uint32_t* n_hard;
+} svx_aln_stats;
+
+int svx_cigar_stats(svx_ctx* ctx, const uint32_t* cigar, const uint64_t* aln_off, uint32_t n_aln,
+                    svx_aln_stats out);
+int svx_cigar_stats_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint64_t n_ops,
+                        const uint64_t* d_aln_off, uint32_t n_aln, svx_aln_stats d_out);
+
+/* ---------------------------------------------------------------- a3 ------- */
+/*
+ * Split-segment classification: the adjacent-pair decision tree of
+ * analyze_read_segments (SVIM_inter.py:62-258) for a batch of reads.
+ *
+ * For read r the caller passes its 1 + k segments in the reference's order
+ * ([primary] + supplementaries, SVIM_inter.py:64) at segs[read_off[r] ..
+ * read_off[r+1]).  q_start/q_end are the values of SVIM_inter.py:68-73 (already
+ * flipped for reverse-strand records).  The kernel sorts each read's segments
+ * stably by (q_start, q_end) (SVIM_inter.py:83) and classifies each adjacent
+ * pair; out[read_off[r] + i] describes sorted pair (i, i+1); the last slot of
+ * each read is SVX_RAW_NONE.  read_len[r] = primary.infer_read_length()
+ * (SVIM_inter.py:120).
+ *
+ * Raw records (a0..a5):
+ *   SVX_RAW_INS    ref_id, start, end, seq_start, seq_len  (slice of primary.query_sequence)
+ *   SVX_RAW_DEL    ref_id, start, end
+ *   SVX_RAW_BND    ref_id1, pos1, dir1, ref_id2, pos2, dir2   (dir: 0 'fwd', 1 'rev');
+ *                  every BND is also a `translocations` tuple (SVIM_inter.py:136...)
+ *   SVX_RAW_TANDEM ref_id, start, end, fully_covered, direction_fwd   (:150-164)
+ *   SVX_RAW_INV    ref_id, start, end, side  (0 left_fwd, 1 left_rev, 2 right_fwd, 3 right_rev)
+ * The post-passes (tandem merge :261-290, interspersed duplications :293-320,
+ * inversion clustering :323-338) consume these records on the host.
+ */
+#define SVX_RAW_NONE 0
+#define SVX_RAW_INS 1
+#define SVX_RAW_DEL 2
+#define SVX_RAW_BND 3
+#define SVX_RAW_TANDEM 4
+#define SVX_RAW_INV 5
+
+typedef struct svx_seg {
+    int32_t q_start, q_end, ref_id, ref_start, ref_end, is_reverse;
+} svx_seg;
+
+typedef struct svx_seg_params {
+    int32_t min_sv_size;
+    int32_t max_sv_size;
+    int32_t query_gap_tolerance;
+    int32_t query_overlap_tolerance;
+    int32_t reference_gap_tolerance;
+    int32_t reference_overlap_tolerance;
+} svx_seg_params;
+
+typedef struct svx_raw {
+    int32_t kind;
+    int32_t a0, a1, a2, a3, a4, a5;
+    int32_t pad;
+} svx_raw;
+
+int svx_segments_classify(svx_ctx* ctx, const svx_seg* segs, const uint32_t* read_off,
+                          uint32_t n_reads, const int32_t* read_len, const svx_seg_params* params,
+                          svx_raw* out);
+int svx_segments_classify_dev(svx_ctx* ctx, const svx_seg* d_segs, uint32_t n_segs,
+                              const uint32_t* d_read_off, uint32_t n_reads,
+                              const int32_t* d_read_len, const svx_seg_params* params,
+                              svx_raw* d_out);
+
+/* ------------------------------------------------------------ a5 + a6 ------ */
+/*
+ * Pair sort + partition: form_partitions (SVIM_COMBINE.py:15-32).
+ *
+ *   keys[i] = group << 32 | pos, where `group` encodes everything of
+ *   Candidate.get_key() (SVCandidate.py:17-19,147-148,292-293,386-387) that
+ *   must be EQUAL inside a partition — (type, rank of the contig name under
+ *   Python str ordering) — and pos is the non-negative key position.
+ *
+ * Output: perm[j] = input index of the j-th candidate in stable sorted order
+ * (ties keep input order, i.e. hap-1 list then hap-2 list, :17,:182);
+ * part_id[j] = partition number of sorted position j; a new partition starts
+ * when group differs or |pos - previous pos| > max_dist (strict, :24-26).
+ * *n_parts = number of partitions (0 when n == 0).
+ */
+int svx_pair_partition(svx_ctx* ctx, const uint64_t* keys, uint32_t n, uint32_t max_dist,
+                       uint32_t* perm, uint32_t* part_id, uint32_t* n_parts);
+int svx_pair_partition_dev(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist,
+                           uint32_t* d_perm, uint32_t* d_part_id, uint32_t* d_n_parts);
+
+/* ---------------------------------------------------------------- a7 ------- */
+/*
+ * Batched global (Needleman-Wunsch, unit cost) edit distance, the arithmetic of
+ * edlib.align(a, b)["editDistance"] as called by compute_distance
+ * (SVIM_COMBINE.py:50,64,76,88,100).  Sequences are bytes in one pool;
+ * pair p compares seq[a_off[p] .. a_off[p]+a_len[p]) with
+ * seq[b_off[p] .. b_off[p]+b_len[p)).  dist[p] receives the exact distance when
+ * it is <= k_max and any value > k_max otherwise (complete linkage cut at
+ * max_edit_distance only needs "> t").  k_max = 0xFFFFFFFF
+ * requests exact distances.
+ */
+int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_t seq_bytes,
+                            const uint64_t* a_off, const uint32_t* a_len, const uint64_t* b_off,
+                            const uint32_t* b_len, uint32_t n_pairs, uint32_t k_max,
+                            uint32_t* dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVX_H_ */

@@ -1,0 +1,108 @@
+"""ctypes wrapper of oracle/libsvx_oracle.so (C restatement of the hot path).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package svim_asm_amd never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsvx_oracle.so")
+
+SEG_DTYPE = np.dtype([("q_start", "<i4"), ("q_end", "<i4"), ("ref_id", "<i4"), ("ref_start", "<i4"),
+                      ("ref_end", "<i4"), ("is_reverse", "<i4")])
+RAW_DTYPE = np.dtype([("kind", "<i4"), ("a0", "<i4"), ("a1", "<i4"), ("a2", "<i4"), ("a3", "<i4"),
+                      ("a4", "<i4"), ("a5", "<i4"), ("pad", "<i4")])
+
+
+def build(force=False):
+    src = os.path.join(HERE, "svx_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-shared", "-o", LIB_PATH, src])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(LIB_PATH)
+        P = C.c_void_p
+        l.orc_cigar_extract.restype = C.c_uint64
+        l.orc_cigar_extract.argtypes = [P, P, C.c_uint32, P, C.c_uint32, P, P, P, P, P, C.c_uint64]
+        l.orc_cigar_count.restype = C.c_uint64
+        l.orc_cigar_count.argtypes = [P, C.c_uint64, C.c_uint32]
+        l.orc_cigar_stats.restype = None
+        l.orc_cigar_stats.argtypes = [P, P, C.c_uint32, P, P, P, P, P]
+        l.orc_segments_classify.restype = None
+        l.orc_segments_classify.argtypes = [P, P, C.c_uint32, P, P, P]
+        l.orc_pair_partition.restype = C.c_uint32
+        l.orc_pair_partition.argtypes = [P, C.c_uint32, C.c_uint32, P, P]
+        l.orc_edit_distance.restype = C.c_uint32
+        l.orc_edit_distance.argtypes = [P, C.c_uint32, P, C.c_uint32]
+        _lib = l
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+def cigar_extract(cigar, aln_off, ref_start=None, min_len=40):
+    cigar = np.ascontiguousarray(cigar, np.uint32)
+    aln_off = np.ascontiguousarray(aln_off, np.uint64)
+    rs = None if ref_start is None else np.ascontiguousarray(ref_start, np.int32)
+    n_aln = len(aln_off) - 1 if len(aln_off) else 0
+    n_ops = int(aln_off[-1]) if n_aln else 0
+    cap = int(lib().orc_cigar_count(_p(cigar), n_ops, int(min_len)))
+    out = {"aln": np.empty(cap, np.uint32), "ref_pos": np.empty(cap, np.uint32),
+           "read_pos": np.empty(cap, np.uint32), "len": np.empty(cap, np.uint32),
+           "type": np.empty(cap, np.uint8)}
+    n = lib().orc_cigar_extract(_p(cigar), _p(aln_off), n_aln, _p(rs), int(min_len), _p(out["aln"]),
+                                _p(out["ref_pos"]), _p(out["read_pos"]), _p(out["len"]),
+                                _p(out["type"]), cap)
+    assert n == cap
+    return out
+
+
+def cigar_stats(cigar, aln_off):
+    cigar = np.ascontiguousarray(cigar, np.uint32)
+    aln_off = np.ascontiguousarray(aln_off, np.uint64)
+    n_aln = len(aln_off) - 1 if len(aln_off) else 0
+    keys = ("ref_len", "q_start", "q_end", "read_len", "n_hard")
+    out = {k: np.zeros(n_aln, np.uint32) for k in keys}
+    lib().orc_cigar_stats(_p(cigar), _p(aln_off), n_aln, *[_p(out[k]) for k in keys])
+    return out
+
+
+def segments_classify(segs, read_off, read_len, params):
+    segs = np.ascontiguousarray(segs, SEG_DTYPE)
+    read_off = np.ascontiguousarray(read_off, np.uint32)
+    read_len = np.ascontiguousarray(read_len, np.int32)
+    prm = np.ascontiguousarray(params, np.int32)
+    out = np.zeros(len(segs), RAW_DTYPE)
+    n_reads = len(read_off) - 1 if len(read_off) else 0
+    if n_reads:
+        lib().orc_segments_classify(_p(segs), _p(read_off), n_reads, _p(read_len), _p(prm), _p(out))
+    return out
+
+
+def pair_partition(keys, max_dist):
+    keys = np.ascontiguousarray(keys, np.uint64)
+    n = len(keys)
+    perm = np.empty(n, np.uint32)
+    part = np.empty(n, np.uint32)
+    n_parts = lib().orc_pair_partition(_p(keys), n, int(max_dist), _p(perm), _p(part))
+    return perm, part, int(n_parts)
+
+
+def edit_distance(a: bytes, b: bytes):
+    aa = np.frombuffer(a, np.uint8) if len(a) else np.zeros(0, np.uint8)
+    bb = np.frombuffer(b, np.uint8) if len(b) else np.zeros(0, np.uint8)
+    return int(lib().orc_edit_distance(_p(aa), len(a), _p(bb), len(b)))

@@ -1,0 +1,266 @@
+"""ctypes binding of libsvx.so (C-ABI declared in include/svx.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no device is
+usable, loading / context creation raises.  numpy arrays go through the host-pointer
+entry points; torch tensors already in HBM go through the *_dev entry points.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsvx.so")
+
+SVX_OK = 0
+SVX_E_INVALID = -1
+SVX_E_CAPACITY = -2
+SVX_E_HIP = -3
+SVX_E_NOMEM = -4
+SVX_E_TOO_LARGE = -5
+SVX_E_NODEVICE = -6
+_STATUS = {0: "SVX_OK", -1: "SVX_E_INVALID", -2: "SVX_E_CAPACITY", -3: "SVX_E_HIP", -4: "SVX_E_NOMEM",
+           -5: "SVX_E_TOO_LARGE", -6: "SVX_E_NODEVICE"}
+
+SIG_INS, SIG_DEL = 0, 1
+RAW_NONE, RAW_INS, RAW_DEL, RAW_BND, RAW_TANDEM, RAW_INV = range(6)
+
+
+class SvxError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__("%s: %s" % (_STATUS.get(status, status), msg))
+
+
+class SigSoa(C.Structure):
+    _fields_ = [("aln", C.c_void_p), ("ref_pos", C.c_void_p), ("read_pos", C.c_void_p),
+                ("len", C.c_void_p), ("type", C.c_void_p)]
+
+
+class AlnStats(C.Structure):
+    _fields_ = [("ref_len", C.c_void_p), ("q_start", C.c_void_p), ("q_end", C.c_void_p),
+                ("read_len", C.c_void_p), ("n_hard", C.c_void_p)]
+
+
+class SegParams(C.Structure):
+    _fields_ = [("min_sv_size", C.c_int32), ("max_sv_size", C.c_int32),
+                ("query_gap_tolerance", C.c_int32), ("query_overlap_tolerance", C.c_int32),
+                ("reference_gap_tolerance", C.c_int32), ("reference_overlap_tolerance", C.c_int32)]
+
+
+SEG_DTYPE = np.dtype([("q_start", "<i4"), ("q_end", "<i4"), ("ref_id", "<i4"), ("ref_start", "<i4"),
+                      ("ref_end", "<i4"), ("is_reverse", "<i4")])
+RAW_DTYPE = np.dtype([("kind", "<i4"), ("a0", "<i4"), ("a1", "<i4"), ("a2", "<i4"), ("a3", "<i4"),
+                      ("a4", "<i4"), ("a5", "<i4"), ("pad", "<i4")])
+
+# symbol -> (restype, argtypes); must list every symbol include/svx.h declares
+_P = C.c_void_p
+SYMBOLS = {
+    "svx_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "svx_ctx_create_on_stream": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "svx_ctx_destroy": (None, [_P]),
+    "svx_ctx_sync": (C.c_int, [_P]),
+    "svx_last_error": (C.c_char_p, [_P]),
+    "svx_version": (C.c_char_p, []),
+    "svx_device_count": (C.c_int, []),
+    "svx_ctx_set_timing": (C.c_int, [_P, C.c_int]),
+    "svx_ctx_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "svx_cigar_extract": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, SigSoa, C.c_uint64,
+                                    C.POINTER(C.c_uint64)]),
+    "svx_cigar_extract_soa": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, SigSoa,
+                                        C.c_uint64, C.POINTER(C.c_uint64)]),
+    "svx_cigar_extract_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, C.c_uint32, SigSoa,
+                                        C.c_uint64, _P]),
+    "svx_cigar_extract_soa_dev": (C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_uint32, _P, C.c_uint32,
+                                            SigSoa, C.c_uint64, _P]),
+    "svx_cigar_stats": (C.c_int, [_P, _P, _P, C.c_uint32, AlnStats]),
+    "svx_cigar_stats_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, AlnStats]),
+    "svx_segments_classify": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.POINTER(SegParams), _P]),
+    "svx_segments_classify_dev": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P,
+                                            C.POINTER(SegParams), _P]),
+    "svx_pair_partition": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32)]),
+    "svx_pair_partition_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "svx_edit_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_uint32,
+                                          _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsvx.so and bind every declared symbol.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvxError(SVX_E_NODEVICE, "libsvx.so not built (%s); run `python -m svim_asm_amd.build` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+def _as(a, dtype):
+    if a is None:
+        return None
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Context:
+    """One device + one stream + scratch HBM (svx_ctx).  Not thread-safe; one per GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = _P()
+        if stream is None:
+            rc = self.lib.svx_ctx_create(int(device), C.byref(h))
+        else:
+            rc = self.lib.svx_ctx_create_on_stream(int(device), _P(stream), C.byref(h))
+        if rc != SVX_OK:
+            raise SvxError(rc, "svx_ctx_create(device=%d) failed — a HIP device is required; "
+                           "there is no CPU fallback" % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != SVX_OK:
+            raise SvxError(rc, (self.lib.svx_last_error(self.h) or b"").decode())
+
+    def sync(self):
+        self._check(self.lib.svx_ctx_sync(self.h))
+
+    def set_timing(self, on=True):
+        self._check(self.lib.svx_ctx_set_timing(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        t, d = C.c_float(), C.c_float()
+        self._check(self.lib.svx_ctx_last_kernel_ms(self.h, C.byref(t), C.byref(d)))
+        return t.value, d.value
+
+    # ---------------------------------------------------------------- a1 + a2
+    def cigar_extract(self, cigar, aln_off, ref_start=None, min_len=40, cap=None, op=None):
+        """Batch analyze_cigar_indel.  `cigar`: packed u32 words (or lengths when `op` is given).
+        Returns dict(aln, ref_pos, read_pos, len, type) in (alignment, op) order."""
+        cigar = _as(cigar, np.uint32)
+        aln_off = _as(aln_off, np.uint64)
+        ref_start = _as(ref_start, np.int32)
+        op = _as(op, np.uint8)
+        n_aln = len(aln_off) - 1 if len(aln_off) else 0
+        n_ops = int(aln_off[-1]) if n_aln else 0
+        if len(cigar) < n_ops or (op is not None and len(op) < n_ops):
+            raise SvxError(SVX_E_INVALID, "cigar shorter than aln_off[-1]")
+        if ref_start is not None and len(ref_start) != n_aln:
+            raise SvxError(SVX_E_INVALID, "ref_start length != n_aln")
+        if cap is None:
+            cap = max(1024, n_ops // 16)
+        while True:
+            out = {"aln": np.empty(cap, np.uint32), "ref_pos": np.empty(cap, np.uint32),
+                   "read_pos": np.empty(cap, np.uint32), "len": np.empty(cap, np.uint32),
+                   "type": np.empty(cap, np.uint8)}
+            soa = SigSoa(_ptr(out["aln"]), _ptr(out["ref_pos"]), _ptr(out["read_pos"]),
+                         _ptr(out["len"]), _ptr(out["type"]))
+            n = C.c_uint64(0)
+            if op is None:
+                rc = self.lib.svx_cigar_extract(self.h, _ptr(cigar), _ptr(aln_off), n_aln,
+                                                _ptr(ref_start), int(min_len), soa, cap, C.byref(n))
+            else:
+                rc = self.lib.svx_cigar_extract_soa(self.h, _ptr(op), _ptr(cigar), _ptr(aln_off), n_aln,
+                                                    _ptr(ref_start), int(min_len), soa, cap, C.byref(n))
+            if rc == SVX_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(rc)
+            k = int(n.value)
+            return {key: v[:k] for key, v in out.items()}
+
+    def cigar_extract_dev(self, d_cigar, n_ops, d_aln_off, n_aln, d_ref_start, min_len, d_out, cap,
+                          d_n_out, d_op=None):
+        """Device-pointer form; arguments are integer device addresses (tensor.data_ptr())."""
+        soa = SigSoa(*d_out)
+        if d_op is None:
+            rc = self.lib.svx_cigar_extract_dev(self.h, d_cigar, n_ops, d_aln_off, n_aln, d_ref_start,
+                                                int(min_len), soa, cap, d_n_out)
+        else:
+            rc = self.lib.svx_cigar_extract_soa_dev(self.h, d_op, d_cigar, n_ops, d_aln_off, n_aln,
+                                                    d_ref_start, int(min_len), soa, cap, d_n_out)
+        self._check(rc)
+
+    def cigar_stats(self, cigar, aln_off):
+        cigar = _as(cigar, np.uint32)
+        aln_off = _as(aln_off, np.uint64)
+        n_aln = len(aln_off) - 1 if len(aln_off) else 0
+        out = {k: np.zeros(n_aln, np.uint32) for k in ("ref_len", "q_start", "q_end", "read_len", "n_hard")}
+        st = AlnStats(*[_ptr(out[k]) for k in ("ref_len", "q_start", "q_end", "read_len", "n_hard")])
+        self._check(self.lib.svx_cigar_stats(self.h, _ptr(cigar), _ptr(aln_off), n_aln, st))
+        return out
+
+    # ---------------------------------------------------------------- a3
+    def segments_classify(self, segs, read_off, read_len, params):
+        segs = np.ascontiguousarray(segs, dtype=SEG_DTYPE)
+        read_off = _as(read_off, np.uint32)
+        read_len = _as(read_len, np.int32)
+        n_reads = len(read_off) - 1 if len(read_off) else 0
+        out = np.zeros(len(segs), dtype=RAW_DTYPE)
+        if n_reads == 0 or len(segs) == 0:
+            return out
+        p = params if isinstance(params, SegParams) else SegParams(*[int(x) for x in params])
+        self._check(self.lib.svx_segments_classify(self.h, _ptr(segs), _ptr(read_off), n_reads,
+                                                   _ptr(read_len), C.byref(p), _ptr(out)))
+        return out
+
+    # ---------------------------------------------------------------- a5 + a6
+    def pair_partition(self, keys, max_dist):
+        keys = _as(keys, np.uint64)
+        n = len(keys)
+        perm = np.empty(n, np.uint32)
+        part = np.empty(n, np.uint32)
+        n_parts = C.c_uint32(0)
+        self._check(self.lib.svx_pair_partition(self.h, _ptr(keys), n, int(max_dist), _ptr(perm),
+                                                _ptr(part), C.byref(n_parts)))
+        return perm, part, int(n_parts.value)
+
+    # ---------------------------------------------------------------- a7
+    def edit_distance_batch(self, seq, a_off, a_len, b_off, b_len, k_max=0xFFFFFFFF):
+        seq = _as(seq, np.uint8)
+        a_off = _as(a_off, np.uint64)
+        b_off = _as(b_off, np.uint64)
+        a_len = _as(a_len, np.uint32)
+        b_len = _as(b_len, np.uint32)
+        n = len(a_off)
+        dist = np.zeros(n, np.uint32)
+        if n:
+            self._check(self.lib.svx_edit_distance_batch(self.h, _ptr(seq), len(seq), _ptr(a_off),
+                                                         _ptr(a_len), _ptr(b_off), _ptr(b_len), n,
+                                                         int(k_max) & 0xFFFFFFFF, _ptr(dist)))
+        return dist
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use; raises without a GPU)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,142 @@
+// svx_ctx.hip — context lifecycle, workspace, timing.  Part of libsvx.so (C-ABI in include/svx.h).
+#include "svx_internal.h"
+
+extern "C" const char* svx_version(void) { return "svx 0.1.0 (gfx950)"; }
+
+extern "C" int svx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int ctx_create_common(int device, void* stream, bool own, svx_ctx** out) {
+    if (!out) return SVX_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SVX_E_NODEVICE;
+    if (device < 0 || device >= n) return SVX_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SVX_E_HIP;
+    svx_ctx* c = new (std::nothrow) svx_ctx();
+    if (!c) return SVX_E_NOMEM;
+    c->device = device;
+    if (own) {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return SVX_E_HIP;
+        }
+        c->own_stream = true;
+    } else {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+        c->own_stream = false;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return SVX_OK;
+}
+
+extern "C" int svx_ctx_create(int device, svx_ctx** out) {
+    return ctx_create_common(device, nullptr, true, out);
+}
+extern "C" int svx_ctx_create_on_stream(int device, void* hip_stream, svx_ctx** out) {
+    return ctx_create_common(device, hip_stream, false, out);
+}
+
+extern "C" void svx_ctx_destroy(svx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int svx_ctx_sync(svx_ctx* ctx) {
+    if (!ctx) return SVX_E_INVALID;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SVX_OK;
+}
+
+extern "C" const char* svx_last_error(const svx_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+static int grow(svx_ctx* ctx, char** buf, size_t* have, size_t want) {
+    if (want <= *have) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    // earlier work on the stream may still use the old buffer
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) {
+        SVX_HIP(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    size_t sz = svx_align_up(want + want / 8, 1 << 20);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        SVX_SET_ERR(ctx, "hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+        return SVX_E_NOMEM;
+    }
+    *buf = static_cast<char*>(p);
+    *have = sz;
+    return SVX_OK;
+}
+
+int svx_ws_reserve(svx_ctx* ctx, size_t total) {
+    ctx->ws_used = 0;
+    return grow(ctx, &ctx->ws, &ctx->ws_bytes, total);
+}
+int svx_stage_reserve(svx_ctx* ctx, size_t total) {
+    ctx->stage_used = 0;
+    return grow(ctx, &ctx->stage, &ctx->stage_bytes, total);
+}
+
+extern "C" int svx_ctx_set_timing(svx_ctx* ctx, int enabled) {
+    if (!ctx) return SVX_E_INVALID;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    if (enabled && !ctx->ev[0]) {
+        for (int i = 0; i < 4; ++i) SVX_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    }
+    ctx->timing = enabled != 0;
+    ctx->ev_valid = false;
+    return SVX_OK;
+}
+
+int svx_timing_begin(svx_ctx* ctx) {
+    if (!ctx->timing) return SVX_OK;
+    ctx->ev_valid = false;
+    SVX_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    return SVX_OK;
+}
+int svx_timing_mark(svx_ctx* ctx, int which) {
+    if (!ctx->timing) return SVX_OK;
+    SVX_HIP(ctx, hipEventRecord(ctx->ev[which], ctx->stream));
+    return SVX_OK;
+}
+int svx_timing_end(svx_ctx* ctx) {
+    if (!ctx->timing) return SVX_OK;
+    SVX_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_valid = true;
+    return SVX_OK;
+}
+
+extern "C" int svx_ctx_last_kernel_ms(svx_ctx* ctx, float* ms_total, float* ms_dominant) {
+    if (!ctx) return SVX_E_INVALID;
+    if (!ctx->timing || !ctx->ev_valid) {
+        SVX_SET_ERR(ctx, "no timed call recorded (svx_ctx_set_timing(ctx,1) then a *_dev call)");
+        return SVX_E_INVALID;
+    }
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SVX_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+    float t = 0.f, d = 0.f;
+    SVX_HIP(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]));
+    SVX_HIP(ctx, hipEventElapsedTime(&d, ctx->ev[1], ctx->ev[2]));
+    if (ms_total) *ms_total = t;
+    if (ms_dominant) *ms_dominant = d;
+    return SVX_OK;
+}

@@ -1,0 +1,71 @@
+// svx_internal.h — context, workspace and error plumbing shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "svx.h"
+
+struct svx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // growable HBM workspace (bump-allocated per call, reused across calls)
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t ws_used = 0;
+    // second, independent region for host-pointer entry points (staged inputs/outputs)
+    char* stage = nullptr;
+    size_t stage_bytes = 0;
+    size_t stage_used = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    int n_cu = 256;
+    char err[512] = {0};
+};
+
+#define SVX_SET_ERR(ctx, ...)                                   \
+    do {                                                        \
+        if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+    } while (0)
+
+#define SVX_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            SVX_SET_ERR(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),    \
+                        __FILE__, __LINE__);                                            \
+            return (e__ == hipErrorOutOfMemory) ? SVX_E_NOMEM : SVX_E_HIP;              \
+        }                                                                               \
+    } while (0)
+
+static inline size_t svx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Reserve `total` bytes of workspace for this call (may reallocate; synchronises the
+// stream first when it has to, so earlier kernels never lose their scratch).
+int svx_ws_reserve(svx_ctx* ctx, size_t total);
+int svx_stage_reserve(svx_ctx* ctx, size_t total);
+
+template <typename T>
+static inline T* svx_ws_take(svx_ctx* ctx, size_t count) {
+    size_t off = svx_align_up(ctx->ws_used, 256);
+    ctx->ws_used = off + count * sizeof(T);
+    return reinterpret_cast<T*>(ctx->ws + off);
+}
+template <typename T>
+static inline T* svx_stage_take(svx_ctx* ctx, size_t count) {
+    size_t off = svx_align_up(ctx->stage_used, 256);
+    ctx->stage_used = off + count * sizeof(T);
+    return reinterpret_cast<T*>(ctx->stage + off);
+}
+static inline size_t svx_take_bytes(size_t count, size_t elem) {
+    return svx_align_up(count * elem, 256) + 256;
+}
+
+int svx_timing_begin(svx_ctx* ctx);           // records ev[0]
+int svx_timing_mark(svx_ctx* ctx, int which); // records ev[which] (1: dominant start, 2: dominant end)
+int svx_timing_end(svx_ctx* ctx);             // records ev[3]

@@ -1,0 +1,78 @@
+"""HIP split-segment classification (svx_segments_classify) vs the CPU oracle.
+
+Reference: adjacent-pair decision tree of analyze_read_segments (SVIM_inter.py:62-258).
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+from svim_asm_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEFAULT = (40, 100000, 50, 50, 50, 50)  # min_sv, max_sv, qgt, qot, rgt, rot (SVIM_input_parsing.py defaults)
+
+
+def random_reads(rng, n_reads, max_k, n_contigs=3, spread=300):
+    """Segments engineered to sit near every threshold of the decision tree."""
+    ks = rng.integers(0, max_k + 1, size=n_reads)
+    off = np.concatenate(([0], np.cumsum(ks))).astype(np.uint32)
+    n = int(off[-1])
+    segs = np.zeros(n, dtype=_lib.SEG_DTYPE)
+    read_len = rng.integers(1000, 200000, size=n_reads).astype(np.int32)
+    for r in range(n_reads):
+        q = 0
+        ref = int(rng.integers(0, 1_000_000))
+        for i in range(off[r], off[r + 1]):
+            ln = int(rng.integers(100, 5000))
+            q_start = q + int(rng.choice([-60, -51, -50, -49, 0, 10, 49, 50, 51, 90, 200, 5000]))
+            q_start = max(0, q_start)
+            segs[i]["q_start"] = q_start
+            segs[i]["q_end"] = q_start + ln
+            q = q_start + ln
+            jump = int(rng.choice([-200000, -100001, -5000, -300, -51, -50, -49, -40, 0, 39, 40, 41, 50, 51, 300, 5000, 100001, 250000]))
+            segs[i]["ref_id"] = int(rng.integers(0, n_contigs)) if rng.random() < 0.2 else 0
+            segs[i]["ref_start"] = max(0, ref + jump + int(rng.integers(-spread, spread)))
+            segs[i]["ref_end"] = segs[i]["ref_start"] + ln + int(rng.integers(-50, 50))
+            segs[i]["is_reverse"] = int(rng.random() < 0.3)
+            ref = int(segs[i]["ref_end"])
+        # shuffle within the read so that the kernel's stable sort matters; add ties
+        sl = slice(off[r], off[r + 1])
+        if off[r + 1] - off[r] > 1:
+            perm = rng.permutation(off[r + 1] - off[r])
+            segs[sl] = segs[sl][perm]
+            if rng.random() < 0.3:
+                segs[off[r] + 1]["q_start"] = segs[off[r]]["q_start"]
+                segs[off[r] + 1]["q_end"] = segs[off[r]]["q_end"]
+    return segs, off, read_len
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_reads_match_oracle(svx_ctx, seed):
+    rng = np.random.default_rng(seed)
+    segs, off, rl = random_reads(rng, n_reads=int(rng.integers(1, 3000)), max_k=int(rng.choice([2, 6, 40])))
+    for params in (DEFAULT, (40, 1000, 50, 50, 50, 50), (50, 20, 0, 0, 0, 0), (1, 100000, 500, 500, 500, 500)):
+        got = svx_ctx.segments_classify(segs, off, rl, params)
+        exp = orc.segments_classify(segs, off, rl, params)
+        assert np.array_equal(got, exp)
+        kinds = set(np.unique(exp["kind"]))
+    assert kinds  # non-trivial
+
+
+def test_every_branch_family_is_exercised():
+    """The generator reaches INS, DEL, BND, TANDEM and INV records (oracle-side check, CPU)."""
+    rng = np.random.default_rng(0)
+    segs, off, rl = random_reads(rng, 4000, 6)
+    exp = orc.segments_classify(segs, off, rl, DEFAULT)
+    assert set(np.unique(exp["kind"])) == {0, 1, 2, 3, 4, 5}
+    inv = exp[exp["kind"] == 5]
+    assert set(np.unique(inv["a3"])) == {0, 1, 2, 3}
+
+
+def test_empty_and_single_segment_reads(svx_ctx):
+    segs = np.zeros(3, dtype=_lib.SEG_DTYPE)
+    off = np.array([0, 0, 1, 1, 3], dtype=np.uint32)
+    rl = np.array([10, 10, 10, 10], dtype=np.int32)
+    got = svx_ctx.segments_classify(segs, off, rl, DEFAULT)
+    exp = orc.segments_classify(segs, off, rl, DEFAULT)
+    assert np.array_equal(got, exp)
+    assert svx_ctx.segments_classify(segs[:0], np.zeros(1, np.uint32), rl[:0], DEFAULT).shape == (0,)
