@@ -118,7 +118,7 @@ def test_capacity_protocol(svx_ctx):
     rc = svx_ctx.lib.svx_cigar_extract(svx_ctx.h, cig.ctypes.data, off.ctypes.data, len(off) - 1,
                                        rs.ctypes.data, 40, soa, cap, C.byref(n))
     assert rc == _lib.SVX_E_CAPACITY and n.value == n_true
-    assert all((b[cap:] == (0xAB if b.dtype == np.uint8 else 0xABABABAB)).all() for b in bufs), "wrote past cap"
+    assert all((b[cap:] == 0xAB).all() for b in bufs), "wrote past cap"
     exp = orc.cigar_extract(cig, off, rs, 40)
     assert np.array_equal(bufs[1][:cap], exp["ref_pos"][:cap])
 
