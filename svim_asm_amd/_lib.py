@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsvx.so")
+LIB_PATH = os.environ.get("SVX_LIB") or os.path.join(HERE, "libsvx.so")  # SVX_LIB: A/B builds
 
 SVX_OK = 0
 SVX_E_INVALID = -1

@@ -12,7 +12,7 @@
 //   A  k_cigar_tiles<STAGE>   one WAVE per tile of 4096 ops; 4 rounds of 1024 ops; per round:
 //                             coalesced dwordx4 loads (1 KiB/wave-instr) → wave-private padded LDS
 //                             transpose → 16 consecutive ops per lane → lane-local segmented walk →
-//                             wave segmented scan (__shfl_up) → signatures staged into the tile's
+//                             wave segmented scan (DPP row_shr/row_bcast) → signatures staged into the tile's
 //                             slab (256 x 16 B) with tile-local cursors; tile descriptor
 //                             {count, seen_head, ref_tail, read_tail, a_lo} written at the end.
 //   B  k_desc_scan            segmented exclusive scan over the tile descriptors: per-tile carry-in
@@ -35,6 +35,7 @@ constexpr int kTileOps = kRoundOps * kRounds;  // 4096 ops per tile (16 KiB)
 constexpr int kSlab = 256;                     // staged signatures per tile
 constexpr int kWaves = 4;                      // waves (= tiles) per workgroup
 constexpr int kXposeU4 = 64 * 5;               // padded transpose buffer: 5 uint4 per lane
+constexpr int kScanBlock = 1024;               // tile descriptors per scan workgroup
 
 enum { MODE_STAGE = 0, MODE_DIRECT = 1 };
 
@@ -53,7 +54,9 @@ struct CigarArgs {
     uint32_t* carry_ref;
     uint32_t* carry_read;
     uint32_t* dense_list;
-    uint32_t* n_dense;
+    uint32_t* n_dense;   // [0] dense-tile count, [1] scan ticket
+    uint4* blk_agg;      // per scan block: {has_start, ref_tail, read_tail, count}
+    uint4* blk_prefix;   // exclusive scan of blk_agg
     svx_sig_soa out;
     uint64_t cap;
 };
@@ -120,15 +123,73 @@ __device__ __forceinline__ void store_final(const CigarArgs& p, uint64_t slot, u
     }
 }
 
+// DPP lane movement (gfx9 family): identity 0 flows into lanes without a source.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
+// inclusive wave scan: segmented (flag f resets) sums of r and d, plain sum of c
+#define SVX_SEG_STEP(CTRL, RM)                                                     \
+    {                                                                              \
+        const uint32_t f2 = dpp0<CTRL, RM>(f), r2 = dpp0<CTRL, RM>(sr),            \
+                       d2 = dpp0<CTRL, RM>(sd), c2 = dpp0<CTRL, RM>(sc);           \
+        sr += f ? 0u : r2;                                                         \
+        sd += f ? 0u : d2;                                                         \
+        f |= f2;                                                                   \
+        sc += c2;                                                                  \
+    }
+#define SVX_SEG_SCAN()                                                             \
+    SVX_SEG_STEP(kDppShr1, 0xF) SVX_SEG_STEP(kDppShr2, 0xF) SVX_SEG_STEP(kDppShr4, 0xF) \
+    SVX_SEG_STEP(kDppShr8, 0xF) SVX_SEG_STEP(kDppBcast15, 0xA) SVX_SEG_STEP(kDppBcast31, 0xC)
+
+// One round of a tile: lane reads uint4 #(k*64+lane), k = 0..3 (coalesced 1 KiB per wave
+// instruction) through a per-tile buffer resource whose num_records is the tile's valid byte
+// count: the hardware range check returns 0 for anything past the end of the batch (word 0 =
+// "0M", a no-op for both cursors), so the ragged last tile needs no guarded scalar path.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <bool SOA>
+__device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t ro_,
+                                           uint32_t ro, int lane, uint4 (&q)[4], uint4& o) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+            rc, (int)((ro + (uint32_t)(k * 64 + lane) * 4u) * 4u), 0, 0);
+        q[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    if (SOA) {  // 16 op codes of this lane's 16 consecutive ops
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ro_, (int)(ro + (uint32_t)lane * 16u), 0, 0);
+        o = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
+#ifndef SVX_TILE_MIN_WAVES
+#define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int kQueue = 64;  // signatures flushed per pass (one per lane)
+
 template <int MODE, bool SOA>
-__global__ __launch_bounds__(64 * kWaves) void k_cigar_tiles(CigarArgs p) {
+__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ uint32_t s_head[kWaves][kTileOps / 32];
+    __shared__ uint4 s_queue[kWaves][kQueue];
+    __shared__ uint2 s_carry[kWaves][64];
 
-    const int wave = threadIdx.x >> 6;
+    // the wave index is wave-uniform: tell the compiler so that tile indices, loop bounds and
+    // carries live in SGPRs and the tile/round loops are scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     uint4* xp = s_xpose[wave];
     uint32_t* hmask = s_head[wave];
+    uint4* queue = s_queue[wave];
+    uint2* lcarry = s_carry[wave];
 
     uint32_t work = blockIdx.x * kWaves + wave;
     const uint32_t work_stride = gridDim.x * kWaves;
@@ -139,8 +200,16 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_tiles(CigarArgs p) {
         const uint64_t g0 = (uint64_t)tile * kTileOps;
         const uint64_t tile_end = (g0 + kTileOps < p.n_ops) ? g0 + kTileOps : p.n_ops;
 
+        // first round's loads go out before the (latency-bound) alignment-start lookup
+        const uint32_t tile_len = (uint32_t)(tile_end - g0);
+        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.cigar + g0, tile_len * 4u);
+        const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(SOA ? (const void*)(p.op + g0) : (const void*)p.cigar,
+                                                      SOA ? tile_len : 0u);
+        uint4 q[4], qo = make_uint4(0, 0, 0, 0);
+        load_round<SOA>(rs_c, rs_o, 0u, lane, q, qo);
+
         // ---- alignment starts inside this tile → 4096-bit mask in LDS ----
-        const uint32_t a_lo = wave_lower_bound(p.aln_off, p.n_aln + 1, g0, lane);
+        const uint32_t a_lo = __builtin_amdgcn_readfirstlane(wave_lower_bound(p.aln_off, p.n_aln + 1, g0, lane));
         hmask[lane] = 0;
         hmask[lane + 64] = 0;
         wave_lds_sync();
@@ -164,146 +233,148 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_tiles(CigarArgs p) {
         uint32_t tile_cnt = 0;
         uint32_t obase = 0;
         if (MODE == MODE_DIRECT) {
-            carry_r = p.carry_ref[tile];
-            carry_d = p.carry_read[tile];
+            const uint4 bp = p.blk_prefix[tile / kScanBlock];
+            const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
+            const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
+            carry_r = local_head ? lr : lr + bp.y;
+            carry_d = local_head ? ld : ld + bp.z;
             seen = true;  // carry-in already holds "since the last start before the tile"
-            obase = p.out_base[tile];
+            obase = (lb & 0x7FFFFFFFu) + bp.w;
         }
 
         for (int round = 0; round < kRounds; ++round) {
-            const uint64_t r0 = g0 + (uint64_t)round * kRoundOps;
-            if (r0 >= tile_end) break;  // wave-uniform
+            const uint32_t ro = (uint32_t)round * kRoundOps;
+            if (ro >= tile_len) break;  // wave-uniform
 
-            // ---- coalesced load: lane reads uint4 #(k*64+lane) of this round ----
-            uint4 q[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t e0 = r0 + (uint64_t)(k * 64 + lane) * 4;
-                if (e0 + 4 <= tile_end) {
-                    q[k] = *reinterpret_cast<const uint4*>(p.cigar + e0);
-                } else {
-                    uint32_t t[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) t[j] = (e0 + j < tile_end) ? p.cigar[e0 + j] : 0u;
-                    q[k] = make_uint4(t[0], t[1], t[2], t[3]);
-                }
-            }
-            uint32_t opw[4] = {0, 0, 0, 0};  // SoA: 16 op codes of this lane's 16 consecutive ops
-            if (SOA) {
-                const uint64_t e0 = r0 + (uint64_t)lane * 16;
-                if (e0 + 16 <= tile_end) {
-                    uint4 o = *reinterpret_cast<const uint4*>(p.op + e0);
-                    opw[0] = o.x; opw[1] = o.y; opw[2] = o.z; opw[3] = o.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        uint32_t b = (e0 + j < tile_end) ? p.op[e0 + j] : 0u;
-                        opw[j >> 2] |= b << ((j & 3) * 8);
-                    }
-                }
-            }
             // ---- transpose through wave-private LDS: 5-uint4 stride per lane is conflict-free ----
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = k * 64 + lane;
                 xp[(i >> 2) * 5 + (i & 3)] = q[k];
             }
+            const uint4 opw4 = qo;
+            // software pipeline: next round's global loads are in flight during this round's math
+            if (round + 1 < kRounds && ro + kRoundOps < tile_len)
+                load_round<SOA>(rs_c, rs_o, ro + kRoundOps, lane, q, qo);
             wave_lds_sync();
-            uint32_t w[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint4 v = xp[lane * 5 + j];
-                w[4 * j + 0] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-            }
             const uint32_t lbase = round * kRoundOps + lane * kLaneOps;  // tile-local index of op 0
             const uint32_t hm = (hmask[lbase >> 5] >> (lbase & 31)) & 0xFFFFu;
-            wave_lds_sync();  // xp is rewritten next round
+            const uint32_t opw[4] = {opw4.x, opw4.y, opw4.z, opw4.w};
+            uint32_t hmo = hm;  // prefix-OR: bit i set iff an alignment start sits at a slot <= i
+            hmo |= hmo << 1; hmo |= hmo << 2; hmo |= hmo << 4; hmo |= hmo << 8;
+            const uint4* myx = xp + lane * 5;  // this lane's 16 consecutive ops, 4 per uint4
 
-            // ---- lane-local segmented walk over 16 consecutive ops ----
-            uint32_t rr = 0, rd = 0, emask = 0;
-            uint32_t pr[16], pd[16], ln[16];
+            // ---- pre-pass: which ops emit (I or D with len >= min_len, SVIM_intra.py:18,22) ----
+            // rolled over the four uint4 groups: the words stay in LDS, not in 16 registers
+            uint32_t emask = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const uint4 v4 = myx[j];
+                const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
+                uint32_t e4 = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                uint32_t op, len;
-                if (SOA) {
-                    op = (opw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-                    len = w[i];
-                } else {
-                    op = w[i] & 15u;
-                    len = w[i] >> 4;
+                for (int t = 3; t >= 0; --t) {
+                    uint32_t op, len;
+                    if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
+                    else { op = wv[t] & 15u; len = wv[t] >> 4; }
+                    e4 = (e4 << 1) | (((op - 1u) < 2u && len >= p.min_len) ? 1u : 0u);
                 }
-                ln[i] = len;
-                if ((hm >> i) & 1u) { rr = 0; rd = 0; }
-                pr[i] = rr;
-                pd[i] = rd;
-                // ops advancing the reference cursor: M(0) D(2) =(7) X(8); the query cursor:
-                // M(0) I(1) S(4) =(7) X(8)   (SVIM_intra.py:14-29; N,H,P,B: nothing)
-                const bool valid = SOA ? (op < 16u) : true;
-                const uint32_t aref = (valid && ((0x185u >> op) & 1u)) ? len : 0u;
-                const uint32_t ard = (valid && ((0x193u >> op) & 1u)) ? len : 0u;
-                rr += aref;
-                rd += ard;
-                const bool em = (op - 1u) < 2u && len >= p.min_len;  // I or D, inclusive threshold
-                emask |= (em ? 1u : 0u) << i;
-                // keep the type in ln's spare top bit? no: len may use 28 bits; type re-derived below
-                w[i] = op;
+                emask |= e4 << (4 * j);
             }
-            const uint32_t cnt = __popc(emask);
+            uint32_t sc = __popc(emask);
+            {   // plain inclusive DPP scan of the counts
+                sc += dpp0<kDppShr1, 0xF>(sc); sc += dpp0<kDppShr2, 0xF>(sc);
+                sc += dpp0<kDppShr4, 0xF>(sc); sc += dpp0<kDppShr8, 0xF>(sc);
+                sc += dpp0<kDppBcast15, 0xA>(sc); sc += dpp0<kDppBcast31, 0xC>(sc);
+            }
+            const uint32_t xc = dpp0<kDppWaveShr1, 0xF>(sc);
+            const uint32_t C = __builtin_amdgcn_readlane(sc, 63);
 
-            // ---- wave segmented inclusive scan of (flag, ref, read) + plain scan of cnt ----
-            uint32_t f = hm != 0 ? 1u : 0u, sr = rr, sd = rd, sc = cnt;
+            uint32_t f = 0, sr = 0, sd = 0;
+            // one pass per 64 signatures of this round (a single pass unless the CIGAR is indel-dense)
+            for (uint32_t qbase = 0; qbase == 0 || qbase < C; qbase += kQueue) {
+                // ---- lane-local segmented walk over 16 consecutive ops ----
+                uint32_t rr = 0, rd = 0;
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) {
+                    const uint4 v4 = myx[j];
+                    const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
+                    const uint32_t hm4 = hm >> (4 * j), em4 = emask >> (4 * j);
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t f2 = __shfl_up(f, d);
-                uint32_t r2 = __shfl_up(sr, d);
-                uint32_t d2 = __shfl_up(sd, d);
-                uint32_t c2 = __shfl_up(sc, d);
-                if (lane >= d) {
-                    if (!f) { sr += r2; sd += d2; }
-                    f |= f2;
-                    sc += c2;
-                }
-            }
-            // exclusive values for this lane
-            uint32_t xf = __shfl_up(f, 1), xr = __shfl_up(sr, 1), xd = __shfl_up(sd, 1),
-                     xc = __shfl_up(sc, 1);
-            if (lane == 0) { xf = 0; xr = 0; xd = 0; xc = 0; }
-            uint32_t in_r, in_d;
-            bool pre;
-            if (xf) {
-                in_r = xr; in_d = xd; pre = false;
-            } else {
-                in_r = xr + carry_r; in_d = xd + carry_d; pre = !seen;
-            }
-
-            // ---- emit ----
-            if (__any(emask != 0)) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if ((emask >> i) & 1u) {
-                        const bool own = (hm & ((2u << i) - 1u)) != 0;  // a start at or before op i in-lane
-                        const uint32_t ref = own ? pr[i] : pr[i] + in_r;
-                        const uint32_t rdp = own ? pd[i] : pd[i] + in_d;
-                        const bool prec = own ? false : pre;
-                        const uint32_t rank = tile_cnt + xc + __popc(emask & ((1u << i) - 1u));
-                        const uint32_t type = (w[i] == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
-                        if (MODE == MODE_STAGE) {
-                            if (rank < kSlab) {
-                                uint32_t w0 = (lbase + i) | (type << 12) | ((prec ? 1u : 0u) << 13);
-                                p.slab[(uint64_t)tile * kSlab + rank] = make_uint4(w0, ref, rdp, ln[i]);
-                            }
-                        } else {
-                            const uint64_t g = g0 + lbase + i;
-                            const uint32_t aln = find_aln(p.aln_off, p.n_aln, a_lo, g);
-                            store_final(p, (uint64_t)obase + rank, aln, ref, rdp, ln[i], type);
+                    for (int t = 0; t < 4; ++t) {
+                        uint32_t op, len;
+                        if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
+                        else { op = wv[t] & 15u; len = wv[t] >> 4; }
+                        if (__any((hm4 >> t) & 1u)) {  // wave-uniform: most op slots hold no alignment start
+                            if ((hm4 >> t) & 1u) { rr = 0; rd = 0; }
                         }
+                        if (__any((em4 >> t) & 1u)) {  // wave-uniform: most op slots emit nothing
+                            if ((em4 >> t) & 1u) {
+                                const uint32_t i = 4 * j + t;
+                                const uint32_t qi = xc + __popc(emask & ((1u << i) - 1u)) - qbase;
+                                if (qi < (uint32_t)kQueue) {
+                                    // bit 10: an alignment start at or before op i inside this lane
+                                    const uint32_t meta = (uint32_t)lane | (i << 6) | (((hmo >> i) & 1u) << 10) |
+                                                          (op << 16);
+                                    queue[qi] = make_uint4(rr, rd, wv[t], meta);
+                                }
+                            }
+                        }
+                        // ops advancing the reference cursor: M(0) D(2) =(7) X(8); the query cursor:
+                        // M(0) I(1) S(4) =(7) X(8)   (SVIM_intra.py:14-29; N,H,P,B: nothing)
+                        const bool valid = SOA ? (op < 16u) : true;
+                        rr += (valid && ((0x185u >> op) & 1u)) ? len : 0u;
+                        rd += (valid && ((0x193u >> op) & 1u)) ? len : 0u;
                     }
                 }
+                if (qbase == 0) {
+                    // ---- wave segmented inclusive scan of (flag, ref, read) (DPP) ----
+                    f = hm != 0 ? 1u : 0u; sr = rr; sd = rd;
+                    uint32_t sc_unused = 0;
+                    { uint32_t& sc = sc_unused; SVX_SEG_SCAN() }
+                    const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
+                                   xd = dpp0<kDppWaveShr1, 0xF>(sd);
+                    // carry-in of this lane; bit 31 of .y... keep a separate flag word instead
+                    const uint32_t in_r = xf ? xr : xr + carry_r;
+                    const uint32_t in_d = xf ? xd : xd + carry_d;
+                    lcarry[lane] = make_uint2(in_r, in_d);
+                }
+                wave_lds_sync();
+                // ---- flush: lane j finishes signature qbase + j ----
+                const uint32_t n_here = (C - qbase) < (uint32_t)kQueue ? (C - qbase) : (uint32_t)kQueue;
+                // lanes up to and including the first lane holding a start still lack the tile carry
+                // (ballot taken with all lanes active)
+                const uint64_t hb = __ballot(hm != 0);
+                const uint32_t first_head_lane = hb ? (uint32_t)__ffsll((unsigned long long)hb) - 1u : 64u;
+                if ((uint32_t)lane < n_here) {
+                    const uint4 e = queue[lane];
+                    const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 15u, own = (e.w >> 10) & 1u;
+                    const uint2 cin = lcarry[L];
+                    const bool prec = !own && !seen && (L <= first_head_lane);
+                    const uint32_t ref = own ? e.x : e.x + cin.x;
+                    const uint32_t rdp = own ? e.y : e.y + cin.y;
+                    uint32_t op, len;
+                    if (SOA) { op = (e.w >> 16) & 0xFFu; len = e.z; }
+                    else { op = e.z & 15u; len = e.z >> 4; }
+                    const uint32_t type = (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
+                    const uint32_t rank = tile_cnt + qbase + lane;
+                    const uint32_t loc = round * kRoundOps + L * kLaneOps + slot;
+                    if (MODE == MODE_STAGE) {
+                        if (rank < (uint32_t)kSlab) {
+                            const uint32_t w0 = loc | (type << 12) | ((prec ? 1u : 0u) << 13);
+                            p.slab[(uint64_t)tile * kSlab + rank] = make_uint4(w0, ref, rdp, len);
+                        }
+                    } else {
+                        const uint32_t aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + loc);
+                        store_final(p, (uint64_t)obase + rank, aln, ref, rdp, len, type);
+                    }
+                }
+                wave_lds_sync();  // queue / lcarry / xp are rewritten by the next pass or round
             }
 
-            // ---- carry to the next round (wave-uniform via lane 63's inclusive values) ----
-            const uint32_t F = __shfl(f, 63), R = __shfl(sr, 63), D = __shfl(sd, 63),
-                           C = __shfl(sc, 63);
+            // ---- carry to the next round (wave-uniform: lane 63's inclusive values) ----
+            const uint32_t F = __builtin_amdgcn_readlane(f, 63), R = __builtin_amdgcn_readlane(sr, 63),
+                           D = __builtin_amdgcn_readlane(sd, 63);
             if (F) { carry_r = R; carry_d = D; seen = true; }
             else { carry_r += R; carry_d += D; }
             tile_cnt += C;
@@ -315,79 +386,94 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_tiles(CigarArgs p) {
     }
 }
 
-// ---- B: segmented exclusive scan over tile descriptors (single workgroup, chunked) ----
-__global__ __launch_bounds__(1024) void k_desc_scan(const uint4* __restrict__ desc, uint32_t n_tiles,
-                                                    uint32_t* __restrict__ out_base,
-                                                    uint32_t* __restrict__ carry_ref,
-                                                    uint32_t* __restrict__ carry_read,
-                                                    uint32_t* __restrict__ dense_list,
-                                                    uint32_t* __restrict__ n_dense,
-                                                    uint64_t* __restrict__ n_out) {
+// ---- B: segmented exclusive scan over tile descriptors ----
+// Each workgroup scans kScanBlock descriptors locally and publishes its aggregate; the LAST
+// workgroup to arrive (ticket counter, agent-scope fences, no spinning) scans the block
+// aggregates into blk_prefix.  Consumers combine local values with blk_prefix[tile / kScanBlock].
+// Per tile: carry_ref/carry_read = cursor sums since the last alignment start inside the scan
+// block (bit 31 of out_base set) or since the block start (bit clear → add the block prefix).
+__global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restrict__ desc, uint32_t n_tiles,
+                                                          uint32_t* __restrict__ out_base,
+                                                          uint32_t* __restrict__ carry_ref,
+                                                          uint32_t* __restrict__ carry_read,
+                                                          uint32_t* __restrict__ dense_list,
+                                                          uint32_t* __restrict__ n_dense,
+                                                          uint4* __restrict__ blk_agg,
+                                                          uint4* __restrict__ blk_prefix,
+                                                          uint32_t* __restrict__ ticket,
+                                                          uint64_t* __restrict__ n_out) {
     __shared__ uint32_t s_f[16], s_r[16], s_d[16], s_c[16];
-    __shared__ uint32_t s_ndense;
+    __shared__ uint32_t s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_ndense = 0;
-    uint32_t cf = 0, cr = 0, cd = 0;  // running carry (uniform)
-    uint64_t cc = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += 1024) {
-        const uint32_t t = base + tid;
-        uint32_t f = 0, r = 0, d = 0, c = 0;
+    const uint32_t n_blocks = gridDim.x;
+    {
+        const uint32_t t = blockIdx.x * kScanBlock + tid;
+        uint32_t f = 0, sr = 0, sd = 0, sc = 0;
         if (t < n_tiles) {
-            uint4 v = desc[t];
-            c = v.x & 0x7FFFFFFFu;
+            const uint4 v = desc[t];
+            sc = v.x & 0x7FFFFFFFu;
             f = v.x >> 31;
-            r = v.y;
-            d = v.z;
-            if (c > (uint32_t)kSlab) dense_list[atomicAdd(&s_ndense, 1u)] = t;
+            sr = v.y;
+            sd = v.z;
+            if (sc > (uint32_t)kSlab) dense_list[atomicAdd(n_dense, 1u)] = t;
         }
-        uint32_t sf = f, sr = r, sd = d, sc = c;
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) {
-            uint32_t f2 = __shfl_up(sf, k), r2 = __shfl_up(sr, k), d2 = __shfl_up(sd, k),
-                     c2 = __shfl_up(sc, k);
-            if (lane >= k) {
-                if (!sf) { sr += r2; sd += d2; }
-                sf |= f2;
-                sc += c2;
-            }
-        }
-        if (lane == 63) { s_f[wave] = sf; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
+        SVX_SEG_SCAN()
+        if (lane == 63) { s_f[wave] = f; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
         __syncthreads();
-        // prefix over preceding waves, seeded with the running carry
+        uint32_t pf = 0, pr_ = 0, pd_ = 0, pc = 0;  // prefix over preceding waves
+        uint32_t af = 0, ar = 0, ad = 0, ac = 0;    // aggregate over all waves
+        for (int w2 = 0; w2 < kScanBlock / 64; ++w2) {
+            if (w2 == wave) { pf = af; pr_ = ar; pd_ = ad; pc = ac; }
+            if (s_f[w2]) { af = 1; ar = s_r[w2]; ad = s_d[w2]; }
+            else { ar += s_r[w2]; ad += s_d[w2]; }
+            ac += s_c[w2];
+        }
+        const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
+                       xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
+        if (t < n_tiles) {
+            carry_ref[t] = xf ? xr : pr_ + xr;
+            carry_read[t] = xf ? xd : pd_ + xd;
+            out_base[t] = (pc + xc) | ((xf | pf) << 31);
+        }
+        if (tid == 0) blk_agg[blockIdx.x] = make_uint4(af, ar, ad, ac);
+    }
+    // ---- last-arriving workgroup scans the block aggregates ----
+    __threadfence();  // release: this block's aggregate is visible device-wide before the ticket
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == n_blocks - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();  // acquire: drop stale lines before reading the other blocks' aggregates
+    uint32_t cf = 0, cr = 0, cd = 0;
+    uint64_t cc = 0;
+    for (uint32_t base = 0; base < n_blocks; base += kScanBlock) {
+        const uint32_t b = base + tid;
+        uint32_t f = 0, sr = 0, sd = 0, sc = 0;
+        if (b < n_blocks) {
+            const uint4 v = blk_agg[b];
+            f = v.x; sr = v.y; sd = v.z; sc = v.w;
+        }
+        SVX_SEG_SCAN()
+        __syncthreads();
+        if (lane == 63) { s_f[wave] = f; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
+        __syncthreads();
         uint32_t pf = cf, pr_ = cr, pd_ = cd;
         uint64_t pc = cc;
-        for (int w2 = 0; w2 < wave; ++w2) {
-            if (s_f[w2]) { pf = 1; pr_ = s_r[w2]; pd_ = s_d[w2]; }
-            else { pr_ += s_r[w2]; pd_ += s_d[w2]; }
-            pc += s_c[w2];
+        uint32_t af = cf, ar = cr, ad = cd;
+        uint64_t ac = cc;
+        for (int w2 = 0; w2 < kScanBlock / 64; ++w2) {
+            if (w2 == wave) { pf = af; pr_ = ar; pd_ = ad; pc = ac; }
+            if (s_f[w2]) { af = 1; ar = s_r[w2]; ad = s_d[w2]; }
+            else { ar += s_r[w2]; ad += s_d[w2]; }
+            ac += s_c[w2];
         }
-        // exclusive within the wave
-        uint32_t xf = __shfl_up(sf, 1), xr = __shfl_up(sr, 1), xd = __shfl_up(sd, 1),
-                 xc = __shfl_up(sc, 1);
-        if (lane == 0) { xf = 0; xr = 0; xd = 0; xc = 0; }
-        uint32_t er = xf ? xr : pr_ + xr;
-        uint32_t ed = xf ? xd : pd_ + xd;
-        if (t < n_tiles) {
-            carry_ref[t] = er;
-            carry_read[t] = ed;
-            out_base[t] = (uint32_t)(pc + xc);
-        }
-        // new running carry = prefix through the last wave
-        uint32_t nf = cf, nr = cr, nd = cd;
-        uint64_t nc = cc;
-        for (int w2 = 0; w2 < 16; ++w2) {
-            if (s_f[w2]) { nf = 1; nr = s_r[w2]; nd = s_d[w2]; }
-            else { nr += s_r[w2]; nd += s_d[w2]; }
-            nc += s_c[w2];
-        }
-        cf = nf; cr = nr; cd = nd; cc = nc;
-        __syncthreads();
+        const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
+                       xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
+        if (b < n_blocks)
+            blk_prefix[b] = make_uint4(xf | pf, xf ? xr : pr_ + xr, xf ? xd : pd_ + xd, (uint32_t)(pc + xc));
+        cf = af; cr = ar; cd = ad; cc = ac;
     }
-    if (tid == 0) {
-        *n_dense = s_ndense;
-        *n_out = cc;
-    }
+    if (tid == 0) *n_out = cc;
 }
 
 // ---- C: gather sparse tiles' staged signatures into the final SoA ----
@@ -398,8 +484,12 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_gather(CigarArgs p) {
         const uint32_t cnt = dsc.x & 0x7FFFFFFFu;
         if (cnt == 0 || cnt > (uint32_t)kSlab) continue;
         const uint32_t a_lo = dsc.w;
-        const uint32_t cr = p.carry_ref[tile], cd = p.carry_read[tile];
-        const uint64_t ob = p.out_base[tile];
+        const uint4 bp = p.blk_prefix[tile / kScanBlock];
+        const uint32_t lb = p.out_base[tile];
+        const bool local_head = (lb >> 31) != 0;
+        const uint32_t cr = p.carry_ref[tile] + (local_head ? 0u : bp.y);
+        const uint32_t cd = p.carry_read[tile] + (local_head ? 0u : bp.z);
+        const uint64_t ob = (uint64_t)(lb & 0x7FFFFFFFu) + bp.w;
         const uint64_t g0 = (uint64_t)tile * kTileOps;
         for (uint32_t r = lane; r < cnt; r += 64) {
             const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
@@ -493,7 +583,8 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t n_tiles = (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
     size_t need = svx_take_bytes(n_tiles, sizeof(uint4)) +
                   svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
-                  4 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t));
+                  4 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
+                  2 * svx_take_bytes((n_tiles + kScanBlock - 1) / kScanBlock, sizeof(uint4));
     int rc = svx_ws_reserve(ctx, need);
     if (rc != SVX_OK) return rc;
 
@@ -513,6 +604,9 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     a.carry_read = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.dense_list = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.n_dense = svx_ws_take<uint32_t>(ctx, 4);
+    const uint32_t n_scan_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
+    a.blk_agg = svx_ws_take<uint4>(ctx, n_scan_blocks);
+    a.blk_prefix = svx_ws_take<uint4>(ctx, n_scan_blocks);
     a.out = d_out;
     a.cap = cap;
 
@@ -520,14 +614,16 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t blocks_cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
+    SVX_HIP(ctx, hipMemsetAsync(a.n_dense, 0, 4 * sizeof(uint32_t), ctx->stream));
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
     hipLaunchKernelGGL((k_cigar_tiles<MODE_STAGE, SOA>), dim3(blocks_all), dim3(64 * kWaves), 0,
                        ctx->stream, a);
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
-    hipLaunchKernelGGL(k_desc_scan, dim3(1), dim3(1024), 0, ctx->stream, a.desc, n_tiles, a.out_base,
-                       a.carry_ref, a.carry_read, a.dense_list, a.n_dense, d_n_out);
+    hipLaunchKernelGGL(k_desc_scan, dim3(n_scan_blocks), dim3(kScanBlock), 0, ctx->stream, a.desc, n_tiles,
+                       a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
+                       a.blk_prefix, a.n_dense + 1, d_n_out);
     hipLaunchKernelGGL(k_cigar_gather, dim3(blocks_all < blocks_cap ? blocks_all : blocks_cap),
                        dim3(64 * kWaves), 0, ctx->stream, a);
     hipLaunchKernelGGL((k_cigar_tiles<MODE_DIRECT, SOA>),
