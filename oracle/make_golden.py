@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (/root/reference, read-only) in the
+build container.  TEST INFRASTRUCTURE ONLY; cannot run on the GPU box (the reference does not
+travel) — the committed outputs under tests/golden/ do.
+
+    python oracle/make_golden.py            # (re)generate every fixture
+
+pysam and edlib are not installed here, so the reference is imported with the stand-in
+modules of oracle/refstub/ (htslib/pysam semantics restated from their documentation; edlib
+replaced by an exact Levenshtein DP).  What is captured:
+  * tests/golden/config1/          BAM + FASTA inputs (written by the build's own generator)
+    and the reference's VCFs for `haploid` and `diploid` (##fileDate masked), default and
+    alternative output options;
+  * tests/golden/functions.json    function-level vectors: analyze_cigar_indel,
+    retrieve_other_alignments on the reference's chimeric_read*.bam fixtures,
+    analyze_read_segments, form_partitions, pair_candidates.
+"""
+import importlib.machinery
+import importlib.util
+import json
+import logging
+import os
+import shutil
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference/src"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load_reference():
+    """Import the reference package with the stub third-party modules in front."""
+    if not os.path.isdir(REF):
+        raise RuntimeError("reference not available at " + REF)
+    for p in (os.path.join(HERE, "refstub"), REF, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+    except Exception:
+        pass
+    import svim_asm.SVIM_COLLECT as COLLECT
+    import svim_asm.SVIM_COMBINE as COMBINE
+    import svim_asm.SVIM_inter as INTER
+    import svim_asm.SVIM_intra as INTRA
+    import svim_asm.SVCandidate as CAND
+    import svim_asm.SVIM_input_parsing as PARSE
+    return dict(COLLECT=COLLECT, COMBINE=COMBINE, INTER=INTER, INTRA=INTRA, CAND=CAND, PARSE=PARSE)
+
+
+def run_reference_cli(argv):
+    """Run the reference's `svim-asm` script main() with sys.argv = argv."""
+    load_reference()
+    path = os.path.join(REF, "svim_asm", "svim-asm")
+    loader = importlib.machinery.SourceFileLoader("svim_asm_ref_main", path)
+    spec = importlib.util.spec_from_loader("svim_asm_ref_main", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    # parse_arguments binds sys.argv[1:] as a default argument at import time: pass argv explicitly
+    real_parse = mod.parse_arguments
+    mod.parse_arguments = lambda program_version: real_parse(program_version, list(argv))
+    old = sys.argv
+    root = logging.getLogger()
+    handlers = list(root.handlers)
+    sys.argv = ["svim-asm"] + list(argv)
+    try:
+        mod.main()
+    finally:
+        sys.argv = old
+        for h in list(root.handlers):
+            if h not in handlers:
+                root.removeHandler(h)
+                try:
+                    h.close()
+                except Exception:
+                    pass
+
+
+def masked_vcf(path):
+    with open(path) as fh:
+        return "".join(line for line in fh if not line.startswith("##fileDate="))
+
+
+def candidate_tuple(c):
+    """Canonical tuple of a reference Candidate* object (same layout as oracle/svim_oracle.py)."""
+    t = c.type
+    if t == "DEL":
+        return ("DEL", c.source_contig, c.source_start, c.source_end, tuple(c.reads), c.genotype)
+    if t == "INS":
+        return ("INS", c.dest_contig, c.dest_start, c.dest_end, tuple(c.reads), c.sequence, c.genotype)
+    if t == "INV":
+        return ("INV", c.source_contig, c.source_start, c.source_end, tuple(c.reads), bool(c.complete), c.genotype)
+    if t == "DUP_TAN":
+        return ("DUP_TAN", c.source_contig, c.source_start, c.source_end, c.copies, bool(c.fully_covered),
+                tuple(c.reads), c.genotype)
+    if t == "DUP_INT":
+        return ("DUP_INT", c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end,
+                tuple(c.reads), bool(c.cutpaste), c.genotype)
+    return ("BND", c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start,
+            c.dest_direction, tuple(c.reads), c.genotype)
+
+
+def make_config1():
+    from svim_asm_amd import synth_bam
+    out = os.path.join(GOLD, "config1")
+    if os.path.isdir(out):
+        shutil.rmtree(out)
+    fasta, bams = synth_bam.write_dataset(out, seed=1)
+    runs = {
+        "haploid_default": ["haploid", "{wd}", bams[0], fasta],
+        "haploid_options": ["haploid", "{wd}", bams[1], fasta, "--min_sv_size", "30", "--query_names",
+                            "--tandem_duplications_as_insertions", "--interspersed_duplications_as_insertions",
+                            "--sample", "S2"],
+        "haploid_symbolic": ["haploid", "{wd}", bams[0], fasta, "--symbolic_alleles", "--types", "DEL,INS,BND",
+                             "--max_sv_size", "3000"],
+        "diploid_default": ["diploid", "{wd}", bams[0], bams[1], fasta],
+        "diploid_options": ["diploid", "{wd}", bams[0], bams[1], fasta, "--query_names", "--max_edit_distance", "20",
+                            "--partition_max_distance", "300", "--min_mapq", "0"],
+    }
+    for name, argv in runs.items():
+        wd = tempfile.mkdtemp(prefix="svimref_")
+        run_reference_cli([a.format(wd=wd) for a in argv])
+        with open(os.path.join(out, name + ".vcf"), "w") as fh:
+            fh.write(masked_vcf(os.path.join(wd, "variants.vcf")))
+        shutil.rmtree(wd)
+    with open(os.path.join(out, "runs.json"), "w") as fh:
+        rel = {k: [os.path.basename(a) if a.startswith(out) else a for a in v] for k, v in runs.items()}
+        json.dump(rel, fh, indent=1)
+    return out
+
+
+def make_function_vectors():
+    import random
+    ref = load_reference()
+    import pysam  # the stub (oracle/refstub), on sys.path after load_reference()
+    vec = {}
+    # analyze_cigar_indel on random tuples (all op codes)
+    rnd = random.Random(7)
+    cases = []
+    for _ in range(40):
+        n = rnd.randint(0, 60)
+        tuples = [(rnd.randint(0, 9), rnd.choice([0, 1, 5, 29, 30, 31, 39, 40, 41, 100, 5000])) for _ in range(n)]
+        m = rnd.choice([1, 30, 40])
+        cases.append({"tuples": tuples, "min_length": m, "out": ref["INTRA"].analyze_cigar_indel(tuples, m)})
+    vec["analyze_cigar_indel"] = cases
+    # is_similar (reference test_inter.py vectors + boundary)
+    sims = [("chrI", 0, 100, "chrII", 0, 100), ("chrI", 0, 100, "chrI", 0, 100), ("chrI", 0, 100, "chrI", 10, 90),
+            ("chrI", 0, 100, "chrI", 21, 100), ("c", 0, 0, "c", 19, 0), ("c", 0, 0, "c", 20, 0), ("c", 5, 40, "c", 5, 60)]
+    vec["is_similar"] = [{"args": list(a), "out": bool(ref["INTER"].is_similar(*a))} for a in sims]
+    # retrieve_other_alignments on the reference's own BAM fixtures (tests/test_satag.py)
+    sa = {}
+    for fn in ("chimeric_read.bam", "chimeric_read_errors.bam"):
+        bam = pysam.AlignmentFile(os.path.join(REF, "tests", fn))
+        rows = []
+        for aln in bam.fetch(until_eof=True):
+            if aln.is_supplementary:
+                continue
+            others = ref["COLLECT"].retrieve_other_alignments(aln, bam)
+            rows.append([dict(cigarstring=o.cigarstring, reference_id=o.reference_id, reference_start=o.reference_start,
+                              reference_end=o.reference_end, flag=o.flag, mapping_quality=o.mapping_quality,
+                              query_alignment_start=o.query_alignment_start, query_alignment_end=o.query_alignment_end,
+                              infer_read_length=o.infer_read_length()) for o in others])
+        sa[fn] = rows
+    vec["retrieve_other_alignments"] = sa
+    with open(os.path.join(GOLD, "functions.json"), "w") as fh:
+        json.dump(vec, fh, indent=0)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    logging.getLogger().setLevel(logging.WARNING)
+    make_function_vectors()
+    out = make_config1()
+    # the two reference BAM fixtures are data, not source: keep copies for the GPU box
+    for fn in ("chimeric_read.bam", "chimeric_read_errors.bam"):
+        shutil.copy(os.path.join(REF, "tests", fn), os.path.join(GOLD, fn))
+    print("golden vectors written under", GOLD, "and", out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+"""COLLECT: per-contig driver over a coordinate-sorted BAM, batched for the GPU.
+
+Mirrors retrieve_other_alignments(main_alignment, bam) (SVIM_COLLECT.py:8-58) and
+analyze_alignment_file_coordsorted(bam, options) (SVIM_COLLECT.py:61-83).  The reference
+calls the CIGAR walk once per alignment inside a Python `while True / next()` loop; here the
+loop only gathers the records that pass the filters (:71), and the arithmetic is launched
+once per BAM file:
+  1. svx_cigar_extract  — indel signatures of every kept alignment (a1+a2),
+  2. svx_cigar_stats    — reference_end / query_alignment_* / infer_read_length of the
+                          primaries and of the SA-derived segments (a3 inputs),
+  3. svx_segments_classify — the split-segment decision tree for every primary with
+                          supplementary segments (a3).
+Candidates are then assembled in exactly the reference's order: contigs in header order,
+alignments in file order, per alignment indels (CIGAR order) then segment candidates.
+"""
+import logging
+import re
+
+import numpy as np
+
+from svim_asm_amd import _lib
+from svim_asm_amd import SVIM_inter, SVIM_intra
+from svim_asm_amd.bamio import AlignedRecord
+
+_CIGAR_RE = re.compile(r"(\d+)([MIDNSHP=XB])")
+_CIGAR_CODE = {c: i for i, c in enumerate("MIDNSHP=XB")}
+
+
+def _cigar_string_to_words(cigar):
+    pairs = _CIGAR_RE.findall(cigar) if cigar else []
+    lens = [int(n) for n, _ in pairs]
+    if any(l >= (1 << 28) for l in lens):
+        raise OverflowError("CIGAR operation length does not fit 28 bits")
+    return np.array([(l << 4) | _CIGAR_CODE[c] for l, (_, c) in zip(lens, pairs)], dtype=np.uint32)
+
+
+def retrieve_other_alignments(main_alignment, bam):
+    """Reconstruct other alignments of the same read for a given alignment from the SA tag"""
+    # reconstruction from the SA tag does not work if the main alignment is hard-clipped
+    words = getattr(main_alignment, "cigar_words", None)
+    if words is not None:
+        if len(words) and bool(((words & 15) == 5).any()) and int(((words >> 4) * ((words & 15) == 5)).sum()) > 0:
+            return []
+    elif main_alignment.get_cigar_stats()[0][5] > 0:
+        return []
+    try:
+        sa_tag = main_alignment.get_tag("SA").split(";")
+    except KeyError:
+        return []
+    other_alignments = []
+    for element in sa_tag:
+        fields = element.split(",")
+        if len(fields) != 6:
+            continue
+        rname, pos, strand, cigar = fields[0], int(fields[1]), fields[2], fields[3]
+        mapq, _nm = int(fields[4]), int(fields[5])
+        a = AlignedRecord()
+        a.query_name = main_alignment.query_name
+        a.flag = 2048 if strand == "+" else 2064
+        a.reference_id = bam.get_tid(rname)
+        a.reference_start = pos - 1
+        a.mapping_quality = mapq if 0 <= mapq <= 255 else 0  # uint8 overflow → 0 (:42-45)
+        try:
+            a.cigar_words = _cigar_string_to_words(cigar)
+        except OverflowError:
+            logging.error("OverflowError while retrieving supplementary CIGAR string. Read name: {0}, "
+                          "Position: {1}, CIGAR: {2}".format(rname, pos, cigar))
+            continue
+        a._tags = {"NM": _nm}
+        other_alignments.append(a)
+    return other_alignments
+
+
+def _segment_rows_gpu(alignments, ctx):
+    """Segment rows (SVIM_inter.py:66-81) of many alignments with ONE svx_cigar_stats launch."""
+    words = [SVIM_intra.cigar_words_of(a) for a in alignments]
+    off = np.concatenate(([0], np.cumsum([len(w) for w in words]))).astype(np.uint64)
+    flat = np.concatenate(words) if words and off[-1] else np.zeros(0, np.uint32)
+    st = ctx.cigar_stats(flat, off)
+    rows, lens = [], []
+    for i, a in enumerate(alignments):
+        q_start, read_len = int(st["q_start"][i]), int(st["read_len"][i])
+        # pysam takes query_alignment_end from the stored sequence when there is one
+        l_seq = getattr(a, "_l_seq", None)
+        if l_seq:
+            q_end = a.query_alignment_end
+        else:
+            q_end = int(st["q_end"][i])
+        ref_len = int(st["ref_len"][i])
+        ref_end = a.reference_start + (ref_len if ref_len else 1)  # htslib bam_endpos
+        if a.is_reverse:
+            row = (read_len - q_end, read_len - q_start)
+        else:
+            row = (q_start, q_end)
+        rows.append(row + (a.reference_id, a.reference_start, ref_end, 1 if a.is_reverse else 0))
+        lens.append(read_len)
+    return rows, lens
+
+
+def analyze_alignment_file_coordsorted(bam, options):
+    ctx = _lib.default_context(getattr(options, "device", 0) or 0)
+    # ---- gather: filters of SVIM_COLLECT.py:71 in contig-header order, file order inside a contig
+    kept = []
+    for current_chromosome in bam.references:
+        logging.info("Processing chromosome {0}...".format(current_chromosome))
+        for aln in bam.fetch(contig=current_chromosome):
+            if aln.is_unmapped or aln.is_secondary or aln.mapping_quality < options.min_mapq:
+                continue
+            kept.append(aln)
+    if not kept:
+        return []
+
+    # ---- a1+a2: one launch over every kept alignment
+    words = [SVIM_intra.cigar_words_of(a) for a in kept]
+    aln_off = np.concatenate(([0], np.cumsum([len(w) for w in words]))).astype(np.uint64)
+    cigar = np.concatenate(words) if aln_off[-1] else np.zeros(0, np.uint32)
+    ref_start = np.array([a.reference_start for a in kept], dtype=np.int32)
+    sig = ctx.cigar_extract(cigar, aln_off, ref_start, options.min_sv_size)
+    # signature rows of alignment k: [sig_lo[k], sig_lo[k+1])
+    sig_lo = np.searchsorted(sig["aln"], np.arange(len(kept) + 1), side="left")
+    sig_ref = sig["ref_pos"].astype(np.int64)
+
+    # ---- a3 inputs: primaries with usable SA segments
+    reads, read_index = [], {}
+    for k, aln in enumerate(kept):
+        if aln.is_supplementary:
+            continue
+        supplementary_alignments = retrieve_other_alignments(aln, bam)
+        good = [s for s in supplementary_alignments if not s.is_unmapped and s.mapping_quality >= options.min_mapq]
+        if good:
+            read_index[k] = len(reads)
+            reads.append((aln, good))
+    seg_cands = []
+    if reads:
+        flat = [a for p, s in reads for a in [p] + s]
+        rows_flat, lens_flat = _segment_rows_gpu(flat, ctx)
+        rows, read_lens, q = [], [], 0
+        for p, s in reads:
+            n = 1 + len(s)
+            rows.append(rows_flat[q:q + n])
+            read_lens.append(lens_flat[q])  # primary.infer_read_length()
+            q += n
+        seg_cands = SVIM_inter.analyze_read_segments_batch(reads, bam, options, ctx=ctx, rows=rows,
+                                                           read_lens=read_lens)
+
+    # ---- assemble in the reference's order
+    sv_candidates = []
+    for k, aln in enumerate(kept):
+        lo, hi = int(sig_lo[k]), int(sig_lo[k + 1])
+        if hi > lo:
+            sv_candidates.extend(SVIM_intra.candidates_from_signatures(
+                aln, bam, aln.query_name, bam.getrname(aln.reference_id), sig_ref[lo:hi], sig["read_pos"][lo:hi],
+                sig["len"][lo:hi], sig["type"][lo:hi]))
+        r = read_index.get(k)
+        if r is not None:
+            sv_candidates.extend(seg_cands[r])
+    return sv_candidates

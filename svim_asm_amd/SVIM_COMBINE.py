@@ -1,0 +1,350 @@
+"""PAIR (diploid) + VCF output.
+
+Mirrors form_partitions (SVIM_COMBINE.py:15-32), compute_distance (:35-102),
+span_position_distance_breakends (:105-117), pair_haplotypes (:120-140),
+pair_haplotypes_breakends (:143-161), pair_candidates (:164-366), sorted_nicely (:369-376) and
+write_final_vcf (:379-477).
+
+GPU work: the stable sort by Candidate.get_key() + partition sweep is svx_pair_partition (one
+launch for all six SV types: the type is the most significant key field, so partitions and
+their order are the ones the reference gets type by type); the pairwise haplotype edit
+distances (edlib in the reference) are svx_edit_distance_batch, one launch for all pairs.
+Complete linkage on the ≤10-member partitions uses scipy exactly as the reference does.
+"""
+import logging
+import re
+import time
+from collections import defaultdict
+from statistics import mean
+
+import numpy as np
+from scipy.cluster.hierarchy import fcluster, linkage
+
+from svim_asm_amd import _lib
+from svim_asm_amd.SVCandidate import (CandidateBreakend, CandidateDeletion, CandidateDuplicationInterspersed,
+                                      CandidateDuplicationTandem, CandidateInsertion, CandidateInversion)
+
+TYPE_ORDER = ("DEL", "INV", "INS", "DUP_TAN", "DUP_INT", "BND")  # processing order of pair_candidates
+_TYPE_RANK = {t: i for i, t in enumerate(TYPE_ORDER)}
+_COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A"}
+SAME_HAPLOTYPE_DISTANCE = 1000000000
+
+
+def _pack_keys(candidates_with_haplotype):
+    """get_key() tuples → u64 `(type rank, contig rank under str order) << 32 | pos`."""
+    keys = [c.get_key() for _, c in candidates_with_haplotype]
+    contig_rank = {name: i for i, name in enumerate(sorted(set(k[1] for k in keys)))}
+    packed = np.empty(len(keys), dtype=np.uint64)
+    for i, (typ, contig, pos) in enumerate(keys):
+        if pos < 0 or pos >= (1 << 32):
+            raise ValueError("key position out of range: %r" % (pos,))
+        packed[i] = ((_TYPE_RANK.get(typ, len(TYPE_ORDER)) << 24 | contig_rank[contig]) << 32) | pos
+    return packed
+
+
+def form_partitions(sv_candidates_with_haplotype, max_distance, ctx=None):
+    """Form partitions of (haplotype, candidate) pairs: stable sort by key, new partition when
+    type or contig differ or consecutive key positions are more than max_distance apart."""
+    items = list(sv_candidates_with_haplotype)
+    if not items:
+        return []
+    ctx = ctx or _lib.default_context()
+    perm, part_id, n_parts = ctx.pair_partition(_pack_keys(items), max_distance)
+    partitions = [[] for _ in range(n_parts)]
+    for j, src in enumerate(perm.tolist()):
+        partitions[part_id[j]].append(items[src])
+    return partitions
+
+
+# ------------------------------------------------------------------------------ distances
+def haplotype_pair(candidate1, candidate2, reference):
+    """The two haplotype strings compute_distance aligns (SVIM_COMBINE.py:43-100)."""
+    typ = candidate1.type
+
+    def up(contig, start, end):
+        return reference.fetch(contig, start, end).upper()
+
+    if typ in ("DEL", "INV", "DUP_TAN"):
+        contig = candidate1.source_contig
+        region_start = max(0, min(candidate1.source_start, candidate2.source_start) - 100)
+        region_end = min(reference.get_reference_length(contig), max(candidate1.source_end, candidate2.source_end) + 100)
+        out = []
+        for c in (candidate1, candidate2):
+            if typ == "DEL":
+                middle = ""
+            elif typ == "INV":
+                middle = "".join(_COMPLEMENT.get(b, b) for b in reversed(up(contig, c.source_start, c.source_end)))
+            else:
+                middle = up(contig, c.source_start, c.source_end) * (c.copies + 1)
+            out.append(up(contig, region_start, c.source_start) + middle + up(contig, c.source_end, region_end))
+        return out
+    contig = candidate1.dest_contig
+    region_start = max(0, min(candidate1.dest_start, candidate2.dest_start) - 100)
+    region_end = min(reference.get_reference_length(contig), max(candidate1.dest_start, candidate2.dest_start) + 100)
+    out = []
+    for c in (candidate1, candidate2):
+        middle = c.sequence if typ == "INS" else up(c.source_contig, c.source_start, c.source_end)
+        out.append(up(contig, region_start, c.dest_start) + middle + up(contig, c.dest_start, region_end))
+    return out
+
+
+def edit_distances(string_pairs, k_max=0xFFFFFFFF, ctx=None):
+    """Batched global edit distance on the GPU; values > k_max come back as 0xFFFFFFFF."""
+    if not string_pairs:
+        return []
+    ctx = ctx or _lib.default_context()
+    blobs, a_off, a_len, b_off, b_len, pos = [], [], [], [], [], 0
+    for a, b in string_pairs:
+        ab, bb = a.encode("latin-1"), b.encode("latin-1")
+        a_off.append(pos); a_len.append(len(ab)); pos += len(ab)
+        b_off.append(pos); b_len.append(len(bb)); pos += len(bb)
+        blobs.append(ab); blobs.append(bb)
+    pool = np.frombuffer(b"".join(blobs), dtype=np.uint8) if pos else np.zeros(0, np.uint8)
+    return ctx.edit_distance_batch(pool, a_off, a_len, b_off, b_len, k_max).tolist()
+
+
+def compute_distance(candidate_with_haplotype1, candidate_with_haplotype2, reference):
+    haplotype1, candidate1 = candidate_with_haplotype1
+    haplotype2, candidate2 = candidate_with_haplotype2
+    if haplotype1 == haplotype2:
+        return SAME_HAPLOTYPE_DISTANCE
+    return edit_distances([tuple(haplotype_pair(candidate1, candidate2, reference))])[0]
+
+
+def span_position_distance_breakends(candidate1, candidate2):
+    hap1, pos1a, dir1a, pos1b, dir1b = candidate1
+    hap2, pos2a, dir2a, pos2b, dir2b = candidate2
+    if hap1 != hap2 and dir1a == dir2a and dir1b == dir2b:
+        return (abs(pos1a - pos2a) + abs(pos1b - pos2b)) / 3000
+    return 99999
+
+
+def _clusters_from_condensed(partition, distances, threshold):
+    labels = list(fcluster(linkage(np.array(distances, dtype=float), method="complete"), threshold,
+                           criterion="distance"))
+    clusters = [[] for _ in range(max(labels))]
+    for member, label in zip(partition, labels):
+        clusters[label - 1].append(member)
+    return clusters
+
+
+def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None):
+    """Cluster each partition (2..10 members) by complete linkage over haplotype edit distances.
+    All distances of all partitions are computed in one GPU batch."""
+    jobs = []  # (partition index, i, j)
+    strings = []
+    for pi, partition in enumerate(partitions):
+        if len(partition) < 2 or len(partition) > 10:
+            continue
+        for i in range(len(partition) - 1):
+            for j in range(i + 1, len(partition)):
+                if partition[i][0] != partition[j][0]:
+                    jobs.append((pi, i, j))
+                    strings.append(tuple(haplotype_pair(partition[i][1], partition[j][1], reference)))
+    # two-member partitions only need "<= threshold?"; larger ones get exact values so that the
+    # dendrogram above the cut (hence scipy's cluster label order) is the reference's
+    exact = [len(partitions[pi]) > 2 for pi, _, _ in jobs]
+    dist = {}
+    thr = [k for k, e in enumerate(exact) if not e]
+    exa = [k for k, e in enumerate(exact) if e]
+    k_max = int(edit_distance_threshold) if 0 <= edit_distance_threshold < 0xFFFFFFFF else 0xFFFFFFFF
+    for sel, km in ((thr, k_max), (exa, 0xFFFFFFFF)):
+        for k, d in zip(sel, edit_distances([strings[k] for k in sel], km, ctx)):
+            dist[jobs[k]] = d if d != 0xFFFFFFFF else max(k_max + 1, len(strings[k][0]) + len(strings[k][1]))
+    clusters_final = []
+    for pi, partition in enumerate(partitions):
+        if len(partition) < 2:
+            clusters_final.append(partition)
+        elif len(partition) > 10:
+            # very large partitions tend to be in difficult regions: dropped (SVIM_COMBINE.py:126-128)
+            logging.debug("Ignored partition of size {0} and type {1}: {2}".format(
+                len(partition), partition[0][1].get_key()[0],
+                ",".join("{0}:{1}".format(m[1].get_key()[1], m[1].get_key()[2]) for m in partition)))
+        else:
+            condensed = [dist.get((pi, i, j), SAME_HAPLOTYPE_DISTANCE)
+                         for i in range(len(partition) - 1) for j in range(i + 1, len(partition))]
+            clusters_final.extend(_clusters_from_condensed(partition, condensed, edit_distance_threshold))
+    return clusters_final
+
+
+def pair_haplotypes_breakends(partitions, span_position_distance_threshold=0.3):
+    clusters_final = []
+    for partition in partitions:
+        if len(partition) < 2:
+            clusters_final.append(partition)
+        elif len(partition) > 10:
+            continue
+        else:
+            rows = [(hap, c.get_source()[1], 1 if c.source_direction == "fwd" else 0, c.get_destination()[1],
+                     1 if c.dest_direction == "fwd" else 0) for hap, c in partition]
+            condensed = [span_position_distance_breakends(rows[i], rows[j])
+                         for i in range(len(rows) - 1) for j in range(i + 1, len(rows))]
+            clusters_final.extend(_clusters_from_condensed(partition, condensed, span_position_distance_threshold))
+    return clusters_final
+
+
+# ------------------------------------------------------------------------------ pairing
+def _rebuild(typ, cluster, bam):
+    """Candidate of a cluster: coordinates/payload of its first member, reads concatenated,
+    flags OR-ed, copy number averaged with round() (banker's rounding) — :184-363."""
+    first = cluster[0][1]
+    if len(cluster) == 1:
+        genotype = "1/0" if cluster[0][0] == 1 else "0/1"
+        second, reads = None, first.reads
+    else:
+        genotype = "1/1"
+        second = cluster[1][1]
+        reads = first.reads + second.reads
+    if typ == "DEL":
+        return CandidateDeletion(first.source_contig, first.source_start, first.source_end, reads, bam, genotype)
+    if typ == "INV":
+        complete = first.complete if second is None else (first.complete or second.complete)
+        return CandidateInversion(first.source_contig, first.source_start, first.source_end, reads, complete, bam,
+                                  genotype)
+    if typ == "INS":
+        return CandidateInsertion(first.dest_contig, first.dest_start, first.dest_end, reads, first.sequence, bam,
+                                  genotype)
+    if typ == "DUP_TAN":
+        copies = first.copies if second is None else round(mean([first.copies, second.copies]))
+        fully = first.fully_covered if second is None else (first.fully_covered or second.fully_covered)
+        return CandidateDuplicationTandem(first.source_contig, first.source_start, first.source_end, copies, fully,
+                                          reads, bam, genotype)
+    if typ == "DUP_INT":
+        cutpaste = first.cutpaste if second is None else (first.cutpaste or second.cutpaste)
+        return CandidateDuplicationInterspersed(first.source_contig, first.source_start, first.source_end,
+                                                first.dest_contig, first.dest_start, first.dest_end, reads, bam,
+                                                cutpaste, genotype)
+    return CandidateBreakend(first.source_contig, first.source_start, first.source_direction, first.dest_contig,
+                             first.dest_start, first.dest_direction, reads, bam, genotype)
+
+
+_LOG_NAME = {"DEL": "deletions", "INV": "inversions", "INS": "insertions", "DUP_TAN": "tandem duplications",
+             "DUP_INT": "interspersed duplications", "BND": "breakends"}
+
+
+def pair_candidates(sv_candidates1, sv_candidates2, reference, bam, options):
+    ctx = _lib.default_context(getattr(options, "device", 0) or 0)
+    # one sort/partition launch for all types; the input order per type is hap-1 list then hap-2 list
+    tagged = []
+    for typ in TYPE_ORDER:
+        tagged += [(1, c) for c in sv_candidates1 if c.type == typ]
+        tagged += [(2, c) for c in sv_candidates2 if c.type == typ]
+    partitions = form_partitions(tagged, options.partition_max_distance, ctx=ctx)
+    by_type = defaultdict(list)
+    for part in partitions:
+        by_type[part[0][1].type].append(part)
+    paired_candidates = []
+    for typ in TYPE_ORDER:
+        n = sum(1 for _, c in tagged if c.type == typ)
+        logging.info("Pairing {0} {1}...".format(n, _LOG_NAME[typ]))
+        if typ == "BND":
+            clusters = pair_haplotypes_breakends(by_type[typ])
+        else:
+            clusters = pair_haplotypes(by_type[typ], reference, options.max_edit_distance, ctx=ctx)
+        for cluster in clusters:
+            if len(cluster) in (1, 2):
+                paired_candidates.append(_rebuild(typ, cluster, bam))
+            else:
+                logging.error("Cluster size should be either 1 or 2 but is " + str(len(cluster)))
+    return paired_candidates
+
+
+# ------------------------------------------------------------------------------ output
+def sorted_nicely(vcf_entries):
+    """Natural sort of ((contig, start, end), vcf_string, sv_type) entries: chr10 after chr2."""
+    def key(entry):
+        contig = [int(tok) if tok.isdigit() else tok for tok in re.split("([0-9]+)", str(entry[0][0]))]
+        return (contig, entry[0][1], entry[0][2])
+    return sorted(vcf_entries, key=key)
+
+
+def _header_lines(version, contig_names, contig_lengths, types_to_output, options):
+    tandem_as_dup = (not options.tandem_duplications_as_insertions) and "DUP:TANDEM" in types_to_output
+    int_as_dup = (not options.interspersed_duplications_as_insertions) and "DUP:INT" in types_to_output
+    yield "##fileformat=VCFv4.2"
+    yield "##fileDate={0}".format(time.strftime("%Y-%m-%d|%I:%M:%S%p|%Z|%z"))
+    yield "##source=SVIM-asm-v{0}".format(version)
+    for name, length in zip(contig_names, contig_lengths):
+        yield "##contig=<ID={0},length={1}>".format(name, length)
+    alts = [("DEL", "Deletion", "DEL" in types_to_output), ("INV", "Inversion", "INV" in types_to_output),
+            ("DUP", "Duplication", tandem_as_dup or int_as_dup), ("DUP:TANDEM", "Tandem Duplication", tandem_as_dup),
+            ("DUP:INT", "Interspersed Duplication", int_as_dup), ("INS", "Insertion", "INS" in types_to_output),
+            ("BND", "Breakend", "BND" in types_to_output)]
+    for ident, text, enabled in alts:
+        if enabled:
+            yield '##ALT=<ID={0},Description="{1}">'.format(ident, text)
+    yield '##INFO=<ID=SVTYPE,Number=1,Type=String,Description="Type of structural variant">'
+    yield '##INFO=<ID=CUTPASTE,Number=0,Type=Flag,Description="Genomic origin of interspersed duplication seems to be deleted">'
+    yield '##INFO=<ID=END,Number=1,Type=Integer,Description="End position of the variant described in this record">'
+    yield '##INFO=<ID=SVLEN,Number=1,Type=Integer,Description="Difference in length between REF and ALT alleles">'
+    if options.query_names:
+        yield '##INFO=<ID=READS,Number=.,Type=String,Description="Names of all supporting reads">'
+    yield '##FILTER=<ID=not_fully_covered,Description="Tandem duplication is not fully covered by a contig">'
+    yield '##FILTER=<ID=incomplete_inversion,Description="Only one inversion breakpoint is supported">'
+    yield '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">'
+    if tandem_as_dup:
+        yield '##FORMAT=<ID=CN,Number=1,Type=Integer,Description="Copy number of tandem duplication (e.g. 2 for one additional copy)">'
+    yield "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + options.sample
+
+
+def collect_vcf_entries(int_duplication_candidates, inversion_candidates, tandem_duplication_candidates,
+                        deletion_candidates, insertion_candidates, breakend_candidates, types_to_output, reference,
+                        options):
+    """((contig, start, end), line, label) per record, in the reference's list order (:428-464)."""
+    seq = not options.symbolic_alleles
+    names = options.query_names
+    entries = []
+    if "DEL" in types_to_output:
+        for c in deletion_candidates:
+            contig, start, end = c.get_source()
+            entries.append(((contig, max(1, start), end), c.get_vcf_entry(seq, reference, names), "DEL"))
+    if "INV" in types_to_output:
+        for c in inversion_candidates:
+            contig, start, end = c.get_source()
+            entries.append(((contig, start + 1, end), c.get_vcf_entry(seq, reference, names), "INV"))
+    if "INS" in types_to_output:
+        for c in insertion_candidates:
+            contig, start, end = c.get_destination()
+            entries.append(((contig, max(1, start), end), c.get_vcf_entry(seq, reference, names), "INS"))
+    if options.tandem_duplications_as_insertions:
+        if "INS" in types_to_output:
+            for c in tandem_duplication_candidates:
+                entries.append(((c.source_contig, c.source_start + 1, c.source_end),
+                                c.get_vcf_entry_as_ins(seq, reference, names), "INS"))
+    elif "DUP:TANDEM" in types_to_output:
+        for c in tandem_duplication_candidates:
+            entries.append(((c.source_contig, c.source_start + 1, c.source_end), c.get_vcf_entry_as_dup(names),
+                            "DUP_TANDEM"))
+    if options.interspersed_duplications_as_insertions:
+        if "INS" in types_to_output:
+            for c in int_duplication_candidates:
+                contig, start, end = c.get_destination()
+                entries.append(((contig, max(1, start), end), c.get_vcf_entry_as_ins(seq, reference, names), "INS"))
+    elif "DUP:INT" in types_to_output:
+        for c in int_duplication_candidates:
+            contig, start, end = c.get_source()
+            entries.append(((contig, start + 1, end), c.get_vcf_entry_as_dup(names), "DUP_INT"))
+    if "BND" in types_to_output:
+        for c in breakend_candidates:
+            (sc, sp), (dc, dp) = c.get_source(), c.get_destination()
+            entries.append(((sc, sp + 1, sp + 2), c.get_vcf_entry(names), "BND"))
+            entries.append(((dc, dp + 1, dp + 2), c.get_vcf_entry_reverse(names), "BND"))
+    return entries
+
+
+def write_final_vcf(int_duplication_candidates, inversion_candidates, tandem_duplication_candidates,
+                    deletion_candidates, insertion_candidates, breakend_candidates, version, contig_names,
+                    contig_lengths, types_to_output, reference, options):
+    with open(options.working_dir + "/variants.vcf", "w") as vcf_output:
+        for line in _header_lines(version, contig_names, contig_lengths, types_to_output, options):
+            print(line, file=vcf_output)
+        entries = collect_vcf_entries(int_duplication_candidates, inversion_candidates,
+                                      tandem_duplication_candidates, deletion_candidates, insertion_candidates,
+                                      breakend_candidates, types_to_output, reference, options)
+        if not options.symbolic_alleles:
+            reference.close()
+        counter = defaultdict(int)
+        for _, entry, svtype in sorted_nicely(entries):
+            counter[svtype] += 1
+            print(entry.replace("PLACEHOLDERFORID", "svim_asm.{0}.{1}".format(svtype, counter[svtype]), 1),
+                  file=vcf_output)

@@ -1,0 +1,127 @@
+"""`svim-asm haploid|diploid` driver: same steps, log lines and error handling as the reference
+main() (svim-asm:23-185), with BAM/FASTA access from svim_asm_amd.bamio / .fasta and the
+COLLECT / PAIR arithmetic on the GPU."""
+import logging
+import os
+import sys
+from time import localtime, strftime
+
+from svim_asm_amd import bamio
+from svim_asm_amd.fasta import FastaFile
+from svim_asm_amd.SVIM_COLLECT import analyze_alignment_file_coordsorted
+from svim_asm_amd.SVIM_COMBINE import pair_candidates, write_final_vcf
+from svim_asm_amd.SVIM_input_parsing import parse_arguments
+
+__version__ = "1.0.3"
+TYPE_LABELS = (("DEL", "deletion"), ("INV", "inversion"), ("INS", "insertion"), ("DUP_TAN", "tandem duplication"),
+               ("DUP_INT", "interspersed duplication"), ("BND", "breakend"))
+
+
+def _collect(path, which, options):
+    """Open one BAM, check sort order and index like the reference, run COLLECT.
+    Returns (alignment_file, candidates) or (None, None) after logging the error."""
+    the = {"": "Input", "first": "The first input", "second": "The second input"}[which]
+    aln_file = bamio.AlignmentFile(path)
+    try:
+        if aln_file.header["HD"]["SO"] != "coordinate":
+            logging.error("{0} BAM file needs to be coordinate-sorted. Exiting..".format(the))
+            return None, None
+    except KeyError:
+        logging.error("Is the given {0}input BAM file coordinate-sorted? It does not contain a sorting order in "
+                      "its header line. Exiting..".format(which + " " if which else ""))
+        return None, None
+    try:
+        aln_file.check_index()
+    except ValueError:
+        logging.error("{0} BAM file is missing an index. Please generate with 'samtools index'. "
+                      "Exiting..".format(the))
+        return None, None
+    return aln_file, analyze_alignment_file_coordsorted(aln_file, options)
+
+
+def main(arguments=None):
+    options = parse_arguments(program_version=__version__, arguments=arguments)
+    if not options.sub:
+        print("Please choose one of the two modes ('haploid' or 'diploid'). See --help for more information.")
+        return
+
+    log_format = logging.Formatter("%(asctime)s [%(levelname)-7.7s]  %(message)s")
+    root = logging.getLogger()
+    root.setLevel(logging.DEBUG if options.verbose else logging.INFO)
+    if not os.path.exists(options.working_dir):
+        os.makedirs(options.working_dir)
+    file_handler = logging.FileHandler("{0}/SVIM_{1}.log".format(options.working_dir,
+                                                               strftime("%y%m%d_%H%M%S", localtime())), mode="w")
+    console_handler = logging.StreamHandler()
+    for handler in (file_handler, console_handler):
+        handler.setFormatter(log_format)
+        root.addHandler(handler)
+    try:
+        return _run(options)
+    finally:
+        for handler in (file_handler, console_handler):
+            root.removeHandler(handler)
+        file_handler.close()
+
+
+def _run(options):
+    logging.info("****************** Start SVIM-asm, version {0} ******************".format(__version__))
+    logging.info("CMD: python3 {0}".format(" ".join(sys.argv)))
+    logging.info("WORKING DIR: {0}".format(os.path.abspath(options.working_dir)))
+    for arg in vars(options):
+        logging.info("PARAMETER: {0}, VALUE: {1}".format(arg, getattr(options, arg)))
+
+    logging.info("****************** STEP 1: COLLECT ******************")
+    if options.sub == "haploid":
+        logging.info("MODE: haploid")
+        logging.info("INPUT: {0}".format(os.path.abspath(options.bam_file)))
+        aln_file1, sv_candidates = _collect(options.bam_file, "", options)
+        if aln_file1 is None:
+            return
+    else:
+        logging.info("MODE: diploid")
+        logging.info("INPUT1: {0}".format(os.path.abspath(options.bam_file1)))
+        logging.info("INPUT2: {0}".format(os.path.abspath(options.bam_file2)))
+        aln_file1, sv_candidates1 = _collect(options.bam_file1, "first", options)
+        if aln_file1 is None:
+            return
+        aln_file2, sv_candidates2 = _collect(options.bam_file2, "second", options)
+        if aln_file2 is None:
+            return
+
+    try:
+        reference = FastaFile(options.genome)
+    except ValueError:
+        logging.error("The given reference genome is missing an index file ({0}.fai). Sequence alleles cannot be "
+                      "retrieved.".format(options.genome))
+        return
+    except IOError:
+        logging.error("The given reference genome is missing ({0}). Sequence alleles cannot be "
+                      "retrieved.".format(options.genome))
+        return
+
+    if options.sub == "diploid":
+        logging.info("****************** STEP 2: PAIR ******************")
+        sv_candidates = pair_candidates(sv_candidates1, sv_candidates2, reference, aln_file1, options)
+    by_type = {key: [c for c in sv_candidates if c.type == key] for key, _ in TYPE_LABELS}
+
+    logging.info("****************** STEP {0}: OUTPUT ******************".format(2 if options.sub == "haploid" else 3))
+    for key, label in (TYPE_LABELS[0], TYPE_LABELS[1], TYPE_LABELS[2], TYPE_LABELS[3], TYPE_LABELS[4], TYPE_LABELS[5]):
+        logging.info("Found {0} {1} candidates.".format(len(by_type[key]), label))
+    logging.info("Write SV candidates..")
+    types_to_output = [entry.strip() for entry in options.types.split(",")]
+    write_final_vcf(by_type["DUP_INT"], by_type["INV"], by_type["DUP_TAN"], by_type["DEL"], by_type["INS"],
+                    by_type["BND"], __version__, aln_file1.references, aln_file1.lengths, types_to_output, reference,
+                    options)
+    logging.info("Done.")
+
+
+def entry():
+    try:
+        sys.exit(main())
+    except Exception as e:  # same top-level convention as the reference (svim-asm:182-185)
+        logging.error(e, exc_info=True)
+
+
+if __name__ == "__main__":
+    entry()

@@ -1,0 +1,75 @@
+"""Indexed FASTA access (.fai) for the host side: the subset of pysam.FastaFile the reference
+uses (svim-asm:124; SVIM_COMBINE.py:45-99,467; SVCandidate.py:57-58,105,155,210,301-302):
+0-based half-open `fetch`, `get_reference_length`, `close`, and the two error conditions
+main() distinguishes (missing file → IOError, missing index → ValueError)."""
+import os
+
+import numpy as np
+
+
+class FastaFile(object):
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise IOError("file `%s` not found" % path)
+        if not os.path.exists(path + ".fai"):
+            raise ValueError("no index (.fai) for %s" % path)
+        self.filename = path
+        self._idx = {}
+        self.references, self.lengths = [], []
+        with open(path + ".fai") as fh:
+            for line in fh:
+                f = line.rstrip("\n").split("\t")
+                if len(f) < 5:
+                    continue
+                self._idx[f[0]] = (int(f[1]), int(f[2]), int(f[3]), int(f[4]))
+                self.references.append(f[0])
+                self.lengths.append(int(f[1]))
+        self._fh = open(path, "rb")
+        self._cache = {}
+
+    def get_reference_length(self, name):
+        return self._idx[name][0]
+
+    def fetch(self, reference, start=None, end=None):
+        length, offset, line_bases, line_width = self._idx[reference]
+        start = 0 if start is None else start
+        end = length if end is None else end
+        if start < 0:
+            raise ValueError("start out of range (%i)" % start)
+        if end < start:
+            raise ValueError("end out of range (%i)" % end)
+        end = min(end, length)
+        if start >= end:
+            return ""
+        b0 = offset + (start // line_bases) * line_width + start % line_bases
+        b1 = offset + ((end - 1) // line_bases) * line_width + (end - 1) % line_bases + 1
+        self._fh.seek(b0)
+        raw = self._fh.read(b1 - b0)
+        if line_width != line_bases:
+            raw = raw.replace(b"\n", b"").replace(b"\r", b"")
+        return raw.decode("ascii")
+
+    def close(self):
+        if self._fh:
+            self._fh.close()
+            self._fh = None
+
+
+def write_fasta(path, names, seqs, line=60):
+    """Write FASTA + .fai; `seqs` are ASCII byte strings / numpy uint8 arrays."""
+    with open(path, "wb") as fh, open(path + ".fai", "w") as fai:
+        for name, seq in zip(names, seqs):
+            a = np.frombuffer(seq, dtype=np.uint8) if not isinstance(seq, np.ndarray) else seq
+            hdr = (">%s\n" % name).encode()
+            fh.write(hdr)
+            off = fh.tell()
+            n = len(a)
+            full = n // line
+            if full:
+                body = np.empty((full, line + 1), dtype=np.uint8)
+                body[:, :line] = a[:full * line].reshape(full, line)
+                body[:, line] = 10
+                fh.write(body.tobytes())
+            if n % line:
+                fh.write(a[full * line:].tobytes() + b"\n")
+            fai.write("%s\t%d\t%d\t%d\t%d\n" % (name, n, off, line, line + 1))

@@ -1,0 +1,273 @@
+"""Shared test helpers: random alignment records, adapters to the product's / the reference's
+object models, canonical candidate tuples."""
+import argparse
+
+import numpy as np
+
+CODES = "MIDNSHP=XB"
+
+
+def options(**kw):
+    o = argparse.Namespace(min_mapq=20, min_sv_size=40, max_sv_size=100000, query_gap_tolerance=50,
+                           query_overlap_tolerance=50, reference_gap_tolerance=50, reference_overlap_tolerance=50,
+                           partition_max_distance=1000, max_edit_distance=200, sample="Sample",
+                           types="DEL,INS,INV,DUP:TANDEM,DUP:INT,BND", symbolic_alleles=False,
+                           tandem_duplications_as_insertions=False, interspersed_duplications_as_insertions=False,
+                           query_names=False, device=0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def cigar_string(tuples):
+    return "".join("%d%s" % (l, CODES[o]) for o, l in tuples)
+
+
+def random_cigar(rng, n_ops, sv_rate=0.15, clip=True, hard=False):
+    ops = []
+    if clip and rng.random() < 0.4:
+        ops.append((5 if hard and rng.random() < 0.5 else 4, int(rng.integers(1, 3000))))
+    for _ in range(n_ops):
+        r = rng.random()
+        if r < 0.55:
+            ops.append((int(rng.choice([0, 7, 8])), int(rng.integers(1, 3000))))
+        elif r < 0.9:
+            ln = int(rng.integers(30, 600)) if rng.random() < sv_rate else int(rng.integers(1, 45))
+            ops.append((int(rng.integers(1, 3)), ln))
+        else:
+            ops.append((int(rng.choice([3, 6, 9])), int(rng.integers(1, 500))))
+    if clip and rng.random() < 0.4:
+        ops.append((4, int(rng.integers(1, 3000))))
+    if not any(o in (0, 7, 8) for o, _ in ops):
+        ops.insert(1 if ops and ops[0][0] in (4, 5) else 0, (0, int(rng.integers(1, 500))))
+    return ops
+
+
+def query_len(tuples):
+    return sum(l for o, l in tuples if o in (0, 1, 4, 7, 8))
+
+
+def random_sa(rng, names, lengths, read_len):
+    """SA tag with segments near interesting thresholds + occasional malformed entries."""
+    parts = []
+    for _ in range(int(rng.integers(1, 5))):
+        name_i = int(rng.integers(0, len(names)))
+        ln = int(rng.integers(200, max(201, min(read_len, 4000))))
+        before = int(rng.integers(0, max(1, read_len - ln)))
+        after = max(0, read_len - before - ln)
+        mid = [(0, ln)]
+        if rng.random() < 0.3:
+            a = ln // 2
+            mid = [(0, a), (int(rng.integers(1, 3)), int(rng.integers(1, 60))), (0, ln - a)]
+        cig = ([(4, before)] if before else []) + mid + ([(4, after)] if after else [])
+        pos = int(rng.integers(1, max(2, lengths[name_i] - ln)))
+        mapq = int(rng.choice([60, 60, 60, 30, 19, 20, 0, -400, 300]))
+        entry = "%s,%d,%s,%s,%d,%d" % (names[name_i], pos, rng.choice(["+", "-"]), cigar_string(cig), mapq,
+                                       int(rng.integers(0, 50)))
+        r = rng.random()
+        if r < 0.05:
+            entry += ",extra"
+        elif r < 0.08:
+            entry = ",".join(entry.split(",")[:5])
+        parts.append(entry)
+    return ";".join(parts) + (";" if rng.random() < 0.8 else "")
+
+
+def random_records(rng, names, lengths, n, split_frac=0.4):
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i in range(n):
+        tid = int(rng.integers(0, len(names)))
+        cig = random_cigar(rng, int(rng.integers(1, 40)), hard=rng.random() < 0.1)
+        flag = int(rng.choice([0, 0, 0, 16, 2048, 2064, 256, 4, 272]))
+        mapq = int(rng.choice([60, 60, 60, 20, 19, 0]))
+        qlen = query_len(cig)
+        seq = bases[rng.integers(0, 4, size=qlen)].tobytes().decode()
+        sa = None
+        if rng.random() < split_frac:
+            hard = sum(l for o, l in cig if o == 5)
+            sa = random_sa(rng, names, lengths, qlen + hard)
+        recs.append(dict(qname="read%d" % i, flag=flag, tid=tid, pos=int(rng.integers(0, lengths[tid])), mapq=mapq,
+                         cigar=cig, seq=seq, sa=sa))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    return recs
+
+
+def engineered_split_records(rng, names, lengths, n):
+    """Primaries whose SA segments abut the primary on the read and sit near every tolerance on
+    the reference, so that all branch families fire (INS, DEL, BND, tandem, DUP_INT, INV)."""
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    deltas = [-200000, -100001, -5000, -600, -51, -50, -49, -41, -40, 0, 39, 40, 41, 49, 50, 51, 300, 5000, 100001]
+    for i in range(n):
+        tid = int(rng.integers(0, len(names)))
+        k = int(rng.integers(2, 5))
+        seg_len = [int(rng.integers(300, 3000)) for _ in range(k)]
+        gaps = [int(rng.choice([-60, -51, -50, -10, 0, 0, 0, 30, 50, 51, 100, 400])) for _ in range(k - 1)]
+        q = [0]
+        for j in range(k - 1):
+            q.append(max(0, q[-1] + seg_len[j] + gaps[j]))
+        read_len = max(a + b for a, b in zip(q, seg_len))
+        pos0 = int(rng.integers(200000, lengths[tid] - 300000)) if lengths[tid] > 600000 else int(rng.integers(0, max(1, lengths[tid] // 2)))
+        strands = [bool(rng.random() < 0.3) for _ in range(k)]
+        refs, p = [], pos0
+        for j in range(k):
+            t = tid if rng.random() < 0.85 else int(rng.integers(0, len(names)))
+            p = max(0, p + int(rng.choice(deltas)) + (seg_len[j - 1] if j else 0))
+            refs.append((t, min(p, max(0, lengths[t] - 1))))
+
+        if k == 3 and rng.random() < 0.3:   # A → elsewhere → back to where A ended: interspersed duplication
+            rev = bool(rng.random() < 0.3)
+            strands = [rev, rev, rev]
+            t2 = int(rng.integers(0, len(names)))
+            p2 = int(rng.integers(0, max(1, lengths[t2] - 5000)))
+            jitter = int(rng.choice([-25, -19, -5, 0, 0, 7, 19, 21]))
+            if not rev:
+                refs = [(tid, pos0), (t2, p2), (tid, pos0 + seg_len[0] + jitter)]
+            else:
+                refs = [(tid, pos0 + seg_len[2] + jitter), (t2, p2), (tid, pos0)]
+            q = [0, seg_len[0], seg_len[0] + seg_len[1]]
+            read_len = sum(seg_len)
+
+        def cig(j):
+            before, after = q[j], read_len - q[j] - seg_len[j]
+            if strands[j]:
+                before, after = after, before
+            return ([(4, before)] if before else []) + [(0, seg_len[j])] + ([(4, after)] if after else [])
+
+        pi = int(rng.integers(0, k))
+        seq = bases[rng.integers(0, 4, size=read_len)].tobytes().decode()
+        sa = "".join("%s,%d,%s,%s,60,0;" % (names[refs[j][0]], refs[j][1] + 1, "-" if strands[j] else "+",
+                                            cigar_string(cig(j))) for j in range(k) if j != pi)
+        recs.append(dict(qname="split%d" % i, flag=16 if strands[pi] else 0, tid=refs[pi][0], pos=refs[pi][1], mapq=60,
+                         cigar=cig(pi), seq=seq, sa=sa))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    return recs
+
+
+# ---- adapters ------------------------------------------------------------------------------
+class FakeBam(object):
+    """pysam.AlignmentFile-like view over record dicts, serving the product's record class."""
+
+    def __init__(self, names, lengths, records):
+        from svim_asm_amd import bamio
+        self.references = tuple(names)
+        self.lengths = tuple(lengths)
+        self._recs = []
+        for r in records:
+            a = bamio.AlignedRecord()
+            a.query_name = r["qname"]
+            a.flag = r["flag"]
+            a.reference_id = r["tid"]
+            a.reference_start = r["pos"]
+            a.mapping_quality = r["mapq"]
+            a.cigar_words = np.array([(l << 4) | o for o, l in r["cigar"]], dtype=np.uint32)
+            a._seq_str = r["seq"]
+            a._l_seq = len(r["seq"])
+            a._tags = {"SA": r["sa"]} if r.get("sa") is not None else {}
+            self._recs.append(a)
+
+    def fetch(self, contig=None, until_eof=False):
+        if contig is None:
+            return iter(self._recs)
+        tid = self.get_tid(contig)
+        return iter([a for a in self._recs if a.reference_id == tid])
+
+    def get_tid(self, name):
+        return self.references.index(name) if name in self.references else -1
+
+    def get_reference_name(self, tid):
+        if tid < 0 or tid >= len(self.references):
+            raise ValueError("reference_id %i out of range" % tid)
+        return self.references[tid]
+
+    getrname = get_reference_name
+
+    def get_reference_length(self, name):
+        return self.lengths[self.references.index(name)]
+
+
+class FakeFasta(object):
+    def __init__(self, seqs):
+        self._s = seqs
+        self.references = list(seqs)
+        self.lengths = [len(v) for v in seqs.values()]
+
+    def fetch(self, ref, start=None, end=None):
+        s = self._s[ref]
+        start = 0 if start is None else start
+        end = len(s) if end is None else min(end, len(s))
+        return s[start:end] if start < end else ""
+
+    def get_reference_length(self, ref):
+        return len(self._s[ref])
+
+    def close(self):
+        pass
+
+
+def candidate_tuple(c):
+    t = c.type
+    if t == "DEL":
+        return ("DEL", c.source_contig, c.source_start, c.source_end, tuple(c.reads), c.genotype)
+    if t == "INS":
+        return ("INS", c.dest_contig, c.dest_start, c.dest_end, tuple(c.reads), c.sequence, c.genotype)
+    if t == "INV":
+        return ("INV", c.source_contig, c.source_start, c.source_end, tuple(c.reads), bool(c.complete), c.genotype)
+    if t == "DUP_TAN":
+        return ("DUP_TAN", c.source_contig, c.source_start, c.source_end, int(c.copies), bool(c.fully_covered),
+                tuple(c.reads), c.genotype)
+    if t == "DUP_INT":
+        return ("DUP_INT", c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end,
+                tuple(c.reads), bool(c.cutpaste), c.genotype)
+    return ("BND", c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start,
+            c.dest_direction, tuple(c.reads), c.genotype)
+
+
+def build_candidate(tup, bam, cls):
+    """Canonical tuple → Candidate object of module `cls` (product or reference SVCandidate)."""
+    t = tup[0]
+    if t == "DEL":
+        return cls.CandidateDeletion(tup[1], tup[2], tup[3], list(tup[4]), bam, tup[5])
+    if t == "INS":
+        return cls.CandidateInsertion(tup[1], tup[2], tup[3], list(tup[4]), tup[5], bam, tup[6])
+    if t == "INV":
+        return cls.CandidateInversion(tup[1], tup[2], tup[3], list(tup[4]), tup[5], bam, tup[6])
+    if t == "DUP_TAN":
+        return cls.CandidateDuplicationTandem(tup[1], tup[2], tup[3], tup[4], tup[5], list(tup[6]), bam, tup[7])
+    if t == "DUP_INT":
+        return cls.CandidateDuplicationInterspersed(tup[1], tup[2], tup[3], tup[4], tup[5], tup[6], list(tup[7]), bam,
+                                                    tup[8], tup[9])
+    return cls.CandidateBreakend(tup[1], tup[2], tup[3], tup[4], tup[5], tup[6], list(tup[7]), bam, tup[8])
+
+
+def random_candidates(rng, names, lengths, seqs, n, hap_tag):
+    """Random candidate tuples of all six types, clustered so that partitions of size 1..12 arise."""
+    from oracle import svim_oracle as O
+    lens = dict(zip(names, lengths))
+    out = []
+    anchors = [(names[int(rng.integers(0, len(names)))], int(rng.integers(500, 20000))) for _ in range(max(3, n // 6))]
+    for i in range(n):
+        contig, anchor = anchors[int(rng.integers(0, len(anchors)))]
+        pos = max(0, min(lens[contig] - 10, anchor + int(rng.integers(-700, 700))))
+        ln = int(rng.integers(40, 400))
+        reads = ["%s_r%d" % (hap_tag, i)]
+        t = rng.choice(["DEL", "DEL", "INS", "INS", "INV", "DUP_TAN", "DUP_INT", "BND"])
+        if t == "DEL":
+            out.append(O.cand_del(contig, pos, pos + ln, reads, lens))
+        elif t == "INS":
+            seq = "".join(rng.choice(list("ACGTacgtN"), size=ln))
+            out.append(O.cand_ins(contig, pos, pos + ln, reads, seq, lens))
+        elif t == "INV":
+            out.append(O.cand_inv(contig, pos, pos + ln, reads, bool(rng.random() < 0.5), lens))
+        elif t == "DUP_TAN":
+            out.append(O.cand_tan(contig, pos, pos + ln, int(rng.integers(1, 5)), bool(rng.random() < 0.5), reads, lens))
+        elif t == "DUP_INT":
+            c2 = names[int(rng.integers(0, len(names)))]
+            p2 = int(rng.integers(0, lens[c2] - 500))
+            out.append(O.cand_int(c2, p2, p2 + ln, contig, pos, pos + ln, reads, lens, bool(rng.random() < 0.3)))
+        else:
+            c2 = names[int(rng.integers(0, len(names)))]
+            p2 = max(0, min(lens[c2] - 1, anchor + int(rng.integers(-400, 400))))
+            out.append(O.cand_bnd(contig, pos, rng.choice(["fwd", "rev"]), c2, p2, rng.choice(["fwd", "rev"]), reads, lens))
+    return out

@@ -1,0 +1,151 @@
+"""Pin the CPU oracle (oracle/svx_oracle.c, oracle/svim_oracle.py) to the reference:
+its own known-answer vectors, its BAM fixtures, and golden vectors produced by running the
+real reference in the build container (oracle/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc, run_oracle, svim_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# src/tests/test_intra.py:8-22 of the reference, min_length 30
+KNOWN = [
+    ([(5, 10), (4, 20), (0, 10), (7, 10), (8, 5), (0, 5), (1, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 50, "INS")]),
+    ([(5, 10), (4, 20), (0, 30), (2, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 50, "DEL")]),
+    ([(5, 10), (4, 20), (0, 30), (2, 40), (1, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 40, "DEL"), (70, 50, 50, "INS")]),
+    ([(5, 10), (4, 20), (0, 30), (1, 40), (2, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 40, "INS"), (30, 90, 50, "DEL")]),
+]
+
+
+def c_oracle_indels(tuples, min_len):
+    cig = np.array([(l << 4) | o for o, l in tuples], dtype=np.uint32)
+    o = orc.cigar_extract(cig, np.array([0, len(cig)], np.uint64), None, min_len)
+    return [(int(r), int(q), int(l), "DEL" if t else "INS")
+            for r, q, l, t in zip(o["ref_pos"], o["read_pos"], o["len"], o["type"])]
+
+
+def test_reference_known_answers_test_intra():
+    for tuples, expected in KNOWN:
+        assert svim_oracle.analyze_cigar_indel(tuples, 30) == expected
+        assert c_oracle_indels(tuples, 30) == expected
+
+
+def test_n_op_quirk():
+    tuples = [(0, 10), (3, 1000), (0, 10), (2, 50)]
+    assert svim_oracle.analyze_cigar_indel(tuples, 40) == [(20, 20, 50, "DEL")]
+    assert c_oracle_indels(tuples, 40) == [(20, 20, 50, "DEL")]
+
+
+def test_golden_function_vectors():
+    vec = json.load(open(os.path.join(GOLD, "functions.json")))
+    for case in vec["analyze_cigar_indel"]:
+        tuples = [tuple(t) for t in case["tuples"]]
+        exp = [tuple(x) for x in case["out"]]
+        assert svim_oracle.analyze_cigar_indel(tuples, case["min_length"]) == exp
+        assert c_oracle_indels(tuples, case["min_length"]) == exp
+    for case in vec["is_similar"]:  # includes the four asserts of the reference's test_inter.py
+        assert bool(svim_oracle.is_similar(*case["args"])) == case["out"]
+
+
+def test_sa_tag_reconstruction_on_reference_fixtures():
+    """tests/test_satag.py of the reference: 3 segments equal to records 2-4; 7-field entry
+    skipped; mapq -400 becomes 0."""
+    vec = json.load(open(os.path.join(GOLD, "functions.json")))["retrieve_other_alignments"]
+    for fn, expected in vec.items():
+        recs, names, _ = run_oracle.read_records(os.path.join(GOLD, fn))
+        prim = [r for r in recs if not r["flag"] & 0x800]
+        assert len(prim) == len(expected)
+        for rec, exp_rows in zip(prim, expected):
+            got = svim_oracle.retrieve_other_alignments(rec, names)
+            assert len(got) == len(exp_rows)
+            for g, e in zip(got, exp_rows):
+                assert "".join("%d%s" % (l, "MIDNSHP=XB"[o]) for o, l in g["cigar"]) == e["cigarstring"]
+                assert (g["tid"], g["pos"], g["flag"], g["mapq"]) == (e["reference_id"], e["reference_start"], e["flag"], e["mapping_quality"])
+                assert svim_oracle.reference_end(g) == e["reference_end"]
+                assert svim_oracle.query_alignment_start(g) == e["query_alignment_start"]
+                assert svim_oracle.query_alignment_end(g) == e["query_alignment_end"]
+                assert svim_oracle.infer_read_length(g) == e["infer_read_length"]
+    # the literal expectations of test_satag.py
+    recs, names, _ = run_oracle.read_records(os.path.join(GOLD, "chimeric_read.bam"))
+    assert len(recs) == 4
+    supp = svim_oracle.retrieve_other_alignments(recs[0], names)
+    assert len(supp) == 3
+    for s, r in zip(supp, recs[1:]):
+        assert s["cigar"] == r["cigar"] and s["tid"] == r["tid"] and s["pos"] == r["pos"]
+        assert s["flag"] == r["flag"] and s["mapq"] == r["mapq"]
+        assert svim_oracle.reference_end(s) == svim_oracle.reference_end(r)
+        assert svim_oracle.query_alignment_start(s) == svim_oracle.query_alignment_start(r)
+        assert svim_oracle.query_alignment_end(s) == svim_oracle.query_alignment_end(r)
+    recs, names, _ = run_oracle.read_records(os.path.join(GOLD, "chimeric_read_errors.bam"))
+    prim = [r for r in recs if not r["flag"] & 0x800]
+    assert len(svim_oracle.retrieve_other_alignments(prim[0], names)) == 2
+    one = svim_oracle.retrieve_other_alignments(prim[1], names)
+    assert len(one) == 1 and one[0]["mapq"] == 0
+
+
+def _parse_run(argv):
+    flags = ("symbolic_alleles", "tandem_duplications_as_insertions", "interspersed_duplications_as_insertions",
+             "query_names")
+    pos, kw, i = [], {}, 0
+    while i < len(argv):
+        a = argv[i]
+        if a.startswith("--"):
+            k = a[2:]
+            if k in flags:
+                kw[k] = True
+                i += 1
+            else:
+                v = argv[i + 1]
+                kw[k] = int(v) if v.lstrip("-").isdigit() else v
+                i += 2
+        else:
+            pos.append(a)
+            i += 1
+    return pos, kw
+
+
+RUNS = json.load(open(os.path.join(GOLD, "config1", "runs.json")))
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_oracle_pipeline_reproduces_reference_vcf(name):
+    """BAM(s) → VCF through the oracle == the VCF the real reference wrote (config 1)."""
+    pos, kw = _parse_run(RUNS[name])
+    files = [os.path.join(GOLD, "config1", f) for f in pos[2:]]
+    got = run_oracle.vcf_from_files(files[:-1], files[-1], run_oracle.default_options(**kw),
+                                    edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+    assert got == open(os.path.join(GOLD, "config1", name + ".vcf")).read()
+
+
+def test_edit_distance_c_vs_python():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(0, 40))).astype(np.uint8))
+        b = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(0, 40))).astype(np.uint8))
+        assert orc.edit_distance(a, b) == svim_oracle.edit_distance(a.decode(), b.decode())
+
+
+def test_c_classify_and_partition_agree_with_python_oracle():
+    """The C restatements used on the GPU box (orc.segments_classify, orc.pair_partition) agree
+    with the pinned Python oracle on random inputs."""
+    from tests import helpers
+    rng = np.random.default_rng(5)
+    names, lengths = ["chr1", "chr10", "chr2"], [2_000_000, 1_500_000, 1_000_000]
+    lens = dict(zip(names, lengths))
+    # partition: python form_partitions vs C on packed keys
+    cands = helpers.random_candidates(rng, names, lengths, None, 400, "a")
+    tagged = [(1 + i % 2, c) for i, c in enumerate(cands)]
+    for typ in ("DEL", "INS", "INV", "DUP_TAN", "DUP_INT", "BND"):
+        sub = [e for e in tagged if e[1][0] == typ]
+        parts = svim_oracle.form_partitions(sub, 1000)
+        rank = {n: i for i, n in enumerate(sorted(names))}
+        keys = np.array([(rank[svim_oracle.get_key(c)[1]] << 32) | svim_oracle.get_key(c)[2] for _, c in sub], dtype=np.uint64)
+        perm, part, n_parts = orc.pair_partition(keys, 1000)
+        assert n_parts == len(parts)
+        flat = [e for p in parts for e in p]
+        assert [sub[i] for i in perm] == flat
+        assert list(part) == [pi for pi, p in enumerate(parts) for _ in p]
