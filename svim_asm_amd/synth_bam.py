@@ -299,7 +299,7 @@ def write_bam(path, contigs, records, level=1):
 
 
 def write_dataset(outdir, seed=1, contigs=CONFIG1_CONTIGS, diploid=True, n_shared=25, n_private=6,
-                  median_aln=30000, mean_m=2000, dense_cluster=True):
+                  median_aln=30000, mean_m=2000, dense_cluster=True, with_splits=True):
     """FASTA + one or two haplotype BAMs under `outdir`; returns their paths."""
     import os
     os.makedirs(outdir, exist_ok=True)
@@ -320,7 +320,8 @@ def write_dataset(outdir, seed=1, contigs=CONFIG1_CONTIGS, diploid=True, n_share
         events = {name: derive_haplotype_events(hrng, shared[name], n_private, length) for name, length in contigs}
         if knot:
             events[contigs[0][0]] = sorted(events[contigs[0][0]] + knot, key=lambda e: e.pos)
-        recs = simulate_haplotype(seed + 3000 + h, genome, contigs, events, median_aln, mean_m, tag="h%d" % (h + 1))
+        recs = simulate_haplotype(seed + 3000 + h, genome, contigs, events, median_aln, mean_m, tag="h%d" % (h + 1),
+                                  with_splits=with_splits)
         path = os.path.join(outdir, "hap%d.bam" % (h + 1))
         write_bam(path, contigs, recs)
         bams.append(path)

@@ -1,0 +1,151 @@
+"""Host-side logic of the product that needs no GPU: BAM/FASTA I/O, candidate model, split-read
+post-passes (fed with raw records from the C oracle), VCF writer, CLI precondition errors."""
+import logging
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc, svim_oracle
+from svim_asm_amd import SVCandidate, SVIM_COLLECT, SVIM_COMBINE, SVIM_inter, bamio, fasta
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+NAMES = ["chr1", "chr10", "chr2", "chrX"]
+LENGTHS = [3_000_000, 1_500_000, 2_000_000, 800_000]
+
+
+def test_bam_reader_on_reference_fixture():
+    f = bamio.AlignmentFile(os.path.join(GOLD, "chimeric_read.bam"))
+    assert len(f) == 4 and f.header["HD"]["SO"] == "queryname"
+    recs = list(f.fetch())
+    assert [len(r.cigar_words) for r in recs] == [638, 272, 93, 77]
+    assert [r.flag for r in recs] == [0, 2048, 2048, 2048]
+    assert all(r._l_seq == 9900 and r.reference_id == 20 for r in recs)
+    assert recs[0].get_tag("SA").count(";") == 3
+    with pytest.raises(ValueError):
+        f.check_index()
+    cig, off, pos, tid = f.batch()
+    assert list(off) == [0, 638, 910, 1003, 1080] and len(cig) == 1080
+
+
+def test_sa_reconstruction_matches_test_satag_expectations():
+    """retrieve_other_alignments (product) on the reference's fixtures — tests/test_satag.py."""
+    f = bamio.AlignmentFile(os.path.join(GOLD, "chimeric_read.bam"))
+    recs = list(f.fetch())
+    supp = SVIM_COLLECT.retrieve_other_alignments(recs[0], f)
+    assert len(supp) == 3
+    for s, r in zip(supp, recs[1:]):
+        assert s.cigarstring == r.cigarstring
+        assert (s.reference_id, s.reference_start, s.reference_end) == (r.reference_id, r.reference_start, r.reference_end)
+        assert (s.flag, s.mapping_quality, s.query_name) == (r.flag, r.mapping_quality, r.query_name)
+        assert s.query_alignment_start == r.query_alignment_start
+        assert s.query_alignment_end == r.query_alignment_end
+    g = bamio.AlignmentFile(os.path.join(GOLD, "chimeric_read_errors.bam"))
+    prim = [r for r in g.fetch() if not r.is_supplementary]
+    assert len(SVIM_COLLECT.retrieve_other_alignments(prim[0], g)) == 2       # 7-field entry skipped
+    one = SVIM_COLLECT.retrieve_other_alignments(prim[1], g)
+    assert len(one) == 1 and one[0].mapping_quality == 0                     # mapq -400 → 0
+
+
+def test_bam_and_fasta_roundtrip(tmp_path):
+    from svim_asm_amd import synth_bam
+    fa, bams = synth_bam.write_dataset(str(tmp_path), seed=3, contigs=(("a", 30000), ("b", 20000)), n_shared=4,
+                                       n_private=1, median_aln=8000, dense_cluster=False, with_splits=False)
+    f = bamio.AlignmentFile(bams[0])
+    assert f.check_index() and f.header["HD"]["SO"] == "coordinate" and f.references == ("a", "b")
+    ref = fasta.FastaFile(fa)
+    assert ref.get_reference_length("a") == 30000
+    whole = ref.fetch("a", 0, 30000)
+    assert len(whole) == 30000 and ref.fetch("a", 59, 125) == whole[59:125] and ref.fetch("a", 29990, 40000) == whole[29990:]
+    assert ref.fetch("a", 10, 10) == ""
+    for r in f.fetch():
+        if r.flag == 0 and len(r.cigar_words) > 3 and not r.has_tag("SA"):
+            # M stretches of the query reproduce the reference up to the low substitution rate
+            s = r.query_sequence
+            assert r.seq_slice(5, 50) == s[5:50] and r.seq_slice(4, 51) == s[4:51]
+            break
+    with pytest.raises(IOError):
+        fasta.FastaFile(str(tmp_path / "missing.fa"))
+    os.remove(fa + ".fai")
+    with pytest.raises(ValueError):
+        fasta.FastaFile(fa)
+
+
+def test_candidate_model_clamps_keys_and_breakend_normalisation():
+    bam = helpers.FakeBam(NAMES, LENGTHS, [])
+    d = SVCandidate.CandidateDeletion("chr2", -5, 2_000_010, ["r"], bam)
+    assert d.get_source() == ("chr2", 0, 2_000_000) and d.get_key() == ("DEL", "chr2", 1_000_000)
+    with pytest.raises(AssertionError):
+        SVCandidate.CandidateDeletion("chr2", 10, 9, ["r"], bam)
+    i = SVCandidate.CandidateInsertion("chr1", 100, 160, ["r"], "ACGT", bam)
+    assert i.get_key() == ("INS", "chr1", 100) and i.get_destination() == ("chr1", 100, 160)
+    b = SVCandidate.CandidateBreakend("chr2", 500, "fwd", "chr10", 700, "rev", ["r"], bam)
+    # "chr10" < "chr2" as strings: endpoints swap and both directions flip
+    assert (b.source_contig, b.source_start, b.source_direction) == ("chr10", 700, "fwd")
+    assert (b.dest_contig, b.dest_start, b.dest_direction) == ("chr2", 500, "rev")
+    same = SVCandidate.CandidateBreakend("chr1", 5, "fwd", "chr1", 5, "fwd", ["r"], bam)
+    assert (same.source_direction, same.dest_direction) == ("rev", "rev")
+    t = SVCandidate.CandidateDuplicationTandem("chr1", 10, 110, 2, True, ["r"], bam)
+    assert t.get_destination() == ("chr1", 110, 310)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_split_read_post_passes_match_oracle(seed):
+    """product post-passes over C-oracle raw records == pinned Python oracle, per read."""
+    rng = np.random.default_rng(seed)
+    recs = helpers.engineered_split_records(rng, NAMES, LENGTHS, 400)
+    o = helpers.options(**([{}, dict(min_sv_size=30, max_sv_size=2000)][seed % 2]))
+    bam = helpers.FakeBam(NAMES, LENGTHS, recs)
+    lens = dict(zip(NAMES, LENGTHS))
+    prm = (o.min_sv_size, o.max_sv_size, o.query_gap_tolerance, o.query_overlap_tolerance,
+           o.reference_gap_tolerance, o.reference_overlap_tolerance)
+    kinds = set()
+    for rec, prim in zip(recs, bam.fetch()):
+        supp = [s for s in SVIM_COLLECT.retrieve_other_alignments(prim, bam) if s.mapping_quality >= o.min_mapq]
+        rows = [SVIM_inter.segment_row(a) for a in [prim] + supp]
+        segs = np.array(rows, dtype=np.int32).view(orc.SEG_DTYPE).reshape(-1)
+        raw = orc.segments_classify(segs, np.array([0, len(rows)], np.uint32),
+                                    np.array([prim.infer_read_length()], np.int32), prm)
+        got = [helpers.candidate_tuple(c) for c in
+               SVIM_inter.candidates_from_raw(raw, prim, bam, o, lambda a, b: prim.query_sequence[a:b])]
+        osupp = [s for s in svim_oracle.retrieve_other_alignments(rec, NAMES) if s["mapq"] >= o.min_mapq]
+        exp = svim_oracle.analyze_read_segments(rec, osupp, NAMES, lens, o)
+        assert got == exp
+        kinds |= {c[0] for c in exp}
+    assert kinds == {"DEL", "INS", "BND", "DUP_TAN", "DUP_INT", "INV"}
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_vcf_writer_matches_oracle(tmp_path, seed):
+    rng = np.random.default_rng(seed)
+    seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=30000)) for n in NAMES}
+    lengths = [30000] * len(NAMES)
+    ref = helpers.FakeFasta(seqs)
+    bam = helpers.FakeBam(NAMES, lengths, [])
+    tuples = helpers.random_candidates(rng, NAMES, lengths, seqs, 150, "x")
+    cands = [helpers.build_candidate(t, bam, SVCandidate) for t in tuples]
+    assert [helpers.candidate_tuple(c) for c in cands] == tuples
+    o = helpers.options(working_dir=str(tmp_path), query_names=bool(seed & 1),
+                        tandem_duplications_as_insertions=seed == 1, interspersed_duplications_as_insertions=seed == 2,
+                        types=["DEL,INS,INV,DUP:TANDEM,DUP:INT,BND", "DEL,INS", "INV,BND,DUP:INT"][seed])
+    by = lambda t: [c for c in cands if c.type == t]
+    SVIM_COMBINE.write_final_vcf(by("DUP_INT"), by("INV"), by("DUP_TAN"), by("DEL"), by("INS"), by("BND"), "1.0.3",
+                                 NAMES, lengths, [t.strip() for t in o.types.split(",")], ref, o)
+    got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == svim_oracle.vcf_text(tuples, ref.fetch, NAMES, lengths, o)
+
+
+def test_sorted_nicely_is_natural_and_stable():
+    e = [(("chr10", 5, 6), "a", "DEL"), (("chr2", 5, 6), "b", "DEL"), (("chr2", 5, 6), "c", "INS"), (("chr1", 9, 9), "d", "DEL")]
+    assert [x[1] for x in SVIM_COMBINE.sorted_nicely(e)] == ["d", "b", "c", "a"]
+
+
+def test_cli_rejects_unsorted_bam_without_touching_the_gpu(tmp_path, caplog):
+    from svim_asm_amd import cli
+    wd = tmp_path / "wd"
+    with caplog.at_level(logging.ERROR):
+        cli.main(["haploid", str(wd), os.path.join(GOLD, "chimeric_read.bam"), os.path.join(GOLD, "config1", "ref.fa")])
+    assert "needs to be coordinate-sorted" in caplog.text
+    assert not (wd / "variants.vcf").exists()
