@@ -6,10 +6,9 @@ import os
 import sys
 from time import localtime, strftime
 
-from svim_asm_amd import bamio
+from svim_asm_amd import bamio, shard
 from svim_asm_amd.fasta import FastaFile
-from svim_asm_amd.SVIM_COLLECT import analyze_alignment_file_coordsorted
-from svim_asm_amd.SVIM_COMBINE import pair_candidates, write_final_vcf
+from svim_asm_amd.SVIM_COMBINE import write_final_vcf
 from svim_asm_amd.SVIM_input_parsing import parse_arguments
 
 __version__ = "1.0.3"
@@ -36,7 +35,20 @@ def _collect(path, which, options):
         logging.error("{0} BAM file is missing an index. Please generate with 'samtools index'. "
                       "Exiting..".format(the))
         return None, None
-    return aln_file, analyze_alignment_file_coordsorted(aln_file, options)
+    return aln_file, shard.collect_sharded(aln_file, options)  # contig shards when launched on several GPUs
+
+
+def _init_distributed(options):
+    """One process per GPU under torch.distributed.run: rank r drives device LOCAL_RANK."""
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size <= 1:
+        return False
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    options.device = int(os.environ.get("LOCAL_RANK", "0"))
+    # candidate lists are exchanged as Python objects (a few MB): host-side gloo group
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world_size)
+    return True
 
 
 def main(arguments=None):
@@ -44,6 +56,16 @@ def main(arguments=None):
     if not options.sub:
         print("Please choose one of the two modes ('haploid' or 'diploid'). See --help for more information.")
         return
+    distributed = _init_distributed(options)
+    try:
+        return _main(options)
+    finally:
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def _main(options):
 
     log_format = logging.Formatter("%(asctime)s [%(levelname)-7.7s]  %(message)s")
     root = logging.getLogger()
@@ -102,12 +124,14 @@ def _run(options):
 
     if options.sub == "diploid":
         logging.info("****************** STEP 2: PAIR ******************")
-        sv_candidates = pair_candidates(sv_candidates1, sv_candidates2, reference, aln_file1, options)
+        sv_candidates = shard.pair_sharded(sv_candidates1, sv_candidates2, reference, aln_file1, options)
     by_type = {key: [c for c in sv_candidates if c.type == key] for key, _ in TYPE_LABELS}
 
     logging.info("****************** STEP {0}: OUTPUT ******************".format(2 if options.sub == "haploid" else 3))
     for key, label in (TYPE_LABELS[0], TYPE_LABELS[1], TYPE_LABELS[2], TYPE_LABELS[3], TYPE_LABELS[4], TYPE_LABELS[5]):
         logging.info("Found {0} {1} candidates.".format(len(by_type[key]), label))
+    if shard.world()[0] != 0:
+        return  # every rank holds the full result; rank 0 writes it
     logging.info("Write SV candidates..")
     types_to_output = [entry.strip() for entry in options.types.split(",")]
     write_final_vcf(by_type["DUP_INT"], by_type["INV"], by_type["DUP_TAN"], by_type["DEL"], by_type["INS"],
