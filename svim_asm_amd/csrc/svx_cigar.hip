@@ -173,14 +173,105 @@ __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_b
 #ifndef SVX_TILE_MIN_WAVES
 #define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int kQueue = 64;  // signatures flushed per pass (one per lane)
+constexpr int kQueue = 64;  // signatures one round may queue in LDS (one flush lane each)
+constexpr uint32_t kDescForceDense = 1u << 30;  // descriptor flag: a round overflowed the queue
+
+enum { WALK_TOTALS = 0, WALK_QUEUE = 1, WALK_DIRECT = 2 };
+
+// per-lane results of one walk over the lane's 16 consecutive ops
+struct WalkOut {
+    uint32_t tail_r, tail_d;  // cursor sums since the last alignment start inside the lane (or lane start)
+    uint32_t n_emit;          // emitting ops of this lane
+    uint32_t n_queued;        // wave-uniform: signatures queued this round (WALK_QUEUE)
+};
+
+// Everything WALK_DIRECT needs to finish a signature on the spot.
+struct DirectCtx {
+    uint32_t in_r, in_d;  // lane carry-in (since the last start before the lane)
+    uint64_t out0;        // output slot of this lane's first signature
+    uint32_t a_lo;
+    uint64_t g_lane0;     // global op index of the lane's op 0
+};
+
+// Lane-local walk (SVIM_intra.py:13-29).  The 16 words stay in LDS (`myx`, 4 per uint4) and the
+// loop over the four groups is rolled, so the working set is a handful of registers.  Alignment
+// starts and emitting ops are rare: both are handled under wave-uniform branches (HU / ballot),
+// the common per-op path is decode + two masked adds.
+template <int WALK, bool SOA>
+__device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, const uint32_t (&opw)[4],
+                                          uint32_t hm, uint32_t hmo, uint32_t HU, int lane, uint4* queue,
+                                          const DirectCtx& dc) {
+    uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const uint4 v4 = myx[j];
+        const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const uint32_t hu4 = HU >> (4 * j), hm4 = hm >> (4 * j);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t op, len;
+            if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
+            else { op = wv[t] & 15u; len = wv[t] >> 4; }
+            if ((hu4 >> t) & 1u) {  // scalar test: some lane starts an alignment at this slot
+                if ((hm4 >> t) & 1u) { base_r = rr; base_d = rd; }
+            }
+            const bool em = (op - 1u) < 2u && len >= p.min_len;  // I or D, inclusive threshold (:18,:22)
+            const uint64_t eb = __ballot(em);
+            if (eb) {  // wave-uniform: most op slots emit nothing
+                if (em) {
+                    const uint32_t i = 4 * j + t;
+                    if (WALK == WALK_QUEUE) {
+                        const uint32_t qi = qn + __popcll(eb & lt);
+                        if (qi < (uint32_t)kQueue) {
+                            // meta: lane | slot << 6 | (start at/before op i inside this lane) << 10 |
+                            //       index among the lane's signatures << 11 | op << 16
+                            const uint32_t meta = (uint32_t)lane | (i << 6) | (((hmo >> i) & 1u) << 10) |
+                                                  (n_emit << 11) | (op << 16);
+                            queue[qi] = make_uint4(rr - base_r, rd - base_d, SOA ? len : wv[t], meta);
+                        }
+                    } else if (WALK == WALK_DIRECT) {
+                        const bool own = ((hmo >> i) & 1u) != 0;
+                        const uint32_t ref = rr - base_r + (own ? 0u : dc.in_r);
+                        const uint32_t rdp = rd - base_d + (own ? 0u : dc.in_d);
+                        const uint32_t aln = find_aln(p.aln_off, p.n_aln, dc.a_lo, dc.g_lane0 + i);
+                        store_final(p, dc.out0 + n_emit, aln, ref, rdp, len, (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS);
+                    }
+                    ++n_emit;
+                }
+                qn += __popcll(eb);
+            }
+            // ops advancing the reference cursor: M(0) D(2) =(7) X(8); the query cursor:
+            // M(0) I(1) S(4) =(7) X(8)   (SVIM_intra.py:14-29; N,H,P,B and codes >= 10: nothing)
+            const uint32_t sop = SOA ? (op < 16u ? op : 15u) : op;
+            rr += len & (uint32_t)__builtin_amdgcn_sbfe(0x185, sop, 1);
+            rd += len & (uint32_t)__builtin_amdgcn_sbfe(0x193, sop, 1);
+        }
+    }
+    WalkOut o;
+    o.tail_r = rr - base_r;
+    o.tail_d = rd - base_d;
+    o.n_emit = n_emit;
+    o.n_queued = qn;
+    return o;
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    v |= dpp0<kDppShr1, 0xF>(v); v |= dpp0<kDppShr2, 0xF>(v); v |= dpp0<kDppShr4, 0xF>(v);
+    v |= dpp0<kDppShr8, 0xF>(v); v |= dpp0<kDppBcast15, 0xA>(v); v |= dpp0<kDppBcast31, 0xC>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+#ifndef SVX_TILE_MIN_WAVES
+#define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
 
 template <int MODE, bool SOA>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ uint32_t s_head[kWaves][kTileOps / 32];
     __shared__ uint4 s_queue[kWaves][kQueue];
-    __shared__ uint2 s_carry[kWaves][64];
+    __shared__ uint4 s_carry[kWaves][64];
 
     // the wave index is wave-uniform: tell the compiler so that tile indices, loop bounds and
     // carries live in SGPRs and the tile/round loops are scalar branches
@@ -189,7 +280,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
     uint4* xp = s_xpose[wave];
     uint32_t* hmask = s_head[wave];
     uint4* queue = s_queue[wave];
-    uint2* lcarry = s_carry[wave];
+    uint4* lcarry = s_carry[wave];
 
     uint32_t work = blockIdx.x * kWaves + wave;
     const uint32_t work_stride = gridDim.x * kWaves;
@@ -229,7 +320,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
 
         // ---- tile state carried across rounds (wave-uniform) ----
         uint32_t carry_r = 0, carry_d = 0;
-        bool seen = false;
+        bool seen = false, overflow = false;
         uint32_t tile_cnt = 0;
         uint32_t obase = 0;
         if (MODE == MODE_DIRECT) {
@@ -262,115 +353,57 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
             const uint32_t opw[4] = {opw4.x, opw4.y, opw4.z, opw4.w};
             uint32_t hmo = hm;  // prefix-OR: bit i set iff an alignment start sits at a slot <= i
             hmo |= hmo << 1; hmo |= hmo << 2; hmo |= hmo << 4; hmo |= hmo << 8;
-            const uint4* myx = xp + lane * 5;  // this lane's 16 consecutive ops, 4 per uint4
+            const uint32_t HU = wave_or_u32(hm);  // slots where ANY lane starts an alignment (SGPR)
+            const uint4* myx = xp + lane * 5;     // this lane's 16 consecutive ops, 4 per uint4
 
-            // ---- pre-pass: which ops emit (I or D with len >= min_len, SVIM_intra.py:18,22) ----
-            // rolled over the four uint4 groups: the words stay in LDS, not in 16 registers
-            uint32_t emask = 0;
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                const uint4 v4 = myx[j];
-                const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
-                uint32_t e4 = 0;
-#pragma unroll
-                for (int t = 3; t >= 0; --t) {
-                    uint32_t op, len;
-                    if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
-                    else { op = wv[t] & 15u; len = wv[t] >> 4; }
-                    e4 = (e4 << 1) | (((op - 1u) < 2u && len >= p.min_len) ? 1u : 0u);
-                }
-                emask |= e4 << (4 * j);
-            }
-            uint32_t sc = __popc(emask);
-            {   // plain inclusive DPP scan of the counts
-                sc += dpp0<kDppShr1, 0xF>(sc); sc += dpp0<kDppShr2, 0xF>(sc);
-                sc += dpp0<kDppShr4, 0xF>(sc); sc += dpp0<kDppShr8, 0xF>(sc);
-                sc += dpp0<kDppBcast15, 0xA>(sc); sc += dpp0<kDppBcast31, 0xC>(sc);
-            }
-            const uint32_t xc = dpp0<kDppWaveShr1, 0xF>(sc);
+            DirectCtx dc;
+            dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
+            const WalkOut wo = walk16<(MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS, SOA>(
+                p, myx, opw, hm, hmo, HU, lane, queue, dc);
+
+            // ---- wave scans (DPP): segmented (flag, ref, read) and plain count ----
+            uint32_t f = hm != 0 ? 1u : 0u, sr = wo.tail_r, sd = wo.tail_d, sc = wo.n_emit;
+            SVX_SEG_SCAN()
+            const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
+                           xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
             const uint32_t C = __builtin_amdgcn_readlane(sc, 63);
+            const uint32_t in_r = xf ? xr : xr + carry_r;   // lane carry-in
+            const uint32_t in_d = xf ? xd : xd + carry_d;
 
-            uint32_t f = 0, sr = 0, sd = 0;
-            // one pass per 64 signatures of this round (a single pass unless the CIGAR is indel-dense)
-            for (uint32_t qbase = 0; qbase == 0 || qbase < C; qbase += kQueue) {
-                // ---- lane-local segmented walk over 16 consecutive ops ----
-                uint32_t rr = 0, rd = 0;
-#pragma unroll 1
-                for (int j = 0; j < 4; ++j) {
-                    const uint4 v4 = myx[j];
-                    const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
-                    const uint32_t hm4 = hm >> (4 * j), em4 = emask >> (4 * j);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+            if (MODE == MODE_STAGE) {
+                if (C) {  // wave-uniform
+                    // lanes at or before the first start of the round still lack the tile's carry-in
+                    lcarry[lane] = make_uint4(in_r, in_d, xc, (!seen && !xf) ? 1u : 0u);
+                    wave_lds_sync();
+                    const uint32_t n_here = wo.n_queued < (uint32_t)kQueue ? wo.n_queued : (uint32_t)kQueue;
+                    if ((uint32_t)lane < n_here) {
+                        const uint4 e = queue[lane];
+                        const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 15u, own = (e.w >> 10) & 1u,
+                                       li = (e.w >> 11) & 31u;
+                        const uint4 cin = lcarry[L];
+                        const uint32_t ref = own ? e.x : e.x + cin.x;
+                        const uint32_t rdp = own ? e.y : e.y + cin.y;
+                        const uint32_t prec = own ? 0u : cin.w;
                         uint32_t op, len;
-                        if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
-                        else { op = wv[t] & 15u; len = wv[t] >> 4; }
-                        if (__any((hm4 >> t) & 1u)) {  // wave-uniform: most op slots hold no alignment start
-                            if ((hm4 >> t) & 1u) { rr = 0; rd = 0; }
-                        }
-                        if (__any((em4 >> t) & 1u)) {  // wave-uniform: most op slots emit nothing
-                            if ((em4 >> t) & 1u) {
-                                const uint32_t i = 4 * j + t;
-                                const uint32_t qi = xc + __popc(emask & ((1u << i) - 1u)) - qbase;
-                                if (qi < (uint32_t)kQueue) {
-                                    // bit 10: an alignment start at or before op i inside this lane
-                                    const uint32_t meta = (uint32_t)lane | (i << 6) | (((hmo >> i) & 1u) << 10) |
-                                                          (op << 16);
-                                    queue[qi] = make_uint4(rr, rd, wv[t], meta);
-                                }
-                            }
-                        }
-                        // ops advancing the reference cursor: M(0) D(2) =(7) X(8); the query cursor:
-                        // M(0) I(1) S(4) =(7) X(8)   (SVIM_intra.py:14-29; N,H,P,B: nothing)
-                        const bool valid = SOA ? (op < 16u) : true;
-                        rr += (valid && ((0x185u >> op) & 1u)) ? len : 0u;
-                        rd += (valid && ((0x193u >> op) & 1u)) ? len : 0u;
-                    }
-                }
-                if (qbase == 0) {
-                    // ---- wave segmented inclusive scan of (flag, ref, read) (DPP) ----
-                    f = hm != 0 ? 1u : 0u; sr = rr; sd = rd;
-                    uint32_t sc_unused = 0;
-                    { uint32_t& sc = sc_unused; SVX_SEG_SCAN() }
-                    const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
-                                   xd = dpp0<kDppWaveShr1, 0xF>(sd);
-                    // carry-in of this lane; bit 31 of .y... keep a separate flag word instead
-                    const uint32_t in_r = xf ? xr : xr + carry_r;
-                    const uint32_t in_d = xf ? xd : xd + carry_d;
-                    lcarry[lane] = make_uint2(in_r, in_d);
-                }
-                wave_lds_sync();
-                // ---- flush: lane j finishes signature qbase + j ----
-                const uint32_t n_here = (C - qbase) < (uint32_t)kQueue ? (C - qbase) : (uint32_t)kQueue;
-                // lanes up to and including the first lane holding a start still lack the tile carry
-                // (ballot taken with all lanes active)
-                const uint64_t hb = __ballot(hm != 0);
-                const uint32_t first_head_lane = hb ? (uint32_t)__ffsll((unsigned long long)hb) - 1u : 64u;
-                if ((uint32_t)lane < n_here) {
-                    const uint4 e = queue[lane];
-                    const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 15u, own = (e.w >> 10) & 1u;
-                    const uint2 cin = lcarry[L];
-                    const bool prec = !own && !seen && (L <= first_head_lane);
-                    const uint32_t ref = own ? e.x : e.x + cin.x;
-                    const uint32_t rdp = own ? e.y : e.y + cin.y;
-                    uint32_t op, len;
-                    if (SOA) { op = (e.w >> 16) & 0xFFu; len = e.z; }
-                    else { op = e.z & 15u; len = e.z >> 4; }
-                    const uint32_t type = (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
-                    const uint32_t rank = tile_cnt + qbase + lane;
-                    const uint32_t loc = round * kRoundOps + L * kLaneOps + slot;
-                    if (MODE == MODE_STAGE) {
+                        if (SOA) { op = (e.w >> 16) & 0xFFu; len = e.z; }
+                        else { op = e.z & 15u; len = e.z >> 4; }
+                        const uint32_t type = (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
+                        const uint32_t rank = tile_cnt + cin.z + li;
                         if (rank < (uint32_t)kSlab) {
-                            const uint32_t w0 = loc | (type << 12) | ((prec ? 1u : 0u) << 13);
-                            p.slab[(uint64_t)tile * kSlab + rank] = make_uint4(w0, ref, rdp, len);
+                            const uint32_t loc = round * kRoundOps + L * kLaneOps + slot;
+                            p.slab[(uint64_t)tile * kSlab + rank] = make_uint4(loc | (type << 12) | (prec << 13), ref, rdp, len);
                         }
-                    } else {
-                        const uint32_t aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + loc);
-                        store_final(p, (uint64_t)obase + rank, aln, ref, rdp, len, type);
                     }
+                    if (wo.n_queued > (uint32_t)kQueue) overflow = true;
                 }
-                wave_lds_sync();  // queue / lcarry / xp are rewritten by the next pass or round
+            } else {
+                if (C) {  // dense tile: second walk finishes each signature on the spot
+                    dc.in_r = in_r; dc.in_d = in_d;
+                    dc.out0 = (uint64_t)obase + tile_cnt + xc;
+                    (void)walk16<WALK_DIRECT, SOA>(p, myx, opw, hm, hmo, HU, lane, queue, dc);
+                }
             }
+            wave_lds_sync();  // queue / lcarry / xp are rewritten by the next round
 
             // ---- carry to the next round (wave-uniform: lane 63's inclusive values) ----
             const uint32_t F = __builtin_amdgcn_readlane(f, 63), R = __builtin_amdgcn_readlane(sr, 63),
@@ -381,7 +414,8 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
         }
 
         if (MODE == MODE_STAGE && lane == 0) {
-            p.desc[tile] = make_uint4(tile_cnt | ((seen ? 1u : 0u) << 31), carry_r, carry_d, a_lo);
+            p.desc[tile] = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31),
+                                      carry_r, carry_d, a_lo);
         }
     }
 }
@@ -411,11 +445,11 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
         uint32_t f = 0, sr = 0, sd = 0, sc = 0;
         if (t < n_tiles) {
             const uint4 v = desc[t];
-            sc = v.x & 0x7FFFFFFFu;
+            sc = v.x & 0x3FFFFFFFu;
             f = v.x >> 31;
             sr = v.y;
             sd = v.z;
-            if (sc > (uint32_t)kSlab) dense_list[atomicAdd(n_dense, 1u)] = t;
+            if (sc > (uint32_t)kSlab || (v.x & kDescForceDense)) dense_list[atomicAdd(n_dense, 1u)] = t;
         }
         SVX_SEG_SCAN()
         if (lane == 63) { s_f[wave] = f; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
@@ -481,8 +515,8 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_gather(CigarArgs p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves) {
         const uint4 dsc = p.desc[tile];
-        const uint32_t cnt = dsc.x & 0x7FFFFFFFu;
-        if (cnt == 0 || cnt > (uint32_t)kSlab) continue;
+        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
+        if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) continue;
         const uint32_t a_lo = dsc.w;
         const uint4 bp = p.blk_prefix[tile / kScanBlock];
         const uint32_t lb = p.out_base[tile];
