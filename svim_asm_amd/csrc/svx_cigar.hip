@@ -180,6 +180,7 @@ enum { WALK_TOTALS = 0, WALK_QUEUE = 1, WALK_DIRECT = 2 };
 
 // per-lane results of one walk over the lane's 16 consecutive ops
 struct WalkOut {
+    uint32_t tot_r, tot_d;    // plain cursor sums over the lane's 16 ops
     uint32_t tail_r, tail_d;  // cursor sums since the last alignment start inside the lane (or lane start)
     uint32_t n_emit;          // emitting ops of this lane
     uint32_t n_queued;        // wave-uniform: signatures queued this round (WALK_QUEUE)
@@ -203,9 +204,12 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
                                           const DirectCtx& dc) {
     uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
     const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane < 32 ? 0u : 1u << (lane - 32);
+    uint4 nxt = myx[0];
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
-        const uint4 v4 = myx[j];
+        const uint4 v4 = nxt;
+        nxt = myx[(j + 1) & 3];  // LDS read of the next group overlaps this group's math
         const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
         const uint32_t hu4 = HU >> (4 * j), hm4 = hm >> (4 * j);
 #pragma unroll
@@ -214,12 +218,15 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
             if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
             else { op = wv[t] & 15u; len = wv[t] >> 4; }
             if ((hu4 >> t) & 1u) {  // scalar test: some lane starts an alignment at this slot
+                asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch, not two selects per op
                 if ((hm4 >> t) & 1u) { base_r = rr; base_d = rd; }
             }
-            const bool em = (op - 1u) < 2u && len >= p.min_len;  // I or D, inclusive threshold (:18,:22)
-            const uint64_t eb = __ballot(em);
+            // I or D with len >= min_len (inclusive threshold, :18,:22): two compares straight into
+            // scalar masks; the per-lane predicate is only derived inside the rarely taken branch
+            const uint64_t eb = __builtin_amdgcn_ballot_w64((op - 1u) < 2u) &
+                                __builtin_amdgcn_ballot_w64(len >= p.min_len);
             if (eb) {  // wave-uniform: most op slots emit nothing
-                if (em) {
+                if (((uint32_t)eb & lane_lo) | ((uint32_t)(eb >> 32) & lane_hi)) {
                     const uint32_t i = 4 * j + t;
                     if (WALK == WALK_QUEUE) {
                         const uint32_t qi = qn + __popcll(eb & lt);
@@ -249,6 +256,8 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
         }
     }
     WalkOut o;
+    o.tot_r = rr;
+    o.tot_d = rd;
     o.tail_r = rr - base_r;
     o.tail_d = rd - base_d;
     o.n_emit = n_emit;
@@ -361,14 +370,28 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
             const WalkOut wo = walk16<(MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS, SOA>(
                 p, myx, opw, hm, hmo, HU, lane, queue, dc);
 
-            // ---- wave scans (DPP): segmented (flag, ref, read) and plain count ----
-            uint32_t f = hm != 0 ? 1u : 0u, sr = wo.tail_r, sd = wo.tail_d, sc = wo.n_emit;
-            SVX_SEG_SCAN()
-            const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
-                           xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
+            // ---- wave scans (DPP).  Plain inclusive sums of the lane totals and counts; the
+            // segmentation is applied afterwards: the carry-in of lane l is its exclusive sum plus
+            // Q(h) = tail(h) - P(h) of the last lane h < l that holds an alignment start (ballot +
+            // one ds_bpermute per cursor), or plus the round's carry when there is none. ----
+            uint32_t pr = wo.tot_r, pd = wo.tot_d, sc = wo.n_emit;
+#define SVX_ADD3_STEP(CTRL, RM) \
+            pr += dpp0<CTRL, RM>(pr); pd += dpp0<CTRL, RM>(pd); sc += dpp0<CTRL, RM>(sc);
+            SVX_ADD3_STEP(kDppShr1, 0xF) SVX_ADD3_STEP(kDppShr2, 0xF) SVX_ADD3_STEP(kDppShr4, 0xF)
+            SVX_ADD3_STEP(kDppShr8, 0xF) SVX_ADD3_STEP(kDppBcast15, 0xA) SVX_ADD3_STEP(kDppBcast31, 0xC)
+#undef SVX_ADD3_STEP
+            const uint32_t xr = dpp0<kDppWaveShr1, 0xF>(pr), xd = dpp0<kDppWaveShr1, 0xF>(pd),
+                           xc = dpp0<kDppWaveShr1, 0xF>(sc);
             const uint32_t C = __builtin_amdgcn_readlane(sc, 63);
-            const uint32_t in_r = xf ? xr : xr + carry_r;   // lane carry-in
-            const uint32_t in_d = xf ? xd : xd + carry_d;
+            const uint64_t H = __builtin_amdgcn_ballot_w64(hm != 0);
+            const uint64_t hl = H & ((1ull << lane) - 1ull);
+            const uint32_t qr = wo.tail_r - pr, qd = wo.tail_d - pd;
+            const bool xf = hl != 0;  // a start in an earlier lane of this round
+            const int hsrc = xf ? 63 - __clzll((long long)hl) : 0;
+            const uint32_t gq_r = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qr);
+            const uint32_t gq_d = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qd);
+            const uint32_t in_r = xr + (xf ? gq_r : carry_r);   // lane carry-in
+            const uint32_t in_d = xd + (xf ? gq_d : carry_d);
 
             if (MODE == MODE_STAGE) {
                 if (C) {  // wave-uniform
@@ -405,11 +428,17 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
             }
             wave_lds_sync();  // queue / lcarry / xp are rewritten by the next round
 
-            // ---- carry to the next round (wave-uniform: lane 63's inclusive values) ----
-            const uint32_t F = __builtin_amdgcn_readlane(f, 63), R = __builtin_amdgcn_readlane(sr, 63),
-                           D = __builtin_amdgcn_readlane(sd, 63);
-            if (F) { carry_r = R; carry_d = D; seen = true; }
-            else { carry_r += R; carry_d += D; }
+            // ---- carry to the next round (wave-uniform) ----
+            const uint32_t R = __builtin_amdgcn_readlane(pr, 63), D = __builtin_amdgcn_readlane(pd, 63);
+            if (H) {
+                const int hlast = 63 - __clzll((long long)H);
+                carry_r = R + __builtin_amdgcn_readlane(qr, hlast);
+                carry_d = D + __builtin_amdgcn_readlane(qd, hlast);
+                seen = true;
+            } else {
+                carry_r += R;
+                carry_d += D;
+            }
             tile_cnt += C;
         }
 
