@@ -34,7 +34,7 @@ constexpr int kRounds = 4;
 constexpr int kTileOps = kRoundOps * kRounds;  // 4096 ops per tile (16 KiB)
 constexpr int kSlab = 256;                     // staged signatures per tile
 constexpr int kWaves = 4;                      // waves (= tiles) per workgroup
-constexpr int kXposeU4 = 64 * 5;               // padded transpose buffer: 5 uint4 per lane
+constexpr int kXposeU4 = 64 * 4;               // transpose buffer: 4 uint4 per lane, XOR-swizzled
 constexpr int kScanBlock = 1024;               // tile descriptors per scan workgroup
 
 enum { MODE_STAGE = 0, MODE_DIRECT = 1 };
@@ -173,7 +173,7 @@ __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_b
 #ifndef SVX_TILE_MIN_WAVES
 #define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int kQueue = 64;  // signatures one round may queue in LDS (one flush lane each)
+constexpr int kQueue = 32;  // signatures one round may queue in LDS (one flush lane each)
 constexpr uint32_t kDescForceDense = 1u << 30;  // descriptor flag: a round overflowed the queue
 
 enum { WALK_TOTALS = 0, WALK_QUEUE = 1, WALK_DIRECT = 2 };
@@ -199,17 +199,17 @@ struct DirectCtx {
 // starts and emitting ops are rare: both are handled under wave-uniform branches (HU / ballot),
 // the common per-op path is decode + two masked adds.
 template <int WALK, bool SOA>
-__device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, const uint32_t (&opw)[4],
+__device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, int swz, const uint32_t (&opw)[4],
                                           uint32_t hm, uint32_t hmo, uint32_t HU, int lane, uint4* queue,
                                           const DirectCtx& dc) {
     uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane < 32 ? 0u : 1u << (lane - 32);
-    uint4 nxt = myx[0];
+    uint4 nxt = myx[swz];
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
         const uint4 v4 = nxt;
-        nxt = myx[(j + 1) & 3];  // LDS read of the next group overlaps this group's math
+        nxt = myx[((j + 1) & 3) ^ swz];  // LDS read of the next group overlaps this group's math
         const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
         const uint32_t hu4 = HU >> (4 * j), hm4 = hm >> (4 * j);
 #pragma unroll
@@ -280,7 +280,6 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ uint32_t s_head[kWaves][kTileOps / 32];
     __shared__ uint4 s_queue[kWaves][kQueue];
-    __shared__ uint4 s_carry[kWaves][64];
 
     // the wave index is wave-uniform: tell the compiler so that tile indices, loop bounds and
     // carries live in SGPRs and the tile/round loops are scalar branches
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
     uint4* xp = s_xpose[wave];
     uint32_t* hmask = s_head[wave];
     uint4* queue = s_queue[wave];
-    uint4* lcarry = s_carry[wave];
+    uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
 
     uint32_t work = blockIdx.x * kWaves + wave;
     const uint32_t work_stride = gridDim.x * kWaves;
@@ -346,11 +345,14 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
             const uint32_t ro = (uint32_t)round * kRoundOps;
             if (ro >= tile_len) break;  // wave-uniform
 
-            // ---- transpose through wave-private LDS: 5-uint4 stride per lane is conflict-free ----
+            // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
+            // c = i >> 2 as its p = i & 3 -th group; it is stored at c*4 + (p ^ ((c >> 2) & 3)), which
+            // keeps both the ds_write_b128 and the per-group ds_read_b128 bank-conflict free ----
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = k * 64 + lane;
-                xp[(i >> 2) * 5 + (i & 3)] = q[k];
+                const int c = i >> 2;
+                xp[c * 4 + ((i & 3) ^ ((c >> 2) & 3))] = q[k];
             }
             const uint4 opw4 = qo;
             // software pipeline: next round's global loads are in flight during this round's math
@@ -363,12 +365,13 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
             uint32_t hmo = hm;  // prefix-OR: bit i set iff an alignment start sits at a slot <= i
             hmo |= hmo << 1; hmo |= hmo << 2; hmo |= hmo << 4; hmo |= hmo << 8;
             const uint32_t HU = wave_or_u32(hm);  // slots where ANY lane starts an alignment (SGPR)
-            const uint4* myx = xp + lane * 5;     // this lane's 16 consecutive ops, 4 per uint4
+            const uint4* myx = xp + lane * 4;     // this lane's 16 consecutive ops, 4 per uint4 (swizzled)
+            const int swz = (lane >> 2) & 3;
 
             DirectCtx dc;
             dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
             const WalkOut wo = walk16<(MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS, SOA>(
-                p, myx, opw, hm, hmo, HU, lane, queue, dc);
+                p, myx, swz, opw, hm, hmo, HU, lane, queue, dc);
 
             // ---- wave scans (DPP).  Plain inclusive sums of the lane totals and counts; the
             // segmentation is applied afterwards: the carry-in of lane l is its exclusive sum plus
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
                 if (C) {  // dense tile: second walk finishes each signature on the spot
                     dc.in_r = in_r; dc.in_d = in_d;
                     dc.out0 = (uint64_t)obase + tile_cnt + xc;
-                    (void)walk16<WALK_DIRECT, SOA>(p, myx, opw, hm, hmo, HU, lane, queue, dc);
+                    (void)walk16<WALK_DIRECT, SOA>(p, myx, swz, opw, hm, hmo, HU, lane, queue, dc);
                 }
             }
             wave_lds_sync();  // queue / lcarry / xp are rewritten by the next round

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect PMC counters of the bench kernels in separate passes (rocprofv3 --pmc; no sys/hip tracing).
+# usage: tools/pmc.sh <outdir> [bench args...]
+out=$1; shift
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
+           "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out" -o pass$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > /dev/null 2>> "$out/err.txt"
+done
+python3 - "$out" <<'PY'
+import csv, collections, glob, json, sys
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(out + "/pass*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "svx" in k or "anonymous" in k:
+            short = k.split("(")[0].split("::")[-1] + ("<DIRECT>" if "<1," in k else "")
+            agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[short]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
+for k, d in res.items():
+    print(k, json.dumps({c: round(v) for c, v in sorted(d.items())}))
+PY
