@@ -54,7 +54,7 @@ struct CigarArgs {
     uint32_t* carry_ref;
     uint32_t* carry_read;
     uint32_t* dense_list;
-    uint32_t* n_dense;   // [0] dense-tile count, [1] scan ticket
+    uint32_t* n_dense;   // [0] dense-tile counter, [1] scan ticket (both left at 0 by the scan), [2] published count
     uint4* blk_agg;      // per scan block: {has_start, ref_tail, read_tail, count}
     uint4* blk_prefix;   // exclusive scan of blk_agg
     svx_sig_soa out;
@@ -203,8 +203,10 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
                                           uint32_t hm, uint32_t hmo, uint32_t HU, int lane, uint4* queue,
                                           const DirectCtx& dc) {
     uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t lane_lo = lane < 32 ? 1u << lane : 0u, lane_hi = lane < 32 ? 0u : 1u << (lane - 32);
+    uint32_t hs = 0;  // this lane has passed an alignment start
+#ifdef SVX_EXP_NOWALK  // perf experiment only: memory + scan floor without the per-op work
+    { const uint4 v = myx[swz]; WalkOut o; o.tot_r = v.x; o.tot_d = v.y; o.tail_r = v.z; o.tail_d = v.w; o.n_emit = 0; o.n_queued = 0; return o; }
+#endif
     uint4 nxt = myx[swz];
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
@@ -219,28 +221,29 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
             else { op = wv[t] & 15u; len = wv[t] >> 4; }
             if ((hu4 >> t) & 1u) {  // scalar test: some lane starts an alignment at this slot
                 asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch, not two selects per op
-                if ((hm4 >> t) & 1u) { base_r = rr; base_d = rd; }
+                if ((hm4 >> t) & 1u) { base_r = rr; base_d = rd; hs = 1u; }
             }
             // I or D with len >= min_len (inclusive threshold, :18,:22): two compares straight into
             // scalar masks; the per-lane predicate is only derived inside the rarely taken branch
             const uint64_t eb = __builtin_amdgcn_ballot_w64((op - 1u) < 2u) &
                                 __builtin_amdgcn_ballot_w64(len >= p.min_len);
             if (eb) {  // wave-uniform: most op slots emit nothing
-                if (((uint32_t)eb & lane_lo) | ((uint32_t)(eb >> 32) & lane_hi)) {
+                if ((op - 1u) < 2u && len >= p.min_len) {
                     const uint32_t i = 4 * j + t;
                     if (WALK == WALK_QUEUE) {
-                        const uint32_t qi = qn + __popcll(eb & lt);
+                        // rank among the lanes emitting at this slot: mbcnt over the scalar mask
+                        const uint32_t qi = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(eb >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)eb, 0u));
                         if (qi < (uint32_t)kQueue) {
                             // meta: lane | slot << 6 | (start at/before op i inside this lane) << 10 |
-                            //       index among the lane's signatures << 11 | op << 16
-                            const uint32_t meta = (uint32_t)lane | (i << 6) | (((hmo >> i) & 1u) << 10) |
-                                                  (n_emit << 11) | (op << 16);
+                            //       index among the lane's signatures << 11 | op << 16 (SoA only)
+                            const uint32_t meta = (uint32_t)lane | (i << 6) | (hs << 10) | (n_emit << 11) |
+                                                  (SOA ? (op << 16) : 0u);
                             queue[qi] = make_uint4(rr - base_r, rd - base_d, SOA ? len : wv[t], meta);
                         }
                     } else if (WALK == WALK_DIRECT) {
-                        const bool own = ((hmo >> i) & 1u) != 0;
-                        const uint32_t ref = rr - base_r + (own ? 0u : dc.in_r);
-                        const uint32_t rdp = rd - base_d + (own ? 0u : dc.in_d);
+                        const uint32_t ref = rr - base_r + (hs ? 0u : dc.in_r);
+                        const uint32_t rdp = rd - base_d + (hs ? 0u : dc.in_d);
                         const uint32_t aln = find_aln(p.aln_off, p.n_aln, dc.a_lo, dc.g_lane0 + i);
                         store_final(p, dc.out0 + n_emit, aln, ref, rdp, len, (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS);
                     }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
 
     uint32_t work = blockIdx.x * kWaves + wave;
     const uint32_t work_stride = gridDim.x * kWaves;
-    const uint32_t n_work = (MODE == MODE_DIRECT) ? *p.n_dense : p.n_tiles;
+    const uint32_t n_work = (MODE == MODE_DIRECT) ? p.n_dense[2] : p.n_tiles;
 
     for (; work < n_work; work += work_stride) {
         const uint32_t tile = (MODE == MODE_DIRECT) ? p.dense_list[work] : work;
@@ -539,13 +542,22 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
             blk_prefix[b] = make_uint4(xf | pf, xf ? xr : pr_ + xr, xf ? xd : pd_ + xd, (uint32_t)(pc + xc));
         cf = af; cr = ar; cd = ad; cc = ac;
     }
-    if (tid == 0) *n_out = cc;
+    if (tid == 0) {
+        *n_out = cc;
+        // publish the dense-tile count and leave the counters zeroed for the next call
+        n_dense[2] = n_dense[0];
+        n_dense[0] = 0;
+        *ticket = 0;
+    }
 }
 
 // ---- C: gather sparse tiles' staged signatures into the final SoA ----
 __global__ __launch_bounds__(64 * kWaves) void k_cigar_gather(CigarArgs p) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves) {
+    // half a wave per sparse tile (a tile of 4096 ops carries ~30 signatures): lane = signature
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane >> 5, l32 = lane & 31;
+    for (uint32_t pair = blockIdx.x * kWaves + wave; pair * 2 < p.n_tiles; pair += gridDim.x * kWaves) {
+        const uint32_t tile = pair * 2 + sub;
+        if (tile >= p.n_tiles) continue;
         const uint4 dsc = p.desc[tile];
         const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
         if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) continue;
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_gather(CigarArgs p) {
         const uint32_t cd = p.carry_read[tile] + (local_head ? 0u : bp.z);
         const uint64_t ob = (uint64_t)(lb & 0x7FFFFFFFu) + bp.w;
         const uint64_t g0 = (uint64_t)tile * kTileOps;
-        for (uint32_t r = lane; r < cnt; r += 64) {
+        for (uint32_t r = l32; r < cnt; r += 32) {
             const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
             const uint32_t loc = rec.x & 0xFFFu, type = (rec.x >> 12) & 1u, prec = (rec.x >> 13) & 1u;
             const uint32_t aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + loc);
@@ -663,13 +675,13 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     a.n_aln = n_aln;
     a.n_tiles = n_tiles;
     a.min_len = min_len;
+    a.n_dense = reinterpret_cast<uint32_t*>(ctx->ws);  // workspace header: zero at allocation, self-cleaning
     a.desc = svx_ws_take<uint4>(ctx, n_tiles);
     a.slab = svx_ws_take<uint4>(ctx, (size_t)n_tiles * kSlab);
     a.out_base = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.carry_ref = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.carry_read = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.dense_list = svx_ws_take<uint32_t>(ctx, n_tiles);
-    a.n_dense = svx_ws_take<uint32_t>(ctx, 4);
     const uint32_t n_scan_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
     a.blk_agg = svx_ws_take<uint4>(ctx, n_scan_blocks);
     a.blk_prefix = svx_ws_take<uint4>(ctx, n_scan_blocks);
@@ -680,7 +692,6 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t blocks_cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
-    SVX_HIP(ctx, hipMemsetAsync(a.n_dense, 0, 4 * sizeof(uint32_t), ctx->stream));
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
     hipLaunchKernelGGL((k_cigar_tiles<MODE_STAGE, SOA>), dim3(blocks_all), dim3(64 * kWaves), 0,
@@ -690,10 +701,13 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     hipLaunchKernelGGL(k_desc_scan, dim3(n_scan_blocks), dim3(kScanBlock), 0, ctx->stream, a.desc, n_tiles,
                        a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
                        a.blk_prefix, a.n_dense + 1, d_n_out);
-    hipLaunchKernelGGL(k_cigar_gather, dim3(blocks_all < blocks_cap ? blocks_all : blocks_cap),
+    const uint32_t blocks_gather = (blocks_all + 1) / 2;
+    hipLaunchKernelGGL(k_cigar_gather, dim3(blocks_gather < blocks_cap ? blocks_gather : blocks_cap),
                        dim3(64 * kWaves), 0, ctx->stream, a);
+    // dense tiles are rare: a small grid that exits at once when the published count is 0
+    const uint32_t blocks_dense = (uint32_t)ctx->n_cu;
     hipLaunchKernelGGL((k_cigar_tiles<MODE_DIRECT, SOA>),
-                       dim3(blocks_all < blocks_cap ? blocks_all : blocks_cap), dim3(64 * kWaves), 0,
+                       dim3(blocks_all < blocks_dense ? blocks_all : blocks_dense), dim3(64 * kWaves), 0,
                        ctx->stream, a);
     SVX_HIP(ctx, hipGetLastError());
     return svx_timing_end(ctx);

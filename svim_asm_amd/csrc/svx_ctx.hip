@@ -84,12 +84,16 @@ static int grow(svx_ctx* ctx, char** buf, size_t* have, size_t want) {
     }
     *buf = static_cast<char*>(p);
     *have = sz;
+    // kernels keep self-cleaning counters at the start of the workspace: they start out as zero
+    SVX_HIP(ctx, hipMemsetAsync(p, 0, 4096, ctx->stream));
     return SVX_OK;
 }
 
 int svx_ws_reserve(svx_ctx* ctx, size_t total) {
-    ctx->ws_used = 0;
-    return grow(ctx, &ctx->ws, &ctx->ws_bytes, total);
+    // the first 4 KiB of the workspace are a header of self-cleaning counters (zeroed at
+    // allocation, left at zero by the kernels that use them); per-call scratch starts after it
+    ctx->ws_used = 4096;
+    return grow(ctx, &ctx->ws, &ctx->ws_bytes, total + 4096);
 }
 int svx_stage_reserve(svx_ctx* ctx, size_t total) {
     ctx->stage_used = 0;
