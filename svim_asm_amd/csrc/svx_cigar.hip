@@ -200,7 +200,7 @@ struct DirectCtx {
 // the common per-op path is decode + two masked adds.
 template <int WALK, bool SOA>
 __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, int swz, const uint32_t (&opw)[4],
-                                          uint32_t hm, uint32_t hmo, uint32_t HU, int lane, uint4* queue,
+                                          uint32_t hm, uint32_t HU, int lane, uint4* queue,
                                           const DirectCtx& dc) {
     uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
     uint32_t hs = 0;  // this lane has passed an alignment start
@@ -278,181 +278,188 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
 #define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
 
+// One tile (4096 ops) processed by one wave.  MODE_STAGE: signatures go to the tile's slab with
+// tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
 template <int MODE, bool SOA>
+__device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t tile, const int lane, uint4* xp,
+                                             uint32_t* hmask, uint4* queue) {
+    uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
+    const uint64_t g0 = (uint64_t)tile * kTileOps;
+    const uint64_t tile_end = (g0 + kTileOps < p.n_ops) ? g0 + kTileOps : p.n_ops;
+
+    // first round's loads go out before the (latency-bound) alignment-start lookup
+    const uint32_t tile_len = (uint32_t)(tile_end - g0);
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.cigar + g0, tile_len * 4u);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(SOA ? (const void*)(p.op + g0) : (const void*)p.cigar,
+                                                  SOA ? tile_len : 0u);
+    uint4 q[4], qo = make_uint4(0, 0, 0, 0);
+    load_round<SOA>(rs_c, rs_o, 0u, lane, q, qo);
+
+    // ---- alignment starts inside this tile → 4096-bit mask in LDS; `dup` = two alignments start
+    // at the same op (empty alignments), which disables the popcount shortcut for the index ----
+    const uint32_t a_lo = __builtin_amdgcn_readfirstlane(wave_lower_bound(p.aln_off, p.n_aln + 1, g0, lane));
+    hmask[lane] = 0;
+    hmask[lane + 64] = 0;
+    wave_lds_sync();
+    bool dup = false;
+    for (uint64_t a = (uint64_t)a_lo + lane;; a += 64) {
+        bool in = false, twice = false;
+        if (a < p.n_aln) {
+            uint64_t off = p.aln_off[a];
+            if (off < tile_end) {
+                in = true;
+                const uint32_t bit = (uint32_t)(off - g0);
+                twice = (atomicOr(&hmask[bit >> 5], 1u << (bit & 31)) >> (bit & 31)) & 1u;
+            }
+        }
+        dup = dup || __any(twice);
+        if (!__all(in)) break;
+    }
+    wave_lds_sync();
+
+    // ---- tile state carried across rounds (wave-uniform) ----
+    uint32_t carry_r = 0, carry_d = 0;
+    bool seen = false, overflow = false;
+    uint32_t tile_cnt = 0, heads_before = 0;
+    uint32_t obase = 0;
+    if (MODE == MODE_DIRECT) {
+        const uint4 bp = p.blk_prefix[tile / kScanBlock];
+        const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
+        const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
+        carry_r = local_head ? lr : lr + bp.y;
+        carry_d = local_head ? ld : ld + bp.z;
+        seen = true;  // carry-in already holds "since the last start before the tile"
+        obase = (lb & 0x7FFFFFFFu) + bp.w;
+    }
+
+    for (int round = 0; round < kRounds; ++round) {
+        const uint32_t ro = (uint32_t)round * kRoundOps;
+        if (ro >= tile_len) break;  // wave-uniform
+
+        // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
+        // c = i >> 2 as its p = i & 3 -th group; it is stored at c*4 + (p ^ ((c >> 2) & 3)), which
+        // keeps both the ds_write_b128 and the per-group ds_read_b128 bank-conflict free ----
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = k * 64 + lane;
+            const int c = i >> 2;
+            xp[c * 4 + ((i & 3) ^ ((c >> 2) & 3))] = q[k];
+        }
+        const uint4 opw4 = qo;
+        // software pipeline: next round's global loads are in flight during this round's math
+        if (round + 1 < kRounds && ro + kRoundOps < tile_len)
+            load_round<SOA>(rs_c, rs_o, ro + kRoundOps, lane, q, qo);
+        wave_lds_sync();
+        const uint32_t lbase = round * kRoundOps + lane * kLaneOps;  // tile-local index of op 0
+        const uint32_t hm = (hmask[lbase >> 5] >> (lbase & 31)) & 0xFFFFu;
+        const uint32_t opw[4] = {opw4.x, opw4.y, opw4.z, opw4.w};
+        const uint32_t HU = wave_or_u32(hm);  // slots where ANY lane starts an alignment (SGPR)
+        const uint4* myx = xp + lane * 4;     // this lane's 16 consecutive ops, 4 per uint4 (swizzled)
+        const int swz = (lane >> 2) & 3;
+
+        DirectCtx dc;
+        dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
+        const WalkOut wo = walk16<(MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS, SOA>(
+            p, myx, swz, opw, hm, HU, lane, queue, dc);
+
+        // ---- wave scans (DPP).  Plain inclusive sums of the lane totals, signature counts and
+        // alignment-start counts; the segmentation is applied afterwards: the carry-in of lane l is
+        // its exclusive sum plus Q(h) = tail(h) - P(h) of the last lane h < l that holds an
+        // alignment start (ballot + one ds_bpermute per cursor), or plus the round's carry. ----
+        uint32_t pr = wo.tot_r, pd = wo.tot_d, sc = wo.n_emit | ((uint32_t)__popc(hm) << 16);
+#define SVX_ADD3_STEP(CTRL, RM) \
+        pr += dpp0<CTRL, RM>(pr); pd += dpp0<CTRL, RM>(pd); sc += dpp0<CTRL, RM>(sc);
+        SVX_ADD3_STEP(kDppShr1, 0xF) SVX_ADD3_STEP(kDppShr2, 0xF) SVX_ADD3_STEP(kDppShr4, 0xF)
+        SVX_ADD3_STEP(kDppShr8, 0xF) SVX_ADD3_STEP(kDppBcast15, 0xA) SVX_ADD3_STEP(kDppBcast31, 0xC)
+#undef SVX_ADD3_STEP
+        // sc packs two counters: signatures (low 16 bits, <= 1024) and alignment starts (high 16 bits)
+        const uint32_t xr = dpp0<kDppWaveShr1, 0xF>(pr), xd = dpp0<kDppWaveShr1, 0xF>(pd),
+                       xch = dpp0<kDppWaveShr1, 0xF>(sc);
+        const uint32_t xc = xch & 0xFFFFu;
+        const uint32_t CH = __builtin_amdgcn_readlane(sc, 63);
+        const uint32_t C = CH & 0xFFFFu;
+        const uint64_t H = __builtin_amdgcn_ballot_w64(hm != 0);
+        const uint64_t hl = H & ((1ull << lane) - 1ull);
+        const uint32_t qr = wo.tail_r - pr, qd = wo.tail_d - pd;
+        const bool xf = hl != 0;  // a start in an earlier lane of this round
+        const int hsrc = xf ? 63 - __clzll((long long)hl) : 0;
+        const uint32_t gq_r = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qr);
+        const uint32_t gq_d = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qd);
+        const uint32_t in_r = xr + (xf ? gq_r : carry_r);   // lane carry-in
+        const uint32_t in_d = xd + (xf ? gq_d : carry_d);
+
+        if (MODE == MODE_STAGE) {
+            if (C) {  // wave-uniform
+                // .z: signatures before this lane | "still lacks the tile's carry-in" << 31
+                // .w: alignment starts before this lane in the round | this lane's start mask << 16
+                lcarry[lane] = make_uint4(in_r, in_d, xc | ((!seen && !xf) ? 0x80000000u : 0u), (xch >> 16) | (hm << 16));
+                wave_lds_sync();
+                const uint32_t n_here = wo.n_queued < (uint32_t)kQueue ? wo.n_queued : (uint32_t)kQueue;
+                if ((uint32_t)lane < n_here) {
+                    const uint4 e = queue[lane];
+                    const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 15u, own = (e.w >> 10) & 1u,
+                                   li = (e.w >> 11) & 31u;
+                    const uint4 cin = lcarry[L];
+                    const uint32_t ref = own ? e.x : e.x + cin.x;
+                    const uint32_t rdp = own ? e.y : e.y + cin.y;
+                    const uint32_t prec = own ? 0u : (cin.z >> 31);
+                    uint32_t op, len;
+                    if (SOA) { op = (e.w >> 16) & 0xFFu; len = e.z; }
+                    else { op = e.z & 15u; len = e.z >> 4; }
+                    const uint32_t type = (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
+                    const uint32_t rank = tile_cnt + (cin.z & 0xFFFFu) + li;
+                    if (rank < (uint32_t)kSlab) {
+                        // alignment index: a_lo - 1 + (alignment starts at or before the op inside the tile)
+                        const uint32_t m = heads_before + (cin.w & 0xFFFFu) + __popc((cin.w >> 16) & ((2u << slot) - 1u));
+                        uint32_t aln = a_lo + m - 1u;
+                        if (dup) aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + round * kRoundOps + L * kLaneOps + slot);
+                        p.slab[(uint64_t)tile * kSlab + rank] = make_uint4(aln, ref, rdp, len | (type << 28) | (prec << 29));
+                    }
+                }
+                if (wo.n_queued > (uint32_t)kQueue) overflow = true;
+            }
+        } else {
+            if (C) {  // dense tile: second walk finishes each signature on the spot
+                dc.in_r = in_r; dc.in_d = in_d;
+                dc.out0 = (uint64_t)obase + tile_cnt + xc;
+                (void)walk16<WALK_DIRECT, SOA>(p, myx, swz, opw, hm, HU, lane, queue, dc);
+            }
+        }
+        wave_lds_sync();  // queue / lcarry / xp are rewritten by the next round
+
+        // ---- carry to the next round (wave-uniform) ----
+        const uint32_t R = __builtin_amdgcn_readlane(pr, 63), D = __builtin_amdgcn_readlane(pd, 63);
+        if (H) {
+            const int hlast = 63 - __clzll((long long)H);
+            carry_r = R + __builtin_amdgcn_readlane(qr, hlast);
+            carry_d = D + __builtin_amdgcn_readlane(qd, hlast);
+            seen = true;
+        } else {
+            carry_r += R;
+            carry_d += D;
+        }
+        tile_cnt += C;
+        heads_before += CH >> 16;
+    }
+
+    if (MODE == MODE_STAGE && lane == 0) {
+        p.desc[tile] = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31),
+                                  carry_r, carry_d, a_lo);
+    }
+}
+
+// ---- A: stream every tile once ----
+template <bool SOA>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ uint32_t s_head[kWaves][kTileOps / 32];
     __shared__ uint4 s_queue[kWaves][kQueue];
-
     // the wave index is wave-uniform: tell the compiler so that tile indices, loop bounds and
     // carries live in SGPRs and the tile/round loops are scalar branches
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    uint4* xp = s_xpose[wave];
-    uint32_t* hmask = s_head[wave];
-    uint4* queue = s_queue[wave];
-    uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
-
-    uint32_t work = blockIdx.x * kWaves + wave;
-    const uint32_t work_stride = gridDim.x * kWaves;
-    const uint32_t n_work = (MODE == MODE_DIRECT) ? p.n_dense[2] : p.n_tiles;
-
-    for (; work < n_work; work += work_stride) {
-        const uint32_t tile = (MODE == MODE_DIRECT) ? p.dense_list[work] : work;
-        const uint64_t g0 = (uint64_t)tile * kTileOps;
-        const uint64_t tile_end = (g0 + kTileOps < p.n_ops) ? g0 + kTileOps : p.n_ops;
-
-        // first round's loads go out before the (latency-bound) alignment-start lookup
-        const uint32_t tile_len = (uint32_t)(tile_end - g0);
-        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.cigar + g0, tile_len * 4u);
-        const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(SOA ? (const void*)(p.op + g0) : (const void*)p.cigar,
-                                                      SOA ? tile_len : 0u);
-        uint4 q[4], qo = make_uint4(0, 0, 0, 0);
-        load_round<SOA>(rs_c, rs_o, 0u, lane, q, qo);
-
-        // ---- alignment starts inside this tile → 4096-bit mask in LDS ----
-        const uint32_t a_lo = __builtin_amdgcn_readfirstlane(wave_lower_bound(p.aln_off, p.n_aln + 1, g0, lane));
-        hmask[lane] = 0;
-        hmask[lane + 64] = 0;
-        wave_lds_sync();
-        for (uint64_t a = (uint64_t)a_lo + lane;; a += 64) {
-            bool in = false;
-            if (a < p.n_aln) {
-                uint64_t off = p.aln_off[a];
-                if (off < tile_end) {
-                    in = true;
-                    uint32_t bit = (uint32_t)(off - g0);
-                    atomicOr(&hmask[bit >> 5], 1u << (bit & 31));
-                }
-            }
-            if (!__all(in)) break;
-        }
-        wave_lds_sync();
-
-        // ---- tile state carried across rounds (wave-uniform) ----
-        uint32_t carry_r = 0, carry_d = 0;
-        bool seen = false, overflow = false;
-        uint32_t tile_cnt = 0;
-        uint32_t obase = 0;
-        if (MODE == MODE_DIRECT) {
-            const uint4 bp = p.blk_prefix[tile / kScanBlock];
-            const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
-            const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
-            carry_r = local_head ? lr : lr + bp.y;
-            carry_d = local_head ? ld : ld + bp.z;
-            seen = true;  // carry-in already holds "since the last start before the tile"
-            obase = (lb & 0x7FFFFFFFu) + bp.w;
-        }
-
-        for (int round = 0; round < kRounds; ++round) {
-            const uint32_t ro = (uint32_t)round * kRoundOps;
-            if (ro >= tile_len) break;  // wave-uniform
-
-            // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
-            // c = i >> 2 as its p = i & 3 -th group; it is stored at c*4 + (p ^ ((c >> 2) & 3)), which
-            // keeps both the ds_write_b128 and the per-group ds_read_b128 bank-conflict free ----
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = k * 64 + lane;
-                const int c = i >> 2;
-                xp[c * 4 + ((i & 3) ^ ((c >> 2) & 3))] = q[k];
-            }
-            const uint4 opw4 = qo;
-            // software pipeline: next round's global loads are in flight during this round's math
-            if (round + 1 < kRounds && ro + kRoundOps < tile_len)
-                load_round<SOA>(rs_c, rs_o, ro + kRoundOps, lane, q, qo);
-            wave_lds_sync();
-            const uint32_t lbase = round * kRoundOps + lane * kLaneOps;  // tile-local index of op 0
-            const uint32_t hm = (hmask[lbase >> 5] >> (lbase & 31)) & 0xFFFFu;
-            const uint32_t opw[4] = {opw4.x, opw4.y, opw4.z, opw4.w};
-            uint32_t hmo = hm;  // prefix-OR: bit i set iff an alignment start sits at a slot <= i
-            hmo |= hmo << 1; hmo |= hmo << 2; hmo |= hmo << 4; hmo |= hmo << 8;
-            const uint32_t HU = wave_or_u32(hm);  // slots where ANY lane starts an alignment (SGPR)
-            const uint4* myx = xp + lane * 4;     // this lane's 16 consecutive ops, 4 per uint4 (swizzled)
-            const int swz = (lane >> 2) & 3;
-
-            DirectCtx dc;
-            dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
-            const WalkOut wo = walk16<(MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS, SOA>(
-                p, myx, swz, opw, hm, hmo, HU, lane, queue, dc);
-
-            // ---- wave scans (DPP).  Plain inclusive sums of the lane totals and counts; the
-            // segmentation is applied afterwards: the carry-in of lane l is its exclusive sum plus
-            // Q(h) = tail(h) - P(h) of the last lane h < l that holds an alignment start (ballot +
-            // one ds_bpermute per cursor), or plus the round's carry when there is none. ----
-            uint32_t pr = wo.tot_r, pd = wo.tot_d, sc = wo.n_emit;
-#define SVX_ADD3_STEP(CTRL, RM) \
-            pr += dpp0<CTRL, RM>(pr); pd += dpp0<CTRL, RM>(pd); sc += dpp0<CTRL, RM>(sc);
-            SVX_ADD3_STEP(kDppShr1, 0xF) SVX_ADD3_STEP(kDppShr2, 0xF) SVX_ADD3_STEP(kDppShr4, 0xF)
-            SVX_ADD3_STEP(kDppShr8, 0xF) SVX_ADD3_STEP(kDppBcast15, 0xA) SVX_ADD3_STEP(kDppBcast31, 0xC)
-#undef SVX_ADD3_STEP
-            const uint32_t xr = dpp0<kDppWaveShr1, 0xF>(pr), xd = dpp0<kDppWaveShr1, 0xF>(pd),
-                           xc = dpp0<kDppWaveShr1, 0xF>(sc);
-            const uint32_t C = __builtin_amdgcn_readlane(sc, 63);
-            const uint64_t H = __builtin_amdgcn_ballot_w64(hm != 0);
-            const uint64_t hl = H & ((1ull << lane) - 1ull);
-            const uint32_t qr = wo.tail_r - pr, qd = wo.tail_d - pd;
-            const bool xf = hl != 0;  // a start in an earlier lane of this round
-            const int hsrc = xf ? 63 - __clzll((long long)hl) : 0;
-            const uint32_t gq_r = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qr);
-            const uint32_t gq_d = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qd);
-            const uint32_t in_r = xr + (xf ? gq_r : carry_r);   // lane carry-in
-            const uint32_t in_d = xd + (xf ? gq_d : carry_d);
-
-            if (MODE == MODE_STAGE) {
-                if (C) {  // wave-uniform
-                    // lanes at or before the first start of the round still lack the tile's carry-in
-                    lcarry[lane] = make_uint4(in_r, in_d, xc, (!seen && !xf) ? 1u : 0u);
-                    wave_lds_sync();
-                    const uint32_t n_here = wo.n_queued < (uint32_t)kQueue ? wo.n_queued : (uint32_t)kQueue;
-                    if ((uint32_t)lane < n_here) {
-                        const uint4 e = queue[lane];
-                        const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 15u, own = (e.w >> 10) & 1u,
-                                       li = (e.w >> 11) & 31u;
-                        const uint4 cin = lcarry[L];
-                        const uint32_t ref = own ? e.x : e.x + cin.x;
-                        const uint32_t rdp = own ? e.y : e.y + cin.y;
-                        const uint32_t prec = own ? 0u : cin.w;
-                        uint32_t op, len;
-                        if (SOA) { op = (e.w >> 16) & 0xFFu; len = e.z; }
-                        else { op = e.z & 15u; len = e.z >> 4; }
-                        const uint32_t type = (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
-                        const uint32_t rank = tile_cnt + cin.z + li;
-                        if (rank < (uint32_t)kSlab) {
-                            const uint32_t loc = round * kRoundOps + L * kLaneOps + slot;
-                            p.slab[(uint64_t)tile * kSlab + rank] = make_uint4(loc | (type << 12) | (prec << 13), ref, rdp, len);
-                        }
-                    }
-                    if (wo.n_queued > (uint32_t)kQueue) overflow = true;
-                }
-            } else {
-                if (C) {  // dense tile: second walk finishes each signature on the spot
-                    dc.in_r = in_r; dc.in_d = in_d;
-                    dc.out0 = (uint64_t)obase + tile_cnt + xc;
-                    (void)walk16<WALK_DIRECT, SOA>(p, myx, swz, opw, hm, hmo, HU, lane, queue, dc);
-                }
-            }
-            wave_lds_sync();  // queue / lcarry / xp are rewritten by the next round
-
-            // ---- carry to the next round (wave-uniform) ----
-            const uint32_t R = __builtin_amdgcn_readlane(pr, 63), D = __builtin_amdgcn_readlane(pd, 63);
-            if (H) {
-                const int hlast = 63 - __clzll((long long)H);
-                carry_r = R + __builtin_amdgcn_readlane(qr, hlast);
-                carry_d = D + __builtin_amdgcn_readlane(qd, hlast);
-                seen = true;
-            } else {
-                carry_r += R;
-                carry_d += D;
-            }
-            tile_cnt += C;
-        }
-
-        if (MODE == MODE_STAGE && lane == 0) {
-            p.desc[tile] = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31),
-                                      carry_r, carry_d, a_lo);
-        }
-    }
+    for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves)
+        process_tile<MODE_STAGE, SOA>(p, tile, lane, s_xpose[wave], s_head[wave], s_queue[wave]);
 }
 
 // ---- B: segmented exclusive scan over tile descriptors ----
@@ -506,13 +513,15 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
         }
         if (tid == 0) blk_agg[blockIdx.x] = make_uint4(af, ar, ad, ac);
     }
-    // ---- last-arriving workgroup scans the block aggregates ----
-    __threadfence();  // release: this block's aggregate is visible device-wide before the ticket
+    // ---- last-arriving workgroup scans the block aggregates (one lane fences for the block) ----
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == n_blocks - 1) ? 1u : 0u;
+    if (tid == 0) {
+        __threadfence();  // release: this block's results are visible device-wide before the ticket
+        s_last = (atomicAdd(ticket, 1u) == n_blocks - 1) ? 1u : 0u;
+        if (s_last) __threadfence();  // acquire: drop stale lines before reading the other blocks' aggregates
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();  // acquire: drop stale lines before reading the other blocks' aggregates
     uint32_t cf = 0, cr = 0, cd = 0;
     uint64_t cc = 0;
     for (uint32_t base = 0; base < n_blocks; base += kScanBlock) {
@@ -551,31 +560,40 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
     }
 }
 
-// ---- C: gather sparse tiles' staged signatures into the final SoA ----
-__global__ __launch_bounds__(64 * kWaves) void k_cigar_gather(CigarArgs p) {
-    // half a wave per sparse tile (a tile of 4096 ops carries ~30 signatures): lane = signature
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane >> 5, l32 = lane & 31;
+// ---- C: finish.  (1) sparse tiles: half a wave per tile copies the staged records into the final
+// SoA at the scanned output base (a tile of 4096 ops carries ~30 signatures: lane = signature),
+// adding the tile carry-in where the record lacks it and ref_start of its alignment.
+// (2) dense tiles (rare) are re-walked with carry-in and output base known. ----
+template <bool SOA>
+__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_finish(CigarArgs p) {
+    __shared__ uint4 s_xpose[kWaves][kXposeU4];
+    __shared__ uint32_t s_head[kWaves][kTileOps / 32];
+    __shared__ uint4 s_queue[kWaves][kQueue];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, sub = lane >> 5, l32 = lane & 31;
     for (uint32_t pair = blockIdx.x * kWaves + wave; pair * 2 < p.n_tiles; pair += gridDim.x * kWaves) {
         const uint32_t tile = pair * 2 + sub;
         if (tile >= p.n_tiles) continue;
+        const uint4 rec0 = p.slab[(uint64_t)tile * kSlab + l32];  // speculative: issued with the descriptor
         const uint4 dsc = p.desc[tile];
-        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
-        if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) continue;
-        const uint32_t a_lo = dsc.w;
         const uint4 bp = p.blk_prefix[tile / kScanBlock];
         const uint32_t lb = p.out_base[tile];
+        const uint32_t lcr = p.carry_ref[tile], lcd = p.carry_read[tile];
+        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
+        if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) continue;
         const bool local_head = (lb >> 31) != 0;
-        const uint32_t cr = p.carry_ref[tile] + (local_head ? 0u : bp.y);
-        const uint32_t cd = p.carry_read[tile] + (local_head ? 0u : bp.z);
+        const uint32_t cr = lcr + (local_head ? 0u : bp.y);
+        const uint32_t cd = lcd + (local_head ? 0u : bp.z);
         const uint64_t ob = (uint64_t)(lb & 0x7FFFFFFFu) + bp.w;
-        const uint64_t g0 = (uint64_t)tile * kTileOps;
         for (uint32_t r = l32; r < cnt; r += 32) {
-            const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
-            const uint32_t loc = rec.x & 0xFFFu, type = (rec.x >> 12) & 1u, prec = (rec.x >> 13) & 1u;
-            const uint32_t aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + loc);
-            store_final(p, ob + r, aln, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), rec.w, type);
+            const uint4 rec = (r == (uint32_t)l32) ? rec0 : p.slab[(uint64_t)tile * kSlab + r];
+            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+            store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
         }
     }
+    const uint32_t n_dense = p.n_dense[2];
+    for (uint32_t work = blockIdx.x * kWaves + wave; work < n_dense; work += gridDim.x * kWaves)
+        process_tile<MODE_DIRECT, SOA>(p, p.dense_list[work], lane, s_xpose[wave], s_head[wave], s_queue[wave]);
 }
 
 // ---- per-alignment CIGAR statistics: one wave per alignment ----
@@ -694,21 +712,15 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     if (rc != SVX_OK) return rc;
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-    hipLaunchKernelGGL((k_cigar_tiles<MODE_STAGE, SOA>), dim3(blocks_all), dim3(64 * kWaves), 0,
-                       ctx->stream, a);
+    hipLaunchKernelGGL((k_cigar_tiles<SOA>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     hipLaunchKernelGGL(k_desc_scan, dim3(n_scan_blocks), dim3(kScanBlock), 0, ctx->stream, a.desc, n_tiles,
                        a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
                        a.blk_prefix, a.n_dense + 1, d_n_out);
-    const uint32_t blocks_gather = (blocks_all + 1) / 2;
-    hipLaunchKernelGGL(k_cigar_gather, dim3(blocks_gather < blocks_cap ? blocks_gather : blocks_cap),
+    const uint32_t blocks_finish = (blocks_all + 1) / 2;
+    hipLaunchKernelGGL((k_cigar_finish<SOA>), dim3(blocks_finish < blocks_cap ? blocks_finish : blocks_cap),
                        dim3(64 * kWaves), 0, ctx->stream, a);
-    // dense tiles are rare: a small grid that exits at once when the published count is 0
-    const uint32_t blocks_dense = (uint32_t)ctx->n_cu;
-    hipLaunchKernelGGL((k_cigar_tiles<MODE_DIRECT, SOA>),
-                       dim3(blocks_all < blocks_dense ? blocks_all : blocks_dense), dim3(64 * kWaves), 0,
-                       ctx->stream, a);
     SVX_HIP(ctx, hipGetLastError());
     return svx_timing_end(ctx);
 }
