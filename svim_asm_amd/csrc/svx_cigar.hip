@@ -30,9 +30,12 @@ namespace {
 
 constexpr int kLaneOps = 16;
 constexpr int kRoundOps = 64 * kLaneOps;       // 1024 ops per wave round (4 KiB)
-constexpr int kRounds = 4;
+#ifndef SVX_ROUNDS
+#define SVX_ROUNDS 4
+#endif
+constexpr int kRounds = SVX_ROUNDS;
 constexpr int kTileOps = kRoundOps * kRounds;  // 4096 ops per tile (16 KiB)
-constexpr int kSlab = 256;                     // staged signatures per tile
+constexpr int kSlab = 64 * SVX_ROUNDS;         // staged signatures per tile (1/16 of its ops)
 constexpr int kWaves = 4;                      // waves (= tiles) per workgroup
 constexpr int kXposeU4 = 64 * 4;               // transpose buffer: 4 uint4 per lane, XOR-swizzled
 constexpr int kScanBlock = 1024;               // tile descriptors per scan workgroup
@@ -158,6 +161,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 template <bool SOA>
 __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t ro_,
                                            uint32_t ro, int lane, uint4 (&q)[4], uint4& o) {
+#ifdef SVX_EXP_NOLOAD  // perf experiment only: no HBM traffic
+    for (int k = 0; k < 4; ++k) q[k] = make_uint4(ro + lane, (400u << 4), (3u << 4) | 1u, (77u << 4));
+    o = make_uint4(0, 0, 0, 0);
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
@@ -297,11 +305,18 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
 
     // ---- alignment starts inside this tile → 4096-bit mask in LDS; `dup` = two alignments start
     // at the same op (empty alignments), which disables the popcount shortcut for the index ----
+#ifdef SVX_EXP_NOPROLOGUE  // perf experiment only
+    const uint32_t a_lo = 0;
+#else
     const uint32_t a_lo = __builtin_amdgcn_readfirstlane(wave_lower_bound(p.aln_off, p.n_aln + 1, g0, lane));
-    hmask[lane] = 0;
-    hmask[lane + 64] = 0;
+#endif
+#pragma unroll
+    for (int i = lane; i < kTileOps / 32; i += 64) hmask[i] = 0;
     wave_lds_sync();
     bool dup = false;
+#ifdef SVX_EXP_NOPROLOGUE
+    if (false)
+#endif
     for (uint64_t a = (uint64_t)a_lo + lane;; a += 64) {
         bool in = false, twice = false;
         if (a < p.n_aln) {
