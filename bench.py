@@ -133,10 +133,36 @@ def main():
     d_n = torch.zeros(1, dtype=torch.int64, device=dev)
     outs = (o_aln.data_ptr(), o_ref.data_ptr(), o_read.data_ptr(), o_len.data_ptr(), o_type.data_ptr())
 
+    # a3 inputs resident in HBM: 5 % of the alignments are primaries of chimeric reads with 1-3
+    # SA-derived segments; rows as SVIM_inter.py:66-81 builds them
+    rng = np.random.default_rng(77 + rank)
+    n_reads = max(1, n_aln // 20)
+    k = rng.integers(2, 5, size=n_reads)
+    read_off_np = np.concatenate(([0], np.cumsum(k))).astype(np.uint32)
+    n_segs = int(read_off_np[-1])
+    segs_np = np.zeros(n_segs, dtype=_lib.SEG_DTYPE)
+    qs = rng.integers(0, 200000, size=n_segs)
+    segs_np["q_start"] = qs
+    segs_np["q_end"] = qs + rng.integers(500, 50000, size=n_segs)
+    segs_np["ref_id"] = rng.integers(0, 24, size=n_segs)
+    segs_np["ref_start"] = rng.integers(0, 50_000_000, size=n_segs)
+    segs_np["ref_end"] = segs_np["ref_start"] + rng.integers(500, 50000, size=n_segs)
+    segs_np["is_reverse"] = rng.random(n_segs) < 0.1
+    d_segs = torch.from_numpy(segs_np.view(np.int32).reshape(-1, 6).copy()).to(dev)
+    d_read_off = torch.from_numpy(read_off_np.view(np.int32)).to(dev)
+    d_read_len = torch.from_numpy(rng.integers(100000, 5000000, size=n_reads).astype(np.int32)).to(dev)
+    d_raw = torch.empty((n_segs, 8), dtype=torch.int32, device=dev)
+    seg_prm = _lib.SegParams(args.min_sv_size, 100000, 50, 50, 50, 50)
+    import ctypes as C
+
     def step():
+        # a1 + a2: every CIGAR op of the batch, once
         ctx.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
                               args.min_sv_size, outs, cap, d_n.data_ptr(),
                               d_op=None if d_op is None else d_op.data_ptr())
+        # a3: split-segment decision tree for the chimeric reads of the batch
+        ctx._check(ctx.lib.svx_segments_classify_dev(ctx.h, d_segs.data_ptr(), n_segs, d_read_off.data_ptr(), n_reads,
+                                                     d_read_len.data_ptr(), C.byref(seg_prm), d_raw.data_ptr()))
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -169,8 +195,14 @@ def main():
     # ---- roofline of the dominant kernel (k_cigar_tiles), HIP events on the launch stream ----
     ctx.set_timing(True)
     k_ms, p_ms = [], []
+
+    def cigar_only():
+        ctx.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
+                              args.min_sv_size, outs, cap, d_n.data_ptr(),
+                              d_op=None if d_op is None else d_op.data_ptr())
+
     for _ in range(max(5, min(20, args.steps))):
-        step()
+        cigar_only()
         ctx.sync()
         tot_ms, dom_ms = ctx.last_kernel_ms()
         k_ms.append(dom_ms)
@@ -222,11 +254,13 @@ def main():
                             "resident in HBM, %s layout" % (args.config, "haploid 3 Gbp" if args.config == 2 else
                                                             "10x indel density", args.samples, args.layout),
                 "ops_per_step_per_gpu": n_ops, "alignments_per_step_per_gpu": n_aln,
-                "signatures_per_step_per_gpu": n_sig, "min_sv_size": args.min_sv_size,
+                "signatures_per_step_per_gpu": n_sig, "chimeric_reads_per_step_per_gpu": n_reads,
+                "segments_per_step_per_gpu": n_segs, "min_sv_size": args.min_sv_size,
+                "step": "a1+a2 svx_cigar_extract_dev + a3 svx_segments_classify_dev",
                 "parallelism": "sample/contig shards x%d, no data-path collective" % world,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_cigar_tiles<STAGE>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "k_cigar_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_avg * 1e3,
                 "path_ms": p_avg * 1e3, "path_achieved": algo_bytes / p_avg / 1e9,

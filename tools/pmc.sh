@@ -12,14 +12,15 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out" -o pass$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > /dev/null 2>> "$out/err.txt"
 done
 python3 - "$out" <<'PY'
-import csv, collections, glob, json, sys
+import csv, collections, glob, json, re, sys
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(out + "/pass*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "svx" in k or "anonymous" in k:
-            short = k.split("(")[0].split("::")[-1] + ("<DIRECT>" if "<1," in k else "")
+        m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", k)
+        if m:
+            short = m.group(1) + (m.group(2) or "")
             agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[short]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
