@@ -154,6 +154,9 @@ def main():
     d_raw = torch.empty((n_segs, 8), dtype=torch.int32, device=dev)
     seg_prm = _lib.SegParams(args.min_sv_size, 100000, 50, 50, 50, 50)
     import ctypes as C
+    # a3 is independent of a1/a2: it runs on a second context (own HIP stream) and overlaps the
+    # CIGAR kernels; torch.cuda.synchronize() in barrier() waits for every stream of the device
+    ctx2 = _lib.Context(local_rank)
 
     def step():
         # a1 + a2: every CIGAR op of the batch, once
@@ -161,8 +164,9 @@ def main():
                               args.min_sv_size, outs, cap, d_n.data_ptr(),
                               d_op=None if d_op is None else d_op.data_ptr())
         # a3: split-segment decision tree for the chimeric reads of the batch
-        ctx._check(ctx.lib.svx_segments_classify_dev(ctx.h, d_segs.data_ptr(), n_segs, d_read_off.data_ptr(), n_reads,
-                                                     d_read_len.data_ptr(), C.byref(seg_prm), d_raw.data_ptr()))
+        ctx2._check(ctx2.lib.svx_segments_classify_dev(ctx2.h, d_segs.data_ptr(), n_segs, d_read_off.data_ptr(),
+                                                       n_reads, d_read_len.data_ptr(), C.byref(seg_prm),
+                                                       d_raw.data_ptr()))
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -256,7 +260,7 @@ def main():
                 "ops_per_step_per_gpu": n_ops, "alignments_per_step_per_gpu": n_aln,
                 "signatures_per_step_per_gpu": n_sig, "chimeric_reads_per_step_per_gpu": n_reads,
                 "segments_per_step_per_gpu": n_segs, "min_sv_size": args.min_sv_size,
-                "step": "a1+a2 svx_cigar_extract_dev + a3 svx_segments_classify_dev",
+                "step": "a1+a2 svx_cigar_extract_dev (stream 1) + a3 svx_segments_classify_dev (stream 2)",
                 "parallelism": "sample/contig shards x%d, no data-path collective" % world,
             },
             "roofline": {

@@ -5,10 +5,10 @@
 // (q_start, q_end) (:83), then one raw record per adjacent pair (:91-258).
 //
 // Layout: segs[] AoS of 6 x i32 (24 B, svx_seg) grouped per read by read_off[]; out[] one
-// 32-B svx_raw per segment slot (pair i of read r at read_off[r] + i).  One lane per read:
-// reads carry 1..k segments with k tiny, so the work is a few hundred
-// integer compares per read; the sort runs in a per-read slice of an HBM scratch copy.
-// 24 B in + 32 B out per segment; bound by launch latency, not bandwidth.
+// 32-B svx_raw per segment slot (pair i of read r at read_off[r] + i).  Eight lanes per read, one
+// lane per segment: reads carry 1..k segments with k tiny; ranking by width-8
+// shuffles replaces the sort, reads with more than 8 segments take a serial path with an HBM
+// scratch slice.  24 B in + 32 B out per segment; bound by launch latency, not bandwidth.
 #include "svx_internal.h"
 
 namespace {
@@ -33,7 +33,7 @@ __device__ __forceinline__ svx_raw raw(int kind, int a0 = 0, int a1 = 0, int a2 
 constexpr int kFwd = 0, kRev = 1;
 
 // cur = segment earlier on the read, nxt = the following one (SVIM_inter.py:92-93)
-__device__ svx_raw classify(const svx_seg& cur, const svx_seg& nxt, int32_t read_len,
+__device__ __forceinline__ svx_raw classify(const svx_seg& cur, const svx_seg& nxt, int32_t read_len,
                             const svx_seg_params& o) {
     const int32_t gap_q = nxt.q_start - cur.q_end;  // distance_on_read (:95)
     const bool q_no_overlap = gap_q >= -o.query_overlap_tolerance;
@@ -119,36 +119,88 @@ __device__ svx_raw classify(const svx_seg& cur, const svx_seg& nxt, int32_t read
     return raw(SVX_RAW_BND, chr, cur.ref_start, kRev, chr, nxt.ref_start, kFwd);
 }
 
-__global__ __launch_bounds__(256) void k_segments(SegArgs p) {
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < p.n_reads;
-         r += gridDim.x * blockDim.x) {
-        const uint32_t b = p.read_off[r], e = p.read_off[r + 1];
-        if (e <= b) continue;
-        svx_seg* s = p.sorted + b;
-        const uint32_t k = e - b;
-        // stable insertion sort by (q_start, q_end) into the scratch slice (:83)
-        for (uint32_t i = 0; i < k; ++i) {
-            const svx_seg x = p.segs[b + i];
-            uint32_t j = i;
-            while (j > 0) {
-                const svx_seg y = s[j - 1];
-                if (y.q_start > x.q_start || (y.q_start == x.q_start && y.q_end > x.q_end)) {
-                    s[j] = y;
-                    --j;
-                } else {
-                    break;
-                }
+// serial path for reads with more than 8 segments: stable insertion sort in the HBM scratch slice
+__device__ __forceinline__ void segments_serial(const SegArgs& p, uint32_t r) {
+    const uint32_t b = p.read_off[r], e = p.read_off[r + 1];
+    svx_seg* s = p.sorted + b;
+    const uint32_t k = e - b;
+    for (uint32_t i = 0; i < k; ++i) {
+        const svx_seg x = p.segs[b + i];
+        uint32_t j = i;
+        while (j > 0) {
+            const svx_seg y = s[j - 1];
+            if (y.q_start > x.q_start || (y.q_start == x.q_start && y.q_end > x.q_end)) {
+                s[j] = y;
+                --j;
+            } else {
+                break;
             }
-            s[j] = x;
         }
-        const int32_t rl = p.read_len[r];
-        svx_seg cur = s[0];
-        for (uint32_t i = 0; i + 1 < k; ++i) {
-            const svx_seg nxt = s[i + 1];
-            p.out[b + i] = classify(cur, nxt, rl, p.o);
-            cur = nxt;
+        s[j] = x;
+    }
+    const int32_t rl = p.read_len[r];
+    svx_seg cur = s[0];
+    for (uint32_t i = 0; i + 1 < k; ++i) {
+        const svx_seg nxt = s[i + 1];
+        p.out[b + i] = classify(cur, nxt, rl, p.o);
+        cur = nxt;
+    }
+    p.out[e - 1] = raw(SVX_RAW_NONE);
+}
+
+// Eight reads per wave: a group of 8 lanes owns one read, one lane per segment (reads carry a
+// handful of segments).  Every lane ranks its segment by (q_start, q_end, original index) against
+// the others of its group with width-8 shuffles (= the stable sort of SVIM_inter.py:83), segments
+// move to their sorted lane with ds_permute, and lane i classifies the adjacent pair (i, i+1).
+// The dependent-load chain per read is read_off → segments → store; reads with more than 8
+// segments take the serial path (HBM scratch slice) on their group's first lane.
+constexpr int kGroup = 8;
+
+__global__ __launch_bounds__(256) void k_segments(SegArgs p) {
+    const int lane = threadIdx.x & 63, gl = lane & (kGroup - 1), gbase = lane & ~(kGroup - 1);
+    const uint32_t group = (blockIdx.x * 256 + threadIdx.x) / kGroup, n_groups = gridDim.x * 256 / kGroup;
+    for (uint32_t r0 = 0; r0 < p.n_reads; r0 += n_groups) {
+        const uint32_t r = r0 + group;
+        const bool live = r < p.n_reads;
+        uint32_t b = 0, e = 0;
+        if (live) { b = p.read_off[r]; e = p.read_off[r + 1]; }
+        const uint32_t k = e > b ? e - b : 0;
+        const bool small = k <= (uint32_t)kGroup;
+        if (!small && gl == 0) segments_serial(p, r);
+        svx_seg s;
+        s.q_start = s.q_end = s.ref_id = s.ref_start = s.ref_end = s.is_reverse = 0;
+        int32_t rl = 0;
+        if (small && (uint32_t)gl < k) {
+            s = p.segs[b + gl];
+            rl = p.read_len[r];
         }
-        p.out[e - 1] = raw(SVX_RAW_NONE);
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            const int qs = __shfl(s.q_start, j, kGroup), qe = __shfl(s.q_end, j, kGroup);
+            const bool before = qs < s.q_start || (qs == s.q_start && (qe < s.q_end || (qe == s.q_end && j < gl)));
+            rank += (before && (uint32_t)j < k) ? 1 : 0;
+        }
+        if (!small || (uint32_t)gl >= k) rank = gl;  // idle lanes keep distinct destinations
+        const int dst = (gbase + rank) << 2;
+        svx_seg t;
+        t.q_start = __builtin_amdgcn_ds_permute(dst, s.q_start);
+        t.q_end = __builtin_amdgcn_ds_permute(dst, s.q_end);
+        t.ref_id = __builtin_amdgcn_ds_permute(dst, s.ref_id);
+        t.ref_start = __builtin_amdgcn_ds_permute(dst, s.ref_start);
+        t.ref_end = __builtin_amdgcn_ds_permute(dst, s.ref_end);
+        t.is_reverse = __builtin_amdgcn_ds_permute(dst, s.is_reverse);
+        svx_seg n;
+        n.q_start = __shfl_down(t.q_start, 1, kGroup);
+        n.q_end = __shfl_down(t.q_end, 1, kGroup);
+        n.ref_id = __shfl_down(t.ref_id, 1, kGroup);
+        n.ref_start = __shfl_down(t.ref_start, 1, kGroup);
+        n.ref_end = __shfl_down(t.ref_end, 1, kGroup);
+        n.is_reverse = __shfl_down(t.is_reverse, 1, kGroup);
+        if (small && k > 0) {
+            if ((uint32_t)gl + 1 < k) p.out[b + gl] = classify(t, n, rl, p.o);
+            else if ((uint32_t)gl + 1 == k) p.out[b + gl] = raw(SVX_RAW_NONE);
+        }
     }
 }
 
@@ -172,7 +224,7 @@ extern "C" int svx_segments_classify_dev(svx_ctx* ctx, const svx_seg* d_segs, ui
     a.n_reads = n_reads;
     a.o = *params;
     a.out = d_out;
-    uint32_t blocks = (n_reads + 255) / 256;
+    uint32_t blocks = (n_reads + 31) / 32;  // eight lanes per read
     uint32_t cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;

@@ -49,7 +49,7 @@ def random_reads(rng, n_reads, max_k, n_contigs=3, spread=300):
 @pytest.mark.parametrize("seed", range(5))
 def test_random_reads_match_oracle(svx_ctx, seed):
     rng = np.random.default_rng(seed)
-    segs, off, rl = random_reads(rng, n_reads=int(rng.integers(1, 3000)), max_k=int(rng.choice([2, 6, 40])))
+    segs, off, rl = random_reads(rng, n_reads=int(rng.integers(1, 3000)), max_k=int(rng.choice([2, 6, 40, 90])))
     for params in (DEFAULT, (40, 1000, 50, 50, 50, 50), (50, 20, 0, 0, 0, 0), (1, 100000, 500, 500, 500, 500)):
         got = svx_ctx.segments_classify(segs, off, rl, params)
         exp = orc.segments_classify(segs, off, rl, params)
