@@ -14,6 +14,7 @@ import struct
 _CIGAR_RE = re.compile(r"(\d+)([MIDNSHP=XB])")
 _CODES = "MIDNSHP=XB"
 _SEQ = "=ACMGRSVTWYHKDBN"
+_HEX2BASE = str.maketrans("0123456789abcdef", _SEQ)
 
 
 class AlignedSegment(object):
@@ -248,11 +249,9 @@ class AlignmentFile(object):
         nb = (l_seq + 1) // 2
         sb = data[q:q + nb]
         q += nb
-        chars = []
-        for i in range(l_seq):
-            b = sb[i >> 1]
-            chars.append(_SEQ[(b >> 4) if (i & 1) == 0 else (b & 15)])
-        a._seq = "".join(chars)
+        # one hex digit per 4-bit base code, then a character translation (fast, still independent
+        # of the product's numpy decoder)
+        a._seq = sb.hex().translate(_HEX2BASE)[:l_seq]
         q += l_seq  # qualities
         a.flag = flag
         a.reference_id = tid

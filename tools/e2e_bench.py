@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""End-to-end BAM → VCF wall-clock of the product CLI next to the CPU oracle pipeline, on a
+synthetic diploid sample written as real BAM + FASTA files (scaled).
+
+    python tools/e2e_bench.py --scale 0.1 [--keep DIR]
+
+--scale 1.0 = GRCh38 contig lengths (3.1 Gbp); 0.1 (default) = every contig at 1/10 length.
+Prints one JSON object: generation time, product phases (BAM open/inflate, COLLECT, PAIR, VCF)
+and total, oracle (CPython restatement of the reference, C edit distance) total, and whether
+the two VCFs are identical.  The oracle is used here as the reference-equivalent CPU path and
+checker only.
+"""
+import argparse
+import json
+import logging
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=0.1)
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("--sv-per-mbp", type=float, default=8.0)
+    ap.add_argument("--skip-oracle", action="store_true")
+    args = ap.parse_args()
+    from svim_asm_amd import synth, synth_bam
+    contigs = tuple((n, max(60000, int(l * args.scale))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
+    out = args.keep or tempfile.mkdtemp(prefix="svx_e2e_")
+    res = {"scale": args.scale, "genome_bp": int(sum(c[1] for c in contigs)), "dir": out}
+
+    t0 = time.perf_counter()
+    n_shared = max(4, int(args.sv_per_mbp * max(c[1] for c in contigs) / 1e6))
+    fasta, bams = synth_bam.write_dataset(out, seed=3, contigs=contigs, diploid=True, n_shared=n_shared,
+                                          n_private=max(2, n_shared // 5), median_aln=300000, mean_m=2000)
+    res["generate_s"] = time.perf_counter() - t0
+    res["bam_bytes"] = [os.path.getsize(b) for b in bams]
+
+    # ---- product: timed phases through the same functions the CLI calls
+    from svim_asm_amd import bamio, cli, shard
+    from svim_asm_amd.fasta import FastaFile
+    from svim_asm_amd.SVIM_COMBINE import write_final_vcf
+    from svim_asm_amd.SVIM_input_parsing import parse_arguments
+    wd = os.path.join(out, "wd_product")
+    opts = parse_arguments("1.0.3", ["diploid", wd, bams[0], bams[1], fasta])
+    os.makedirs(wd, exist_ok=True)
+    logging.getLogger().setLevel(logging.WARNING)
+    from svim_asm_amd import _lib
+    _lib.default_context(0)  # context creation / first-touch outside the timed region
+    t_all = time.perf_counter()
+    t = time.perf_counter(); f1 = bamio.AlignmentFile(bams[0]); f2 = bamio.AlignmentFile(bams[1]); res["open_inflate_s"] = time.perf_counter() - t
+    t = time.perf_counter(); c1 = shard.collect_sharded(f1, opts); c2 = shard.collect_sharded(f2, opts); res["collect_s"] = time.perf_counter() - t
+    ref = FastaFile(fasta)
+    t = time.perf_counter(); paired = shard.pair_sharded(c1, c2, ref, f1, opts); res["pair_s"] = time.perf_counter() - t
+    by = {k: [c for c in paired if c.type == k] for k, _ in cli.TYPE_LABELS}
+    t = time.perf_counter()
+    write_final_vcf(by["DUP_INT"], by["INV"], by["DUP_TAN"], by["DEL"], by["INS"], by["BND"], "1.0.3", f1.references,
+                    f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
+    res["vcf_s"] = time.perf_counter() - t
+    res["product_total_s"] = time.perf_counter() - t_all
+    res["candidates"] = [len(c1), len(c2), len(paired)]
+    res["cigar_ops"] = [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]
+    got = "".join(l for l in open(os.path.join(wd, "variants.vcf")) if not l.startswith("##fileDate="))
+
+    if not args.skip_oracle:
+        from oracle import orc, run_oracle
+        t = time.perf_counter()
+        exp = run_oracle.vcf_from_files(bams, fasta, run_oracle.default_options(),
+                                        edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+        res["oracle_total_s"] = time.perf_counter() - t
+        res["vcf_identical"] = (got == exp)
+        res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
+    if not args.keep:
+        shutil.rmtree(out)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
