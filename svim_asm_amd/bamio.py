@@ -75,7 +75,7 @@ def bgzf_decompress(path, threads=None):
         step = (n + threads * 4 - 1) // (threads * 4)
         with ThreadPoolExecutor(threads) as ex:
             list(ex.map(lambda lo: work(lo, min(n, lo + step)), range(0, n, step)))
-    return bytes(out)
+    return out  # bytearray: no second copy of a multi-GB buffer
 
 
 def bgzf_compress(data, level=1):
@@ -296,11 +296,11 @@ class AlignmentFile(object):
     def __init__(self, path, mode="rb"):
         self.filename = path
         data = bgzf_decompress(path)
-        if data[:4] != b"BAM\x01":
+        if bytes(data[:4]) != b"BAM\x01":
             raise ValueError("%s is not a BAM file" % path)
         self._data = data
         l_text = struct.unpack_from("<i", data, 4)[0]
-        self.text = data[8:8 + l_text].split(b"\x00")[0].decode()
+        self.text = bytes(data[8:8 + l_text]).split(b"\x00")[0].decode()
         self.header = _parse_header_text(self.text)
         p = 8 + l_text
         n_ref = struct.unpack_from("<i", data, p)[0]
@@ -308,7 +308,7 @@ class AlignmentFile(object):
         names, lens = [], []
         for _ in range(n_ref):
             l_name = struct.unpack_from("<i", data, p)[0]
-            names.append(data[p + 4:p + 4 + l_name - 1].decode())
+            names.append(bytes(data[p + 4:p + 4 + l_name - 1]).decode())
             p += 4 + l_name
             lens.append(struct.unpack_from("<i", data, p)[0])
             p += 4
@@ -345,7 +345,7 @@ class AlignmentFile(object):
         r.mapping_quality = int(c["mapq"][i])
         r.flag = int(c["flag"][i])
         q = off + 32
-        r.query_name = self._data[q:q + l_rn - 1].decode()
+        r.query_name = bytes(self._data[q:q + l_rn - 1]).decode()
         q += l_rn
         r.cigar_words = np.frombuffer(self._data, dtype="<u4", count=n_cig, offset=q)
         q += 4 * n_cig

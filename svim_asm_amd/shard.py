@@ -12,10 +12,16 @@ rank pairs the key contigs it owns and the results are merged type by type in co
 (Python str) order — the order the reference's sort produces.
 One process per GPU, launched with torch.distributed.run; world size 1 needs no process group.
 """
+import os
+import sys
+
 import numpy as np
 
 
 def _dist():
+    # importing torch costs seconds: only look for a process group when one can exist
+    if "torch.distributed" not in sys.modules and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return None
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
