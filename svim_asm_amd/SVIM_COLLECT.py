@@ -119,6 +119,14 @@ def analyze_alignment_file_coordsorted(bam, options):
     # signature rows of alignment k: [sig_lo[k], sig_lo[k+1])
     sig_lo = np.searchsorted(sig["aln"], np.arange(len(kept) + 1), side="left")
     sig_ref = sig["ref_pos"].astype(np.int64)
+    # the inserted alleles are the only bases COLLECT needs: inflate just their BGZF blocks, in parallel
+    prefetch = getattr(bam, "prefetch_sequence", None)
+    if prefetch is not None and len(sig["aln"]):
+        ins = np.nonzero(sig["type"] == _lib.SIG_INS)[0]
+        rec_index = np.array([getattr(a, "index", -1) for a in kept], dtype=np.int64)[sig["aln"][ins]]
+        ok = rec_index >= 0
+        prefetch(zip(rec_index[ok].tolist(), sig["read_pos"][ins][ok].tolist(),
+                     (sig["read_pos"][ins][ok].astype(np.int64) + sig["len"][ins][ok]).tolist()))
 
     # ---- a3 inputs: primaries with usable SA segments
     reads, read_index = [], {}

@@ -78,6 +78,82 @@ def bgzf_decompress(path, threads=None):
     return out  # bytearray: no second copy of a multi-GB buffer
 
 
+class BgzfLazy(object):
+    """Random access into the uncompressed stream of a BGZF file, inflating blocks on demand.
+
+    Genome-genome alignment BAMs hold a few thousand records whose SEQ/QUAL fields are hundreds
+    of kilobases to megabases long: more than 90 % of the BGZF blocks lie wholly inside those
+    fields and are never needed (COLLECT reads headers, names, CIGARs and tags, and the bases of
+    the inserted alleles only).  The ISIZE trailer of every block gives its uncompressed length
+    without inflating it, so record offsets can be followed through skipped blocks."""
+
+    def __init__(self, path):
+        with open(path, "rb") as fh:
+            self._raw = fh.read()
+        spans = _bgzf_block_spans(self._raw)
+        self._start = np.array([s[0] for s in spans], dtype=np.int64)
+        self._clen = np.array([s[1] for s in spans], dtype=np.int64)
+        isize = np.array([s[2] for s in spans], dtype=np.int64)
+        self._uoff = np.concatenate(([0], np.cumsum(isize))).astype(np.int64)
+        self.size = int(self._uoff[-1])
+        self._cache = {}
+        self._view = memoryview(self._raw)
+        self.blocks_inflated = 0
+
+    def _block(self, i):
+        b = self._cache.get(i)
+        if b is None:
+            st, ln = int(self._start[i]), int(self._clen[i])
+            b = zlib.decompress(self._view[st:st + ln], -15) if self._uoff[i + 1] > self._uoff[i] else b""
+            self._cache[i] = b
+            self.blocks_inflated += 1
+        return b
+
+    def read(self, off, n):
+        """Bytes [off, off+n) of the uncompressed stream."""
+        if n <= 0:
+            return b""
+        end = min(off + n, self.size)
+        i = int(np.searchsorted(self._uoff, off, side="right")) - 1
+        parts = []
+        while off < end:
+            b = self._block(i)
+            lo = off - int(self._uoff[i])
+            take = min(len(b) - lo, end - off)
+            parts.append(b[lo:lo + take])
+            off += take
+            i += 1
+        return parts[0] if len(parts) == 1 else b"".join(parts)
+
+    def prefetch(self, ranges, threads=None):
+        """Inflate, in parallel, every block touched by the (offset, length) ranges."""
+        need = set()
+        for off, n in ranges:
+            if n <= 0:
+                continue
+            i0 = int(np.searchsorted(self._uoff, off, side="right")) - 1
+            i1 = int(np.searchsorted(self._uoff, min(off + n, self.size) - 1, side="right")) - 1
+            need.update(i for i in range(i0, i1 + 1) if i not in self._cache)
+        need = sorted(need)
+        threads = threads or min(16, os.cpu_count() or 1)
+        if len(need) < 32 or threads <= 1:
+            for i in need:
+                self._block(i)
+            return
+        def work(chunk):
+            return [(i, zlib.decompress(self._view[int(self._start[i]):int(self._start[i] + self._clen[i])], -15))
+                    for i in chunk]
+        step = (len(need) + threads * 4 - 1) // (threads * 4)
+        with ThreadPoolExecutor(threads) as ex:
+            for res in ex.map(work, [need[k:k + step] for k in range(0, len(need), step)]):
+                for i, b in res:
+                    self._cache[i] = b
+                    self.blocks_inflated += 1
+
+    def drop_cache(self):
+        self._cache.clear()
+
+
 def bgzf_compress(data, level=1):
     """BGZF-compress `data` (64 KiB minus slack per block) + EOF marker."""
     out = bytearray()
@@ -286,86 +362,117 @@ class AlignedRecord(object):
         return name in self._parse_tags()
 
 
+class _LazySeq(object):
+    """The packed 4-bit SEQ field of one record, sliced straight from the lazily inflated stream."""
+    __slots__ = ("_z", "_off", "_n")
+
+    def __init__(self, z, off, n):
+        self._z, self._off, self._n = z, off, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, sl):
+        a, b, _ = sl.indices(self._n)
+        return np.frombuffer(self._z.read(self._off + a, b - a), dtype=np.uint8)
+
+
 _AUX_FMT = {"c": ("<b", 1), "C": ("<B", 1), "s": ("<h", 2), "S": ("<H", 2), "i": ("<i", 4),
             "I": ("<I", 4), "f": ("<f", 4)}
 
 
 class AlignmentFile(object):
-    """Coordinate-sorted BAM opened for sequential, per-contig streaming."""
+    """Coordinate-sorted BAM opened for sequential, per-contig streaming.  Only the BGZF blocks
+    that hold record headers, names, CIGARs, aux tags and requested SEQ slices are inflated."""
 
     def __init__(self, path, mode="rb"):
         self.filename = path
-        data = bgzf_decompress(path)
-        if bytes(data[:4]) != b"BAM\x01":
+        z = self._z = BgzfLazy(path)
+        head = z.read(0, 12)
+        if head[:4] != b"BAM\x01":
             raise ValueError("%s is not a BAM file" % path)
-        self._data = data
-        l_text = struct.unpack_from("<i", data, 4)[0]
-        self.text = bytes(data[8:8 + l_text]).split(b"\x00")[0].decode()
+        l_text = struct.unpack_from("<i", head, 4)[0]
+        self.text = z.read(8, l_text).split(b"\x00")[0].decode()
         self.header = _parse_header_text(self.text)
         p = 8 + l_text
-        n_ref = struct.unpack_from("<i", data, p)[0]
+        n_ref = struct.unpack_from("<i", z.read(p, 4), 0)[0]
         p += 4
         names, lens = [], []
         for _ in range(n_ref):
-            l_name = struct.unpack_from("<i", data, p)[0]
-            names.append(bytes(data[p + 4:p + 4 + l_name - 1]).decode())
-            p += 4 + l_name
-            lens.append(struct.unpack_from("<i", data, p)[0])
-            p += 4
+            l_name = struct.unpack_from("<i", z.read(p, 4), 0)[0]
+            nb = z.read(p + 4, l_name + 4)
+            names.append(nb[:l_name - 1].decode())
+            lens.append(struct.unpack_from("<i", nb, l_name)[0])
+            p += 8 + l_name
         self.references = tuple(names)
         self.lengths = tuple(lens)
         self._tid = {n: i for i, n in enumerate(names)}
         self._rec_start = p
         self._index_records()
 
-    # ---- columnar index over all records (one pass, struct only)
+    # ---- columnar index over all records: one sequential pass over the record headers; the
+    # name, CIGAR words and tag bytes of every record are copied out, SEQ/QUAL are skipped
     def _index_records(self):
-        data, p, n = self._data, self._rec_start, len(self._data)
-        cols = {k: [] for k in ("off", "size", "tid", "pos", "mapq", "flag", "l_rn", "n_cig", "l_seq")}
+        z, p, n = self._z, self._rec_start, self._z.size
+        cols = {k: [] for k in ("seq_off", "size", "tid", "pos", "mapq", "flag", "n_cig", "l_seq")}
+        names, tags, cig_parts = [], [], []
         unpack = struct.Struct("<iiiBBHHHi").unpack_from
-        while p + 4 <= n:
-            bs, tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq = unpack(data, p)
-            cols["off"].append(p + 4); cols["size"].append(bs); cols["tid"].append(tid)
+        while p + 36 <= n:
+            bs, tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq = unpack(z.read(p, 36), 0)
+            q = p + 36
+            body = z.read(q, l_rn + 4 * n_cig)
+            names.append(body[:l_rn - 1].decode())
+            cig_parts.append(body[l_rn:])
+            q += l_rn + 4 * n_cig
+            tag_off = q + (l_seq + 1) // 2 + l_seq
+            tags.append(z.read(tag_off, p + 4 + bs - tag_off))
+            cols["seq_off"].append(q); cols["size"].append(bs); cols["tid"].append(tid)
             cols["pos"].append(pos); cols["mapq"].append(mapq); cols["flag"].append(flag)
-            cols["l_rn"].append(l_rn); cols["n_cig"].append(n_cig); cols["l_seq"].append(l_seq)
+            cols["n_cig"].append(n_cig); cols["l_seq"].append(l_seq)
             p += 4 + bs
         self._cols = {k: np.asarray(v, dtype=np.int64) for k, v in cols.items()}
-        self.n_records = len(cols["off"])
+        self.n_records = len(names)
+        self._names, self._tags = names, tags
+        self._cigar = np.frombuffer(b"".join(cig_parts), dtype="<u4") if cig_parts else np.zeros(0, np.uint32)
+        self._cig_off = np.concatenate(([0], np.cumsum(self._cols["n_cig"]))).astype(np.int64) \
+            if self.n_records else np.zeros(1, np.int64)
 
     def __len__(self):
         return self.n_records
 
     def record(self, i):
         c = self._cols
-        off, l_rn, n_cig, l_seq = int(c["off"][i]), int(c["l_rn"][i]), int(c["n_cig"][i]), int(c["l_seq"][i])
         r = AlignedRecord()
         r.index = i
         r.reference_id = int(c["tid"][i])
         r.reference_start = int(c["pos"][i])
         r.mapping_quality = int(c["mapq"][i])
         r.flag = int(c["flag"][i])
-        q = off + 32
-        r.query_name = bytes(self._data[q:q + l_rn - 1]).decode()
-        q += l_rn
-        r.cigar_words = np.frombuffer(self._data, dtype="<u4", count=n_cig, offset=q)
-        q += 4 * n_cig
-        r._seq_packed = np.frombuffer(self._data, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q)
-        r._l_seq = l_seq
-        q += (l_seq + 1) // 2 + l_seq
-        r._tags_raw = memoryview(self._data)[q:off + int(c["size"][i])]
+        r.query_name = self._names[i]
+        r.cigar_words = self._cigar[self._cig_off[i]:self._cig_off[i + 1]]
+        r._l_seq = int(c["l_seq"][i])
+        r._seq_packed = _LazySeq(self._z, int(c["seq_off"][i]), (r._l_seq + 1) // 2)
+        r._tags_raw = self._tags[i]
         return r
+
+    def prefetch_sequence(self, requests):
+        """requests: iterable of (record index, first base, last base + 1) that will be sliced soon;
+        the covering BGZF blocks are inflated on a thread pool."""
+        c = self._cols
+        self._z.prefetch([(int(c["seq_off"][i]) + (a >> 1), ((b + 1) >> 1) - (a >> 1)) for i, a, b in requests])
 
     def batch(self, indices=None):
         """Flattened BAM-native CIGAR of the selected records:
         (cigar u32[n_ops], aln_off u64[n+1], ref_start i32[n], tid i32[n])."""
         c = self._cols
-        idx = np.arange(self.n_records) if indices is None else np.asarray(indices, dtype=np.int64)
-        n_cig = c["n_cig"][idx]
+        if indices is None:
+            cigar, n_cig, idx = self._cigar, c["n_cig"], slice(None)
+        else:
+            idx = np.asarray(indices, dtype=np.int64)
+            n_cig = c["n_cig"][idx]
+            parts = [self._cigar[self._cig_off[i]:self._cig_off[i + 1]] for i in idx.tolist()]
+            cigar = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
         aln_off = np.concatenate(([0], np.cumsum(n_cig))).astype(np.uint64)
-        starts = c["off"][idx] + 32 + c["l_rn"][idx]
-        buf = np.frombuffer(self._data, dtype=np.uint8)
-        parts = [buf[s:s + 4 * k] for s, k in zip(starts.tolist(), n_cig.tolist()) if k]
-        cigar = np.concatenate(parts).view("<u4") if parts else np.zeros(0, np.uint32)
         return (np.ascontiguousarray(cigar, dtype=np.uint32), aln_off,
                 c["pos"][idx].astype(np.int32), c["tid"][idx].astype(np.int32))
 
@@ -403,7 +510,7 @@ class AlignmentFile(object):
         return self.lengths[tid]
 
     def close(self):
-        self._data = None
+        self._z = None
 
 
 # ------------------------------------------------------------------------------ writer
