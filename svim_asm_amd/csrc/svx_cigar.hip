@@ -28,16 +28,20 @@
 
 namespace {
 
-constexpr int kLaneOps = 16;
+#ifndef SVX_LANE_OPS
+#define SVX_LANE_OPS 16
+#endif
+constexpr int kLaneOps = SVX_LANE_OPS;          // consecutive ops per lane per round (16 or 32)
+constexpr int kLU = kLaneOps / 4;              // uint4 groups per lane per round
 constexpr int kRoundOps = 64 * kLaneOps;       // 1024 ops per wave round (4 KiB)
 #ifndef SVX_ROUNDS
 #define SVX_ROUNDS 4
 #endif
 constexpr int kRounds = SVX_ROUNDS;
 constexpr int kTileOps = kRoundOps * kRounds;  // 4096 ops per tile (16 KiB)
-constexpr int kSlab = 64 * SVX_ROUNDS;         // staged signatures per tile (1/16 of its ops)
+constexpr int kSlab = kLaneOps * 4 * SVX_ROUNDS; // staged signatures per tile (1/16 of its ops)
 constexpr int kWaves = 4;                      // waves (= tiles) per workgroup
-constexpr int kXposeU4 = 64 * 4;               // transpose buffer: 4 uint4 per lane, XOR-swizzled
+constexpr int kXposeU4 = 64 * kLU;             // transpose buffer: kLU uint4 per lane, XOR-swizzled
 constexpr int kScanBlock = 1024;               // tile descriptors per scan workgroup
 
 enum { MODE_STAGE = 0, MODE_DIRECT = 1 };
@@ -158,30 +162,37 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+// swizzle of the transpose buffer: lane c's p-th uint4 group lives at c*kLU + (p ^ xswz(c)); with
+// kLU groups per lane this spreads any 16 consecutive lanes over the 16 uint4 slots of a 256-B row
+__device__ __forceinline__ int xswz(int c) { return (c / (16 / kLU)) & (kLU - 1); }
+
 template <bool SOA>
 __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t ro_,
-                                           uint32_t ro, int lane, uint4 (&q)[4], uint4& o) {
+                                           uint32_t ro, int lane, uint4 (&q)[kLU], uint32_t (&o)[kLU]) {
 #ifdef SVX_EXP_NOLOAD  // perf experiment only: no HBM traffic
-    for (int k = 0; k < 4; ++k) q[k] = make_uint4(ro + lane, (400u << 4), (3u << 4) | 1u, (77u << 4));
-    o = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < kLU; ++k) { q[k] = make_uint4(ro + lane, (400u << 4), (3u << 4) | 1u, (77u << 4)); o[k] = 0; }
     return;
 #endif
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kLU; ++k) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
             rc, (int)((ro + (uint32_t)(k * 64 + lane) * 4u) * 4u), 0, 0);
         q[k] = make_uint4(v.x, v.y, v.z, v.w);
     }
-    if (SOA) {  // 16 op codes of this lane's 16 consecutive ops
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ro_, (int)(ro + (uint32_t)lane * 16u), 0, 0);
-        o = make_uint4(v.x, v.y, v.z, v.w);
+    if (SOA) {  // the op codes of this lane's kLaneOps consecutive ops, 4 per dword
+#pragma unroll
+        for (int k = 0; k < kLU / 4; ++k) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                ro_, (int)(ro + (uint32_t)lane * kLaneOps + (uint32_t)k * 16u), 0, 0);
+            o[4 * k + 0] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+        }
     }
 }
 
 #ifndef SVX_TILE_MIN_WAVES
 #define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int kQueue = 32;  // signatures one round may queue in LDS (one flush lane each)
+constexpr int kQueue = 2 * kLaneOps;  // signatures one round may queue in LDS (one flush lane each)
 constexpr uint32_t kDescForceDense = 1u << 30;  // descriptor flag: a round overflowed the queue
 
 enum { WALK_TOTALS = 0, WALK_QUEUE = 1, WALK_DIRECT = 2 };
@@ -207,7 +218,7 @@ struct DirectCtx {
 // starts and emitting ops are rare: both are handled under wave-uniform branches (HU / ballot),
 // the common per-op path is decode + two masked adds.
 template <int WALK, bool SOA>
-__device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, int swz, const uint32_t (&opw)[4],
+__device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, int swz, const uint32_t (&opw)[kLU],
                                           uint32_t hm, uint32_t HU, int lane, uint4* queue,
                                           const DirectCtx& dc) {
     uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
@@ -217,9 +228,9 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
 #endif
     uint4 nxt = myx[swz];
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kLU; ++j) {
         const uint4 v4 = nxt;
-        nxt = myx[((j + 1) & 3) ^ swz];  // LDS read of the next group overlaps this group's math
+        nxt = myx[((j + 1) & (kLU - 1)) ^ swz];  // LDS read of the next group overlaps this group's math
         const uint32_t wv[4] = {v4.x, v4.y, v4.z, v4.w};
         const uint32_t hu4 = HU >> (4 * j), hm4 = hm >> (4 * j);
 #pragma unroll
@@ -243,10 +254,10 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
                         const uint32_t qi = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(eb >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)eb, 0u));
                         if (qi < (uint32_t)kQueue) {
-                            // meta: lane | slot << 6 | (start at/before op i inside this lane) << 10 |
-                            //       index among the lane's signatures << 11 | op << 16 (SoA only)
-                            const uint32_t meta = (uint32_t)lane | (i << 6) | (hs << 10) | (n_emit << 11) |
-                                                  (SOA ? (op << 16) : 0u);
+                            // meta: lane | slot << 6 | (start at/before op i inside this lane) << 11 |
+                            //       index among the lane's signatures << 12 | op << 18 (SoA only)
+                            const uint32_t meta = (uint32_t)lane | (i << 6) | (hs << 11) | (n_emit << 12) |
+                                                  (SOA ? (op << 18) : 0u);
                             queue[qi] = make_uint4(rr - base_r, rd - base_d, SOA ? len : wv[t], meta);
                         }
                     } else if (WALK == WALK_DIRECT) {
@@ -300,7 +311,8 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.cigar + g0, tile_len * 4u);
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(SOA ? (const void*)(p.op + g0) : (const void*)p.cigar,
                                                   SOA ? tile_len : 0u);
-    uint4 q[4], qo = make_uint4(0, 0, 0, 0);
+    uint4 q[kLU];
+    uint32_t qo[kLU] = {};
     load_round<SOA>(rs_c, rs_o, 0u, lane, q, qo);
 
     // ---- alignment starts inside this tile → 4096-bit mask in LDS; `dup` = two alignments start
@@ -352,25 +364,27 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         if (ro >= tile_len) break;  // wave-uniform
 
         // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
-        // c = i >> 2 as its p = i & 3 -th group; it is stored at c*4 + (p ^ ((c >> 2) & 3)), which
-        // keeps both the ds_write_b128 and the per-group ds_read_b128 bank-conflict free ----
+        // c = i / kLU as its p = i % kLU -th group; it is stored at c*kLU + (p ^ xswz(c)), which keeps
+        // both the ds_write_b128 and the per-group ds_read_b128 bank-conflict free ----
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kLU; ++k) {
             const int i = k * 64 + lane;
-            const int c = i >> 2;
-            xp[c * 4 + ((i & 3) ^ ((c >> 2) & 3))] = q[k];
+            const int c = i / kLU;
+            xp[c * kLU + ((i & (kLU - 1)) ^ xswz(c))] = q[k];
         }
-        const uint4 opw4 = qo;
+        uint32_t opw[kLU];
+#pragma unroll
+        for (int k = 0; k < kLU; ++k) opw[k] = qo[k];
         // software pipeline: next round's global loads are in flight during this round's math
         if (round + 1 < kRounds && ro + kRoundOps < tile_len)
             load_round<SOA>(rs_c, rs_o, ro + kRoundOps, lane, q, qo);
         wave_lds_sync();
         const uint32_t lbase = round * kRoundOps + lane * kLaneOps;  // tile-local index of op 0
-        const uint32_t hm = (hmask[lbase >> 5] >> (lbase & 31)) & 0xFFFFu;
-        const uint32_t opw[4] = {opw4.x, opw4.y, opw4.z, opw4.w};
+        const uint32_t hm = kLaneOps == 32 ? hmask[lbase >> 5]
+                                           : (hmask[lbase >> 5] >> (lbase & 31)) & ((1u << (kLaneOps & 31)) - 1u);
         const uint32_t HU = wave_or_u32(hm);  // slots where ANY lane starts an alignment (SGPR)
-        const uint4* myx = xp + lane * 4;     // this lane's 16 consecutive ops, 4 per uint4 (swizzled)
-        const int swz = (lane >> 2) & 3;
+        const uint4* myx = xp + lane * kLU;   // this lane's consecutive ops, 4 per uint4 (swizzled)
+        const int swz = xswz(lane);
 
         DirectCtx dc;
         dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
@@ -405,27 +419,27 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
 
         if (MODE == MODE_STAGE) {
             if (C) {  // wave-uniform
-                // .z: signatures before this lane | "still lacks the tile's carry-in" << 31
-                // .w: alignment starts before this lane in the round | this lane's start mask << 16
-                lcarry[lane] = make_uint4(in_r, in_d, xc | ((!seen && !xf) ? 0x80000000u : 0u), (xch >> 16) | (hm << 16));
+                // .z: signatures before this lane | alignment starts before this lane in the round << 12
+                //     | "still lacks the tile's carry-in" << 31;   .w: this lane's start mask
+                lcarry[lane] = make_uint4(in_r, in_d, xc | ((xch >> 16) << 12) | ((!seen && !xf) ? 0x80000000u : 0u), hm);
                 wave_lds_sync();
                 const uint32_t n_here = wo.n_queued < (uint32_t)kQueue ? wo.n_queued : (uint32_t)kQueue;
                 if ((uint32_t)lane < n_here) {
                     const uint4 e = queue[lane];
-                    const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 15u, own = (e.w >> 10) & 1u,
-                                   li = (e.w >> 11) & 31u;
+                    const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 31u, own = (e.w >> 11) & 1u,
+                                   li = (e.w >> 12) & 63u;
                     const uint4 cin = lcarry[L];
                     const uint32_t ref = own ? e.x : e.x + cin.x;
                     const uint32_t rdp = own ? e.y : e.y + cin.y;
                     const uint32_t prec = own ? 0u : (cin.z >> 31);
                     uint32_t op, len;
-                    if (SOA) { op = (e.w >> 16) & 0xFFu; len = e.z; }
+                    if (SOA) { op = (e.w >> 18) & 0xFFu; len = e.z; }
                     else { op = e.z & 15u; len = e.z >> 4; }
                     const uint32_t type = (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
-                    const uint32_t rank = tile_cnt + (cin.z & 0xFFFFu) + li;
+                    const uint32_t rank = tile_cnt + (cin.z & 0xFFFu) + li;
                     if (rank < (uint32_t)kSlab) {
                         // alignment index: a_lo - 1 + (alignment starts at or before the op inside the tile)
-                        const uint32_t m = heads_before + (cin.w & 0xFFFFu) + __popc((cin.w >> 16) & ((2u << slot) - 1u));
+                        const uint32_t m = heads_before + ((cin.z >> 12) & 0xFFFu) + __popc(cin.w & ((slot == 31u) ? 0xFFFFFFFFu : ((2u << slot) - 1u)));
                         uint32_t aln = a_lo + m - 1u;
                         if (dup) aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + round * kRoundOps + L * kLaneOps + slot);
                         p.slab[(uint64_t)tile * kSlab + rank] = make_uint4(aln, ref, rdp, len | (type << 28) | (prec << 29));
