@@ -105,7 +105,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        except TypeError:  # older signature without device_id
+            dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from svim_asm_amd import _lib
     batch = build_batch(args, rank)
