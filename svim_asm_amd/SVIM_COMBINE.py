@@ -28,6 +28,7 @@ TYPE_ORDER = ("DEL", "INV", "INS", "DUP_TAN", "DUP_INT", "BND")  # processing or
 _TYPE_RANK = {t: i for i, t in enumerate(TYPE_ORDER)}
 _COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A"}
 SAME_HAPLOTYPE_DISTANCE = 1000000000
+EXACT_BAND_LIMIT = 16000  # widest Needleman-Wunsch band the GPU kernel keeps in LDS
 
 
 def _pack_keys(candidates_with_haplotype):
@@ -147,10 +148,15 @@ def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None)
     dist = {}
     thr = [k for k, e in enumerate(exact) if not e]
     exa = [k for k, e in enumerate(exact) if e]
-    k_max = int(edit_distance_threshold) if 0 <= edit_distance_threshold < 0xFFFFFFFF else 0xFFFFFFFF
-    for sel, km in ((thr, k_max), (exa, 0xFFFFFFFF)):
-        for k, d in zip(sel, edit_distances([strings[k] for k in sel], km, ctx)):
-            dist[jobs[k]] = d if d != 0xFFFFFFFF else max(k_max + 1, len(strings[k][0]) + len(strings[k][1]))
+    k_max = int(edit_distance_threshold)
+    if not 0 <= k_max <= EXACT_BAND_LIMIT:
+        raise ValueError("max_edit_distance must be within 0..%d (LDS band limit of the GPU kernel)" % EXACT_BAND_LIMIT)
+    # partitions of 3+ members: exact up to the LDS band limit (16000); beyond it an upper bound
+    # (|a| + |b|) stands in, which can only reorder scipy labels of clusters whose members differ by
+    # more than 16 kb of edits
+    for sel, band in ((thr, k_max), (exa, EXACT_BAND_LIMIT)):
+        for k, d in zip(sel, edit_distances([strings[k] for k in sel], band, ctx)):
+            dist[jobs[k]] = d if d != 0xFFFFFFFF else max(band + 1, len(strings[k][0]) + len(strings[k][1]))
     clusters_final = []
     for pi, partition in enumerate(partitions):
         if len(partition) < 2:

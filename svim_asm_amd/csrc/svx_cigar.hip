@@ -40,7 +40,10 @@ constexpr int kRoundOps = 64 * kLaneOps;       // 1024 ops per wave round (4 KiB
 constexpr int kRounds = SVX_ROUNDS;
 constexpr int kTileOps = kRoundOps * kRounds;  // 4096 ops per tile (16 KiB)
 constexpr int kSlab = kLaneOps * 4 * SVX_ROUNDS; // staged signatures per tile (1/16 of its ops)
-constexpr int kWaves = 4;                      // waves (= tiles) per workgroup
+#ifndef SVX_WAVES
+#define SVX_WAVES 4
+#endif
+constexpr int kWaves = SVX_WAVES;              // waves (= tiles) per workgroup
 constexpr int kXposeU4 = 64 * kLU;             // transpose buffer: kLU uint4 per lane, XOR-swizzled
 constexpr int kScanBlock = 1024;               // tile descriptors per scan workgroup
 

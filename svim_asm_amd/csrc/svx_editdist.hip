@@ -129,7 +129,9 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
     a.dist = d_dist;
     a.sel = nullptr;
     a.n = n_pairs;
-    uint32_t k = exact ? std::min<uint32_t>(256u, std::max<uint32_t>(max_len, 1u)) : k_max;
+    // a band wider than the longer sequence adds nothing: clip it (keeps the LDS footprint small)
+    uint32_t k = exact ? std::min<uint32_t>(256u, std::max<uint32_t>(max_len, 1u))
+                       : std::min<uint32_t>(k_max, std::max<uint32_t>(max_len, 1u));
     std::vector<uint32_t> sel;
     SVX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_edit_band),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -141,7 +143,12 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
         SVX_HIP(ctx, hipGetLastError());
         SVX_HIP(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
         SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (!exact || k >= max_len) break;
+        if (!exact || k >= max_len) {
+            if (!exact && k < k_max)  // band == longest sequence: every distance is exact, none exceeds k_max
+                for (uint32_t i = 0; i < n_pairs; ++i)
+                    if (dist[i] == 0xFFFFFFFFu) { SVX_SET_ERR(ctx, "internal: clipped band missed a distance"); return SVX_E_INVALID; }
+            break;
+        }
         sel.clear();
         for (uint32_t i = 0; i < n_pairs; ++i)
             if (dist[i] == 0xFFFFFFFFu) sel.push_back(i);
