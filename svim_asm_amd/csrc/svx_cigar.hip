@@ -329,6 +329,10 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     for (int i = lane; i < kTileOps / 32; i += 64) hmask[i] = 0;
     wave_lds_sync();
     bool dup = false;
+    // hu: for every round, the op slots (0..kLaneOps-1) at which ANY lane starts an alignment —
+    // gathered here once per tile (kLaneOps == 16: four 16-bit fields in 64 bits) instead of a
+    // wave OR-reduction of the lanes' masks in every round
+    uint32_t hu_lo = 0, hu_hi = 0;
 #ifdef SVX_EXP_NOPROLOGUE
     if (false)
 #endif
@@ -340,10 +344,18 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
                 in = true;
                 const uint32_t bit = (uint32_t)(off - g0);
                 twice = (atomicOr(&hmask[bit >> 5], 1u << (bit & 31)) >> (bit & 31)) & 1u;
+                if (kLaneOps == 16 && kRounds <= 4) {
+                    const uint32_t f = ((bit / kRoundOps) & 1u) * 16u + (bit & 15u);
+                    if ((bit / kRoundOps) & 2u) hu_hi |= 1u << f; else hu_lo |= 1u << f;
+                }
             }
         }
         dup = dup || __any(twice);
         if (!__all(in)) break;
+    }
+    if (kLaneOps == 16 && kRounds <= 4) {
+        hu_lo = wave_or_u32(hu_lo);
+        hu_hi = wave_or_u32(hu_hi);
     }
     wave_lds_sync();
 
@@ -385,7 +397,9 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         const uint32_t lbase = round * kRoundOps + lane * kLaneOps;  // tile-local index of op 0
         const uint32_t hm = kLaneOps == 32 ? hmask[lbase >> 5]
                                            : (hmask[lbase >> 5] >> (lbase & 31)) & ((1u << (kLaneOps & 31)) - 1u);
-        const uint32_t HU = wave_or_u32(hm);  // slots where ANY lane starts an alignment (SGPR)
+        // slots where ANY lane starts an alignment (SGPR)
+        const uint32_t HU = (kLaneOps == 16 && kRounds <= 4) ? (((round & 2) ? hu_hi : hu_lo) >> ((round & 1) * 16)) & 0xFFFFu
+                                                              : wave_or_u32(hm);
         const uint4* myx = xp + lane * kLU;   // this lane's consecutive ops, 4 per uint4 (swizzled)
         const int swz = xswz(lane);
 
