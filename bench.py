@@ -116,8 +116,11 @@ def main():
     n_ops = int(batch["aln_off"][-1])
     n_aln = len(batch["aln_off"]) - 1
 
-    stream = torch.cuda.current_stream(dev)
-    ctx = _lib.Context(local_rank, stream=stream.cuda_stream)
+    # two contexts (own HIP stream + own HBM workspace each) alternate between consecutive steps:
+    # batches are independent, so the scan/finish tail of step i overlaps the streaming kernel of
+    # step i+1; each context writes its own output buffers
+    ctxs = [_lib.Context(local_rank), _lib.Context(local_rank)]
+    ctx = ctxs[0]
 
     cig_np = batch["cigar"]
     d_off = torch.from_numpy(batch["aln_off"].astype(np.int64)).to(dev)
@@ -129,13 +132,14 @@ def main():
         d_cig = torch.from_numpy((cig_np >> 4).astype(np.uint32).view(np.int32)).to(dev)
         d_op = torch.from_numpy((cig_np & 15).astype(np.uint8)).to(dev)
     cap = max(1024, n_ops // 16)
-    o_aln = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_ref = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_read = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_len = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_type = torch.empty(cap, dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(1, dtype=torch.int64, device=dev)
-    outs = (o_aln.data_ptr(), o_ref.data_ptr(), o_read.data_ptr(), o_len.data_ptr(), o_type.data_ptr())
+    out_sets = []
+    for _ in range(2):
+        o = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)] + \
+            [torch.empty(cap, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)]
+        out_sets.append(o)
+    o_aln, o_ref, o_read, o_len, o_type, d_n = out_sets[0]
+    outs = tuple(t.data_ptr() for t in out_sets[0][:5])
+    torch.cuda.synchronize(dev)
 
     # a3 inputs resident in HBM: 5 % of the alignments are primaries of chimeric reads with 1-3
     # SA-derived segments; rows as SVIM_inter.py:66-81 builds them
@@ -162,11 +166,16 @@ def main():
     # CIGAR kernels; torch.cuda.synchronize() in barrier() waits for every stream of the device
     ctx2 = _lib.Context(local_rank)
 
+    step_no = [0]
+
     def step():
-        # a1 + a2: every CIGAR op of the batch, once
-        ctx.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
-                              args.min_sv_size, outs, cap, d_n.data_ptr(),
-                              d_op=None if d_op is None else d_op.data_ptr())
+        # a1 + a2: every CIGAR op of the batch, once; consecutive steps alternate contexts
+        which = step_no[0] & 1
+        step_no[0] += 1
+        c, o = ctxs[which], out_sets[which]
+        c.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
+                            args.min_sv_size, tuple(t.data_ptr() for t in o[:5]), cap, o[5].data_ptr(),
+                            d_op=None if d_op is None else d_op.data_ptr())
         # a3: split-segment decision tree for the chimeric reads of the batch
         ctx2._check(ctx2.lib.svx_segments_classify_dev(ctx2.h, d_segs.data_ptr(), n_segs, d_read_off.data_ptr(),
                                                        n_reads, d_read_len.data_ptr(), C.byref(seg_prm),
@@ -178,6 +187,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    torch.cuda.synchronize(dev)  # uploads ran on torch's stream; the contexts use their own
     for _ in range(args.warmup):
         step()
     barrier()
@@ -187,6 +197,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     n_sig = int(d_n.item())
+    if args.steps > 1 and int(out_sets[1][5].item()) != n_sig:
+        raise SystemExit("the two pipelined contexts disagree on the signature count")
     if n_sig > cap:
         raise SystemExit("output capacity too small: %d > %d" % (n_sig, cap))
 
@@ -264,7 +276,8 @@ def main():
                 "ops_per_step_per_gpu": n_ops, "alignments_per_step_per_gpu": n_aln,
                 "signatures_per_step_per_gpu": n_sig, "chimeric_reads_per_step_per_gpu": n_reads,
                 "segments_per_step_per_gpu": n_segs, "min_sv_size": args.min_sv_size,
-                "step": "a1+a2 svx_cigar_extract_dev (stream 1) + a3 svx_segments_classify_dev (stream 2)",
+                "step": "a1+a2 svx_cigar_extract_dev (two contexts/streams alternate between steps) + "
+                        "a3 svx_segments_classify_dev (third stream)",
                 "parallelism": "sample/contig shards x%d, no data-path collective" % world,
             },
             "roofline": {
