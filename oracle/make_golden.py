@@ -132,6 +132,36 @@ def make_config1():
     return out
 
 
+MEDIUM = dict(seed=3, scale=0.02, n_shared=40, n_private=8, median_aln=300000, mean_m=2000)
+
+
+def medium_contigs():
+    from svim_asm_amd import synth
+    return tuple((n, max(60000, int(l * MEDIUM["scale"]))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
+
+
+def make_medium():
+    """62 Mbp diploid sample (24 contigs at 1/50 of GRCh38): too big to commit as BAM, so only the
+    reference's VCF and the SHA-256 of the generated inputs are stored; tests regenerate the inputs
+    with the same seeds (svim_asm_amd/synth_bam.py is deterministic)."""
+    import gzip
+    import hashlib
+    from svim_asm_amd import synth_bam
+    d = tempfile.mkdtemp(prefix="svx_medium_")
+    fasta, bams = synth_bam.write_dataset(d, seed=MEDIUM["seed"], contigs=medium_contigs(), n_shared=MEDIUM["n_shared"],
+                                          n_private=MEDIUM["n_private"], median_aln=MEDIUM["median_aln"],
+                                          mean_m=MEDIUM["mean_m"])
+    wd = os.path.join(d, "wd")
+    run_reference_cli(["diploid", wd, bams[0], bams[1], fasta])
+    vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
+    with gzip.open(os.path.join(GOLD, "medium_diploid.vcf.gz"), "wb", compresslevel=9) as fh:
+        fh.write(vcf.encode())
+    digest = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in [fasta] + bams}
+    with open(os.path.join(GOLD, "medium_inputs.json"), "w") as fh:
+        json.dump({"params": MEDIUM, "sha256": digest, "records": sum(1 for l in vcf.split("\n") if l and l[0] != "#")}, fh, indent=1)
+    shutil.rmtree(d)
+
+
 def make_function_vectors():
     import random
     ref = load_reference()
@@ -174,6 +204,7 @@ def main():
     logging.getLogger().setLevel(logging.WARNING)
     make_function_vectors()
     out = make_config1()
+    make_medium()
     # the two reference BAM fixtures are data, not source: keep copies for the GPU box
     for fn in ("chimeric_read.bam", "chimeric_read_errors.bam"):
         shutil.copy(os.path.join(REF, "tests", fn), os.path.join(GOLD, fn))

@@ -1,0 +1,51 @@
+"""62 Mbp diploid sample (24 GRCh38-proportioned contigs): the VCF written by the REAL reference
+(tests/golden/medium_diploid.vcf.gz, made by oracle/make_golden.py) must be reproduced by the CPU
+oracle (CPU test) and by the product CLI on the GPU (-m gpu).  The BAM/FASTA inputs are
+regenerated from fixed seeds; their SHA-256 is checked against the generation-time digests."""
+import gzip
+import hashlib
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(GOLD, "medium_inputs.json")))
+
+
+@pytest.fixture(scope="module")
+def medium_dataset(tmp_path_factory):
+    from svim_asm_amd import synth, synth_bam
+    prm = META["params"]
+    contigs = tuple((n, max(60000, int(l * prm["scale"]))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
+    d = str(tmp_path_factory.mktemp("medium"))
+    fasta, bams = synth_bam.write_dataset(d, seed=prm["seed"], contigs=contigs, n_shared=prm["n_shared"],
+                                          n_private=prm["n_private"], median_aln=prm["median_aln"], mean_m=prm["mean_m"])
+    for f in [fasta] + bams:
+        if hashlib.sha256(open(f, "rb").read()).hexdigest() != META["sha256"][os.path.basename(f)]:
+            pytest.skip("regenerated inputs differ from the ones the golden VCF was made from (generator/zlib drift)")
+    return fasta, bams
+
+
+def expected_vcf():
+    return gzip.open(os.path.join(GOLD, "medium_diploid.vcf.gz"), "rb").read().decode()
+
+
+def test_oracle_reproduces_reference_vcf_medium(medium_dataset):
+    from oracle import orc, run_oracle
+    fasta, bams = medium_dataset
+    got = run_oracle.vcf_from_files(bams, fasta, run_oracle.default_options(),
+                                    edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+    exp = expected_vcf()
+    assert got == exp
+    assert sum(1 for l in exp.split("\n") if l and l[0] != "#") == META["records"]
+
+
+@pytest.mark.gpu
+def test_cli_reproduces_reference_vcf_medium(svx_ctx, medium_dataset, tmp_path):
+    from svim_asm_amd import cli
+    fasta, bams = medium_dataset
+    cli.main(["diploid", str(tmp_path), bams[0], bams[1], fasta])
+    got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == expected_vcf()
