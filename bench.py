@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--layout", default="packed", choices=("packed", "soa"))
+    ap.add_argument("--pipeline", action="store_true",
+                    help="alternate two contexts between consecutive steps (independent batches overlap; "
+                         "per-kernel durations then overlap too, so the default keeps one context)")
     return ap.parse_args()
 
 
@@ -116,10 +119,10 @@ def main():
     n_ops = int(batch["aln_off"][-1])
     n_aln = len(batch["aln_off"]) - 1
 
-    # two contexts (own HIP stream + own HBM workspace each) alternate between consecutive steps:
-    # batches are independent, so the scan/finish tail of step i overlaps the streaming kernel of
-    # step i+1; each context writes its own output buffers
-    ctxs = [_lib.Context(local_rank), _lib.Context(local_rank)]
+    # --pipeline: two contexts (own HIP stream + own HBM workspace each) alternate between
+    # consecutive steps; batches are independent, so step i+1 overlaps the tail of step i.  Default:
+    # one context, kernels of consecutive steps run back to back.
+    ctxs = [_lib.Context(local_rank), _lib.Context(local_rank)] if args.pipeline else [_lib.Context(local_rank)]
     ctx = ctxs[0]
 
     cig_np = batch["cigar"]
@@ -133,7 +136,7 @@ def main():
         d_op = torch.from_numpy((cig_np & 15).astype(np.uint8)).to(dev)
     cap = max(1024, n_ops // 16)
     out_sets = []
-    for _ in range(2):
+    for _ in range(len(ctxs)):
         o = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)] + \
             [torch.empty(cap, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)]
         out_sets.append(o)
@@ -170,7 +173,7 @@ def main():
 
     def step():
         # a1 + a2: every CIGAR op of the batch, once; consecutive steps alternate contexts
-        which = step_no[0] & 1
+        which = step_no[0] % len(ctxs)
         step_no[0] += 1
         c, o = ctxs[which], out_sets[which]
         c.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
@@ -197,7 +200,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     n_sig = int(d_n.item())
-    if args.steps > 1 and int(out_sets[1][5].item()) != n_sig:
+    if len(ctxs) > 1 and args.steps > 1 and int(out_sets[1][5].item()) != n_sig:
         raise SystemExit("the two pipelined contexts disagree on the signature count")
     if n_sig > cap:
         raise SystemExit("output capacity too small: %d > %d" % (n_sig, cap))
@@ -212,17 +215,15 @@ def main():
     else:
         total_ops = n_ops
 
-    # ---- roofline of the dominant kernel (k_cigar_tiles), HIP events on the launch stream ----
+    # ---- roofline of the dominant kernel (k_cigar_tiles): HIP events on its launch stream around
+    # every launch of the a1+a2 path (context 0; event pairs bracket the kernel itself) ----
+    torch.cuda.synchronize(dev)
     ctx.set_timing(True)
     k_ms, p_ms = [], []
-
-    def cigar_only():
+    for _ in range(max(5, min(20, args.steps))):
         ctx.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
                               args.min_sv_size, outs, cap, d_n.data_ptr(),
                               d_op=None if d_op is None else d_op.data_ptr())
-
-    for _ in range(max(5, min(20, args.steps))):
-        cigar_only()
         ctx.sync()
         tot_ms, dom_ms = ctx.last_kernel_ms()
         k_ms.append(dom_ms)
@@ -276,8 +277,8 @@ def main():
                 "ops_per_step_per_gpu": n_ops, "alignments_per_step_per_gpu": n_aln,
                 "signatures_per_step_per_gpu": n_sig, "chimeric_reads_per_step_per_gpu": n_reads,
                 "segments_per_step_per_gpu": n_segs, "min_sv_size": args.min_sv_size,
-                "step": "a1+a2 svx_cigar_extract_dev (two contexts/streams alternate between steps) + "
-                        "a3 svx_segments_classify_dev (third stream)",
+                "step": "a1+a2 svx_cigar_extract_dev (stream 1%s) + a3 svx_segments_classify_dev (own stream)"
+                        % ("; two contexts alternate between steps" if args.pipeline else ""),
                 "parallelism": "sample/contig shards x%d, no data-path collective" % world,
             },
             "roofline": {

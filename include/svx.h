@@ -67,6 +67,13 @@ int svx_device_count(void);
 int svx_ctx_set_timing(svx_ctx* ctx, int enabled);
 int svx_ctx_last_kernel_ms(svx_ctx* ctx, float* ms_total, float* ms_dominant);
 
+/* Pipelining independent batches over two contexts: make everything enqueued on `ctx` from now on
+ * wait until the streaming (dominant) kernel of `other`'s most recent svx_cigar_extract*_dev call
+ * has finished — the scan/finish tail of that call may still overlap.  The first call only arms
+ * `other` (it starts recording an event after its streaming kernel); no-op until one was recorded.
+ * Both contexts must live on the same device. */
+int svx_ctx_wait_dominant(svx_ctx* ctx, svx_ctx* other);
+
 /* ------------------------------------------------------------ a1 + a2 ------ */
 /*
  * CIGAR walk → indel signatures.

@@ -65,6 +65,7 @@ SYMBOLS = {
     "svx_device_count": (C.c_int, []),
     "svx_ctx_set_timing": (C.c_int, [_P, C.c_int]),
     "svx_ctx_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "svx_ctx_wait_dominant": (C.c_int, [_P, _P]),
     "svx_cigar_extract": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, SigSoa, C.c_uint64,
                                     C.POINTER(C.c_uint64)]),
     "svx_cigar_extract_soa": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, SigSoa,
@@ -147,6 +148,10 @@ class Context:
 
     def sync(self):
         self._check(self.lib.svx_ctx_sync(self.h))
+
+    def wait_dominant(self, other):
+        """Order this context's next launches after `other`'s latest streaming kernel (pipelining)."""
+        self._check(self.lib.svx_ctx_wait_dominant(self.h, other.h))
 
     def set_timing(self, on=True):
         self._check(self.lib.svx_ctx_set_timing(self.h, 1 if on else 0))

@@ -761,6 +761,11 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     hipLaunchKernelGGL((k_cigar_tiles<SOA>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
+    if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)
+        if (!ctx->ev_dom) SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dom, hipEventDisableTiming));
+        SVX_HIP(ctx, hipEventRecord(ctx->ev_dom, ctx->stream));
+        ctx->ev_dom_recorded = true;
+    }
     hipLaunchKernelGGL(k_desc_scan, dim3(n_scan_blocks), dim3(kScanBlock), 0, ctx->stream, a.desc, n_tiles,
                        a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
                        a.blk_prefix, a.n_dense + 1, d_n_out);

@@ -51,6 +51,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* ctx) {
     if (ctx->stage) (void)hipFree(ctx->stage);
     for (int i = 0; i < 4; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_dom) (void)hipEventDestroy(ctx->ev_dom);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -98,6 +99,19 @@ int svx_ws_reserve(svx_ctx* ctx, size_t total) {
 int svx_stage_reserve(svx_ctx* ctx, size_t total) {
     ctx->stage_used = 0;
     return grow(ctx, &ctx->stage, &ctx->stage_bytes, total);
+}
+
+extern "C" int svx_ctx_wait_dominant(svx_ctx* ctx, svx_ctx* other) {
+    if (!ctx || !other) return SVX_E_INVALID;
+    if (ctx->device != other->device) {
+        SVX_SET_ERR(ctx, "svx_ctx_wait_dominant: contexts live on different devices");
+        return SVX_E_INVALID;
+    }
+    other->want_dom = true;  // from now on `other` records an event after its streaming kernel
+    if (!other->ev_dom_recorded) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, other->ev_dom, 0));
+    return SVX_OK;
 }
 
 extern "C" int svx_ctx_set_timing(svx_ctx* ctx, int enabled) {

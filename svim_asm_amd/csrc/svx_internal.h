@@ -24,6 +24,10 @@ struct svx_ctx {
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    // recorded right after the streaming kernel of every cigar call (svx_ctx_wait_dominant)
+    hipEvent_t ev_dom = nullptr;
+    bool ev_dom_recorded = false;
+    bool want_dom = false;
     int n_cu = 256;
     char err[512] = {0};
 };
