@@ -300,6 +300,16 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
 #define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
 
+#ifdef SVX_EXP_PROF  // perf experiment only (tools/prof_phases.py): per-tile phase clocks
+constexpr uint32_t kProfTiles = 32768;
+__device__ uint32_t g_prof[kProfTiles * 8];  // 5 phase sums (shader clocks), lifetime and begin in 100 MHz ticks
+#define SVX_PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define SVX_PROF_ADD(i, d) prof_acc[i] += (uint32_t)(d)
+#else
+#define SVX_PROF_T(v)
+#define SVX_PROF_ADD(i, d)
+#endif
+
 // One tile (4096 ops) processed by one wave.  MODE_STAGE: signatures go to the tile's slab with
 // tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
 template <int MODE, bool SOA>
@@ -314,6 +324,11 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.cigar + g0, tile_len * 4u);
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(SOA ? (const void*)(p.op + g0) : (const void*)p.cigar,
                                                   SOA ? tile_len : 0u);
+#ifdef SVX_EXP_PROF
+    uint32_t prof_acc[8] = {};
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    SVX_PROF_T(t_begin);
     uint4 q[kLU];
     uint32_t qo[kLU] = {};
     load_round<SOA>(rs_c, rs_o, 0u, lane, q, qo);
@@ -359,6 +374,8 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     }
     wave_lds_sync();
 
+    SVX_PROF_T(t_pro);
+    SVX_PROF_ADD(0, t_pro - t_begin);
     // ---- tile state carried across rounds (wave-uniform) ----
     uint32_t carry_r = 0, carry_d = 0;
     bool seen = false, overflow = false;
@@ -378,6 +395,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         const uint32_t ro = (uint32_t)round * kRoundOps;
         if (ro >= tile_len) break;  // wave-uniform
 
+        SVX_PROF_T(t_r0);
         // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
         // c = i / kLU as its p = i % kLU -th group; it is stored at c*kLU + (p ^ xswz(c)), which keeps
         // both the ds_write_b128 and the per-group ds_read_b128 bank-conflict free ----
@@ -394,6 +412,8 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         if (round + 1 < kRounds && ro + kRoundOps < tile_len)
             load_round<SOA>(rs_c, rs_o, ro + kRoundOps, lane, q, qo);
         wave_lds_sync();
+        SVX_PROF_T(t_r1);
+        SVX_PROF_ADD(1, t_r1 - t_r0);  // wait for the round's data + transpose
         const uint32_t lbase = round * kRoundOps + lane * kLaneOps;  // tile-local index of op 0
         const uint32_t hm = kLaneOps == 32 ? hmask[lbase >> 5]
                                            : (hmask[lbase >> 5] >> (lbase & 31)) & ((1u << (kLaneOps & 31)) - 1u);
@@ -408,6 +428,8 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         const WalkOut wo = walk16<(MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS, SOA>(
             p, myx, swz, opw, hm, HU, lane, queue, dc);
 
+        SVX_PROF_T(t_r2);
+        SVX_PROF_ADD(2, t_r2 - t_r1);  // walk
         // ---- wave scans (DPP).  Plain inclusive sums of the lane totals, signature counts and
         // alignment-start counts; the segmentation is applied afterwards: the carry-in of lane l is
         // its exclusive sum plus Q(h) = tail(h) - P(h) of the last lane h < l that holds an
@@ -472,6 +494,8 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
             }
         }
         wave_lds_sync();  // queue / lcarry / xp are rewritten by the next round
+        SVX_PROF_T(t_r3);
+        SVX_PROF_ADD(3, t_r3 - t_r2);  // scans + flush
 
         // ---- carry to the next round (wave-uniform) ----
         const uint32_t R = __builtin_amdgcn_readlane(pr, 63), D = __builtin_amdgcn_readlane(pd, 63);
@@ -488,6 +512,18 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         heads_before += CH >> 16;
     }
 
+#ifdef SVX_EXP_PROF
+    SVX_PROF_T(t_end);
+    SVX_PROF_ADD(4, t_end - t_begin);
+    prof_acc[5] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt_begin);
+    prof_acc[6] = (uint32_t)rt_begin;
+    if (MODE == MODE_STAGE && lane < 8) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v = (lane == i) ? prof_acc[i] : v;
+        g_prof[(tile % kProfTiles) * 8 + lane] = v;
+    }
+#endif
     if (MODE == MODE_STAGE && lane == 0) {
         p.desc[tile] = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31),
                                   carry_r, carry_d, a_lo);
@@ -933,3 +969,10 @@ extern "C" int svx_cigar_stats(svx_ctx* ctx, const uint32_t* cigar, const uint64
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SVX_OK;
 }
+
+#ifdef SVX_EXP_PROF
+extern "C" int svx_debug_prof(uint32_t* out, uint32_t n_tiles) {
+    if (n_tiles > kProfTiles) n_tiles = kProfTiles;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(uint32_t) * 8 * n_tiles) == hipSuccess ? 0 : -1;
+}
+#endif
