@@ -220,10 +220,20 @@ struct DirectCtx {
 // loop over the four groups is rolled, so the working set is a handful of registers.  Alignment
 // starts and emitting ops are rare: both are handled under wave-uniform branches (HU / ballot),
 // the common per-op path is decode + two masked adds.
-template <int WALK, bool SOA>
+//
+// FAST24 (packed layout only, every length of the round < 2^24 — checked by the caller): the op
+// code never leaves the raw word.  v_bfe reads its bit offset from the word's low 5 bits, so the
+// 9-bit op tables are replicated at bit 16 (offset op or op + 16, whatever the length's lowest bit
+// is); the masked add becomes one 24-bit multiply-add per cursor, and "I or D and long enough"
+// one compare of (word & -isID(op)) against (min_len << 4, at least 1).  8 VALU per op, not 11.
+template <int WALK, bool SOA, bool FAST24>
 __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, int swz, const uint32_t (&opw)[kLU],
                                           uint32_t hm, uint32_t HU, int lane, uint4* queue,
                                           const DirectCtx& dc) {
+    static_assert(!(SOA && FAST24), "FAST24 reads op and length from one packed word");
+    // emit threshold on the packed word: len >= min_len  <=>  (len << 4 | op) >= min_len << 4 for
+    // min_len >= 1; for min_len == 0 every I/D op qualifies and its word is >= 1 (op bits)
+    const uint32_t thr = p.min_len >= (1u << 28) ? 0xFFFFFFFFu : (p.min_len ? p.min_len << 4 : 1u);
     uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
     uint32_t hs = 0;  // this lane has passed an alignment start
 #ifdef SVX_EXP_NOWALK  // perf experiment only: memory + scan floor without the per-op work
@@ -241,16 +251,23 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
             uint32_t op, len;
             if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
             else { op = wv[t] & 15u; len = wv[t] >> 4; }
-            if ((hu4 >> t) & 1u) {  // scalar test: some lane starts an alignment at this slot
+            if (__builtin_expect(((hu4 >> t) & 1u) != 0u, 0)) {  // scalar test: some lane starts an alignment at this slot
                 asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch, not two selects per op
                 if ((hm4 >> t) & 1u) { base_r = rr; base_d = rd; hs = 1u; }
             }
-            // I or D with len >= min_len (inclusive threshold, :18,:22): two compares straight into
+            // I or D with len >= min_len (inclusive threshold, :18,:22): compares straight into
             // scalar masks; the per-lane predicate is only derived inside the rarely taken branch
-            const uint64_t eb = __builtin_amdgcn_ballot_w64((op - 1u) < 2u) &
-                                __builtin_amdgcn_ballot_w64(len >= p.min_len);
-            if (eb) {  // wave-uniform: most op slots emit nothing
-                if ((op - 1u) < 2u && len >= p.min_len) {
+            bool emits;
+            uint64_t eb;
+            if (FAST24) {
+                emits = (wv[t] & (uint32_t)__builtin_amdgcn_sbfe(0x00060006, wv[t], 1)) >= thr;
+                eb = __builtin_amdgcn_ballot_w64(emits);
+            } else {
+                emits = (op - 1u) < 2u && len >= p.min_len;
+                eb = __builtin_amdgcn_ballot_w64((op - 1u) < 2u) & __builtin_amdgcn_ballot_w64(len >= p.min_len);
+            }
+            if (__builtin_expect(eb != 0ull, 0)) {  // wave-uniform: most op slots emit nothing
+                if (emits) {
                     const uint32_t i = 4 * j + t;
                     if (WALK == WALK_QUEUE) {
                         // rank among the lanes emitting at this slot: mbcnt over the scalar mask
@@ -275,9 +292,14 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
             }
             // ops advancing the reference cursor: M(0) D(2) =(7) X(8); the query cursor:
             // M(0) I(1) S(4) =(7) X(8)   (SVIM_intra.py:14-29; N,H,P,B and codes >= 10: nothing)
-            const uint32_t sop = SOA ? (op < 16u ? op : 15u) : op;
-            rr += len & (uint32_t)__builtin_amdgcn_sbfe(0x185, sop, 1);
-            rd += len & (uint32_t)__builtin_amdgcn_sbfe(0x193, sop, 1);
+            if (FAST24) {
+                rr += __umul24(len, __builtin_amdgcn_ubfe(0x01850185u, wv[t], 1));
+                rd += __umul24(len, __builtin_amdgcn_ubfe(0x01930193u, wv[t], 1));
+            } else {
+                const uint32_t sop = SOA ? (op < 16u ? op : 15u) : op;
+                rr += len & (uint32_t)__builtin_amdgcn_sbfe(0x185, sop, 1);
+                rd += len & (uint32_t)__builtin_amdgcn_sbfe(0x193, sop, 1);
+            }
         }
     }
     WalkOut o;
@@ -399,6 +421,14 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
         // c = i / kLU as its p = i % kLU -th group; it is stored at c*kLU + (p ^ xswz(c)), which keeps
         // both the ds_write_b128 and the per-group ds_read_b128 bank-conflict free ----
+        // every length of the round below 2^24 (any real CIGAR): the walk may use 24-bit multiply-adds
+        bool fast24 = false;
+        if (!SOA) {
+            uint32_t any = 0;
+#pragma unroll
+            for (int k = 0; k < kLU; ++k) any |= q[k].x | q[k].y | q[k].z | q[k].w;
+            fast24 = __builtin_amdgcn_ballot_w64((any >> 28) != 0u) == 0ull;
+        }
 #pragma unroll
         for (int k = 0; k < kLU; ++k) {
             const int i = k * 64 + lane;
@@ -425,8 +455,9 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
 
         DirectCtx dc;
         dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
-        const WalkOut wo = walk16<(MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS, SOA>(
-            p, myx, swz, opw, hm, HU, lane, queue, dc);
+        constexpr int kWalk1 = (MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS;
+        const WalkOut wo = (!SOA && fast24) ? walk16<kWalk1, SOA, !SOA>(p, myx, swz, opw, hm, HU, lane, queue, dc)
+                                            : walk16<kWalk1, SOA, false>(p, myx, swz, opw, hm, HU, lane, queue, dc);
 
         SVX_PROF_T(t_r2);
         SVX_PROF_ADD(2, t_r2 - t_r1);  // walk
@@ -490,7 +521,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
             if (C) {  // dense tile: second walk finishes each signature on the spot
                 dc.in_r = in_r; dc.in_d = in_d;
                 dc.out0 = (uint64_t)obase + tile_cnt + xc;
-                (void)walk16<WALK_DIRECT, SOA>(p, myx, swz, opw, hm, HU, lane, queue, dc);
+                (void)walk16<WALK_DIRECT, SOA, false>(p, myx, swz, opw, hm, HU, lane, queue, dc);
             }
         }
         wave_lds_sync();  // queue / lcarry / xp are rewritten by the next round

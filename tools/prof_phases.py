@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--min-len", type=int, default=40)
     a = ap.parse_args()
     args = argparse.Namespace(samples=a.samples, distinct=8, config=2)
     from svim_asm_amd import _lib
@@ -39,7 +40,7 @@ def main():
     f.argtypes = [C.c_void_p, C.c_uint32]
 
     def run():
-        ctx.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(), 40,
+        ctx.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(), a.min_len,
                               tuple(t.data_ptr() for t in o[:5]), cap, o[5].data_ptr())
     for _ in range(3):
         run()
