@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=64, help="haplotype samples per GPU per step")
+    ap.add_argument("--samples", type=int, default=256, help="haplotype samples (assemblies) per GPU per step")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic samples (replicated to --samples)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 5), help="BASELINE config: 2 (mean M run 4000) or 5 (400)")
     ap.add_argument("--min-sv-size", type=int, default=40)
@@ -65,18 +65,45 @@ def cpu_baseline(batch, args):
     a_hi = int(np.searchsorted(off, max_ops, side="right")) - 1
     a_hi = max(a_hi, 1)
     n_ops = int(off[a_hi])
-    sub_c, sub_o, sub_r = cig[:n_ops], off[:a_hi + 1], rs[:a_hi]
+    sub_c = np.ascontiguousarray(cig[:n_ops], np.uint32)
+    sub_o = np.ascontiguousarray(off[:a_hi + 1], np.uint64)
+    sub_r = np.ascontiguousarray(rs[:a_hi], np.int32)
+    bufs = orc.cigar_extract(sub_c, sub_o, sub_r, args.min_sv_size)  # sizes the output buffers (untimed)
     t0 = time.perf_counter()
-    orc.cigar_extract(sub_c, sub_o, sub_r, args.min_sv_size)
+    orc.cigar_extract_timed(sub_c, sub_o, sub_r, args.min_sv_size, bufs)
     one = time.perf_counter() - t0
     reps = int(max(1, min(200, args.cpu_seconds / max(one, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(reps):
-        orc.cigar_extract(sub_c, sub_o, sub_r, args.min_sv_size)
+        orc.cigar_extract_timed(sub_c, sub_o, sub_r, args.min_sv_size, bufs)
     dt = time.perf_counter() - t0
     out = {"value": n_ops * reps / dt, "unit": "CIGAR ops/s", "cores": 1, "kind": "port",
            "sample": "%d passes over %d ops / %d alignments of the bench batch (C restatement of "
                      "SVIM_intra.analyze_cigar_indel, gcc -O2, 1 thread, %.1f s)" % (reps, n_ops, a_hi, dt)}
+    # the same C loop on every host core (alignments are independent: one contiguous shard per thread;
+    # ctypes releases the GIL) — informative, the reference itself is single-threaded
+    try:
+        import concurrent.futures as cf
+        nthr = max(1, os.cpu_count() or 1)
+        cuts = [int(x) for x in np.linspace(0, a_hi, nthr + 1)]
+        shards = []
+        for i in range(nthr):
+            lo, hi = cuts[i], cuts[i + 1]
+            if hi > lo:
+                o = np.ascontiguousarray(sub_o[lo:hi + 1] - sub_o[lo], np.uint64)
+                c = np.ascontiguousarray(sub_c[int(sub_o[lo]):int(sub_o[hi])])
+                r = np.ascontiguousarray(sub_r[lo:hi])
+                shards.append((c, o, r, orc.cigar_extract(c, o, r, args.min_sv_size)))
+        reps_mt = max(1, min(reps, 8))
+        with cf.ThreadPoolExecutor(len(shards)) as ex:
+            t0 = time.perf_counter()
+            for _ in range(reps_mt):
+                list(ex.map(lambda sh: orc.cigar_extract_timed(sh[0], sh[1], sh[2], args.min_sv_size, sh[3]), shards))
+            dtm = time.perf_counter() - t0
+        out["all_cores_value"] = n_ops * reps_mt / dtm
+        out["all_cores"] = len(shards)
+    except Exception as e:
+        out["all_cores_error"] = repr(e)
     # CPython restatement of the same loop (what the reference actually executes), small sample
     try:
         from oracle import svim_oracle
@@ -234,6 +261,26 @@ def main():
     algo_bytes = 4 * n_ops + 16 * n_aln + 17 * n_sig
     achieved = algo_bytes / k_avg / 1e9
 
+    # measured device-copy ceiling of this box (SURVEY.md §8d asks for both denominators): 1 GiB
+    # device-to-device copy, bytes read + written over its duration
+    copy_gbs = None
+    try:
+        src = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+        dst = torch.empty_like(src)
+        src.fill_(1)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    except Exception:
+        copy_gbs = None
+
     # correctness spot-check of what the timed loop produced (oracle = checker only)
     if rank == 0:
         from oracle import orc
@@ -286,6 +333,7 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_avg * 1e3,
                 "path_ms": p_avg * 1e3, "path_achieved": algo_bytes / p_avg / 1e9,
+                "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
             },
         }
         if not args.no_cpu_baseline:

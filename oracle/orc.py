@@ -71,6 +71,15 @@ def cigar_extract(cigar, aln_off, ref_start=None, min_len=40):
     return out
 
 
+def cigar_extract_timed(cigar, aln_off, ref_start, min_len, out):
+    """One pass of the C loop into pre-sized buffers `out` (from a previous cigar_extract): what
+    bench.py's cpu_baseline times — no counting pre-pass, no allocation.  Returns the count."""
+    n_aln = len(aln_off) - 1
+    return int(lib().orc_cigar_extract(_p(cigar), _p(aln_off), n_aln, _p(ref_start), int(min_len), _p(out["aln"]),
+                                       _p(out["ref_pos"]), _p(out["read_pos"]), _p(out["len"]),
+                                       _p(out["type"]), len(out["aln"])))
+
+
 def cigar_stats(cigar, aln_off):
     cigar = np.ascontiguousarray(cigar, np.uint32)
     aln_off = np.ascontiguousarray(aln_off, np.uint64)

@@ -673,37 +673,43 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
     }
 }
 
-// ---- C: finish.  (1) sparse tiles: half a wave per tile copies the staged records into the final
-// SoA at the scanned output base (a tile of 4096 ops carries ~30 signatures: lane = signature),
-// adding the tile carry-in where the record lacks it and ref_start of its alignment.
-// (2) dense tiles (rare) are re-walked with carry-in and output base known. ----
+// ---- C: finish, sparse tiles: 16 lanes per tile copy the staged records into the final SoA at the
+// scanned output base (a tile of 4096 ops carries ~30 signatures: lane = signature), adding the
+// tile carry-in where the record lacks it and ref_start of its alignment.  No LDS, few registers:
+// the kernel is a chain of two dependent loads per tile and lives on occupancy. ----
+constexpr int kFinLanes = 16;
+__global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) {
+    const uint32_t tile = blockIdx.x * (256u / kFinLanes) + threadIdx.x / kFinLanes;
+    const uint32_t l = threadIdx.x % kFinLanes;
+    if (tile >= p.n_tiles) return;
+    const uint4 rec0 = p.slab[(uint64_t)tile * kSlab + l];  // speculative: issued with the descriptor
+    const uint4 dsc = p.desc[tile];
+    const uint4 bp = p.blk_prefix[tile / kScanBlock];
+    const uint32_t lb = p.out_base[tile];
+    const uint32_t lcr = p.carry_ref[tile], lcd = p.carry_read[tile];
+    const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
+    if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) return;  // dense: k_cigar_dense
+    const bool local_head = (lb >> 31) != 0;
+    const uint32_t cr = lcr + (local_head ? 0u : bp.y);
+    const uint32_t cd = lcd + (local_head ? 0u : bp.z);
+    const uint64_t ob = (uint64_t)(lb & 0x7FFFFFFFu) + bp.w;
+    for (uint32_t r = l; r < cnt; r += kFinLanes) {
+        const uint4 rec = (r == l) ? rec0 : p.slab[(uint64_t)tile * kSlab + r];
+        const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+        store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
+    }
+}
+
+// ---- D: dense tiles (more than kSlab signatures: adversarial all-indel CIGARs, or a tiny min_len)
+// are re-walked with carry-in and output base known.  Always launched — the host cannot know —
+// and empty in the common case (every workgroup reads the count and leaves). ----
 template <bool SOA>
-__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_finish(CigarArgs p) {
+__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_dense(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ uint32_t s_head[kWaves][kTileOps / 32];
     __shared__ uint4 s_queue[kWaves][kQueue];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, sub = lane >> 5, l32 = lane & 31;
-    for (uint32_t pair = blockIdx.x * kWaves + wave; pair * 2 < p.n_tiles; pair += gridDim.x * kWaves) {
-        const uint32_t tile = pair * 2 + sub;
-        if (tile >= p.n_tiles) continue;
-        const uint4 rec0 = p.slab[(uint64_t)tile * kSlab + l32];  // speculative: issued with the descriptor
-        const uint4 dsc = p.desc[tile];
-        const uint4 bp = p.blk_prefix[tile / kScanBlock];
-        const uint32_t lb = p.out_base[tile];
-        const uint32_t lcr = p.carry_ref[tile], lcd = p.carry_read[tile];
-        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
-        if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) continue;
-        const bool local_head = (lb >> 31) != 0;
-        const uint32_t cr = lcr + (local_head ? 0u : bp.y);
-        const uint32_t cd = lcd + (local_head ? 0u : bp.z);
-        const uint64_t ob = (uint64_t)(lb & 0x7FFFFFFFu) + bp.w;
-        for (uint32_t r = l32; r < cnt; r += 32) {
-            const uint4 rec = (r == (uint32_t)l32) ? rec0 : p.slab[(uint64_t)tile * kSlab + r];
-            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
-            store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
-        }
-    }
+    const int lane = threadIdx.x & 63;
     const uint32_t n_dense = p.n_dense[2];
     for (uint32_t work = blockIdx.x * kWaves + wave; work < n_dense; work += gridDim.x * kWaves)
         process_tile<MODE_DIRECT, SOA>(p, p.dense_list[work], lane, s_xpose[wave], s_head[wave], s_queue[wave]);
@@ -836,9 +842,10 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     hipLaunchKernelGGL(k_desc_scan, dim3(n_scan_blocks), dim3(kScanBlock), 0, ctx->stream, a.desc, n_tiles,
                        a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
                        a.blk_prefix, a.n_dense + 1, d_n_out);
-    const uint32_t blocks_finish = (blocks_all + 1) / 2;
-    hipLaunchKernelGGL((k_cigar_finish<SOA>), dim3(blocks_finish < blocks_cap ? blocks_finish : blocks_cap),
-                       dim3(64 * kWaves), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_cigar_finish, dim3((n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes)), dim3(256), 0,
+                       ctx->stream, a);
+    hipLaunchKernelGGL((k_cigar_dense<SOA>), dim3(blocks_all < blocks_cap ? blocks_all : blocks_cap), dim3(64 * kWaves),
+                       0, ctx->stream, a);
     SVX_HIP(ctx, hipGetLastError());
     return svx_timing_end(ctx);
 }
