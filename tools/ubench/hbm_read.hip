@@ -1,0 +1,47 @@
+// Read-only streaming ceiling: every workgroup reads contiguous 16 KiB tiles (4 x dwordx4 per lane
+// in flight, like k_cigar_tiles), XOR-reduces and writes one word.  Prints GB/s for several sizes.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/hbm_read tools/ubench/hbm_read.hip && /tmp/hbm_read
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_read(const uint4* __restrict__ in, size_t n_u4, uint32_t* out) {
+    const size_t per_block = 256 * UNROLL;
+    uint32_t acc = 0;
+    for (size_t base = (size_t)blockIdx.x * per_block; base < n_u4; base += (size_t)gridDim.x * per_block) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            const size_t i = base + (size_t)k * 256 + threadIdx.x;
+            v[k] = i < n_u4 ? in[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = acc;  // practically never: keeps the loads alive
+}
+
+int main() {
+    const size_t sizes[] = {256ull << 20, 395ull << 20, 1600ull << 20, 4096ull << 20};
+    uint32_t* out; hipMalloc(&out, 1 << 20);
+    for (size_t bytes : sizes) {
+        uint4* in; if (hipMalloc(&in, bytes) != hipSuccess) { printf("alloc %zu failed\n", bytes); continue; }
+        hipMemset(in, 1, bytes);
+        const size_t n = bytes / 16;
+        for (int grid : {2048, 8192, 0}) {
+            const int g = grid ? grid : (int)((n + 256 * 4 - 1) / (256 * 4));
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_read<4>, dim3(g), dim3(256), 0, 0, in, n, out);
+            hipEventRecord(a);
+            const int reps = 10;
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_read<4>, dim3(g), dim3(256), 0, 0, in, n, out);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("read %5zu MiB grid %7d: %.0f GB/s (%.1f us per pass)\n", bytes >> 20, g, bytes * reps / (ms * 1e-3) / 1e9, ms * 1e3 / reps);
+        }
+        hipFree(in);
+    }
+    return 0;
+}
