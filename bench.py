@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--layout", default="packed", choices=("packed", "soa"))
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to smoke-test the "
+                         "multi-rank logic on a box with fewer GPUs than ranks, together with --share-device)")
+    ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses device 0")
     ap.add_argument("--pipeline", action="store_true",
                     help="alternate two contexts between consecutive steps (independent batches overlap; "
                          "per-kernel durations then overlap too, so the default keeps one context)")
@@ -131,15 +135,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the two scalars are reduced
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        except TypeError:  # older signature without device_id
-            dist.init_process_group("nccl", rank=rank, world_size=world)
+        if args.backend == "nccl":
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            except TypeError:  # older signature without device_id
+                dist.init_process_group("nccl", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from svim_asm_amd import _lib
     batch = build_batch(args, rank)
@@ -233,10 +243,10 @@ def main():
         raise SystemExit("output capacity too small: %d > %d" % (n_sig, cap))
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_ops], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_ops], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_ops = int(tot.item())
     else:

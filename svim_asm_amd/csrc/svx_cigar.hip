@@ -9,20 +9,21 @@
 //   out SoA           aln u32, ref_pos u32, read_pos u32, len u32, type u8 (17 B/signature)
 //
 // Pipeline (no inter-workgroup waiting anywhere, so no dispatch-order assumption):
-//   A  k_cigar_tiles<STAGE>   one WAVE per tile of 4096 ops; 4 rounds of 1024 ops; per round:
-//                             coalesced dwordx4 loads (1 KiB/wave-instr) → wave-private padded LDS
+//   A  k_cigar_tiles          one WAVE per tile of 4096 ops; 4 rounds of 1024 ops; per round:
+//                             coalesced dwordx4 loads (1 KiB/wave-instr) → wave-private XOR-swizzled LDS
 //                             transpose → 16 consecutive ops per lane → lane-local segmented walk →
-//                             wave segmented scan (DPP row_shr/row_bcast) → signatures staged into the tile's
+//                             wave scans (DPP row_shr/row_bcast) → signatures staged into the tile's
 //                             slab (256 x 16 B) with tile-local cursors; tile descriptor
 //                             {count, seen_head, ref_tail, read_tail, a_lo} written at the end.
 //   B  k_desc_scan            segmented exclusive scan over the tile descriptors: per-tile carry-in
 //                             (cursor sums since the last alignment start before the tile), output
 //                             base (exclusive signature count) and the list of dense tiles.
-//   C  k_cigar_gather         one wave per sparse tile: slab → final SoA at out_base, adding the
+//   C  k_cigar_finish         16 lanes per sparse tile: slab → final SoA at out_base, adding the
 //                             carry to signatures that precede the tile's first alignment start
-//                             and resolving the alignment index by bounded search in aln_off.
-//   A2 k_cigar_tiles<DIRECT>  dense tiles (> 256 signatures, e.g. adversarial all-indel CIGARs) are
-//                             re-walked with carry-in and output base known, writing final SoA.
+//                             and ref_start of the alignment.
+//   D  k_cigar_dense          dense tiles (> 256 signatures, e.g. adversarial all-indel CIGARs) are
+//                             re-walked with carry-in and output base known (process_tile<DIRECT>),
+//                             writing final SoA; an empty launch in the common case.
 // Output order = (alignment, op) order by construction (prefix sums, no atomically-ordered appends).
 #include "svx_internal.h"
 
