@@ -68,6 +68,44 @@ def test_random_ragged_all_opcodes(svx_ctx, seed):
         assert_same(svx_ctx.cigar_extract(cig, off, rs, min_len), orc.cigar_extract(cig, off, rs, min_len))
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_lengths_up_to_28_bits_mix_fast_and_generic_rounds(svx_ctx, seed):
+    """The packed-word walk uses 24-bit multiply-adds when every length of a 1024-op round is
+    < 2^24 and the generic masked adds otherwise: sprinkle lengths up to the BAM maximum
+    (2^28 - 1) so both kinds of rounds occur inside the same tiles; cursors wrap mod 2^32 exactly
+    like the oracle's uint32 arithmetic."""
+    rng = np.random.default_rng(900 + seed)
+    n_aln = 300
+    cig, off, rs = synth.random_cigar_case(rng, n_aln, max_ops=200)
+    n = len(cig)
+    big = rng.random(n) < (0.0005 if seed < 2 else 0.02)  # rare (most rounds fast) / common
+    lens = np.where(big, rng.integers(1 << 24, 1 << 28, size=n), cig >> 4).astype(np.uint32)
+    lens[rng.integers(0, n, size=5)] = (1 << 28) - 1
+    lens[rng.integers(0, n, size=5)] = 1 << 24
+    lens[rng.integers(0, n, size=5)] = (1 << 24) - 1
+    cig = (lens << 4) | (cig & 15)
+    for min_len in (40, 1 << 24, (1 << 28) - 1):
+        assert_same(svx_ctx.cigar_extract(cig, off, rs, min_len), orc.cigar_extract(cig, off, rs, min_len))
+
+
+@pytest.mark.parametrize("min_len", [0, 1, 2, (1 << 28) - 1, 1 << 28, (1 << 32) - 1])
+def test_min_len_edge_values(svx_ctx, min_len):
+    """min_len 0 emits every I/D op including zero-length ones (len >= 0); min_len above the
+    28-bit length range emits nothing."""
+    rng = np.random.default_rng(77)
+    cig, off, rs = synth.random_cigar_case(rng, 120, max_ops=300)
+    lens = (cig >> 4).copy()
+    lens[rng.integers(0, len(cig), size=200)] = 0          # zero-length ops of every kind
+    lens[rng.integers(0, len(cig), size=20)] = (1 << 28) - 1
+    cig = (lens.astype(np.uint32) << 4) | (cig & 15)
+    got, exp = svx_ctx.cigar_extract(cig, off, rs, min_len), orc.cigar_extract(cig, off, rs, min_len)
+    assert_same(got, exp)
+    if min_len >= 1 << 28:
+        assert len(got["aln"]) == 0
+    if min_len == 0:
+        assert len(got["aln"]) == int(np.isin(cig & 15, (1, 2)).sum())
+
+
 @pytest.mark.parametrize("n_ops", [1, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12289])
 def test_tile_and_round_boundaries(svx_ctx, n_ops):
     rng = np.random.default_rng(n_ops)
