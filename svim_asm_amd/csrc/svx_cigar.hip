@@ -57,6 +57,7 @@ struct CigarArgs {
     const uint32_t* cigar;  // packed words, or len[] in SoA mode
     const uint8_t* op;      // SoA mode only
     const uint64_t* aln_off;
+    uint32_t* tile_alo;   // per tile: number of alignments that start before the tile (k_tile_alo)
     const int32_t* ref_start;  // nullable
     uint64_t n_ops;
     uint32_t n_aln;
@@ -204,8 +205,12 @@ __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_b
 #ifndef SVX_TILE_MIN_WAVES
 #define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int kStage = 64;            // finished records staged in LDS per wave before one burst to the slab
+#ifndef SVX_STAGE
+#define SVX_STAGE 48
+#endif
+constexpr int kStage = SVX_STAGE;  // finished records staged in LDS per wave before one burst to the slab (>= kQueue)
 constexpr int kQueue = 2 * kLaneOps;  // signatures one round may queue in LDS (one flush lane each)
+static_assert(kStage >= kQueue, "one round's records must fit the stage buffer");
 constexpr uint32_t kDescForceDense = 1u << 30;  // descriptor flag: a round overflowed the queue
 
 enum { WALK_TOTALS = 0, WALK_QUEUE = 1, WALK_DIRECT = 2 };
@@ -370,7 +375,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
 #ifdef SVX_EXP_NOPROLOGUE  // perf experiment only
     const uint32_t a_lo = 0;
 #else
-    const uint32_t a_lo = __builtin_amdgcn_readfirstlane(wave_lower_bound(p.aln_off, p.n_aln + 1, g0, lane));
+    const uint32_t a_lo = p.tile_alo[tile];  // wave-uniform: one scalar load instead of a 4-level search
 #endif
 #pragma unroll
     for (int i = lane; i < kTileOps / 32; i += 64) hmask[i] = 0;
@@ -405,6 +410,22 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         hu_hi = wave_or_u32(hu_hi);
     }
     wave_lds_sync();
+    // this lane's start bits of all rounds move to two registers; the mask's LDS then serves as the
+    // per-round signature queue (kQueue * 16 B == the mask's 512 B) — 5.25 KiB of LDS per wave keeps
+    // six 4-wave workgroups on a CU
+    static_assert(!(kLaneOps == 16 && kRounds <= 4) || kQueue * sizeof(uint4) <= (kTileOps / 32) * sizeof(uint32_t),
+                  "queue must fit the start mask's LDS");
+    uint32_t hm01 = 0, hm23 = 0;
+    if (kLaneOps == 16 && kRounds <= 4) {
+        const uint32_t sh = ((uint32_t)lane & 1u) * 16u, wi = (uint32_t)lane >> 1;
+        const uint32_t h0 = (hmask[wi] >> sh) & 0xFFFFu;
+        const uint32_t h1 = kRounds > 1 ? (hmask[32 + wi] >> sh) & 0xFFFFu : 0u;
+        const uint32_t h2 = kRounds > 2 ? (hmask[64 + wi] >> sh) & 0xFFFFu : 0u;
+        const uint32_t h3 = kRounds > 3 ? (hmask[96 + wi] >> sh) & 0xFFFFu : 0u;
+        hm01 = h0 | (h1 << 16);
+        hm23 = h2 | (h3 << 16);
+        wave_lds_sync();
+    }
 
     SVX_PROF_T(t_pro);
     SVX_PROF_ADD(0, t_pro - t_begin);
@@ -473,8 +494,10 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         SVX_PROF_T(t_r1);
         SVX_PROF_ADD(1, t_r1 - t_r0);  // wait for the round's data + transpose
         const uint32_t lbase = round * kRoundOps + lane * kLaneOps;  // tile-local index of op 0
-        const uint32_t hm = kLaneOps == 32 ? hmask[lbase >> 5]
-                                           : (hmask[lbase >> 5] >> (lbase & 31)) & ((1u << (kLaneOps & 31)) - 1u);
+        const uint32_t hm = (kLaneOps == 16 && kRounds <= 4)
+                                ? (((round & 2) ? hm23 : hm01) >> ((round & 1) * 16)) & 0xFFFFu
+                                : (kLaneOps == 32 ? hmask[lbase >> 5]
+                                                  : (hmask[lbase >> 5] >> (lbase & 31)) & ((1u << (kLaneOps & 31)) - 1u));
         // slots where ANY lane starts an alignment (SGPR)
         const uint32_t HU = (kLaneOps == 16 && kRounds <= 4) ? (((round & 2) ? hu_hi : hu_lo) >> ((round & 1) * 16)) & 0xFFFFu
                                                               : wave_or_u32(hm);
@@ -597,19 +620,34 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     }
 }
 
+// ---- A0: per tile, the number of alignments that start before it (= lower bound of the tile's
+// first op in aln_off).  One thread per alignment: alignment a is the last one starting before
+// tile t exactly when aln_off[a] < t*kTileOps <= aln_off[a+1], so every tile t >= 1 has exactly one
+// writer and the streaming kernel's prologue needs no search (four dependent loads per tile). ----
+__global__ __launch_bounds__(256) void k_tile_alo(const uint64_t* __restrict__ aln_off, uint32_t n_aln,
+                                                  uint32_t n_tiles, uint32_t* __restrict__ tile_alo) {
+    const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+    if (a >= n_aln) return;
+    if (a == 0) tile_alo[0] = 0;
+    const uint64_t lo = aln_off[a], hi = aln_off[a + 1];
+    uint64_t t = lo / kTileOps + 1, t_hi = hi / kTileOps;
+    if (t_hi >= n_tiles) t_hi = n_tiles - 1;
+    for (; t <= t_hi; ++t) tile_alo[t] = a + 1;
+}
+
 // ---- A: stream every tile once ----
 template <bool SOA>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ uint32_t s_head[kWaves][kTileOps / 32];
-    __shared__ uint4 s_queue[kWaves][kQueue];
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kTileOps / 32];  // start mask, then the queue
     __shared__ uint4 s_stage[kWaves][kStage];
     // the wave index is wave-uniform: tell the compiler so that tile indices, loop bounds and
     // carries live in SGPRs and the tile/round loops are scalar branches
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves)
-        process_tile<MODE_STAGE, SOA>(p, tile, lane, s_xpose[wave], s_head[wave], s_queue[wave], s_stage[wave]);
+        process_tile<MODE_STAGE, SOA>(p, tile, lane, s_xpose[wave], s_head[wave], reinterpret_cast<uint4*>(s_head[wave]),
+                                      s_stage[wave]);
 }
 
 // ---- B: segmented exclusive scan over tile descriptors ----
@@ -743,13 +781,13 @@ __global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) {
 template <bool SOA>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_dense(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ uint32_t s_head[kWaves][kTileOps / 32];
-    __shared__ uint4 s_queue[kWaves][kQueue];
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kTileOps / 32];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t n_dense = p.n_dense[2];
     for (uint32_t work = blockIdx.x * kWaves + wave; work < n_dense; work += gridDim.x * kWaves)
-        process_tile<MODE_DIRECT, SOA>(p, p.dense_list[work], lane, s_xpose[wave], s_head[wave], s_queue[wave], nullptr);
+        process_tile<MODE_DIRECT, SOA>(p, p.dense_list[work], lane, s_xpose[wave], s_head[wave],
+                                       reinterpret_cast<uint4*>(s_head[wave]), nullptr);
 }
 
 // ---- per-alignment CIGAR statistics: one wave per alignment ----
@@ -835,7 +873,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t n_tiles = (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
     size_t need = svx_take_bytes(n_tiles, sizeof(uint4)) +
                   svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
-                  4 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
+                  5 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
                   2 * svx_take_bytes((n_tiles + kScanBlock - 1) / kScanBlock, sizeof(uint4));
     int rc = svx_ws_reserve(ctx, need);
     if (rc != SVX_OK) return rc;
@@ -856,6 +894,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     a.carry_ref = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.carry_read = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.dense_list = svx_ws_take<uint32_t>(ctx, n_tiles);
+    a.tile_alo = svx_ws_take<uint32_t>(ctx, n_tiles);
     const uint32_t n_scan_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
     a.blk_agg = svx_ws_take<uint4>(ctx, n_scan_blocks);
     a.blk_prefix = svx_ws_take<uint4>(ctx, n_scan_blocks);
@@ -866,6 +905,8 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t blocks_cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
+    hipLaunchKernelGGL(k_tile_alo, dim3((n_aln + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
+                       a.tile_alo);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
     hipLaunchKernelGGL((k_cigar_tiles<SOA>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);

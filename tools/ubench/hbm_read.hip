@@ -1,6 +1,7 @@
 // Read-only streaming ceiling: every workgroup reads contiguous 16 KiB tiles (4 x dwordx4 per lane
 // in flight, like k_cigar_tiles), XOR-reduces and writes one word.  Prints GB/s for several sizes.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/hbm_read tools/ubench/hbm_read.hip && /tmp/hbm_read
+//   hipcc --offload-arch=gfx950 -O3 [-DNT] -o /tmp/hbm_read tools/ubench/hbm_read.hip && /tmp/hbm_read
+// -DNT: nontemporal (streaming) loads
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -15,7 +16,13 @@ __global__ __launch_bounds__(256) void k_read(const uint4* __restrict__ in, size
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k) {
             const size_t i = base + (size_t)k * 256 + threadIdx.x;
+#ifdef NT
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            if (i < n_u4) { const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + i); v[k] = make_uint4(t.x, t.y, t.z, t.w); }
+            else v[k] = make_uint4(0, 0, 0, 0);
+#else
             v[k] = i < n_u4 ? in[i] : make_uint4(0, 0, 0, 0);
+#endif
         }
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
