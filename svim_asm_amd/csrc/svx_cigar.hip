@@ -753,11 +753,18 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
 // tile carry-in where the record lacks it and ref_start of its alignment.  No LDS, few registers:
 // the kernel is a chain of two dependent loads per tile and lives on occupancy. ----
 constexpr int kFinLanes = 16;
+#ifndef SVX_FINSPEC
+#define SVX_FINSPEC 3
+#endif
+constexpr int kFinSpec = SVX_FINSPEC;  // records per lane requested together with the descriptor (48 per tile)
 __global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) {
     const uint32_t tile = blockIdx.x * (256u / kFinLanes) + threadIdx.x / kFinLanes;
     const uint32_t l = threadIdx.x % kFinLanes;
     if (tile >= p.n_tiles) return;
-    const uint4 rec0 = p.slab[(uint64_t)tile * kSlab + l];  // speculative: issued with the descriptor
+    // speculative: slots past the tile's count hold stale bytes and are never used
+    uint4 spec[kFinSpec];
+#pragma unroll
+    for (int k = 0; k < kFinSpec; ++k) spec[k] = p.slab[(uint64_t)tile * kSlab + l + k * kFinLanes];
     const uint4 dsc = p.desc[tile];
     const uint4 bp = p.blk_prefix[tile / kScanBlock];
     const uint32_t lb = p.out_base[tile];
@@ -768,8 +775,26 @@ __global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) {
     const uint32_t cr = lcr + (local_head ? 0u : bp.y);
     const uint32_t cd = lcd + (local_head ? 0u : bp.z);
     const uint64_t ob = (uint64_t)(lb & 0x7FFFFFFFu) + bp.w;
-    for (uint32_t r = l; r < cnt; r += kFinLanes) {
-        const uint4 rec = (r == l) ? rec0 : p.slab[(uint64_t)tile * kSlab + r];
+    // the ref_start gathers of both speculative records go out together
+    uint32_t rs[kFinSpec];
+#pragma unroll
+    for (int k = 0; k < kFinSpec; ++k)
+        rs[k] = (l + k * kFinLanes < cnt && p.ref_start) ? (uint32_t)p.ref_start[spec[k].x] : 0u;
+#pragma unroll
+    for (int k = 0; k < kFinSpec; ++k) {
+        const uint32_t r = l + k * kFinLanes;
+        if (r < cnt && ob + r < p.cap) {
+            const uint4 rec = spec[k];
+            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+            p.out.aln[ob + r] = rec.x;
+            p.out.ref_pos[ob + r] = rec.y + (prec ? cr : 0u) + rs[k];
+            p.out.read_pos[ob + r] = rec.z + (prec ? cd : 0u);
+            p.out.len[ob + r] = len;
+            p.out.type[ob + r] = (uint8_t)type;
+        }
+    }
+    for (uint32_t r = l + kFinSpec * kFinLanes; r < cnt; r += kFinLanes) {
+        const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
         const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
         store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
     }
