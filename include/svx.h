@@ -126,7 +126,9 @@ int svx_cigar_extract_soa(svx_ctx* ctx, const uint8_t* op, const uint32_t* len,
                           uint32_t min_len, svx_sig_soa out, uint64_t cap, uint64_t* n_out);
 
 /* Device-pointer variants.  n_ops must equal aln_off[n_aln] (the caller knows it;
- * the device copy is not read back).  d_n_out: one uint64 in device memory.
+ * the device copy is not read back).  d_cigar / d_len / d_op must be 16-byte aligned;
+ * d_op is fetched as dwords, i.e. it must be readable up to the next multiple of 4 bytes
+ * after n_ops (any hipMalloc'ed buffer is); the extra bytes are ignored.  d_n_out: one uint64 in device memory.
  * Exactly min(count, cap) signatures are written. Asynchronous on the ctx stream. */
 int svx_cigar_extract_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint64_t n_ops,
                           const uint64_t* d_aln_off, uint32_t n_aln, const int32_t* d_ref_start,

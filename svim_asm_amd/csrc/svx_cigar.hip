@@ -180,7 +180,7 @@ __device__ __forceinline__ int xswz(int c) { return (c / (16 / kLU)) & (kLU - 1)
 #define SVX_LOAD_AUX 2  // cache policy of the streaming loads: 2 = nt (read once; 8.5 % faster than the default policy)
 #endif
 template <bool SOA>
-__device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t ro_,
+__device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t ro_, uint32_t tile_len,
                                            uint32_t ro, int lane, uint4 (&q)[kLU], uint32_t (&o)[kLU]) {
 #ifdef SVX_EXP_NOLOAD  // perf experiment only: no HBM traffic
     for (int k = 0; k < kLU; ++k) { q[k] = make_uint4(ro + lane, (400u << 4), (3u << 4) | 1u, (77u << 4)); o[k] = 0; }
@@ -198,6 +198,13 @@ __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_b
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
                 ro_, (int)(ro + (uint32_t)lane * kLaneOps + (uint32_t)k * 16u), 0, SVX_LOAD_AUX);
             o[4 * k + 0] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+        }
+        // bytes at or beyond the tile's last op (ragged last tile only) become op 0
+#pragma unroll
+        for (int j = 0; j < kLU; ++j) {
+            const uint32_t first = ro + (uint32_t)lane * kLaneOps + (uint32_t)j * 4u;  // tile-local op of byte 0
+            const uint32_t valid = first >= tile_len ? 0u : (tile_len - first >= 4u ? 4u : tile_len - first);
+            o[j] &= valid >= 4u ? 0xFFFFFFFFu : ((1u << (8u * valid)) - 1u);
         }
     }
 }
@@ -359,8 +366,11 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     // first round's loads go out before the (latency-bound) alignment-start lookup
     const uint32_t tile_len = (uint32_t)(tile_end - g0);
     const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.cigar + g0, tile_len * 4u);
+    // SoA op bytes: the hardware range check works per DWORD, so the resource covers the tile's bytes
+    // rounded up to 4 (the op array is read at most 3 bytes past n_ops, inside its last dword; those
+    // bytes are masked off in load_round — they would otherwise read as ops of length 0)
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(SOA ? (const void*)(p.op + g0) : (const void*)p.cigar,
-                                                  SOA ? tile_len : 0u);
+                                                  SOA ? ((tile_len + 3u) & ~3u) : 0u);
 #ifdef SVX_EXP_PROF
     uint32_t prof_acc[8] = {};
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
@@ -368,7 +378,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     SVX_PROF_T(t_begin);
     uint4 q[kLU];
     uint32_t qo[kLU] = {};
-    load_round<SOA>(rs_c, rs_o, 0u, lane, q, qo);
+    load_round<SOA>(rs_c, rs_o, tile_len, 0u, lane, q, qo);
 
     // ---- alignment starts inside this tile → 4096-bit mask in LDS; `dup` = two alignments start
     // at the same op (empty alignments), which disables the popcount shortcut for the index ----
@@ -489,7 +499,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         for (int k = 0; k < kLU; ++k) opw[k] = qo[k];
         // software pipeline: next round's global loads are in flight during this round's math
         if (round + 1 < kRounds && ro + kRoundOps < tile_len)
-            load_round<SOA>(rs_c, rs_o, ro + kRoundOps, lane, q, qo);
+            load_round<SOA>(rs_c, rs_o, tile_len, ro + kRoundOps, lane, q, qo);
         wave_lds_sync();
         SVX_PROF_T(t_r1);
         SVX_PROF_ADD(1, t_r1 - t_r0);  // wait for the round's data + transpose

@@ -169,6 +169,23 @@ def test_soa_input_variant(svx_ctx):
     assert_same(svx_ctx.cigar_extract(ln, off, rs, 40, op=op), orc.cigar_extract(cig, off, rs, 40))
 
 
+@pytest.mark.parametrize("n_ops", [1, 2, 3, 5, 1427, 4099, 17647])
+@pytest.mark.parametrize("min_len", [0, 1, 40])
+def test_soa_ragged_tail_not_multiple_of_four(svx_ctx, n_ops, min_len):
+    """The SoA op bytes are fetched as dwords: the last 1-3 ops of a batch whose length is not a
+    multiple of 4 must still be seen (found by tools/fuzz_cigar.py), and the bytes after them must
+    not turn into zero-length signatures when min_len is 0."""
+    rng = np.random.default_rng(n_ops)
+    ops = rng.integers(1, 3, size=n_ops).astype(np.uint8)  # all I/D: the tail always emits
+    lens = rng.integers(0, 90, size=n_ops).astype(np.uint32)
+    off = np.array([0, n_ops // 2, n_ops], dtype=np.uint64)
+    rs = np.array([100, 7], dtype=np.int32)
+    cig = (lens << 4) | ops
+    exp = orc.cigar_extract(cig, off, rs, min_len)
+    assert_same(svx_ctx.cigar_extract(lens, off, rs, min_len, op=ops), exp)
+    assert_same(svx_ctx.cigar_extract(cig, off, rs, min_len), exp)
+
+
 def test_invalid_offsets_rejected(svx_ctx):
     cig = pack([(0, 10), (1, 50)])
     with pytest.raises(_lib.SvxError):
