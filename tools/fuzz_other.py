@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Randomised differential tests of the other C-ABI kernels against the C oracle:
+svx_segments_classify, svx_pair_partition, svx_edit_distance_batch, svx_cigar_stats.
+
+    python tools/fuzz_other.py [--seconds 120] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+from oracle import orc  # noqa: E402
+from svim_asm_amd import _lib, synth  # noqa: E402
+import test_gpu_segments as tseg  # noqa: E402  (random_reads)
+import test_gpu_pair as tpair  # noqa: E402  (make_keys)
+
+
+def fuzz_segments(ctx, rng):
+    n_reads = int(rng.choice([1, 3, 40, 700, 5000]))
+    max_k = int(rng.choice([0, 1, 2, 5, 8, 9, 30, 120]))
+    segs, off, rl = tseg.random_reads(rng, n_reads, max_k, n_contigs=int(rng.integers(1, 5)), spread=int(rng.choice([1, 30, 300, 3000])))
+    prm = (int(rng.choice([1, 40, 50, 1000])), int(rng.choice([20, 1000, 100000, 1 << 30])),
+           int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])))
+    got = ctx.segments_classify(segs, off, rl, prm)
+    exp = orc.segments_classify(segs, off, rl, prm)
+    return np.array_equal(got, exp), "segments n_reads %d max_k %d prm %s" % (n_reads, max_k, prm)
+
+
+def fuzz_pair(ctx, rng):
+    n = int(rng.choice([0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 5000, 70000, 400000]))
+    groups = int(rng.choice([1, 2, 24, 144, 5000]))
+    pos_max = int(rng.choice([1, 5, 1000, 250_000_000, (1 << 32) - 1]))
+    keys = tpair.make_keys(rng, n, groups, pos_max, dup_frac=float(rng.choice([0.0, 0.3, 0.9])))
+    if rng.random() < 0.2 and n:
+        keys |= np.uint64(int(rng.integers(0, 1 << 20))) << np.uint64(44)  # high group bits in use
+    md = int(rng.choice([0, 1, 1000, 1 << 20, (1 << 32) - 1]))
+    perm, part, n_parts = ctx.pair_partition(keys, md)
+    e_perm, e_part, e_n = orc.pair_partition(keys, md)
+    ok = n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
+    return ok, "pair n %d groups %d pos_max %d max_dist %d" % (n, groups, pos_max, md)
+
+
+def fuzz_edit(ctx, rng):
+    n = int(rng.choice([1, 2, 17, 200]))
+    alphabet = np.frombuffer(b"ACGT" if rng.random() < 0.8 else b"ACGTNacgt", dtype=np.uint8)
+    seqs, a_off, a_len, b_off, b_len = [], [], [], [], []
+    pos = 0
+    for _ in range(n):
+        la = int(rng.choice([0, 1, 2, 63, 64, 65, 300, 2000]))
+        a = alphabet[rng.integers(0, len(alphabet), size=la)]
+        mode = rng.random()
+        if mode < 0.3:
+            b = a.copy()
+        elif mode < 0.7 and la > 0:  # a few edits
+            b = list(a)
+            for _ in range(int(rng.integers(1, 12))):
+                j = int(rng.integers(0, len(b) + 1))
+                r = rng.random()
+                if r < 0.34 and b:
+                    b[min(j, len(b) - 1)] = alphabet[int(rng.integers(0, len(alphabet)))]
+                elif r < 0.67:
+                    b.insert(j, alphabet[int(rng.integers(0, len(alphabet)))])
+                elif b:
+                    b.pop(min(j, len(b) - 1))
+            b = np.array(b, dtype=np.uint8)
+        else:
+            b = alphabet[rng.integers(0, len(alphabet), size=int(rng.choice([0, 1, 64, 300, 1500])))]
+        for arr, offs, lens in ((a, a_off, a_len), (b, b_off, b_len)):
+            seqs.append(arr); offs.append(pos); lens.append(len(arr)); pos += len(arr)
+    pool = np.concatenate(seqs) if pos else np.zeros(0, np.uint8)
+    k = int(rng.choice([0, 1, 5, 200, 5000, 0xFFFFFFFF]))
+    got = ctx.edit_distance_batch(pool, np.array(a_off, np.uint64), np.array(a_len, np.uint32),
+                                  np.array(b_off, np.uint64), np.array(b_len, np.uint32), k)
+    ok = True
+    for i in range(n):
+        d = orc.edit_distance(pool[a_off[i]:a_off[i] + a_len[i]].tobytes(), pool[b_off[i]:b_off[i] + b_len[i]].tobytes())
+        e = d if (k == 0xFFFFFFFF or d <= k) else 0xFFFFFFFF
+        ok = ok and int(got[i]) == e
+    return ok, "edit n %d k %d" % (n, k)
+
+
+def fuzz_stats(ctx, rng):
+    n_aln = int(rng.choice([1, 5, 300, 4000]))
+    cig, off, _ = synth.random_cigar_case(rng, n_aln, max_ops=int(rng.choice([0, 3, 70, 700, 20000])))
+    if rng.random() < 0.5 and len(cig):  # leading/trailing clips of every flavour
+        starts = off[:-1][np.diff(off.astype(np.int64)) > 2].astype(np.int64)
+        for s0 in starts[: 200]:
+            cig[s0] = (int(rng.integers(0, 500)) << 4) | int(rng.choice([4, 5]))
+            cig[s0 + 1] = (int(rng.integers(0, 500)) << 4) | int(rng.choice([4, 5, 0]))
+    got = ctx.cigar_stats(cig, off)
+    exp = orc.cigar_stats(cig, off)
+    ok = all(np.array_equal(got[k], exp[k]) for k in exp)
+    return ok, "stats n_aln %d n_ops %d" % (n_aln, len(cig))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    ctx = _lib.default_context(0)
+    fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats]
+    counts = {f.__name__: 0 for f in fns}
+    t0, seed = time.time(), a.seed
+    while time.time() - t0 < a.seconds:
+        f = fns[seed % len(fns)]
+        rng = np.random.default_rng(seed)
+        ok, what = f(ctx, rng)
+        if not ok:
+            print("MISMATCH seed %d: %s" % (seed, what))
+            sys.exit(1)
+        counts[f.__name__] += 1
+        seed += 1
+    print("fuzz ok:", counts, "seeds %d..%d" % (a.seed, seed - 1))
+
+
+if __name__ == "__main__":
+    main()
