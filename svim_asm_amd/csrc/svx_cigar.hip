@@ -41,9 +41,12 @@ constexpr int kRoundOps = 64 * kLaneOps;       // 1024 ops per wave round (4 KiB
 constexpr int kRounds = SVX_ROUNDS;
 constexpr int kTileOps = kRoundOps * kRounds;  // 4096 ops per tile (16 KiB)
 #ifndef SVX_SLAB
-#define SVX_SLAB 256
+#define SVX_SLAB 128
 #endif
-constexpr int kSlab = SVX_SLAB;  // slab records per tile (1/16 of its ops); fuller tiles take the dense path
+// slab records per tile (1/32 of its ops); fuller tiles take the dense path.  The slabs are written
+// once (one burst per tile) and read once: a 2 KiB stride instead of 4 KiB is worth 5 % of the
+// streaming kernel (DRAM locality of the bursts), 1 KiB another 2 % but too tight for SV-dense regions
+constexpr int kSlab = SVX_SLAB;
 #ifndef SVX_WAVES
 #define SVX_WAVES 4
 #endif
