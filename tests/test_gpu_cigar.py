@@ -186,6 +186,23 @@ def test_soa_ragged_tail_not_multiple_of_four(svx_ctx, n_ops, min_len):
     assert_same(svx_ctx.cigar_extract(cig, off, rs, min_len), exp)
 
 
+def test_soa_op_codes_above_15_are_noops(svx_ctx):
+    """SoA op bytes can hold 16..255 (not representable in BAM): like codes 10-15 they advance
+    nothing and emit nothing; rounds containing them take the generic walk, the others the packed one."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    ops = rng.integers(0, 3, size=n).astype(np.uint8)
+    lens = rng.integers(30, 60, size=n).astype(np.uint32)
+    weird = rng.random(n) < 0.001          # a few rounds only
+    ops[weird] = rng.integers(16, 256, size=int(weird.sum())).astype(np.uint8)
+    off = np.array([0, 7000, 7000, n], dtype=np.uint64)
+    rs = np.array([5, 6, 7], dtype=np.int32)
+    got = svx_ctx.cigar_extract(lens, off, rs, 40, op=ops)
+    # oracle on the packed form with the weird ops mapped to a no-op code (9 = B)
+    cig = (lens << 4) | np.where(weird, 9, ops).astype(np.uint32)
+    assert_same(got, orc.cigar_extract(cig, off, rs, 40))
+
+
 def test_invalid_offsets_rejected(svx_ctx):
     cig = pack([(0, 10), (1, 50)])
     with pytest.raises(_lib.SvxError):
