@@ -343,9 +343,6 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-#ifndef SVX_TILE_MIN_WAVES
-#define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
-#endif
 
 #ifdef SVX_EXP_PROF  // perf experiment only (tools/prof_phases.py): per-tile phase clocks
 constexpr uint32_t kProfTiles = 32768;
@@ -385,11 +382,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
 
     // ---- alignment starts inside this tile → 4096-bit mask in LDS; `dup` = two alignments start
     // at the same op (empty alignments), which disables the popcount shortcut for the index ----
-#ifdef SVX_EXP_NOPROLOGUE  // perf experiment only
-    const uint32_t a_lo = 0;
-#else
     const uint32_t a_lo = p.tile_alo[tile];  // wave-uniform: one scalar load instead of a 4-level search
-#endif
 #pragma unroll
     for (int i = lane; i < kTileOps / 32; i += 64) hmask[i] = 0;
     wave_lds_sync();
@@ -398,9 +391,6 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     // gathered here once per tile (kLaneOps == 16: four 16-bit fields in 64 bits) instead of a
     // wave OR-reduction of the lanes' masks in every round
     uint32_t hu_lo = 0, hu_hi = 0;
-#ifdef SVX_EXP_NOPROLOGUE
-    if (false)
-#endif
     for (uint64_t a = (uint64_t)a_lo + lane;; a += 64) {
         bool in = false, twice = false;
         if (a < p.n_aln) {
@@ -426,8 +416,8 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     // this lane's start bits of all rounds move to two registers; the mask's LDS then serves as the
     // per-round signature queue (kQueue * 16 B == the mask's 512 B) — 5.25 KiB of LDS per wave keeps
     // six 4-wave workgroups on a CU
-    static_assert(!(kLaneOps == 16 && kRounds <= 4) || kQueue * sizeof(uint4) <= (kTileOps / 32) * sizeof(uint32_t),
-                  "queue must fit the start mask's LDS");
+    static_assert(kLaneOps == 16 && kRounds <= 4, "the queue aliases the start mask: 16 ops per lane, at most 4 rounds");
+    static_assert(kQueue * sizeof(uint4) <= (kTileOps / 32) * sizeof(uint32_t), "queue must fit the start mask's LDS");
     uint32_t hm01 = 0, hm23 = 0;
     if (kLaneOps == 16 && kRounds <= 4) {
         const uint32_t sh = ((uint32_t)lane & 1u) * 16u, wi = (uint32_t)lane >> 1;
