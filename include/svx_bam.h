@@ -1,0 +1,107 @@
+/*
+ * svx_bam.h — C-ABI of the native BAM ingest of libsvx.so.
+ *
+ * The reference reads alignments through pysam/htslib: `pysam.AlignmentFile(path)`
+ * (svim-asm:63-90), `bam.fetch(contig=...)` (SVIM_COLLECT.py:65), and per record
+ * `cigartuples` (SVIM_intra.py:37), `get_cigar_stats()` / `get_tag("SA")`
+ * (SVIM_COLLECT.py:11,14), `query_sequence[a:b]` (SVIM_intra.py:42, SVIM_inter.py:117,120).
+ * These entry points replace that surface for the hot path with a columnar reader:
+ * one call indexes the records of the requested contigs and returns, for all of them at
+ * once, the fixed fields, names, aux bytes (SA tag located) and ONE flattened array of
+ * BAM-native CIGAR words (`len << 4 | op`, page-locked when a HIP device is present so
+ * that the H2D copy of svx_cigar_extract is a true asynchronous DMA).
+ *
+ * What is inflated: genome-genome alignment records carry SEQ/QUAL fields of 10^5..10^8
+ * bases; only the BGZF blocks that hold record headers, names, CIGARs and aux tags are
+ * inflated (block sizes come from the BSIZE/ISIZE fields, so SEQ/QUAL blocks are hopped
+ * over), plus the blocks of the base ranges later requested with svx_bam_seq_slices.
+ * With a `.bai` next to the BAM (the reference requires one, svim-asm:67-72) every bin
+ * chunk boundary and linear-index entry is a record boundary: the file is cut there and
+ * the pieces are walked by `n_threads` host threads; the per-contig chunk ranges restrict
+ * the walk to the contigs a rank owns (contig sharding).  Without a usable
+ * index the records are walked sequentially from the header.
+ *
+ * Long CIGARs: when a record's stored CIGAR starts with a soft clip as long as the read and
+ * a `CG:B,I` aux array is present, the array is the real CIGAR (SAM spec §4.2.2; same test
+ * as htslib's bam_tag2cigar, which pysam applies on read): it replaces the placeholder
+ * and the CG tag is dropped from the record's aux bytes.
+ *
+ * All functions return SVX_OK (0) or a negative svx_status (svx.h).  A handle is used by
+ * one thread at a time.  Pointers handed out stay valid until the next svx_bam_load on the
+ * handle or svx_bam_close.
+ */
+#ifndef SVX_BAM_H_
+#define SVX_BAM_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svx_bam svx_bam;
+
+/* Open `path` (memory-mapped), parse the BAM header and the reference dictionary, and read
+ * `<path>.bai` / `<stem>.bai` when present.  n_threads <= 0: one per hardware thread, at most 64.
+ * On failure *out is NULL and, when err != NULL, a message is copied into err[err_cap]. */
+int svx_bam_open(const char* path, int n_threads, svx_bam** out, char* err, size_t err_cap);
+void svx_bam_close(svx_bam* bam);
+const char* svx_bam_last_error(const svx_bam* bam);
+
+/* Header text (@HD/@SQ... lines, not NUL-terminated: use *l_text) and reference count. */
+int svx_bam_header(const svx_bam* bam, const char** text, uint64_t* l_text, int32_t* n_ref);
+int svx_bam_reference(const svx_bam* bam, int32_t tid, const char** name, int32_t* length);
+
+/* 0: no index file; 1: .bai parsed and consistent with the file (parallel + per-contig walks);
+ * 2: an index file exists but cannot be used (.csi, stub or inconsistent .bai): sequential walk.
+ * `check_index()` of the reference (svim-asm:67) only needs != 0. */
+int svx_bam_index_state(const svx_bam* bam);
+/* Compressed bytes the index attributes to each contig (0 for contigs without records): the
+ * weights of the contig → rank plan.  span[n_ref].  SVX_E_INVALID when index_state != 1. */
+int svx_bam_contig_spans(const svx_bam* bam, uint64_t* span);
+
+/* Page-lock the CIGAR pool of later svx_bam_load calls in the context of HIP device `device`
+ * (the one the svx_ctx that will consume it lives on); device < 0 (default): pageable memory. */
+int svx_bam_set_pinned_device(svx_bam* bam, int device);
+
+/* Index the records of contigs tids[0..n_tids) (NULL: every record of the file, unplaced ones
+ * included), in file order. */
+int svx_bam_load(svx_bam* bam, const int32_t* tids, int32_t n_tids);
+
+typedef struct svx_bam_columns {
+    uint64_t n_records;
+    const int32_t* tid;        /* refID                                            */
+    const int32_t* pos;        /* 0-based leftmost coordinate (reference_start)     */
+    const int32_t* l_seq;      /* stored sequence length                           */
+    const int32_t* ref_len;    /* Σ len over {M,D,N,=,X} of the (real) CIGAR        */
+    const uint16_t* flag;
+    const uint8_t* mapq;
+    const uint64_t* cigar_off; /* n_records + 1 offsets into `cigar`               */
+    const uint32_t* cigar;     /* BAM-native words of all records, back to back    */
+    const uint64_t* name_off;  /* n_records + 1 offsets into `names` (no NULs)      */
+    const char* names;
+    const uint64_t* aux_off;   /* n_records + 1 offsets into `aux` (CG tag removed) */
+    const uint8_t* aux;
+    const int64_t* sa_off;     /* offset into `aux` of the SA:Z string, -1 if none  */
+    const uint32_t* sa_len;    /* its length without the NUL                       */
+    const uint64_t* voffset;   /* BGZF virtual offset of the record (index builder) */
+    uint64_t blocks_inflated;  /* BGZF blocks inflated so far on this handle        */
+    uint64_t blocks_spanned;   /* BGZF blocks inside the walked file ranges         */
+    int cigar_pinned;          /* 1 when `cigar` is page-locked host memory         */
+    int n_threads;
+} svx_bam_columns;
+
+int svx_bam_get_columns(const svx_bam* bam, svx_bam_columns* out);
+
+/* Decode bases [begin[i], end[i]) of record rec[i] (index into the loaded columns) to ASCII
+ * (=ACMGRSVTWYHKDBN, BAM orientation) at out + out_off[i]; n slices, walked by the handle's
+ * threads.  Ranges are clipped to [0, l_seq]; out_off[i+1] - out_off[i] must hold the
+ * clipped length.  Slices sorted by (rec, begin) reuse inflated blocks. */
+int svx_bam_seq_slices(svx_bam* bam, const uint32_t* rec, const uint32_t* begin, const uint32_t* end,
+                       uint32_t n, const uint64_t* out_off, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVX_BAM_H_ */

@@ -262,6 +262,7 @@ class AlignmentFile(object):
         a.template_length = tlen
         end = p + bs
         tags = {}
+        cg_subtype = None
         while q < end:
             tag = data[q:q + 2].decode()
             typ = chr(data[q + 2])
@@ -280,9 +281,17 @@ class AlignmentFile(object):
                 sub = chr(data[q]); cnt, = struct.unpack_from("<i", data, q + 1)
                 fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
                 tags[tag] = list(struct.unpack_from("<%d%s" % (cnt, fmt), data, q + 5))
+                if tag == "CG":
+                    cg_subtype = sub
                 q += 5 + cnt * struct.calcsize(fmt)
             else:
                 raise ValueError("unknown aux type " + typ)
+        # htslib bam_tag2cigar (applied by sam_read1 / pysam on every record): a CIGAR longer than
+        # 65535 operations is stored in the CG:B,I tag behind a `<l_seq>S<ref_len>N` placeholder
+        # (SAM spec §4.2.2); the real CIGAR replaces the placeholder and the tag disappears
+        if (cg_subtype in ("I", "i") and a._cigar and tid >= 0 and pos >= 0 and a._cigar[0] == (4, l_seq)
+                and len(a._cigar) <= len(tags["CG"]) < (1 << 29)):
+            a._cigar = [(w & 15, w >> 4) for w in (v & 0xFFFFFFFF for v in tags.pop("CG"))]
         a._tags = tags
         return a
 

@@ -119,14 +119,23 @@ def analyze_alignment_file_coordsorted(bam, options):
     # signature rows of alignment k: [sig_lo[k], sig_lo[k+1])
     sig_lo = np.searchsorted(sig["aln"], np.arange(len(kept) + 1), side="left")
     sig_ref = sig["ref_pos"].astype(np.int64)
-    # the inserted alleles are the only bases COLLECT needs: inflate just their BGZF blocks, in parallel
-    prefetch = getattr(bam, "prefetch_sequence", None)
-    if prefetch is not None and len(sig["aln"]):
-        ins = np.nonzero(sig["type"] == _lib.SIG_INS)[0]
+    # the inserted alleles are the only bases COLLECT needs: decode exactly those ranges, all at once
+    # (native reader: its threads inflate just the BGZF members that hold them)
+    ins_seq = None
+    batch_slices = getattr(bam, "sequence_slices", None)
+    ins = np.nonzero(sig["type"] == _lib.SIG_INS)[0]
+    if len(ins):
         rec_index = np.array([getattr(a, "index", -1) for a in kept], dtype=np.int64)[sig["aln"][ins]]
-        ok = rec_index >= 0
-        prefetch(zip(rec_index[ok].tolist(), sig["read_pos"][ins][ok].tolist(),
-                     (sig["read_pos"][ins][ok].astype(np.int64) + sig["len"][ins][ok]).tolist()))
+        lo = sig["read_pos"][ins].astype(np.int64)
+        hi = lo + sig["len"][ins]
+        if batch_slices is not None and (rec_index >= 0).all():
+            ins_seq = np.empty(len(sig["aln"]), dtype=object)
+            ins_seq[ins] = batch_slices(rec_index, lo, hi)
+        else:
+            prefetch = getattr(bam, "prefetch_sequence", None)
+            if prefetch is not None:
+                ok = rec_index >= 0
+                prefetch(zip(rec_index[ok].tolist(), lo[ok].tolist(), hi[ok].tolist()))
 
     # ---- a3 inputs: primaries with usable SA segments
     reads, read_index = [], {}
@@ -158,7 +167,7 @@ def analyze_alignment_file_coordsorted(bam, options):
         if hi > lo:
             sv_candidates.extend(SVIM_intra.candidates_from_signatures(
                 aln, bam, aln.query_name, bam.getrname(aln.reference_id), sig_ref[lo:hi], sig["read_pos"][lo:hi],
-                sig["len"][lo:hi], sig["type"][lo:hi]))
+                sig["len"][lo:hi], sig["type"][lo:hi], None if ins_seq is None else ins_seq[lo:hi]))
         r = read_index.get(k)
         if r is not None:
             sv_candidates.extend(seg_cands[r])

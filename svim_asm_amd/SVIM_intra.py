@@ -52,16 +52,18 @@ def _sequence_slice(alignment, a, b):
     return alignment.query_sequence[a:b]
 
 
-def candidates_from_signatures(alignment, bam, query_name, ref_chr, ref_pos, read_pos, length, typ):
-    """Signature rows of ONE alignment (absolute ref_pos) → Candidate objects (SVIM_intra.py:38-43)."""
+def candidates_from_signatures(alignment, bam, query_name, ref_chr, ref_pos, read_pos, length, typ,
+                               ins_sequences=None):
+    """Signature rows of ONE alignment (absolute ref_pos) → Candidate objects (SVIM_intra.py:38-43).
+    `ins_sequences[i]`, when given, is query_sequence[read_pos[i] : read_pos[i] + length[i]] of row i
+    (decoded in one batch by the caller)."""
     out = []
-    for start, pr, ln, t in zip(ref_pos, read_pos, length, typ):
-        start, pr, ln = int(start), int(pr), int(ln)
+    for i, (start, pr, ln, t) in enumerate(zip(ref_pos.tolist(), read_pos.tolist(), length.tolist(), typ.tolist())):
         if t == _lib.SIG_DEL:
             out.append(CandidateDeletion(ref_chr, start, start + ln, [query_name], bam))
         else:
-            out.append(CandidateInsertion(ref_chr, start, start + ln, [query_name],
-                                          _sequence_slice(alignment, pr, pr + ln), bam))
+            seq = ins_sequences[i] if ins_sequences is not None else _sequence_slice(alignment, pr, pr + ln)
+            out.append(CandidateInsertion(ref_chr, start, start + ln, [query_name], seq, bam))
     return out
 
 

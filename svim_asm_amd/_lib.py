@@ -83,6 +83,18 @@ SYMBOLS = {
     "svx_pair_partition_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "svx_edit_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_uint32,
                                           _P]),
+    # native BAM ingest (include/svx_bam.h)
+    "svx_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "svx_bam_close": (None, [_P]),
+    "svx_bam_last_error": (C.c_char_p, [_P]),
+    "svx_bam_header": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "svx_bam_reference": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
+    "svx_bam_index_state": (C.c_int, [_P]),
+    "svx_bam_contig_spans": (C.c_int, [_P, _P]),
+    "svx_bam_set_pinned_device": (C.c_int, [_P, C.c_int]),
+    "svx_bam_load": (C.c_int, [_P, _P, C.c_int32]),
+    "svx_bam_get_columns": (C.c_int, [_P, _P]),
+    "svx_bam_seq_slices": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P]),
 }
 
 _lib = None

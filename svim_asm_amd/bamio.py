@@ -8,6 +8,7 @@ BGZF multi-member gzip, BAM header / reference dictionary, alignment records, au
 one flattened BAM-native CIGAR array (`len << 4 | op`) for the whole file with no per-op
 Python work; record objects are thin views created on demand.
 """
+import ctypes as C
 import os
 import struct
 import zlib
@@ -30,7 +31,7 @@ _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000
 
 # ------------------------------------------------------------------------------ BGZF
 def _bgzf_block_spans(raw):
-    """(payload_start, payload_len, isize) of every BGZF member in `raw` (SAM spec §4.1)."""
+    """(payload_start, payload_len, isize, member_start) of every BGZF member in `raw` (SAM spec §4.1)."""
     spans = []
     p, n = 0, len(raw)
     while p + 18 <= n:
@@ -46,7 +47,7 @@ def _bgzf_block_spans(raw):
         if bsize is None:
             raise ValueError("gzip member without BGZF BC subfield at offset %d" % p)
         isize = struct.unpack_from("<I", raw, p + bsize - 4)[0]
-        spans.append((end_x, bsize - xlen - 20, isize))
+        spans.append((end_x, bsize - xlen - 20, isize, p))
         p += bsize
     return spans
 
@@ -63,7 +64,7 @@ def bgzf_decompress(path, threads=None):
 
     def work(lo, hi):
         for i in range(lo, hi):
-            st, ln, isz = spans[i]
+            st, ln, isz = spans[i][:3]
             if isz:
                 out[offs[i]:offs[i] + isz] = zlib.decompress(view[st:st + ln], -15)
 
@@ -92,6 +93,7 @@ class BgzfLazy(object):
             self._raw = fh.read()
         spans = _bgzf_block_spans(self._raw)
         self._start = np.array([s[0] for s in spans], dtype=np.int64)
+        self._hdr_start = np.array([s[3] for s in spans], dtype=np.int64)
         self._clen = np.array([s[1] for s in spans], dtype=np.int64)
         isize = np.array([s[2] for s in spans], dtype=np.int64)
         self._uoff = np.concatenate(([0], np.cumsum(isize))).astype(np.int64)
@@ -153,6 +155,14 @@ class BgzfLazy(object):
     def drop_cache(self):
         self._cache.clear()
 
+    def virtual_offset(self, off):
+        """BGZF virtual offset (coffset << 16 | uoffset) of uncompressed offset `off`; positions at
+        the end of a member are expressed as the start of the next one (what htslib writes)."""
+        i = int(np.searchsorted(self._uoff, off, side="right")) - 1
+        i = min(i, len(self._start) - 1)
+        hdr = int(self._hdr_start[i])
+        return (hdr << 16) | (off - int(self._uoff[i]))
+
 
 def bgzf_compress(data, level=1):
     """BGZF-compress `data` (64 KiB minus slack per block) + EOF marker."""
@@ -200,7 +210,8 @@ def _parse_header_text(text):
 class AlignedRecord(object):
     """One BAM record (or an SA-derived pseudo record) with pysam-compatible attribute names."""
     __slots__ = ("query_name", "flag", "reference_id", "reference_start", "mapping_quality",
-                 "cigar_words", "_seq_packed", "_l_seq", "_seq_str", "_tags_raw", "_tags", "index")
+                 "cigar_words", "_seq_packed", "_l_seq", "_seq_str", "_tags_raw", "_tags", "index", "_sa",
+                 "_seq_fetch")
 
     def __init__(self):
         self.query_name = None
@@ -215,6 +226,8 @@ class AlignedRecord(object):
         self._tags_raw = None
         self._tags = None
         self.index = -1
+        self._sa = None          # SA:Z string located by the native reader (None: parse the aux bytes)
+        self._seq_fetch = None   # callable (a, b) -> str decoding bases straight from the BGZF stream
 
     is_unmapped = property(lambda s: bool(s.flag & 0x4))
     is_secondary = property(lambda s: bool(s.flag & 0x100))
@@ -306,6 +319,8 @@ class AlignedRecord(object):
             return ""
         if self._seq_str is not None:
             return self._seq_str[a:b]
+        if self._seq_fetch is not None:
+            return self._seq_fetch(a, b)
         by = self._seq_packed[a >> 1:(b + 1) >> 1]
         dec = _SEQ_PAIR_LUT[by].reshape(-1)
         off = a & 1
@@ -353,6 +368,8 @@ class AlignedRecord(object):
         return tags
 
     def get_tag(self, name):
+        if name == "SA" and self._sa is not None:
+            return self._sa
         tags = self._parse_tags()
         if name not in tags:
             raise KeyError("tag '%s' not present" % name)
@@ -378,66 +395,265 @@ class _LazySeq(object):
 
 
 _AUX_FMT = {"c": ("<b", 1), "C": ("<B", 1), "s": ("<h", 2), "S": ("<H", 2), "i": ("<i", 4),
-            "I": ("<I", 4), "f": ("<f", 4)}
+            "I": ("<I", 4), "f": ("<f", 4), "d": ("<d", 8)}
+
+
+def _restore_long_cigar(words, l_seq, tid, pos, aux):
+    """SAM spec §4.2.2 / htslib bam_tag2cigar: a stored CIGAR that starts with a soft clip as long
+    as the read is a placeholder when a CG:B,I array is present; returns (real words, aux without CG)
+    or None."""
+    if len(words) == 0 or tid < 0 or pos < 0:
+        return None
+    w0 = int(words[0])
+    if (w0 & 15) != 4 or (w0 >> 4) != l_seq:
+        return None
+    q, end = 0, len(aux)
+    while q + 3 <= end:
+        typ = aux[q + 2]
+        start = q
+        q += 3
+        if typ in b"ZH":
+            q = aux.index(b"\x00", q) + 1
+        elif typ == 66:  # 'B'
+            sub, cnt = chr(aux[q]), struct.unpack_from("<I", aux, q + 1)[0]
+            size = _AUX_FMT[sub][1]
+            if aux[start:start + 2] == b"CG":
+                if sub not in "Ii" or cnt < len(words) or cnt >= (1 << 29):
+                    return None
+                real = np.frombuffer(aux, dtype="<u4", count=cnt, offset=q + 5)
+                return real, aux[:start] + aux[q + 5 + cnt * size:]
+            q += 5 + cnt * size
+        elif typ == 65:  # 'A'
+            q += 1
+        else:
+            q += _AUX_FMT[chr(typ)][1]
+        if aux[start:start + 2] == b"CG":
+            return None  # a CG tag that is not an integer array
+    return None
+
+
+class _BamColumns(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("l_seq", C.c_void_p),
+                ("ref_len", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p), ("cigar_off", C.c_void_p),
+                ("cigar", C.c_void_p), ("name_off", C.c_void_p), ("names", C.c_void_p), ("aux_off", C.c_void_p),
+                ("aux", C.c_void_p), ("sa_off", C.c_void_p), ("sa_len", C.c_void_p), ("voffset", C.c_void_p),
+                ("blocks_inflated", C.c_uint64), ("blocks_spanned", C.c_uint64), ("cigar_pinned", C.c_int),
+                ("n_threads", C.c_int)]
+
+
+def _view(addr, n, dtype):
+    """numpy view over `n` items of native memory at `addr` (valid until the next load / close)."""
+    dtype = np.dtype(dtype)
+    if n == 0 or not addr:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
 
 
 class AlignmentFile(object):
-    """Coordinate-sorted BAM opened for sequential, per-contig streaming.  Only the BGZF blocks
-    that hold record headers, names, CIGARs, aux tags and requested SEQ slices are inflated."""
+    """Coordinate-sorted BAM opened for per-contig streaming (pysam.AlignmentFile surface the
+    reference uses).  Records are indexed column-wise by the native reader
+    of libsvx.so (include/svx_bam.h): threads walk the file from the record boundaries a `.bai`
+    provides and inflate only the BGZF members holding record headers, names, CIGARs and tags.
+    `load(contigs)` restricts the walk to the contigs a rank owns; anything that touches the
+    records loads the whole file on demand.  reader="python" selects the pure-Python walker
+    (kept as the differential reference of the native one; also via SVX_BAM_READER=python)."""
 
-    def __init__(self, path, mode="rb"):
+    def __init__(self, path, mode="rb", threads=None, reader=None, device=None):
         self.filename = path
-        z = self._z = BgzfLazy(path)
-        head = z.read(0, 12)
-        if head[:4] != b"BAM\x01":
-            raise ValueError("%s is not a BAM file" % path)
-        l_text = struct.unpack_from("<i", head, 4)[0]
-        self.text = z.read(8, l_text).split(b"\x00")[0].decode()
+        self._reader = reader or os.environ.get("SVX_BAM_READER", "native")
+        self._loaded = None   # None: nothing; "all" or a tuple of tids
+        self._h = None
+        self._z = None
+        self._pin_device = device
+        if self._reader == "native":
+            from svim_asm_amd import _lib
+            self._lib = lib = _lib.load()
+            h, err = C.c_void_p(), C.create_string_buffer(512)
+            rc = lib.svx_bam_open(os.fsencode(path), int(threads or 0), C.byref(h), err, len(err))
+            if rc != 0:
+                msg = err.value.decode(errors="replace")
+                if not os.path.exists(path):
+                    raise FileNotFoundError(msg)
+                raise ValueError(msg)
+            self._h = h
+            text, l_text, n_ref = C.c_char_p(), C.c_uint64(), C.c_int32()
+            tp = C.c_void_p()
+            lib.svx_bam_header(h, C.byref(tp), C.byref(l_text), C.byref(n_ref))
+            self.text = C.string_at(tp, l_text.value).decode() if l_text.value else ""
+            names, lens = [], []
+            for tid in range(n_ref.value):
+                nm, ln = C.c_char_p(), C.c_int32()
+                lib.svx_bam_reference(h, tid, C.byref(nm), C.byref(ln))
+                names.append(nm.value.decode())
+                lens.append(ln.value)
+        else:
+            z = self._z = BgzfLazy(path)
+            head = z.read(0, 12)
+            if head[:4] != b"BAM\x01":
+                raise ValueError("%s is not a BAM file" % path)
+            l_text = struct.unpack_from("<i", head, 4)[0]
+            self.text = z.read(8, l_text).split(b"\x00")[0].decode()
+            p = 8 + l_text
+            n_ref = struct.unpack_from("<i", z.read(p, 4), 0)[0]
+            p += 4
+            names, lens = [], []
+            for _ in range(n_ref):
+                l_name = struct.unpack_from("<i", z.read(p, 4), 0)[0]
+                nb = z.read(p + 4, l_name + 4)
+                names.append(nb[:l_name - 1].decode())
+                lens.append(struct.unpack_from("<i", nb, l_name)[0])
+                p += 8 + l_name
+            self._rec_start = p
         self.header = _parse_header_text(self.text)
-        p = 8 + l_text
-        n_ref = struct.unpack_from("<i", z.read(p, 4), 0)[0]
-        p += 4
-        names, lens = [], []
-        for _ in range(n_ref):
-            l_name = struct.unpack_from("<i", z.read(p, 4), 0)[0]
-            nb = z.read(p + 4, l_name + 4)
-            names.append(nb[:l_name - 1].decode())
-            lens.append(struct.unpack_from("<i", nb, l_name)[0])
-            p += 8 + l_name
         self.references = tuple(names)
         self.lengths = tuple(lens)
         self._tid = {n: i for i, n in enumerate(names)}
-        self._rec_start = p
-        self._index_records()
 
-    # ---- columnar index over all records: one sequential pass over the record headers; the
-    # name, CIGAR words and tag bytes of every record are copied out, SEQ/QUAL are skipped
-    def _index_records(self):
+    # ---------------------------------------------------------------- loading
+    def index_state(self):
+        """0 no index file, 1 usable .bai (parallel / per-contig walks), 2 present but unusable."""
+        if self._h is not None:
+            return int(self._lib.svx_bam_index_state(self._h))
+        base = self.filename
+        return 2 if (os.path.exists(base + ".bai") or os.path.exists(base + ".csi") or
+                     os.path.exists(os.path.splitext(base)[0] + ".bai")) else 0
+
+    def contig_spans(self):
+        """Compressed bytes per contig from the index (None without a usable one)."""
+        if self._h is None or self.index_state() != 1:
+            return None
+        span = np.zeros(len(self.references), dtype=np.uint64)
+        if self._lib.svx_bam_contig_spans(self._h, span.ctypes.data) != 0:
+            return None
+        return span.astype(np.int64)
+
+    def set_device(self, device):
+        """HIP device whose context page-locks the CIGAR pool of later loads (None: pageable)."""
+        self._pin_device = device
+
+    def load(self, contigs=None):
+        """Index the records of `contigs` (names or tids; None = the whole file)."""
+        if contigs is None:
+            want = "all"
+            tids = None
+        else:
+            tids = sorted(set(self._tid[c] if isinstance(c, str) else int(c) for c in contigs))
+            want = tuple(tids)
+        if self._loaded == want:
+            return self
+        if self._h is not None:
+            self._lib.svx_bam_set_pinned_device(self._h, -1 if self._pin_device is None else int(self._pin_device))
+            if tids is None:
+                rc = self._lib.svx_bam_load(self._h, None, 0)
+            else:
+                arr = np.asarray(tids, dtype=np.int32)
+                rc = self._lib.svx_bam_load(self._h, arr.ctypes.data, len(arr))
+            if rc != 0:
+                raise ValueError("%s: %s" % (self.filename, self._lib.svx_bam_last_error(self._h).decode(errors="replace")))
+            self._bind_native_columns()
+        else:
+            self._index_records_python(None if tids is None else set(tids))
+        self._loaded = want
+        return self
+
+    def _ensure(self):
+        if self._loaded is None:
+            self.load(None)
+
+    def _bind_native_columns(self):
+        c = _BamColumns()
+        self._lib.svx_bam_get_columns(self._h, C.byref(c))
+        n = int(c.n_records)
+        self.n_records = n
+        cig_off = _view(c.cigar_off, n + 1, np.uint64).astype(np.int64)
+        self._c_cols = {"tid": _view(c.tid, n, np.int32).astype(np.int64), "pos": _view(c.pos, n, np.int32).astype(np.int64),
+                       "mapq": _view(c.mapq, n, np.uint8).astype(np.int64), "flag": _view(c.flag, n, np.uint16).astype(np.int64),
+                       "n_cig": np.diff(cig_off), "l_seq": _view(c.l_seq, n, np.int32).astype(np.int64),
+                       "ref_len": _view(c.ref_len, n, np.int32).astype(np.int64),
+                       "voffset": _view(c.voffset, n, np.uint64).copy()}
+        self._c_cig_off = cig_off
+        self._c_cigar = _view(c.cigar, int(cig_off[-1]) if n else 0, np.uint32)  # zero-copy (page-locked pool)
+        self._name_off = _view(c.name_off, n + 1, np.uint64).astype(np.int64)
+        self._names_pool = C.string_at(c.names, int(self._name_off[-1])) if n and self._name_off[-1] else b""
+        self._aux_off = _view(c.aux_off, n + 1, np.uint64).astype(np.int64)
+        self._aux_pool = C.string_at(c.aux, int(self._aux_off[-1])) if n and self._aux_off[-1] else b""
+        self._sa_off = _view(c.sa_off, n, np.int64).copy()
+        self._sa_len = _view(c.sa_len, n, np.uint32).astype(np.int64)
+        self.cigar_pinned = bool(c.cigar_pinned)
+
+    @property
+    def blocks_inflated(self):
+        if self._h is not None:
+            c = _BamColumns()
+            self._lib.svx_bam_get_columns(self._h, C.byref(c))
+            return int(c.blocks_inflated)
+        return self._z.blocks_inflated
+
+    @property
+    def blocks_spanned(self):
+        if self._h is not None:
+            c = _BamColumns()
+            self._lib.svx_bam_get_columns(self._h, C.byref(c))
+            return int(c.blocks_spanned)
+        return len(self._z._start)
+
+    # the column containers load the file on first touch
+    @property
+    def _cols(self):
+        self._ensure()
+        return self._c_cols
+
+    @property
+    def _cigar(self):
+        self._ensure()
+        return self._c_cigar
+
+    @property
+    def _cig_off(self):
+        self._ensure()
+        return self._c_cig_off
+
+    # ---- pure-Python walker: one sequential pass over the record headers; the name, CIGAR words
+    # and tag bytes of every record are copied out, SEQ/QUAL are skipped
+    def _index_records_python(self, keep_tids):
         z, p, n = self._z, self._rec_start, self._z.size
-        cols = {k: [] for k in ("seq_off", "size", "tid", "pos", "mapq", "flag", "n_cig", "l_seq")}
+        cols = {k: [] for k in ("seq_off", "tid", "pos", "mapq", "flag", "n_cig", "l_seq", "ref_len", "voffset")}
         names, tags, cig_parts = [], [], []
         unpack = struct.Struct("<iiiBBHHHi").unpack_from
         while p + 36 <= n:
             bs, tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq = unpack(z.read(p, 36), 0)
             q = p + 36
+            if keep_tids is not None and tid not in keep_tids:
+                p += 4 + bs
+                continue
             body = z.read(q, l_rn + 4 * n_cig)
-            names.append(body[:l_rn - 1].decode())
-            cig_parts.append(body[l_rn:])
+            words = np.frombuffer(body, dtype="<u4", count=n_cig, offset=l_rn)
             q += l_rn + 4 * n_cig
             tag_off = q + (l_seq + 1) // 2 + l_seq
-            tags.append(z.read(tag_off, p + 4 + bs - tag_off))
-            cols["seq_off"].append(q); cols["size"].append(bs); cols["tid"].append(tid)
-            cols["pos"].append(pos); cols["mapq"].append(mapq); cols["flag"].append(flag)
-            cols["n_cig"].append(n_cig); cols["l_seq"].append(l_seq)
+            aux = z.read(tag_off, p + 4 + bs - tag_off)
+            real = _restore_long_cigar(words, l_seq, tid, pos, aux)
+            if real is not None:
+                words, aux = real
+            names.append(body[:l_rn - 1].decode())
+            cig_parts.append(words.tobytes())
+            tags.append(aux)
+            cols["seq_off"].append(q); cols["tid"].append(tid); cols["pos"].append(pos)
+            cols["mapq"].append(mapq); cols["flag"].append(flag); cols["n_cig"].append(len(words))
+            cols["l_seq"].append(l_seq)
+            cols["ref_len"].append(int(((words >> 4) * ((0x18D >> (words & 15)) & 1)).sum()) if len(words) else 0)
+            cols["voffset"].append(z.virtual_offset(p))
             p += 4 + bs
-        self._cols = {k: np.asarray(v, dtype=np.int64) for k, v in cols.items()}
+        self._c_cols = {k: np.asarray(v, dtype=np.uint64 if k == "voffset" else np.int64) for k, v in cols.items()}
         self.n_records = len(names)
         self._names, self._tags = names, tags
-        self._cigar = np.frombuffer(b"".join(cig_parts), dtype="<u4") if cig_parts else np.zeros(0, np.uint32)
-        self._cig_off = np.concatenate(([0], np.cumsum(self._cols["n_cig"]))).astype(np.int64) \
+        self._c_cigar = np.frombuffer(b"".join(cig_parts), dtype="<u4") if cig_parts else np.zeros(0, np.uint32)
+        self._c_cig_off = np.concatenate(([0], np.cumsum(self._c_cols["n_cig"]))).astype(np.int64) \
             if self.n_records else np.zeros(1, np.int64)
+        self.cigar_pinned = False
 
     def __len__(self):
+        self._ensure()
         return self.n_records
 
     def record(self, i):
@@ -448,16 +664,53 @@ class AlignmentFile(object):
         r.reference_start = int(c["pos"][i])
         r.mapping_quality = int(c["mapq"][i])
         r.flag = int(c["flag"][i])
-        r.query_name = self._names[i]
         r.cigar_words = self._cigar[self._cig_off[i]:self._cig_off[i + 1]]
         r._l_seq = int(c["l_seq"][i])
-        r._seq_packed = _LazySeq(self._z, int(c["seq_off"][i]), (r._l_seq + 1) // 2)
-        r._tags_raw = self._tags[i]
+        if self._h is not None:
+            r.query_name = self._names_pool[self._name_off[i]:self._name_off[i + 1]].decode()
+            r._tags_raw = self._aux_pool[self._aux_off[i]:self._aux_off[i + 1]]
+            so = int(self._sa_off[i])
+            if so >= 0:
+                r._sa = self._aux_pool[so:so + int(self._sa_len[i])].decode()
+            r._seq_fetch = lambda a, b, _i=i: self.sequence_slices([_i], [a], [b])[0]
+        else:
+            r.query_name = self._names[i]
+            r._seq_packed = _LazySeq(self._z, int(c["seq_off"][i]), (r._l_seq + 1) // 2)
+            r._tags_raw = self._tags[i]
         return r
 
+    def sequence_slices(self, rec, begin, end):
+        """query_sequence[begin:end] of many records at once (list of str), decoded from the BGZF
+        stream by the reader's threads; only the members holding those bases are inflated."""
+        self._ensure()
+        rec = np.ascontiguousarray(rec, dtype=np.uint32)
+        n = len(rec)
+        if n == 0:
+            return []
+        l_seq = self._cols["l_seq"][rec.astype(np.int64)]
+        a = np.minimum(np.maximum(np.asarray(begin, dtype=np.int64), 0), l_seq)
+        b = np.maximum(np.minimum(np.asarray(end, dtype=np.int64), l_seq), a)
+        if self._h is None:
+            out = []
+            for i, x, y in zip(rec.tolist(), a.tolist(), b.tolist()):
+                out.append(self.record(i).seq_slice(x, y))
+            return out
+        off = np.concatenate(([0], np.cumsum(b - a))).astype(np.uint64)
+        buf = np.empty(int(off[-1]), dtype=np.uint8)
+        a32, b32 = a.astype(np.uint32), b.astype(np.uint32)
+        rc = self._lib.svx_bam_seq_slices(self._h, rec.ctypes.data, a32.ctypes.data, b32.ctypes.data, n,
+                                          off.ctypes.data, buf.ctypes.data)
+        if rc != 0:
+            raise ValueError("%s: %s" % (self.filename, self._lib.svx_bam_last_error(self._h).decode(errors="replace")))
+        text = buf.tobytes().decode("ascii")
+        o = off.tolist()
+        return [text[o[k]:o[k + 1]] for k in range(n)]
+
     def prefetch_sequence(self, requests):
-        """requests: iterable of (record index, first base, last base + 1) that will be sliced soon;
-        the covering BGZF blocks are inflated on a thread pool."""
+        """requests: iterable of (record index, first base, last base + 1) that will be sliced soon
+        (pure-Python reader: the covering BGZF blocks are inflated on a thread pool)."""
+        if self._h is not None:
+            return
         c = self._cols
         self._z.prefetch([(int(c["seq_off"][i]) + (a >> 1), ((b + 1) >> 1) - (a >> 1)) for i, a, b in requests])
 
@@ -478,9 +731,7 @@ class AlignmentFile(object):
 
     # ---- pysam-compatible surface
     def check_index(self):
-        base = self.filename
-        if not (os.path.exists(base + ".bai") or os.path.exists(base + ".csi") or
-                os.path.exists(os.path.splitext(base)[0] + ".bai")):
+        if self.index_state() == 0:
             raise ValueError("mapping information not recorded in index or index not available")
         return True
 
@@ -489,8 +740,11 @@ class AlignmentFile(object):
 
     def fetch(self, contig=None, until_eof=False):
         if contig is None:
+            self._ensure()
             return (self.record(i) for i in range(self.n_records))
         tid = self.get_tid(contig)
+        if self._loaded is None or (self._loaded != "all" and tid not in self._loaded):
+            self.load(None if self._loaded is None else set(self._loaded) | {tid})
         return (self.record(int(i)) for i in self.indices_of_contig(tid))
 
     def get_tid(self, name):
@@ -511,6 +765,16 @@ class AlignmentFile(object):
 
     def close(self):
         self._z = None
+        if self._h is not None:
+            self._c_cigar = None
+            self._lib.svx_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------------------ writer
@@ -535,13 +799,15 @@ def _reg2bin(beg, end):
 
 def encode_record(qname, flag, tid, pos, mapq, cigar_words, seq, tags=None, seq_packed=None, l_seq=None):
     """One BAM alignment record (block_size prefix included).  `tags`: list of (tag, type, value)
-    with type 'Z' or 'i'."""
+    with type 'Z' or 'i'.  A CIGAR of more than 65535 operations does not fit the 16-bit
+    n_cigar_op field: it is stored as the CG:B,I array behind the placeholder `<l_seq>S<ref_len>N`
+    (SAM spec §4.2.2), as samtools/htslib write it."""
     cw = np.ascontiguousarray(cigar_words, dtype="<u4")
     name = qname.encode() + b"\x00"
     if seq_packed is None:
         l_seq = len(seq)
         seq_packed = encode_seq(seq)
-    rlen = int(((cw >> 4) * ((0x18D >> (cw & 15)) & 1)).sum()) if len(cw) else 0
+    rlen = int(((cw >> 4).astype(np.int64) * ((0x18D >> (cw & 15)) & 1)).sum()) if len(cw) else 0
     end = pos + (rlen if rlen else 1)
     aux = b""
     for tag, typ, val in (tags or []):
@@ -551,14 +817,82 @@ def encode_record(qname, flag, tid, pos, mapq, cigar_words, seq, tags=None, seq_
             aux += tag.encode() + b"i" + struct.pack("<i", val)
         else:
             raise ValueError("unsupported aux type " + typ)
+    stored = cw
+    if len(cw) > 65535:
+        stored = np.array([(l_seq << 4) | 4, (rlen << 4) | 3], dtype="<u4")
+        aux += b"CGBI" + struct.pack("<I", len(cw)) + cw.tobytes()
     body = struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, _reg2bin(max(pos, 0), max(end, 1)),
-                       len(cw), flag, l_seq, -1, -1, 0)
-    body += name + cw.tobytes() + seq_packed + b"\xff" * l_seq + aux
+                       len(stored), flag, l_seq, -1, -1, 0)
+    body += name + stored.tobytes() + seq_packed + b"\xff" * l_seq + aux
     return struct.pack("<i", len(body)) + body
 
 
+def record_extent(blob):
+    """(tid, pos, end, flag) of an encoded record; end as htslib's bam_endpos (pos + 1 when the
+    CIGAR consumes no reference), the real CIGAR taken from CG when the stored one is a placeholder."""
+    bs, tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiiBBHHHi", blob, 0)
+    words = np.frombuffer(blob, dtype="<u4", count=n_cig, offset=36 + l_rn)
+    rlen = int(((words >> 4).astype(np.int64) * ((0x18D >> (words & 15)) & 1)).sum()) if n_cig else 0
+    unmapped = bool(flag & 4)
+    return tid, pos, pos + (rlen if rlen and not unmapped else 1), flag
+
+
+_BAI_NO_OFFSET = (1 << 64) - 1
+
+
+def build_bai(n_ref, tid, beg, end, flag, voff, voff_end):
+    """Bytes of a `.bai` (SAM spec §5.2) for records given in file order: bins with their chunks
+    (consecutive records of one bin share a chunk), the 16 kb linear index (offset of the first
+    record overlapping each window, gaps back-filled like htslib), the per-contig metadata
+    pseudo-bin 37450 and the count of unplaced reads."""
+    out = [b"BAI\x01", struct.pack("<i", n_ref)]
+    tid = np.asarray(tid, dtype=np.int64)
+    n_no_coor = int((tid < 0).sum())
+    for r in range(n_ref):
+        idx = np.nonzero(tid == r)[0]
+        if len(idx) == 0:
+            out.append(struct.pack("<ii", 0, 0))
+            continue
+        bins, order = {}, []
+        last_bin = None
+        n_win = (max(int(end[i]) for i in idx) - 1 >> 14) + 1
+        lin = np.full(n_win, _BAI_NO_OFFSET, dtype=np.uint64)
+        n_mapped = n_unmapped = 0
+        for i in idx.tolist():
+            b, e = max(int(beg[i]), 0), max(int(end[i]), 1)
+            bn = _reg2bin(b, e)
+            if bn == last_bin:
+                bins[bn][-1][1] = int(voff_end[i])
+            else:
+                if bn not in bins:
+                    bins[bn] = []
+                    order.append(bn)
+                bins[bn].append([int(voff[i]), int(voff_end[i])])
+            last_bin = bn
+            w0, w1 = b >> 14, (e - 1) >> 14
+            np.minimum(lin[w0:w1 + 1], np.uint64(voff[i]), out=lin[w0:w1 + 1])
+            if int(flag[i]) & 4:
+                n_unmapped += 1
+            else:
+                n_mapped += 1
+        for w in range(n_win - 2, -1, -1):
+            if lin[w] == _BAI_NO_OFFSET:
+                lin[w] = lin[w + 1]
+        out.append(struct.pack("<i", len(order) + 1))
+        for bn in order:
+            out.append(struct.pack("<Ii", bn, len(bins[bn])))
+            for cb, ce in bins[bn]:
+                out.append(struct.pack("<QQ", cb, ce))
+        out.append(struct.pack("<Ii", 37450, 2))
+        out.append(struct.pack("<QQQQ", int(voff[idx[0]]), int(voff_end[idx[-1]]), n_mapped, n_unmapped))
+        out.append(struct.pack("<i", n_win))
+        out.append(lin.astype("<u8").tobytes())
+    out.append(struct.pack("<Q", n_no_coor))
+    return b"".join(out)
+
+
 def write_bam(path, references, lengths, record_blobs, sort_order="coordinate", level=1, write_index=True):
-    """Write a BAM file from already-encoded records (see encode_record) + a stub .bai."""
+    """Write a BAM file from already-encoded records (see encode_record) and its `.bai`."""
     text = "@HD\tVN:1.6\tSO:%s\n" % sort_order
     text += "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(references, lengths))
     tb = text.encode()
@@ -566,10 +900,56 @@ def write_bam(path, references, lengths, record_blobs, sort_order="coordinate", 
     for n, l in zip(references, lengths):
         nb = n.encode() + b"\x00"
         hdr += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    data = hdr + b"".join(record_blobs)
+    comp = bgzf_compress(data, level)
     with open(path, "wb") as fh:
-        fh.write(bgzf_compress(hdr + b"".join(record_blobs), level))
+        fh.write(comp)
     if write_index:
-        # structurally valid, empty index: the pipeline streams sequentially per contig and only
-        # requires the index to exist (svim-asm:67-72)
+        # member start offsets of the file just written (fixed 0xFF00-byte payloads, then the EOF member)
+        spans = _bgzf_block_spans(comp)
+        starts = [sp[3] for sp in spans]
+
+        def voffset(u):  # end-of-member positions are written as the start of the next member
+            if u >= len(data):
+                return starts[-1] << 16  # the EOF member
+            return (starts[u // 0xFF00] << 16) | (u % 0xFF00)
+        u = len(hdr)
+        tid, beg, end, flag, vo, ve = [], [], [], [], [], []
+        for blob in record_blobs:
+            t, b, e, f = record_extent(blob)
+            tid.append(t); beg.append(b); end.append(e); flag.append(f)
+            vo.append(voffset(u))
+            u += len(blob)
+            ve.append(voffset(u))
         with open(path + ".bai", "wb") as fh:
-            fh.write(b"BAI\x01" + struct.pack("<i", len(references)) + struct.pack("<ii", 0, 0) * len(references))
+            fh.write(build_bai(len(references), tid, beg, end, flag, vo, ve))
+
+
+def index_bam(path, out=None):
+    """`samtools index` for the files this package reads: walk the records once (native reader,
+    sequential without an index) and write `<path>.bai`."""
+    f = AlignmentFile(path, reader="native")
+    # ignore whatever index is there: virtual offsets come from the walk itself
+    c = f.load(None)._cols
+    n = f.n_records
+    vo = c["voffset"].astype(np.uint64)
+    size = os.path.getsize(path)
+    with open(path, "rb") as fh:
+        fh.seek(max(0, size - 28))
+        eof_at = size - 28 if fh.read(28) == _BGZF_EOF else size
+    ve = np.concatenate((vo[1:], [np.uint64(eof_at << 16)])) if n else vo
+    unmapped = (c["flag"] & 4) != 0
+    rl = np.where((c["ref_len"] > 0) & ~unmapped, c["ref_len"], 1)
+    data = build_bai(len(f.references), c["tid"], c["pos"], c["pos"] + rl, c["flag"], vo, ve)
+    f.close()
+    with open(out or (path + ".bai"), "wb") as fh:
+        fh.write(data)
+    return out or (path + ".bai")
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 3 and sys.argv[1] == "index":
+        print(index_bam(sys.argv[2]))
+    else:
+        print("usage: python -m svim_asm_amd.bamio index <file.bam>")

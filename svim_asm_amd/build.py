@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsvx.so")
-SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip"]
+SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip", "svx_bam.cpp"]
 
 
 def _hipcc():
@@ -30,7 +30,8 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "svx_internal.h"), os.path.join(ROOT, "include", "svx.h")]
+    deps = sources() + [os.path.join(CSRC, "svx_internal.h"), os.path.join(ROOT, "include", "svx.h"),
+                        os.path.join(ROOT, "include", "svx_bam.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -40,7 +41,8 @@ def build_lib(force=False, verbose=False):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB + ".tmp"] + sources()
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB + ".tmp"] + sources() + \
+          ["-lz", "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

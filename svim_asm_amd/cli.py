@@ -20,7 +20,7 @@ def _collect(path, which, options):
     """Open one BAM, check sort order and index like the reference, run COLLECT.
     Returns (alignment_file, candidates) or (None, None) after logging the error."""
     the = {"": "Input", "first": "The first input", "second": "The second input"}[which]
-    aln_file = bamio.AlignmentFile(path)
+    aln_file = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0)
     try:
         if aln_file.header["HD"]["SO"] != "coordinate":
             logging.error("{0} BAM file needs to be coordinate-sorted. Exiting..".format(the))
@@ -59,6 +59,13 @@ def main(arguments=None):
     distributed = _init_distributed(options)
     try:
         return _main(options)
+    except Exception as e:
+        if not distributed:
+            raise
+        # several ranks: a failure must not look like success to the launcher (torch.distributed.run
+        # tears the other ranks down on a non-zero exit instead of leaving them in a collective)
+        logging.error(e, exc_info=True)
+        sys.exit(1)
     finally:
         if distributed:
             import torch.distributed as dist
@@ -72,16 +79,20 @@ def _main(options):
     root.setLevel(logging.DEBUG if options.verbose else logging.INFO)
     if not os.path.exists(options.working_dir):
         os.makedirs(options.working_dir)
-    file_handler = logging.FileHandler("{0}/SVIM_{1}.log".format(options.working_dir,
-                                                               strftime("%y%m%d_%H%M%S", localtime())), mode="w")
-    console_handler = logging.StreamHandler()
-    for handler in (file_handler, console_handler):
+    rank, world_size = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    # one log file per rank (rank 0 keeps the reference's name); only rank 0 talks on the console
+    suffix = "" if world_size <= 1 or rank == 0 else ".rank{0}".format(rank)
+    file_handler = logging.FileHandler("{0}/SVIM_{1}{2}.log".format(options.working_dir,
+                                                                  strftime("%y%m%d_%H%M%S", localtime()), suffix),
+                                       mode="w")
+    handlers = [file_handler] + ([logging.StreamHandler()] if rank == 0 or world_size <= 1 else [])
+    for handler in handlers:
         handler.setFormatter(log_format)
         root.addHandler(handler)
     try:
         return _run(options)
     finally:
-        for handler in (file_handler, console_handler):
+        for handler in handlers:
             root.removeHandler(handler)
         file_handler.close()
 

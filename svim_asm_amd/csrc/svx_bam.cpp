@@ -1,0 +1,941 @@
+// svx_bam.cpp — native BAM ingest of libsvx.so (C-ABI in include/svx_bam.h).
+//
+// Host code only (no kernels).  Replaces what the reference gets from pysam/htslib under
+// `bam.fetch(contig=...)` (SVIM_COLLECT.py:65-71): BGZF inflate, record walk, CIGAR words,
+// aux tags, 4-bit SEQ slices.  Design:
+//   * the file is memory-mapped; a BGZF member is inflated only when bytes of it are needed
+//     (record header / name / CIGAR / aux, or a requested SEQ slice); everything else is
+//     hopped over with the BSIZE / ISIZE fields (SAM spec §4.1);
+//   * a `.bai` gives record boundaries (bin chunk begins/ends, linear index entries): the
+//     requested contigs' ranges are cut there into pieces of about equal compressed size and
+//     walked by a pool of threads, each with its own inflater;
+//   * inflate: libdeflate when the runtime has it (dlopen, optional), else zlib; the CRC32 of
+//     every inflated member is checked, as htslib does.
+#include "svx_bam.h"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "svx.h"
+
+namespace {
+
+inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t le32(const uint8_t* p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+inline uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+// ------------------------------------------------------------------ optional libdeflate
+struct LibDeflate {
+    void* handle = nullptr;
+    void* (*alloc)(void) = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void*, size_t) = nullptr;
+    void (*release)(void*) = nullptr;
+};
+
+const LibDeflate* libdeflate() {
+    static const LibDeflate lib = [] {
+        LibDeflate d;
+        const char* off = getenv("SVX_BAM_ZLIB");  // force the zlib path (tests)
+        if (off && off[0] == '1') return d;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return d;
+        d.alloc = reinterpret_cast<void* (*)(void)>(dlsym(h, "libdeflate_alloc_decompressor"));
+        d.decompress = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(
+            dlsym(h, "libdeflate_deflate_decompress"));
+        d.crc32 = reinterpret_cast<uint32_t (*)(uint32_t, const void*, size_t)>(dlsym(h, "libdeflate_crc32"));
+        d.release = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+        if (d.alloc && d.decompress && d.crc32 && d.release) d.handle = h;
+        else dlclose(h);
+        return d;
+    }();
+    return lib.handle ? &lib : nullptr;
+}
+
+struct Inflater {
+    void* ld = nullptr;
+    z_stream zs;
+    bool z_ready = false;
+    uint64_t n_blocks = 0;
+
+    Inflater() { memset(&zs, 0, sizeof(zs)); }
+    Inflater(const Inflater&) = delete;
+    Inflater& operator=(const Inflater&) = delete;
+    ~Inflater() {
+        if (ld) libdeflate()->release(ld);
+        if (z_ready) inflateEnd(&zs);
+    }
+    // raw deflate stream `in` → exactly out_len bytes, CRC32 checked
+    bool run(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, uint32_t crc) {
+        ++n_blocks;
+        const LibDeflate* L = libdeflate();
+        if (L) {
+            if (!ld) ld = L->alloc();
+            if (!ld) return false;
+            size_t got = 0;
+            if (L->decompress(ld, in, in_len, out, out_len, &got) != 0 || got != out_len) return false;
+            return L->crc32(0, out, out_len) == crc;
+        }
+        if (!z_ready) {
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            z_ready = true;
+        } else if (inflateReset(&zs) != Z_OK) {
+            return false;
+        }
+        zs.next_in = const_cast<Bytef*>(in);
+        zs.avail_in = (uInt)in_len;
+        zs.next_out = out;
+        zs.avail_out = (uInt)out_len;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) return false;
+        return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), out, (uInt)out_len) == crc;
+    }
+};
+
+// ------------------------------------------------------------------ BGZF members
+struct Blk {
+    uint32_t bsize = 0, isize = 0, payload_off = 0, payload_len = 0, crc = 0;
+};
+
+// 0 ok, 1 clean end of file (coff == fsize), -1 malformed
+int parse_block(const uint8_t* map, uint64_t fsize, uint64_t coff, Blk* b) {
+    if (coff == fsize) return 1;
+    if (coff + 18 > fsize) return -1;
+    const uint8_t* p = map + coff;
+    if (p[0] != 0x1F || p[1] != 0x8B || p[2] != 8 || !(p[3] & 4)) return -1;
+    const uint32_t xlen = le16(p + 10);
+    if (coff + 12 + xlen + 8 > fsize) return -1;
+    uint32_t q = 12, end = 12 + xlen, bsize = 0;
+    while (q + 4 <= end) {
+        const uint32_t slen = le16(p + q + 2);
+        if (p[q] == 66 && p[q + 1] == 67 && slen == 2 && q + 6 <= end) bsize = (uint32_t)le16(p + q + 4) + 1;
+        q += 4 + slen;
+    }
+    if (!bsize || bsize < xlen + 20 || coff + bsize > fsize) return -1;
+    b->bsize = bsize;
+    b->payload_off = 12 + xlen;
+    b->payload_len = bsize - xlen - 20;
+    b->crc = le32(p + bsize - 8);
+    b->isize = le32(p + bsize - 4);
+    if (b->isize > 65536) return -1;
+    return 0;
+}
+
+struct VPos {
+    uint64_t coff = 0;
+    uint32_t uoff = 0;
+    bool operator<(const VPos& o) const { return coff != o.coff ? coff < o.coff : uoff < o.uoff; }
+    bool operator==(const VPos& o) const { return coff == o.coff && uoff == o.uoff; }
+};
+
+struct File {
+    const uint8_t* map = nullptr;
+    uint64_t fsize = 0;
+};
+
+// Sequential reader over the uncompressed stream that inflates a member only when bytes of it
+// are copied out.  Positions are kept canonical: never at the end of a member (uoff == isize
+// moves to the start of the next one, empty members are passed), so that they compare equal
+// to the virtual offsets htslib writes into an index.
+struct Cursor {
+    const File* f;
+    Inflater* inf;
+    uint64_t coff = 0;
+    uint32_t uoff = 0;
+    Blk blk;
+    bool eof = false;
+    bool bad = false;
+    uint64_t buf_coff = ~0ull;  // member currently held in `buf`
+    uint64_t n_hopped = 0;      // members passed (inflated or not)
+    std::vector<uint8_t> buf;
+
+    Cursor(const File* file, Inflater* i) : f(file), inf(i) {}
+
+    bool settle() {  // make (coff, uoff) canonical; false on malformed data
+        for (;;) {
+            const int rc = parse_block(f->map, f->fsize, coff, &blk);
+            if (rc == 1) { eof = true; uoff = 0; return true; }
+            if (rc < 0) { bad = true; return false; }
+            if (uoff > blk.isize) { bad = true; return false; }
+            if (uoff < blk.isize) { eof = false; return true; }
+            coff += blk.bsize;
+            uoff = 0;
+            ++n_hopped;
+        }
+    }
+    bool seek(VPos p) {
+        coff = p.coff;
+        uoff = p.uoff;
+        return settle();
+    }
+    VPos tell() const { VPos p; p.coff = coff; p.uoff = uoff; return p; }
+    bool ensure() {
+        if (buf_coff == coff) return true;
+        if (buf.empty()) buf.resize(65536);
+        if (!inf->run(f->map + coff + blk.payload_off, blk.payload_len, buf.data(), blk.isize, blk.crc)) {
+            bad = true;
+            return false;
+        }
+        buf_coff = coff;
+        return true;
+    }
+    bool read(void* dst, size_t n) {
+        uint8_t* d = static_cast<uint8_t*>(dst);
+        while (n) {
+            if (eof || bad) { bad = true; return false; }
+            if (!ensure()) return false;
+            const size_t take = std::min<size_t>(n, blk.isize - uoff);
+            memcpy(d, buf.data() + uoff, take);
+            d += take;
+            n -= take;
+            uoff += (uint32_t)take;
+            if (!settle()) return false;
+        }
+        return true;
+    }
+    bool skip(uint64_t n) {
+        while (n) {
+            if (eof || bad) { bad = true; return false; }
+            const uint64_t take = std::min<uint64_t>(n, blk.isize - uoff);
+            n -= take;
+            uoff += (uint32_t)take;
+            if (!settle()) return false;
+        }
+        return true;
+    }
+};
+
+// ------------------------------------------------------------------ record columns
+struct Chunk {
+    std::vector<int32_t> tid, pos, l_seq, ref_len;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint32_t> n_cig, name_len, aux_len, sa_len;
+    std::vector<int64_t> sa_off;  // relative to the record's aux start
+    std::vector<uint64_t> voffset, seq_coff;
+    std::vector<uint32_t> seq_uoff;
+    std::vector<uint32_t> cigar;
+    std::vector<char> names;
+    std::vector<uint8_t> aux;
+    uint64_t blocks_spanned = 0;
+    std::string err;
+};
+
+// size of one aux value starting at p (type byte at p[0]); 0 on malformed data
+size_t aux_value_size(const uint8_t* p, const uint8_t* end) {
+    if (p >= end) return 0;
+    switch (p[0]) {
+        case 'A': case 'c': case 'C': return 2;
+        case 's': case 'S': return 3;
+        case 'i': case 'I': case 'f': return 5;
+        case 'd': return 9;
+        case 'Z': case 'H': {
+            const uint8_t* q = p + 1;
+            while (q < end && *q) ++q;
+            return q < end ? (size_t)(q - p) + 1 : 0;
+        }
+        case 'B': {
+            if (p + 6 > end) return 0;
+            size_t es;
+            switch (p[1]) {
+                case 'c': case 'C': es = 1; break;
+                case 's': case 'S': es = 2; break;
+                case 'i': case 'I': case 'f': es = 4; break;
+                default: return 0;
+            }
+            const uint64_t cnt = le32(p + 2);
+            const uint64_t tot = 6 + cnt * es;
+            return p + tot <= end ? (size_t)tot : 0;
+        }
+        default: return 0;
+    }
+}
+
+const uint32_t kRefMask = 0x18D;  // M D N = X consume the reference (htslib bam_cigar2rlen)
+
+// Walk records from `start` to `stop` (exclusive; canonical position) or to the end of the file.
+bool walk_records(const File* f, VPos start, bool have_stop, VPos stop, Inflater* inf, Chunk* out) {
+    Cursor c(f, inf);
+    char msg[256];
+    if (!c.seek(start)) { out->err = "malformed BGZF member at a walk start"; return false; }
+    std::vector<uint8_t> body;
+    std::vector<uint8_t> auxbuf;
+    for (;;) {
+        const VPos here = c.tell();
+        if (have_stop) {
+            if (here == stop) break;
+            if (stop < here || c.eof) {
+                out->err = "index does not match the file: a record walk passed an indexed record start";
+                return false;
+            }
+        } else if (c.eof) {
+            break;
+        }
+        uint8_t fix[36];
+        if (!c.read(fix, 36)) { out->err = "truncated BAM record header"; return false; }
+        const int32_t block_size = (int32_t)le32(fix);
+        const int32_t tid = (int32_t)le32(fix + 4), pos = (int32_t)le32(fix + 8);
+        const uint32_t l_rn = fix[12], mapq = fix[13];
+        uint32_t n_cig = le16(fix + 16);
+        const uint32_t flag = le16(fix + 18);
+        const int32_t l_seq = (int32_t)le32(fix + 20);
+        const uint64_t seq_bytes = l_seq > 0 ? ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq : 0;
+        const uint64_t fixed = 32ull + l_rn + 4ull * n_cig + seq_bytes;
+        if (block_size < 32 || l_seq < 0 || l_rn == 0 || (uint64_t)block_size < fixed) {
+            snprintf(msg, sizeof(msg), "corrupt BAM record at virtual offset %llu:%u",
+                     (unsigned long long)here.coff, here.uoff);
+            out->err = msg;
+            return false;
+        }
+        body.resize(l_rn + 4ull * n_cig);
+        if (!c.read(body.data(), body.size())) { out->err = "truncated BAM record (name/CIGAR)"; return false; }
+        const VPos seq_at = c.tell();
+        if (!c.skip(seq_bytes)) { out->err = "truncated BAM record (SEQ/QUAL)"; return false; }
+        const uint64_t aux_bytes = (uint64_t)block_size - fixed;
+        auxbuf.resize(aux_bytes);
+        if (aux_bytes && !c.read(auxbuf.data(), aux_bytes)) { out->err = "truncated BAM record (aux)"; return false; }
+
+        size_t nl = 0;
+        while (nl < l_rn && body[nl]) ++nl;
+        // ---- aux walk: locate SA:Z and CG:B,I
+        const uint8_t* ab = auxbuf.data();
+        const uint8_t* ae = ab + aux_bytes;
+        const uint8_t *sa = nullptr, *cg = nullptr;
+        size_t sa_n = 0, cg_total = 0;
+        for (const uint8_t* p = ab; p + 3 <= ae;) {
+            const size_t vs = aux_value_size(p + 2, ae);
+            if (!vs) {
+                snprintf(msg, sizeof(msg), "malformed aux field in record '%.*s'", (int)nl, (const char*)body.data());
+                out->err = msg;
+                return false;
+            }
+            if (p[0] == 'S' && p[1] == 'A' && p[2] == 'Z' && !sa) { sa = p + 3; sa_n = vs - 2; }
+            if (p[0] == 'C' && p[1] == 'G' && !cg) { cg = p; cg_total = 2 + vs; }
+            p += 2 + vs;
+        }
+        // ---- long CIGAR (SAM spec §4.2.2; condition of htslib bam_tag2cigar)
+        const uint8_t* cig_src = body.data() + l_rn;
+        bool cg_used = false;
+        if (cg && n_cig > 0 && tid >= 0 && pos >= 0 && cg[2] == 'B' && (cg[3] == 'I' || cg[3] == 'i')) {
+            const uint32_t w0 = le32(cig_src);
+            const uint32_t cg_len = le32(cg + 4);
+            if ((w0 & 15) == 4 && (w0 >> 4) == (uint32_t)l_seq && cg_len >= n_cig && cg_len < (1u << 29)) {
+                cig_src = cg + 8;
+                n_cig = cg_len;
+                cg_used = true;
+            }
+        }
+        int64_t rlen = 0;
+        const size_t c0 = out->cigar.size();
+        out->cigar.resize(c0 + n_cig);
+        for (uint32_t k = 0; k < n_cig; ++k) {
+            const uint32_t w = le32(cig_src + 4 * k);
+            out->cigar[c0 + k] = w;
+            if ((kRefMask >> (w & 15)) & 1) rlen += w >> 4;
+        }
+        out->tid.push_back(tid);
+        out->pos.push_back(pos);
+        out->l_seq.push_back(l_seq);
+        out->ref_len.push_back((int32_t)std::min<int64_t>(rlen, 0x7FFFFFFF));
+        out->flag.push_back((uint16_t)flag);
+        out->mapq.push_back((uint8_t)mapq);
+        out->n_cig.push_back(n_cig);
+        out->voffset.push_back((here.coff << 16) | here.uoff);
+        out->seq_coff.push_back(seq_at.coff);
+        out->seq_uoff.push_back(seq_at.uoff);
+        out->name_len.push_back((uint32_t)nl);
+        out->names.insert(out->names.end(), body.begin(), body.begin() + nl);
+        // aux bytes, CG removed when it was moved into the CIGAR (pysam no longer shows the tag)
+        const size_t a0 = out->aux.size();
+        if (cg_used) {
+            out->aux.insert(out->aux.end(), ab, cg);
+            out->aux.insert(out->aux.end(), cg + cg_total, ae);
+            if (sa && sa > cg) sa -= cg_total;
+        } else {
+            out->aux.insert(out->aux.end(), ab, ae);
+        }
+        out->aux_len.push_back((uint32_t)(out->aux.size() - a0));
+        out->sa_off.push_back(sa ? (int64_t)(sa - ab) : -1);
+        out->sa_len.push_back(sa ? (uint32_t)sa_n : 0);
+    }
+    out->blocks_spanned = c.n_hopped;
+    return true;
+}
+
+// ------------------------------------------------------------------ .bai
+struct RefIndex {
+    std::vector<uint64_t> points;  // virtual offsets that are record boundaries (chunk begins/ends, linear index)
+    uint64_t lo = ~0ull, hi = 0;   // [first chunk begin, last chunk end) as virtual offsets
+};
+
+bool read_file(const std::string& p, std::vector<uint8_t>* out) {
+    FILE* fh = fopen(p.c_str(), "rb");
+    if (!fh) return false;
+    fseek(fh, 0, SEEK_END);
+    const long n = ftell(fh);
+    fseek(fh, 0, SEEK_SET);
+    out->resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n >= 0 && fread(out->data(), 1, out->size(), fh) == out->size();
+    fclose(fh);
+    return ok;
+}
+
+bool file_exists(const std::string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+
+bool parse_bai(const std::vector<uint8_t>& d, int32_t n_ref_expected, std::vector<RefIndex>* refs) {
+    size_t p = 0;
+    const size_t n = d.size();
+    if (n < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return false;
+    const int32_t n_ref = (int32_t)le32(d.data() + 4);
+    if (n_ref != n_ref_expected) return false;
+    p = 8;
+    refs->assign(n_ref, RefIndex());
+    for (int32_t r = 0; r < n_ref; ++r) {
+        RefIndex& R = (*refs)[r];
+        if (p + 4 > n) return false;
+        const int32_t n_bin = (int32_t)le32(d.data() + p);
+        p += 4;
+        if (n_bin < 0) return false;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 8 > n) return false;
+            const uint32_t bin = le32(d.data() + p);
+            const int32_t n_chunk = (int32_t)le32(d.data() + p + 4);
+            p += 8;
+            if (n_chunk < 0 || p + 16ull * n_chunk > n) return false;
+            for (int32_t k = 0; k < n_chunk; ++k) {
+                const uint64_t beg = le64(d.data() + p), end = le64(d.data() + p + 8);
+                p += 16;
+                if (bin == 37450) continue;  // metadata pseudo-bin (file range, mapped/unmapped counts)
+                if (end < beg) return false;
+                R.points.push_back(beg);
+                R.points.push_back(end);
+                R.lo = std::min(R.lo, beg);
+                R.hi = std::max(R.hi, end);
+            }
+        }
+        if (p + 4 > n) return false;
+        const int32_t n_intv = (int32_t)le32(d.data() + p);
+        p += 4;
+        if (n_intv < 0 || p + 8ull * n_intv > n) return false;
+        for (int32_t k = 0; k < n_intv; ++k) {
+            const uint64_t v = le64(d.data() + p);
+            p += 8;
+            if (v) R.points.push_back(v);
+        }
+        std::sort(R.points.begin(), R.points.end());
+        R.points.erase(std::unique(R.points.begin(), R.points.end()), R.points.end());
+        // linear-index entries outside the chunk range would be inconsistent
+        if (!R.points.empty() && (R.points.front() < R.lo || R.points.back() > R.hi)) return false;
+    }
+    return true;
+}
+
+template <typename T>
+T* dup_array(const std::vector<T>& v) {
+    T* p = static_cast<T*>(malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+}  // namespace
+
+struct svx_bam {
+    int fd = -1;
+    File file;
+    int n_threads = 1;
+    std::string path, err, text;
+    std::vector<std::string> ref_names;
+    std::vector<int32_t> ref_lens;
+    VPos first_record;
+    int index_state = 0;
+    std::vector<RefIndex> refs;
+    // loaded columns
+    uint64_t n_records = 0;
+    std::vector<int32_t> tid, pos, l_seq, ref_len;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint64_t> cigar_off, name_off, aux_off, voffset, seq_coff;
+    std::vector<uint32_t> seq_uoff, sa_len;
+    std::vector<int64_t> sa_off;
+    uint32_t* cigar = nullptr;
+    bool cigar_pinned = false;
+    std::vector<char> names;
+    std::vector<uint8_t> aux;
+    uint64_t blocks_inflated = 0, blocks_spanned = 0;
+    int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
+
+    void free_cigar() {
+        if (!cigar) return;
+        if (cigar_pinned) (void)hipHostFree(cigar);
+        else free(cigar);
+        cigar = nullptr;
+        cigar_pinned = false;
+    }
+};
+
+static int fail(svx_bam* b, int rc, const std::string& msg) {
+    if (b) b->err = msg;
+    return rc;
+}
+
+extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out, char* err, size_t err_cap) {
+    if (out) *out = nullptr;
+    auto report = [&](const std::string& m, int rc) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", m.c_str());
+        return rc;
+    };
+    if (!path || !out) return report("null argument", SVX_E_INVALID);
+    svx_bam* b = new (std::nothrow) svx_bam();
+    if (!b) return report("out of memory", SVX_E_NOMEM);
+    b->path = path;
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(64u, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+    b->n_threads = n_threads;
+    b->fd = open(path, O_RDONLY);
+    struct stat st;
+    if (b->fd < 0 || fstat(b->fd, &st) != 0) {
+        const std::string m = std::string("cannot open ") + path;
+        svx_bam_close(b);
+        return report(m, SVX_E_INVALID);
+    }
+    b->file.fsize = (uint64_t)st.st_size;
+    if (b->file.fsize) {
+        void* m = mmap(nullptr, b->file.fsize, PROT_READ, MAP_PRIVATE, b->fd, 0);
+        if (m == MAP_FAILED) {
+            svx_bam_close(b);
+            return report("mmap failed", SVX_E_NOMEM);
+        }
+        b->file.map = static_cast<const uint8_t*>(m);
+    }
+    // ---- header
+    Inflater inf;
+    Cursor c(&b->file, &inf);
+    uint8_t head[12];
+    VPos zero;
+    bool ok = c.seek(zero) && c.read(head, 8) && memcmp(head, "BAM\1", 4) == 0;
+    int32_t l_text = 0, n_ref = 0;
+    if (ok) {
+        l_text = (int32_t)le32(head + 4);
+        ok = l_text >= 0;
+    }
+    if (ok) {
+        b->text.resize((size_t)l_text);
+        ok = (l_text == 0 || c.read(&b->text[0], (size_t)l_text)) && c.read(head, 4);
+        const size_t z = b->text.find('\0');
+        if (z != std::string::npos) b->text.resize(z);
+    }
+    if (ok) {
+        n_ref = (int32_t)le32(head);
+        ok = n_ref >= 0;
+    }
+    for (int32_t r = 0; ok && r < n_ref; ++r) {
+        ok = c.read(head, 4);
+        const int32_t l_name = ok ? (int32_t)le32(head) : 0;
+        ok = ok && l_name > 0 && l_name < (1 << 20);
+        std::string name;
+        if (ok) {
+            name.resize((size_t)l_name);
+            ok = c.read(&name[0], (size_t)l_name) && c.read(head, 4);
+            name.resize(strlen(name.c_str()));
+        }
+        if (ok) {
+            b->ref_names.push_back(name);
+            b->ref_lens.push_back((int32_t)le32(head));
+        }
+    }
+    if (!ok) {
+        const std::string m = std::string(path) + " is not a BAM file (bad magic, truncated header or malformed BGZF)";
+        svx_bam_close(b);
+        return report(m, SVX_E_INVALID);
+    }
+    b->first_record = c.tell();
+    b->blocks_inflated += inf.n_blocks;
+    // ---- index
+    const std::string p1 = b->path + ".bai";
+    std::string p2 = b->path;
+    const size_t dot = p2.rfind('.');
+    if (dot != std::string::npos) p2 = p2.substr(0, dot) + ".bai";
+    std::string bai = file_exists(p1) ? p1 : (file_exists(p2) ? p2 : "");
+    if (!bai.empty()) {
+        b->index_state = 2;
+        std::vector<uint8_t> d;
+        if (read_file(bai, &d) && parse_bai(d, n_ref, &b->refs)) {
+            // consistent with the file?  every point must address a member inside the file, and
+            // the first placed record of the file must be the lowest indexed position
+            bool good = true, any = false;
+            VPos lowest;
+            lowest.coff = ~0ull;
+            for (const RefIndex& R : b->refs) {
+                for (uint64_t v : R.points) {
+                    Blk blk;
+                    const uint64_t co = v >> 16;
+                    const int rc = parse_block(b->file.map, b->file.fsize, co, &blk);
+                    if (rc < 0 || (rc == 1 && (v & 0xFFFF)) || (rc == 0 && (v & 0xFFFF) > blk.isize)) good = false;
+                }
+                if (!R.points.empty()) {
+                    any = true;
+                    Cursor k(&b->file, &inf);
+                    VPos p;
+                    p.coff = R.lo >> 16;
+                    p.uoff = (uint32_t)(R.lo & 0xFFFF);
+                    if (!good || !k.seek(p)) { good = false; break; }
+                    if (k.tell() < lowest) lowest = k.tell();
+                }
+            }
+            if (good && any) good = (lowest == b->first_record);
+            if (good && !any) {
+                // an index without any chunk is only right for a file without placed records
+                Cursor k(&b->file, &inf);
+                good = k.seek(b->first_record);
+                if (good && !k.eof) {
+                    uint8_t fix[8];
+                    good = k.read(fix, 8) && (int32_t)le32(fix + 4) < 0;
+                }
+            }
+            if (good) b->index_state = 1;
+        }
+    } else if (file_exists(b->path + ".csi")) {
+        b->index_state = 2;
+    }
+    *out = b;
+    return SVX_OK;
+}
+
+extern "C" void svx_bam_close(svx_bam* b) {
+    if (!b) return;
+    b->free_cigar();
+    if (b->file.map) munmap(const_cast<uint8_t*>(b->file.map), b->file.fsize);
+    if (b->fd >= 0) close(b->fd);
+    delete b;
+}
+
+extern "C" const char* svx_bam_last_error(const svx_bam* b) { return b ? b->err.c_str() : "null handle"; }
+
+extern "C" int svx_bam_header(const svx_bam* b, const char** text, uint64_t* l_text, int32_t* n_ref) {
+    if (!b) return SVX_E_INVALID;
+    if (text) *text = b->text.data();
+    if (l_text) *l_text = b->text.size();
+    if (n_ref) *n_ref = (int32_t)b->ref_names.size();
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_reference(const svx_bam* b, int32_t tid, const char** name, int32_t* length) {
+    if (!b || tid < 0 || (size_t)tid >= b->ref_names.size()) return SVX_E_INVALID;
+    if (name) *name = b->ref_names[tid].c_str();
+    if (length) *length = b->ref_lens[tid];
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_index_state(const svx_bam* b) { return b ? b->index_state : 0; }
+
+extern "C" int svx_bam_set_pinned_device(svx_bam* b, int device) {
+    if (!b) return SVX_E_INVALID;
+    b->pin_device = device;
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_contig_spans(const svx_bam* b, uint64_t* span) {
+    if (!b || !span) return SVX_E_INVALID;
+    if (b->index_state != 1) return SVX_E_INVALID;
+    for (size_t r = 0; r < b->refs.size(); ++r) {
+        const RefIndex& R = b->refs[r];
+        // +1: a contig whose records all sit inside one BGZF member still counts as work
+        span[r] = R.points.empty() ? 0 : ((R.hi >> 16) - (R.lo >> 16)) + 1;
+    }
+    return SVX_OK;
+}
+
+namespace {
+
+struct Piece {
+    VPos start, stop;
+    bool have_stop = true;
+};
+
+// canonical position of a virtual offset (false: malformed)
+bool canonical(const File* f, uint64_t v, VPos* out) {
+    Inflater none;
+    Cursor c(f, &none);
+    VPos p;
+    p.coff = v >> 16;
+    p.uoff = (uint32_t)(v & 0xFFFF);
+    if (!c.seek(p)) return false;
+    *out = c.tell();
+    return true;
+}
+
+}  // namespace
+
+extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
+    if (!b || (tids == nullptr && n_tids > 0) || n_tids < 0) return SVX_E_INVALID;
+    const int32_t n_ref = (int32_t)b->ref_names.size();
+    std::vector<char> want;
+    if (tids) {
+        want.assign((size_t)n_ref, 0);
+        for (int32_t i = 0; i < n_tids; ++i) {
+            if (tids[i] < 0 || tids[i] >= n_ref) return fail(b, SVX_E_INVALID, "svx_bam_load: contig index out of range");
+            want[tids[i]] = 1;
+        }
+    }
+    // ---- cut the requested ranges into pieces
+    std::vector<Piece> pieces;
+    bool filter_after = false;
+    if (b->index_state == 1 && tids) {
+        // boundaries of the requested contigs, in file order
+        uint64_t total = 0;
+        std::vector<std::pair<VPos, VPos>> ranges;  // canonical [lo, hi) per contig
+        std::vector<std::vector<VPos>> pts;
+        for (int32_t r = 0; r < n_ref; ++r) {
+            if (!want[r] || b->refs[r].points.empty()) continue;
+            std::vector<VPos> v;
+            for (uint64_t x : b->refs[r].points) {
+                VPos p;
+                if (!canonical(&b->file, x, &p)) return fail(b, SVX_E_INVALID, "index points at a malformed BGZF member");
+                v.push_back(p);
+            }
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            total += v.back().coff - v.front().coff + 1;
+            pts.push_back(v);
+        }
+        const uint64_t target = std::max<uint64_t>(1 << 16, total / ((uint64_t)b->n_threads * 8) + 1);
+        for (const std::vector<VPos>& v : pts) {
+            size_t s = 0;
+            for (size_t k = 1; k < v.size(); ++k) {
+                if (k + 1 == v.size() || v[k].coff - v[s].coff >= target) {
+                    Piece pc;
+                    pc.start = v[s];
+                    pc.stop = v[k];
+                    pieces.push_back(pc);
+                    s = k;
+                }
+            }
+        }
+    } else if (b->index_state == 1 && !tids) {
+        // every contig through the index (parallel), then whatever follows the last indexed
+        // record (unplaced reads) sequentially
+        std::vector<VPos> v;
+        for (int32_t r = 0; r < n_ref; ++r)
+            for (uint64_t x : b->refs[r].points) {
+                VPos p;
+                if (!canonical(&b->file, x, &p)) return fail(b, SVX_E_INVALID, "index points at a malformed BGZF member");
+                v.push_back(p);
+            }
+        v.push_back(b->first_record);
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        const uint64_t total = v.back().coff - v.front().coff + 1;
+        const uint64_t target = std::max<uint64_t>(1 << 16, total / ((uint64_t)b->n_threads * 8) + 1);
+        size_t s = 0;
+        for (size_t k = 1; k < v.size(); ++k) {
+            if (k + 1 == v.size() || v[k].coff - v[s].coff >= target) {
+                Piece pc;
+                pc.start = v[s];
+                pc.stop = v[k];
+                pieces.push_back(pc);
+                s = k;
+            }
+        }
+        Piece tail;
+        tail.start = v.back();
+        tail.have_stop = false;
+        pieces.push_back(tail);
+    } else {
+        Piece pc;
+        pc.start = b->first_record;
+        pc.have_stop = false;
+        pieces.push_back(pc);
+        filter_after = tids != nullptr;
+    }
+    // ---- walk
+    std::vector<Chunk> chunks(pieces.size());
+    std::atomic<size_t> next(0);
+    std::atomic<bool> failed(false);
+    std::atomic<uint64_t> inflated(0);
+    auto worker = [&]() {
+        Inflater inf;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= pieces.size() || failed.load()) break;
+            if (!walk_records(&b->file, pieces[i].start, pieces[i].have_stop, pieces[i].stop, &inf, &chunks[i]))
+                failed.store(true);
+        }
+        inflated.fetch_add(inf.n_blocks);
+    };
+    const int nt = (int)std::min<size_t>((size_t)b->n_threads, pieces.size());
+    if (nt <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(worker);
+        for (std::thread& t : th) t.join();
+    }
+    b->blocks_inflated += inflated.load();
+    if (failed.load()) {
+        std::string m = "BAM record walk failed";
+        for (const Chunk& ch : chunks)
+            if (!ch.err.empty()) { m = ch.err; break; }
+        if (b->index_state == 1) {
+            // a stale or foreign index: fall back to the sequential walk once
+            b->index_state = 2;
+            const int rc = svx_bam_load(b, tids, n_tids);
+            if (rc == SVX_OK) b->err = "index ignored (" + m + ")";
+            return rc;
+        }
+        return fail(b, SVX_E_INVALID, m);
+    }
+    // ---- concatenate
+    uint64_t n = 0, n_cig = 0, n_name = 0, n_aux = 0, spanned = 0;
+    for (const Chunk& ch : chunks) {
+        spanned += ch.blocks_spanned;
+        for (size_t i = 0; i < ch.tid.size(); ++i) {
+            if (filter_after && (ch.tid[i] < 0 || !want[ch.tid[i]])) continue;
+            ++n;
+            n_cig += ch.n_cig[i];
+            n_name += ch.name_len[i];
+            n_aux += ch.aux_len[i];
+        }
+    }
+    b->free_cigar();
+    const size_t cig_bytes = std::max<uint64_t>(4, n_cig * 4);
+    void* pinned = nullptr;
+    if (b->pin_device >= 0 && hipSetDevice(b->pin_device) == hipSuccess &&
+        hipHostMalloc(&pinned, cig_bytes, hipHostMallocDefault) == hipSuccess) {
+        b->cigar = static_cast<uint32_t*>(pinned);
+        b->cigar_pinned = true;
+    } else {
+        (void)hipGetLastError();
+        b->cigar = static_cast<uint32_t*>(malloc(cig_bytes));
+        if (!b->cigar) return fail(b, SVX_E_NOMEM, "out of memory (CIGAR pool)");
+    }
+    b->n_records = n;
+    b->tid.clear(); b->pos.clear(); b->l_seq.clear(); b->ref_len.clear(); b->flag.clear(); b->mapq.clear();
+    b->voffset.clear(); b->seq_coff.clear(); b->seq_uoff.clear(); b->sa_len.clear(); b->sa_off.clear();
+    b->cigar_off.assign(1, 0); b->name_off.assign(1, 0); b->aux_off.assign(1, 0);
+    b->names.clear(); b->aux.clear();
+    b->tid.reserve(n); b->pos.reserve(n); b->l_seq.reserve(n); b->ref_len.reserve(n); b->flag.reserve(n);
+    b->mapq.reserve(n); b->voffset.reserve(n); b->seq_coff.reserve(n); b->seq_uoff.reserve(n);
+    b->sa_len.reserve(n); b->sa_off.reserve(n); b->cigar_off.reserve(n + 1); b->name_off.reserve(n + 1);
+    b->aux_off.reserve(n + 1); b->names.reserve(n_name); b->aux.reserve(n_aux);
+    uint64_t cw = 0;
+    for (const Chunk& ch : chunks) {
+        size_t co = 0, no = 0, ao = 0;
+        for (size_t i = 0; i < ch.tid.size(); ++i) {
+            const bool keep = !(filter_after && (ch.tid[i] < 0 || !want[ch.tid[i]]));
+            if (keep) {
+                b->tid.push_back(ch.tid[i]); b->pos.push_back(ch.pos[i]); b->l_seq.push_back(ch.l_seq[i]);
+                b->ref_len.push_back(ch.ref_len[i]); b->flag.push_back(ch.flag[i]); b->mapq.push_back(ch.mapq[i]);
+                b->voffset.push_back(ch.voffset[i]); b->seq_coff.push_back(ch.seq_coff[i]);
+                b->seq_uoff.push_back(ch.seq_uoff[i]);
+                memcpy(b->cigar + cw, ch.cigar.data() + co, (size_t)ch.n_cig[i] * 4);
+                cw += ch.n_cig[i];
+                b->cigar_off.push_back(cw);
+                b->names.insert(b->names.end(), ch.names.begin() + no, ch.names.begin() + no + ch.name_len[i]);
+                b->name_off.push_back(b->names.size());
+                b->sa_off.push_back(ch.sa_off[i] < 0 ? -1 : (int64_t)b->aux.size() + ch.sa_off[i]);
+                b->sa_len.push_back(ch.sa_len[i]);
+                b->aux.insert(b->aux.end(), ch.aux.begin() + ao, ch.aux.begin() + ao + ch.aux_len[i]);
+                b->aux_off.push_back(b->aux.size());
+            }
+            co += ch.n_cig[i];
+            no += ch.name_len[i];
+            ao += ch.aux_len[i];
+        }
+    }
+    b->blocks_spanned = spanned;
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_get_columns(const svx_bam* b, svx_bam_columns* o) {
+    if (!b || !o) return SVX_E_INVALID;
+    memset(o, 0, sizeof(*o));
+    o->n_records = b->n_records;
+    o->tid = b->tid.data(); o->pos = b->pos.data(); o->l_seq = b->l_seq.data(); o->ref_len = b->ref_len.data();
+    o->flag = b->flag.data(); o->mapq = b->mapq.data();
+    o->cigar_off = b->cigar_off.data(); o->cigar = b->cigar;
+    o->name_off = b->name_off.data(); o->names = b->names.data();
+    o->aux_off = b->aux_off.data(); o->aux = b->aux.data();
+    o->sa_off = b->sa_off.data(); o->sa_len = b->sa_len.data();
+    o->voffset = b->voffset.data();
+    o->blocks_inflated = b->blocks_inflated;
+    o->blocks_spanned = b->blocks_spanned;
+    o->cigar_pinned = b->cigar_pinned ? 1 : 0;
+    o->n_threads = b->n_threads;
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_t* begin, const uint32_t* end,
+                                  uint32_t n, const uint64_t* out_off, uint8_t* out) {
+    if (!b) return SVX_E_INVALID;
+    if (n == 0) return SVX_OK;
+    if (!rec || !begin || !end || !out_off || !out) return SVX_E_INVALID;
+    for (uint32_t i = 0; i < n; ++i)
+        if (rec[i] >= b->n_records) return fail(b, SVX_E_INVALID, "svx_bam_seq_slices: record index out of range");
+    static const char kLut[17] = "=ACMGRSVTWYHKDBN";
+    std::atomic<bool> failed(false);
+    std::atomic<uint64_t> inflated(0);
+    auto work = [&](uint32_t lo, uint32_t hi) {
+        Inflater inf;
+        Cursor c(&b->file, &inf);
+        std::vector<uint8_t> packed;
+        uint32_t cur_rec = ~0u;
+        uint64_t cur_byte = 0;  // bytes of the record's SEQ field already passed by the cursor
+        for (uint32_t i = lo; i < hi && !failed.load(); ++i) {
+            const uint32_t r = rec[i];
+            const uint32_t L = (uint32_t)b->l_seq[r];
+            const uint32_t a = std::min(begin[i], L), e = std::max(a, std::min(end[i], L));
+            if (out_off[i + 1] - out_off[i] != (uint64_t)(e - a)) { failed.store(true); break; }
+            if (e == a) continue;
+            const uint64_t b0 = a >> 1, b1 = ((uint64_t)e + 1) >> 1;
+            if (r != cur_rec || b0 < cur_byte) {
+                VPos p;
+                p.coff = b->seq_coff[r];
+                p.uoff = b->seq_uoff[r];
+                if (!c.seek(p)) { failed.store(true); break; }
+                cur_rec = r;
+                cur_byte = 0;
+            }
+            packed.resize((size_t)(b1 - b0));
+            if (!c.skip(b0 - cur_byte) || !c.read(packed.data(), packed.size())) { failed.store(true); break; }
+            cur_byte = b1;
+            uint8_t* dst = out + out_off[i];
+            for (uint32_t k = a; k < e; ++k) {
+                const uint8_t by = packed[(k >> 1) - b0];
+                *dst++ = (uint8_t)kLut[(k & 1) ? (by & 15) : (by >> 4)];
+            }
+        }
+        inflated.fetch_add(inf.n_blocks);
+    };
+    const uint32_t nt = (uint32_t)std::max(1, std::min<int>(b->n_threads, (int)(n / 16 + 1)));
+    if (nt <= 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < nt; ++t) {
+            const uint32_t lo = (uint32_t)((uint64_t)n * t / nt), hi = (uint32_t)((uint64_t)n * (t + 1) / nt);
+            th.emplace_back(work, lo, hi);
+        }
+        for (std::thread& t : th) t.join();
+    }
+    b->blocks_inflated += inflated.load();
+    if (failed.load()) return fail(b, SVX_E_INVALID, "svx_bam_seq_slices: bad slice bounds or malformed BGZF data");
+    return SVX_OK;
+}

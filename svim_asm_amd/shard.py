@@ -50,7 +50,14 @@ def lpt_assign(weights, n_bins):
 
 
 def contig_weights(bam):
-    """CIGAR ops per contig (the unit of COLLECT work); falls back to record counts."""
+    """Work per contig for the rank plan.  With a usable `.bai` the compressed bytes the index
+    attributes to each contig (ingest dominates COLLECT and nothing has to be inflated to know
+    them); otherwise CIGAR ops per contig, which needs the whole file indexed first."""
+    spans = getattr(bam, "contig_spans", None)
+    if spans is not None:
+        w = spans()
+        if w is not None:
+            return w
     cols = getattr(bam, "_cols", None)
     n = len(bam.references)
     w = np.zeros(n, dtype=np.int64)
@@ -79,6 +86,24 @@ class ContigView(object):
         return getattr(self._bam, name)
 
 
+def _gather_or_raise(compute):
+    """all_gather_object of compute()'s result.  A rank whose compute() raises still takes part in
+    the exchange (with an error marker), so the others do not wait for it until the process-group
+    timeout; every rank then raises."""
+    d = _dist()
+    try:
+        mine = ("ok", compute())
+    except Exception as e:  # noqa: BLE001 — forwarded to every rank below
+        import traceback
+        mine = ("error", "rank %d: %s\n%s" % (d.get_rank(), e, traceback.format_exc()))
+    gathered = [None] * d.get_world_size()
+    d.all_gather_object(gathered, mine)
+    errors = [payload for status, payload in gathered if status == "error"]
+    if errors:
+        raise RuntimeError("sharded step failed on %d of %d ranks:\n%s" % (len(errors), len(gathered), "\n".join(errors)))
+    return [payload for _, payload in gathered]
+
+
 def collect_sharded(bam, options, collect_fn=None):
     """Distributed analyze_alignment_file_coordsorted: same return value on every rank."""
     if collect_fn is None:
@@ -88,13 +113,16 @@ def collect_sharded(bam, options, collect_fn=None):
         return collect_fn(bam, options)
     owner = lpt_assign(contig_weights(bam), size)
     mine = [i for i, r in enumerate(owner) if r == rank]
-    per_contig = []
-    for i in mine:  # one COLLECT call per owned contig keeps the per-contig lists separable
-        per_contig.append((i, collect_fn(ContigView(bam, [i]), options)))
-    gathered = [None] * size
-    _dist().all_gather_object(gathered, per_contig)
+
+    def local():
+        load = getattr(bam, "load", None)
+        if load is not None:  # walk / inflate only the BGZF ranges of the contigs this rank owns
+            load([bam.references[i] for i in mine])
+        # one COLLECT call per owned contig keeps the per-contig lists separable
+        return [(i, collect_fn(ContigView(bam, [i]), options)) for i in mine]
+
     merged = {}
-    for part in gathered:
+    for part in _gather_or_raise(local):
         for i, cands in part:
             merged[i] = cands
     out = []
@@ -120,9 +148,7 @@ def pair_sharded(sv_candidates1, sv_candidates2, reference, bam, options, pair_f
     owner = dict(zip(contigs, lpt_assign([counts[n] for n in contigs], size)))
     mine1 = [c for c in sv_candidates1 if owner[key_contig(c)] == rank]
     mine2 = [c for c in sv_candidates2 if owner[key_contig(c)] == rank]
-    local = pair_fn(mine1, mine2, reference, bam, options)
-    gathered = [None] * size
-    _dist().all_gather_object(gathered, local)
+    gathered = _gather_or_raise(lambda: pair_fn(mine1, mine2, reference, bam, options))
     everything = [c for part in gathered for c in part]
     out = []
     for typ in type_order:  # reference order: type by type, sorted (contig name, position) inside

@@ -1,4 +1,4 @@
-"""C-ABI surface: libsvx.so loads on a CPU-only box and exports every symbol include/svx.h declares."""
+"""C-ABI surface: libsvx.so loads on a CPU-only box and exports every symbol include/*.h declares."""
 import ctypes
 import os
 import re
@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "svx.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include")))
+                   if h.endswith(".h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(svx_[a-z0-9_]+)\s*\(", text)))
 
