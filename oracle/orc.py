@@ -46,6 +46,8 @@ def lib():
         l.orc_pair_partition.argtypes = [P, C.c_uint32, C.c_uint32, P, P]
         l.orc_edit_distance.restype = C.c_uint32
         l.orc_edit_distance.argtypes = [P, C.c_uint32, P, C.c_uint32]
+        l.orc_edit_distance_banded.restype = C.c_uint32
+        l.orc_edit_distance_banded.argtypes = [P, C.c_uint32, P, C.c_uint32]
         _lib = l
     return _lib
 
@@ -115,3 +117,10 @@ def edit_distance(a: bytes, b: bytes):
     aa = np.frombuffer(a, np.uint8) if len(a) else np.zeros(0, np.uint8)
     bb = np.frombuffer(b, np.uint8) if len(b) else np.zeros(0, np.uint8)
     return int(lib().orc_edit_distance(_p(aa), len(a), _p(bb), len(b)))
+
+
+def edit_distance_banded(a: bytes, b: bytes):
+    """Exact distance by the band-doubling DP (for sequences too long for the full matrix)."""
+    aa = np.frombuffer(a, np.uint8) if len(a) else np.zeros(0, np.uint8)
+    bb = np.frombuffer(b, np.uint8) if len(b) else np.zeros(0, np.uint8)
+    return int(lib().orc_edit_distance_banded(_p(aa), len(a), _p(bb), len(b)))

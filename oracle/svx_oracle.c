@@ -282,3 +282,45 @@ uint32_t orc_edit_distance(const uint8_t* a, uint32_t la, const uint8_t* b, uint
     free(row);
     return d;
 }
+
+/* Same distance for long sequences: Ukkonen's diagonal band |i - j| <= k with the band doubled
+ * until the result is <= k (then it is exact).  O(max(la, lb) * d) instead of O(la * lb); pinned
+ * against orc_edit_distance by tests/test_oracle_pins.py.  Plain integer DP, no bit-vectors. */
+static uint32_t banded_once(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb, uint32_t k) {
+    const uint32_t INF = 0x3FFFFFFFu;
+    const uint32_t diff = la > lb ? la - lb : lb - la;
+    if (diff > k) return INF;
+    uint32_t* prev = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)lb + 2));
+    uint32_t* cur = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)lb + 2));
+    for (uint32_t j = 0; j <= lb + 1; ++j) { prev[j] = (j <= lb && j <= k) ? j : INF; cur[j] = INF; }
+    for (uint32_t i = 1; i <= la; ++i) {
+        const uint32_t lo = i > k ? i - k : 1;                      /* first column of the band, >= 1 */
+        const uint32_t hi = (uint64_t)i + k < lb ? i + k : lb;      /* last column of the band        */
+        cur[lo - 1] = (lo == 1 && i <= k) ? i : INF;                /* D[i][0] = i while inside the band */
+        for (uint32_t j = lo; j <= hi; ++j) {
+            uint32_t best = prev[j - 1] + (a[i - 1] != b[j - 1]);
+            if (prev[j] + 1 < best) best = prev[j] + 1;
+            if (cur[j - 1] + 1 < best) best = cur[j - 1] + 1;
+            cur[j] = best > INF ? INF : best;
+        }
+        cur[hi + 1] = INF;                                          /* lb + 1 at most: allocated      */
+        if (lo >= 2) cur[lo - 2] = INF;
+        uint32_t* t = prev; prev = cur; cur = t;
+    }
+    const uint32_t d = prev[lb];
+    free(prev);
+    free(cur);
+    return d;
+}
+
+uint32_t orc_edit_distance_banded(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb) {
+    if (la == 0) return lb;
+    if (lb == 0) return la;
+    const uint32_t longest = la > lb ? la : lb;
+    for (uint32_t k = 64;; k = k * 4) {
+        if (k > longest) k = longest;
+        const uint32_t d = banded_once(a, la, b, lb, k);
+        if (d <= k) return d;
+        if (k == longest) return d;
+    }
+}

@@ -28,7 +28,6 @@ TYPE_ORDER = ("DEL", "INV", "INS", "DUP_TAN", "DUP_INT", "BND")  # processing or
 _TYPE_RANK = {t: i for i, t in enumerate(TYPE_ORDER)}
 _COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A"}
 SAME_HAPLOTYPE_DISTANCE = 1000000000
-EXACT_BAND_LIMIT = 16000  # widest Needleman-Wunsch band the GPU kernel keeps in LDS
 
 
 def _pack_keys(candidates_with_haplotype):
@@ -90,7 +89,8 @@ def haplotype_pair(candidate1, candidate2, reference):
 
 
 def edit_distances(string_pairs, k_max=0xFFFFFFFF, ctx=None):
-    """Batched global edit distance on the GPU; values > k_max come back as 0xFFFFFFFF."""
+    """Batched global edit distance on the GPU (exact at any length); with a threshold, values
+    > k_max come back as 0xFFFFFFFF."""
     if not string_pairs:
         return []
     ctx = ctx or _lib.default_context()
@@ -148,15 +148,16 @@ def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None)
     dist = {}
     thr = [k for k, e in enumerate(exact) if not e]
     exa = [k for k, e in enumerate(exact) if e]
-    k_max = int(edit_distance_threshold)
-    if not 0 <= k_max <= EXACT_BAND_LIMIT:
-        raise ValueError("max_edit_distance must be within 0..%d (LDS band limit of the GPU kernel)" % EXACT_BAND_LIMIT)
-    # partitions of 3+ members: exact up to the LDS band limit (16000); beyond it an upper bound
-    # (|a| + |b|) stands in, which can only reorder scipy labels of clusters whose members differ by
-    # more than 16 kb of edits
-    for sel, band in ((thr, k_max), (exa, EXACT_BAND_LIMIT)):
-        for k, d in zip(sel, edit_distances([strings[k] for k in sel], band, ctx)):
-            dist[jobs[k]] = d if d != 0xFFFFFFFF else max(band + 1, len(strings[k][0]) + len(strings[k][1]))
+    # any threshold the reference accepts: a negative one pairs nothing, one beyond 32 bits everything
+    k_max = min(max(int(edit_distance_threshold), -1), 0xFFFFFFFE)
+    if thr and k_max >= 0:
+        for k, d in zip(thr, edit_distances([strings[k] for k in thr], k_max, ctx)):
+            dist[jobs[k]] = d if d != 0xFFFFFFFF else k_max + 1
+    elif thr:
+        for k in thr:
+            dist[jobs[k]] = 0 if strings[k][0] == strings[k][1] else 1  # only "> threshold" matters
+    for k, d in zip(exa, edit_distances([strings[k] for k in exa], 0xFFFFFFFF, ctx)):
+        dist[jobs[k]] = d
     clusters_final = []
     for pi, partition in enumerate(partitions):
         if len(partition) < 2:

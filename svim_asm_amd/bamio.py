@@ -164,20 +164,28 @@ class BgzfLazy(object):
         return (hdr << 16) | (off - int(self._uoff[i]))
 
 
-def bgzf_compress(data, level=1):
-    """BGZF-compress `data` (64 KiB minus slack per block) + EOF marker."""
-    out = bytearray()
+def _bgzf_member(chunk, level):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(chunk) + co.flush()
+    return b"".join((struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, len(comp) + 25), comp,
+                     struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))))
+
+
+def bgzf_compress(data, level=1, threads=None):
+    """BGZF-compress `data` (64 KiB minus slack per block) + EOF marker.  Members are independent, so
+    they are deflated on a thread pool (zlib releases the GIL); the bytes do not depend on the pool."""
     mv = memoryview(data)
-    for p in range(0, len(data), 0xFF00):
-        chunk = mv[p:p + 0xFF00]
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
-        comp = co.compress(chunk) + co.flush()
-        bsize = len(comp) + 25
-        out += struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize)
-        out += comp
-        out += struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
-    out += _BGZF_EOF
-    return bytes(out)
+    starts = range(0, len(data), 0xFF00)
+    threads = threads or min(32, os.cpu_count() or 1)
+    if len(starts) < 64 or threads <= 1:
+        parts = [_bgzf_member(mv[p:p + 0xFF00], level) for p in starts]
+    else:
+        step = 64
+        def work(lo):
+            return b"".join(_bgzf_member(mv[p:p + 0xFF00], level) for p in starts[lo:lo + step])
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(work, range(0, len(starts), step)))
+    return b"".join(parts) + _BGZF_EOF
 
 
 # ------------------------------------------------------------------------------ header

@@ -35,7 +35,11 @@ def _collect(path, which, options):
         logging.error("{0} BAM file is missing an index. Please generate with 'samtools index'. "
                       "Exiting..".format(the))
         return None, None
-    return aln_file, shard.collect_sharded(aln_file, options)  # contig shards when launched on several GPUs
+    candidates = shard.collect_sharded(aln_file, options)  # contig shards when launched on several GPUs
+    logging.info("INGEST: rank {0}/{1} indexed {2} records ({3} of the {4} BGZF members it walked were "
+                 "inflated)".format(shard.world()[0], shard.world()[1], len(aln_file), aln_file.blocks_inflated,
+                                    aln_file.blocks_spanned))
+    return aln_file, candidates
 
 
 def _init_distributed(options):

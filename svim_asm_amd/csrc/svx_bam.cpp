@@ -781,6 +781,7 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
         inflated.fetch_add(inf.n_blocks);
     };
     const int nt = (int)std::min<size_t>((size_t)b->n_threads, pieces.size());
+    if (getenv("SVX_BAM_DEBUG")) fprintf(stderr, "svx_bam_load: %zu pieces, %d threads\n", pieces.size(), nt);
     if (nt <= 1) {
         worker();
     } else {

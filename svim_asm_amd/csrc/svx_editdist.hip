@@ -1,24 +1,47 @@
-// svx_editdist.hip — batched global unit-cost edit distance on gfx950.
+// svx_editdist.hip — batched global unit-cost edit distance on gfx950, exact at any length.
 //
 // Arithmetic of edlib.align(a, b)["editDistance"] (default mode NW) as called by
-// compute_distance (reference SVIM_COMBINE.py:50,64,76,88,100).  The pairing step only
-// needs "distance <= max_edit_distance or not" (complete linkage cut), so
-// the kernel is a thresholded (Ukkonen-banded) Needleman-Wunsch:
-//   one workgroup per pair; the band |j - i| <= k lives in LDS as ONE array V[d]
-//   (d = j - i); anti-diagonal s = i + j is updated in place — cells of one anti-diagonal
-//   are independent, read only the opposite-parity neighbours V[d±1] (anti-diagonal s-1)
-//   and their own previous value (s-2) — one __syncthreads per anti-diagonal.
-// Result: exact distance when <= k, 0xFFFFFFFF otherwise.  k_max = 0xFFFFFFFF ("exact") is
-// served by re-running unresolved pairs with a 4x wider band until the band covers the
-// longer sequence.  Bytes compare exactly (the reference does not fold case of INS alleles).
+// compute_distance (reference SVIM_COMBINE.py:50,64,76,88,100).  The algorithm is the
+// published bit-vector one edlib itself implements (Myers 1999, block formulation with
+// horizontal carries of Hyyrö 2003, Ukkonen's band cut-off); the mapping is for a 64-lane wave:
+//
+//   * one wave per haplotype pair.  The longer sequence is the pattern (rows), cut into
+//     64-row blocks; lane l owns block l of the current strip of 64 blocks (4096 rows) and keeps
+//     the block's vertical delta vectors Pv / Mv in two 64-bit registers;
+//   * the wave is a systolic array over anti-diagonals of (block, column): at step t lane l
+//     processes column t - l.  The horizontal delta leaving the bottom of a block (-1/0/+1) and the
+//     text symbol of the column move down one lane per step with one DPP `wave_shr:1` each —
+//     no LDS traffic and no barrier on the recurrence; text symbols enter at lane 0 from a
+//     64-symbol register chunk (one coalesced load per 64 steps, v_readlane per step);
+//   * match vectors Peq[symbol][block] live in LDS, one 8-byte column per lane (conflict-free
+//     ds_read_b64), loaded one step ahead of their use.  Symbols are the distinct byte values of
+//     the pattern, ranked on the fly (bytes compare exactly: the reference does not fold case of
+//     INS alleles); text bytes that do not occur in the pattern share an all-zero row.  The fast
+//     instantiation holds 16 symbols (any DNA/IUPAC data); pairs with a richer alphabet are
+//     re-run by a 256-symbol instantiation (128 KiB of LDS, one wave per CU);
+//   * patterns longer than 4096 rows are processed strip after strip; the horizontal deltas
+//     along a strip's bottom row are packed 2 bits per column into an HBM scratch stream that
+//     feeds lane 0 of the next strip;
+//   * Ukkonen band at strip granularity: strip s only visits columns within k of its rows.
+//     Cells outside are replaced by valid path costs (deltas of +1), so the result D' is always
+//     an upper bound and equals the distance when D' <= k (or when nothing was cut).
+//
+// Result contract (include/svx.h): exact distance when <= k_max, 0xFFFFFFFF otherwise;
+// k_max = 0xFFFFFFFF requests exact distances: unresolved pairs are re-run with a 4x wider band
+// until the band covers the whole matrix.
+//
+// VALU-bound integer work (≈ 50 VALU per 64 cells); no MFMA, HBM traffic is negligible.
 #include "svx_internal.h"
 
 #include <algorithm>
+#include <numeric>
 
 namespace {
 
-constexpr uint32_t kInf = 0x3FFFFFFFu;
-constexpr uint32_t kMaxBand = 16000;  // (2k+3) * 4 B must fit in 160 KiB of LDS
+constexpr uint32_t kStripRows = 64 * 64;
+constexpr uint32_t kUnproven = 0x80000000u;   // flag: D' > band and cells were cut (upper bound only)
+constexpr uint32_t kAlphabet = 0xFFFFFFFEu;   // marker: pattern alphabet exceeds this instantiation
+constexpr int kDppWaveShr1 = 0x138;
 
 struct EdArgs {
     const uint8_t* seq;
@@ -26,61 +49,212 @@ struct EdArgs {
     const uint32_t* a_len;
     const uint64_t* b_off;
     const uint32_t* b_len;
-    const uint32_t* sel;  // nullable: indices of the pairs to (re)compute
+    const uint32_t* order;        // pair processed by workgroup w (longest first)
+    const uint64_t* stream_off;   // per launch slot w: offset (in u64 words) of its 2 delta streams
+    uint64_t* stream;             // HBM scratch for strip boundaries
+    const uint32_t* band;         // per launch slot w: Ukkonen band k of that pair
     uint32_t n;
-    uint32_t k;
     uint32_t* dist;
 };
 
-__global__ __launch_bounds__(256) void k_edit_band(EdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t V[];  // V[0 .. 2k+2], entry d+k+1
-    const int tid = threadIdx.x;
-    const int k = (int)p.k;
-    for (uint32_t w = blockIdx.x; w < p.n; w += gridDim.x) {
-        const uint32_t pi = p.sel ? p.sel[w] : w;
-        const uint8_t* a = p.seq + p.a_off[pi];
-        const uint8_t* b = p.seq + p.b_off[pi];
-        const int la = (int)p.a_len[pi], lb = (int)p.b_len[pi];
-        const int diff = lb - la;
-        if (diff > k || -diff > k) {  // distance >= |la - lb| > k
-            if (tid == 0) p.dist[pi] = 0xFFFFFFFFu;
-            continue;
-        }
-        for (int i = tid; i < 2 * k + 3; i += blockDim.x) V[i] = kInf;
-        __syncthreads();
-        const int S = la + lb;
-        for (int s = 0; s <= S; ++s) {
-            // cells (i, j) with i + j = s, d = j - i ≡ s (mod 2), |d| <= k, 0<=i<=la, 0<=j<=lb
-            int dlo = -k, dhi = k;
-            if (dlo < -s) dlo = -s;             // j >= 0 → d >= -s ... (i <= s)
-            if (dhi > s) dhi = s;               // i >= 0 → d <= s
-            if (dlo < s - 2 * la) dlo = s - 2 * la;  // i <= la → d >= s - 2 la
-            if (dhi > 2 * lb - s) dhi = 2 * lb - s;  // j <= lb → d <= 2 lb - s
-            if (((dlo - s) & 1) != 0) ++dlo;    // parity of d must equal parity of s
-            for (int d = dlo + 2 * tid; d <= dhi; d += 2 * (int)blockDim.x) {
-                const int i = (s - d) >> 1, j = (s + d) >> 1;
-                uint32_t v;
-                if (i == 0) v = (uint32_t)j;
-                else if (j == 0) v = (uint32_t)i;
-                else {
-                    const uint32_t diag = V[d + k + 1] + (a[i - 1] != b[j - 1] ? 1u : 0u);
-                    const uint32_t up = V[d + k + 2] + 1u;    // (i-1, j): diagonal d+1
-                    const uint32_t left = V[d + k] + 1u;      // (i, j-1): diagonal d-1
-                    v = diag < up ? diag : up;
-                    v = v < left ? v : left;
-                    if (v > kInf) v = kInf;
-                }
-                V[d + k + 1] = v;
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const uint32_t v = V[diff + k + 1];
-            p.dist[pi] = (v <= (uint32_t)k) ? v : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-    }
+__device__ __forceinline__ uint32_t shr1_in(uint32_t fresh, uint32_t v) {
+    // lane l receives v of lane l-1; lane 0 receives `fresh`
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)v, kDppWaveShr1, 0xF, 0xF, false);
 }
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CAP>
+__global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    uint64_t* peq = lds;                                                  // [(CAP + 1) * 64]
+    uint8_t* cmap = reinterpret_cast<uint8_t*>(peq + (CAP + 1) * 64);     // byte value -> symbol (CAP: absent)
+    uint32_t* present = reinterpret_cast<uint32_t*>(cmap + 256);          // 256-bit set of pattern bytes
+    const uint32_t lane = threadIdx.x;
+    const uint32_t w = blockIdx.x;
+    const uint32_t pi = p.order ? p.order[w] : w;
+    uint32_t la = p.a_len[pi], lb = p.b_len[pi];
+    const uint8_t* A = p.seq + p.a_off[pi];
+    const uint8_t* B = p.seq + p.b_off[pi];
+    // pattern = longer sequence (more lanes busy, fewer steps); the distance is symmetric
+    const uint8_t* P = la >= lb ? A : B;
+    const uint8_t* T = la >= lb ? B : A;
+    const uint32_t m = la >= lb ? la : lb, n = la >= lb ? lb : la;
+    if (n == 0) {
+        if (lane == 0) p.dist[pi] = m;
+        return;
+    }
+    const uint32_t k = p.band[w];
+    const uint32_t n_strips = (m + kStripRows - 1) / kStripRows;
+    if (n_strips > 1 && m - n > k) {  // the end cell lies outside the band: only "> k" is known
+        if (lane == 0) p.dist[pi] = m | kUnproven;
+        return;
+    }
+    // ---- alphabet of the pattern
+    if (lane < 8) present[lane] = 0;
+    wave_lds_fence();
+    for (uint32_t i = lane; i < m; i += 64) {
+        const uint32_t c = P[i];
+        atomicOr(&present[c >> 5], 1u << (c & 31));
+    }
+    wave_lds_fence();
+    uint32_t sigma = 0;
+    {
+        uint32_t below[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            below[q] = sigma;
+            sigma += __popc(present[q]);
+        }
+        if (sigma > (uint32_t)CAP) {
+            if (lane == 0) p.dist[pi] = kAlphabet;
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t v = lane + 64 * q;
+            const uint32_t word = present[v >> 5], bit = v & 31;
+            uint32_t rank = __popc(word & ((1u << bit) - 1u));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rank += ((uint32_t)j == (v >> 5)) ? below[j] : 0u;
+            cmap[v] = ((word >> bit) & 1u) ? (uint8_t)rank : (uint8_t)CAP;
+        }
+    }
+    wave_lds_fence();
+
+    uint64_t* s_in = nullptr;
+    uint64_t* s_out = nullptr;
+    if (n_strips > 1) {
+        const uint64_t words = ((uint64_t)n + 31) / 32;
+        s_in = p.stream + p.stream_off[w];
+        s_out = s_in + words;
+    }
+    uint32_t base = 0;           // D'[last row of the strip][c_lo - 1]
+    uint32_t prev_c_hi = 0;
+    uint32_t carried = 0;        // D'[last row of the previous strip][c_lo of this strip - 1]
+    bool cut = false;            // some strip skipped columns
+    uint32_t result = 0;
+    for (uint32_t s = 0; s < n_strips; ++s) {
+        const uint32_t row_lo = s * kStripRows + 1;
+        const uint32_t row_hi = min(m, (s + 1) * kStripRows);
+        const uint32_t height = row_hi - row_lo + 1;
+        const uint32_t nblk = (height + 63) / 64;
+        const uint32_t outbit = (s + 1 == n_strips) ? ((height - 1) & 63) : 63;
+        uint32_t c_lo = 1, c_hi = n;
+        if (n_strips > 1) {
+            c_lo = row_lo > (uint64_t)k + 1 ? row_lo - k : 1;
+            c_hi = (uint32_t)min((uint64_t)n, (uint64_t)row_hi + k);
+            if (c_lo != 1 || c_hi != n) cut = true;
+        }
+        // where the next strip starts (its left neighbour column is captured on the way)
+        uint32_t cap_col = 0xFFFFFFFFu;
+        if (s + 1 < n_strips) {
+            const uint32_t nlo = row_hi + 1;
+            const uint32_t ncl = nlo > (uint64_t)k + 1 ? nlo - k : 1;
+            cap_col = ncl - 1;
+        }
+        base = (s == 0 ? c_lo - 1 : carried) + height;
+        // ---- Peq of this strip's blocks (lane-private LDS columns)
+        for (uint32_t c = 0; c <= min(sigma, (uint32_t)CAP); ++c) peq[c * 64 + lane] = 0;
+        peq[CAP * 64 + lane] = 0;
+        if (lane < nblk) {
+            const uint32_t r0 = row_lo - 1 + 64 * lane;  // 0-based pattern index of the block's first row
+            for (uint32_t r = 0; r < 64 && r0 + r < row_hi; ++r) {
+                const uint32_t code = cmap[P[r0 + r]];
+                peq[code * 64 + lane] |= 1ull << r;
+            }
+        }
+        wave_lds_fence();
+
+        const uint32_t ncols = c_hi - c_lo + 1;
+        const uint32_t nsteps = ncols + nblk - 1;
+        const uint32_t last = nblk - 1;
+        uint64_t Pv = ~0ull, Mv = 0;
+        uint32_t val = base;        // running D' on the strip's last row (meaningful on lane `last`)
+        uint32_t captured = base;   // value at cap_col (== c_lo - 1 unless seen later)
+        uint64_t acc = 0;           // packed outgoing deltas (lane `last`)
+        uint32_t hout_prev = 0, code_cur = CAP;
+        uint32_t codechunk = CAP, hchunk = 1;
+        uint64_t eq_cur = 0;
+        auto load_chunk = [&](uint32_t t0) {
+            const uint32_t col = c_lo + t0 + lane;
+            codechunk = CAP;
+            hchunk = 1;  // +1: top row of the matrix, or columns the previous strip did not visit
+            if (col <= c_hi) {
+                codechunk = cmap[T[col - 1]];
+                if (s > 0 && col <= prev_c_hi) {
+                    const uint64_t wv = s_in[(col - 1) >> 5];
+                    hchunk = (uint32_t)(wv >> (2 * ((col - 1) & 31))) & 3u;
+                }
+            }
+        };
+        load_chunk(0);
+        code_cur = shr1_in((uint32_t)__builtin_amdgcn_readlane((int)codechunk, 0), code_cur);
+        eq_cur = peq[code_cur * 64 + lane];
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            const uint32_t tl = t & 63;
+            const uint32_t fresh_h = (uint32_t)__builtin_amdgcn_readlane((int)hchunk, (int)tl);
+            // next step's symbol and match vector (independent of this step's recurrence)
+            if (tl == 63) load_chunk(t + 1);
+            const uint32_t fresh_c = (uint32_t)__builtin_amdgcn_readlane((int)codechunk, (int)((t + 1) & 63));
+            const uint32_t code_next = shr1_in(fresh_c, code_cur);
+            const uint64_t eq_next = peq[code_next * 64 + lane];
+
+            const uint32_t hin = shr1_in(fresh_h, hout_prev);
+            const bool active = lane < nblk && t >= lane && (t - lane) < ncols;
+            const uint64_t hneg = hin == 2 ? 1ull : 0ull, hpos = hin == 1 ? 1ull : 0ull;
+            uint64_t Eq = eq_cur;
+            const uint64_t Xv = Eq | Mv;
+            Eq |= hneg;
+            const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint64_t Ph = Mv | ~(Xh | Pv);
+            uint64_t Mh = Pv & Xh;
+            const uint32_t sh = lane == last ? outbit : 63u;
+            const uint32_t ho = ((Ph >> sh) & 1ull) ? 1u : (((Mh >> sh) & 1ull) ? 2u : 0u);
+            Ph = (Ph << 1) | hpos;
+            Mh = (Mh << 1) | hneg;
+            if (active) {
+                Pv = Mh | ~(Xv | Ph);
+                Mv = Ph & Xv;
+                hout_prev = ho;
+            }
+            if (active && lane == last) {
+                const uint32_t col = c_lo + t - lane;
+                val += (ho == 1u ? 1u : 0u) - (ho == 2u ? 1u : 0u);
+                if (col == cap_col) captured = val;
+                if (s_out) {
+                    acc |= (uint64_t)ho << (2 * ((col - 1) & 31));
+                    if (((col - 1) & 31) == 31 || col == c_hi) {
+                        s_out[(col - 1) >> 5] = acc;
+                        acc = 0;
+                    }
+                }
+            }
+            code_cur = code_next;
+            eq_cur = eq_next;
+        }
+        carried = (uint32_t)__builtin_amdgcn_readlane((int)captured, (int)last);
+        result = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)last);
+        prev_c_hi = c_hi;
+        if (s_out) {
+            // the next strip reads what lane `last` just wrote (same wave): make it visible
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            uint64_t* tmp = s_in;
+            s_in = s_out;
+            s_out = tmp;
+        }
+        wave_lds_fence();
+    }
+    if (lane == 0) p.dist[pi] = (cut && result > k) ? (result | kUnproven) : result;
+}
+
+template <int CAP>
+constexpr size_t lds_bytes() { return (size_t)(CAP + 1) * 64 * 8 + 256 + 32; }
 
 }  // namespace
 
@@ -92,34 +266,51 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
     if (n_pairs == 0) return SVX_OK;
     if (!a_off || !a_len || !b_off || !b_len || !dist || (seq_bytes && !seq)) return SVX_E_INVALID;
     const bool exact = (k_max == 0xFFFFFFFFu);
-    uint32_t max_len = 0;
     for (uint32_t i = 0; i < n_pairs; ++i) {
         if (a_off[i] + a_len[i] > seq_bytes || b_off[i] + b_len[i] > seq_bytes) {
             SVX_SET_ERR(ctx, "pair %u reads past the sequence pool", i);
             return SVX_E_INVALID;
         }
-        max_len = std::max(max_len, std::max(a_len[i], b_len[i]));
-    }
-    if (!exact && k_max > kMaxBand) {
-        if (max_len <= kMaxBand) k_max = max_len;  // a band as wide as the longest sequence is exact
-        else {
-            SVX_SET_ERR(ctx, "k_max=%u exceeds the LDS band limit %u", k_max, kMaxBand);
+        if (a_len[i] >= kUnproven || b_len[i] >= kUnproven) {
+            SVX_SET_ERR(ctx, "pair %u: sequences of 2^31 bytes or more are not supported", i);
             return SVX_E_TOO_LARGE;
         }
     }
     SVX_HIP(ctx, hipSetDevice(ctx->device));
-    size_t need = svx_take_bytes(seq_bytes ? seq_bytes : 1, 1) + 2 * svx_take_bytes(n_pairs, 8) +
-                  4 * svx_take_bytes(n_pairs, 4);
+    // launch order: most expensive pairs first (steps ~ strips * columns), so that the long tail of a
+    // few contig-sized alleles overlaps the many small ones
+    std::vector<uint32_t> order(n_pairs);
+    std::iota(order.begin(), order.end(), 0u);
+    auto cost = [&](uint32_t i) {
+        const uint64_t m = std::max(a_len[i], b_len[i]), n = std::min(a_len[i], b_len[i]);
+        return ((m + kStripRows - 1) / kStripRows) * (n + 64);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost(x) > cost(y); });
+    auto stream_words = [&](uint32_t i) -> uint64_t {
+        const uint64_t m = std::max(a_len[i], b_len[i]), n = std::min(a_len[i], b_len[i]);
+        return m > kStripRows ? 2 * ((n + 31) / 32) : 0;
+    };
+    uint64_t total_stream = 0;
+    std::vector<uint64_t> soff(n_pairs);
+    for (uint32_t w = 0; w < n_pairs; ++w) {
+        soff[w] = total_stream;
+        total_stream += stream_words(order[w]);
+    }
+    size_t need = svx_take_bytes(seq_bytes ? seq_bytes : 1, 1) + 3 * svx_take_bytes(n_pairs, 8) +
+                  5 * svx_take_bytes(n_pairs, 4) + svx_take_bytes(total_stream ? total_stream : 1, 8);
     int rc = svx_stage_reserve(ctx, need);
     if (rc != SVX_OK) return rc;
     EdArgs a;
     uint8_t* d_seq = svx_stage_take<uint8_t>(ctx, seq_bytes ? seq_bytes : 1);
     uint64_t* d_ao = svx_stage_take<uint64_t>(ctx, n_pairs);
     uint64_t* d_bo = svx_stage_take<uint64_t>(ctx, n_pairs);
+    uint64_t* d_so = svx_stage_take<uint64_t>(ctx, n_pairs);
     uint32_t* d_al = svx_stage_take<uint32_t>(ctx, n_pairs);
     uint32_t* d_bl = svx_stage_take<uint32_t>(ctx, n_pairs);
-    uint32_t* d_sel = svx_stage_take<uint32_t>(ctx, n_pairs);
+    uint32_t* d_ord = svx_stage_take<uint32_t>(ctx, n_pairs);
+    uint32_t* d_band = svx_stage_take<uint32_t>(ctx, n_pairs);
     uint32_t* d_dist = svx_stage_take<uint32_t>(ctx, n_pairs);
+    uint64_t* d_stream = svx_stage_take<uint64_t>(ctx, total_stream ? total_stream : 1);
     if (seq_bytes) SVX_HIP(ctx, hipMemcpyAsync(d_seq, seq, seq_bytes, hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_ao, a_off, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_bo, b_off, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -127,41 +318,77 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
     SVX_HIP(ctx, hipMemcpyAsync(d_bl, b_len, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
     a.seq = d_seq; a.a_off = d_ao; a.a_len = d_al; a.b_off = d_bo; a.b_len = d_bl;
     a.dist = d_dist;
-    a.sel = nullptr;
-    a.n = n_pairs;
-    // a band wider than the longer sequence adds nothing: clip it (keeps the LDS footprint small)
-    uint32_t k = exact ? std::min<uint32_t>(256u, std::max<uint32_t>(max_len, 1u))
-                       : std::min<uint32_t>(k_max, std::max<uint32_t>(max_len, 1u));
-    std::vector<uint32_t> sel;
-    SVX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_edit_band),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    a.stream = d_stream;
+    a.stream_off = d_so;
+    a.order = d_ord;
+    a.band = d_band;
+    SVX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_edit_myers<256>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<256>()));
+    rc = svx_timing_begin(ctx);
+    if (rc != SVX_OK) return rc;
+    rc = svx_timing_mark(ctx, 1);
+    if (rc != SVX_OK) return rc;
+    // band per pair: the threshold itself, or (exact request) 256 widened per pair below
+    std::vector<uint32_t> band_of(n_pairs, exact ? 256u : k_max);
+    std::vector<uint32_t> todo = order, big, again, lst_band;
+    std::vector<uint64_t> lst_soff;
     for (;;) {
-        a.k = k;
-        const size_t lds = ((size_t)2 * k + 3) * 4;
-        uint32_t grid = std::min<uint32_t>(a.n, (uint32_t)ctx->n_cu * 8u);
-        hipLaunchKernelGGL(k_edit_band, dim3(grid), dim3(256), lds, ctx->stream, a);
-        SVX_HIP(ctx, hipGetLastError());
-        SVX_HIP(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (!exact || k >= max_len) {
-            if (!exact && k < k_max)  // band == longest sequence: every distance is exact, none exceeds k_max
-                for (uint32_t i = 0; i < n_pairs; ++i)
-                    if (dist[i] == 0xFFFFFFFFu) { SVX_SET_ERR(ctx, "internal: clipped band missed a distance"); return SVX_E_INVALID; }
-            break;
+        // one round: fast instantiation over `todo`, then the 256-symbol one over what it rejected
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::vector<uint32_t>& lst = pass == 0 ? todo : big;
+            if (lst.empty()) continue;
+            uint64_t at = 0;
+            lst_soff.resize(lst.size());
+            lst_band.resize(lst.size());
+            for (size_t w2 = 0; w2 < lst.size(); ++w2) {
+                lst_soff[w2] = at;
+                at += stream_words(lst[w2]);
+                lst_band[w2] = band_of[lst[w2]];
+            }
+            SVX_HIP(ctx, hipMemcpyAsync(d_ord, lst.data(), lst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            SVX_HIP(ctx, hipMemcpyAsync(d_so, lst_soff.data(), lst.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            SVX_HIP(ctx, hipMemcpyAsync(d_band, lst_band.data(), lst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            a.n = (uint32_t)lst.size();
+            if (pass == 0)
+                hipLaunchKernelGGL(k_edit_myers<16>, dim3(a.n), dim3(64), lds_bytes<16>(), ctx->stream, a);
+            else
+                hipLaunchKernelGGL(k_edit_myers<256>, dim3(a.n), dim3(64), lds_bytes<256>(), ctx->stream, a);
+            SVX_HIP(ctx, hipGetLastError());
+            SVX_HIP(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+            SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (pass == 0) {
+                big.clear();
+                for (uint32_t i : todo)
+                    if (dist[i] == kAlphabet) big.push_back(i);
+            }
         }
-        sel.clear();
-        for (uint32_t i = 0; i < n_pairs; ++i)
-            if (dist[i] == 0xFFFFFFFFu) sel.push_back(i);
-        if (sel.empty()) break;
-        uint32_t nk = std::min<uint32_t>(std::max<uint32_t>(k * 4, 1u), max_len);
-        if (nk > kMaxBand) {
-            SVX_SET_ERR(ctx, "exact distance needs a band of %u > LDS limit %u", nk, kMaxBand);
-            return SVX_E_TOO_LARGE;
+        for (uint32_t i : big)
+            if (dist[i] == kAlphabet) {
+                SVX_SET_ERR(ctx, "internal: pair %u rejected by the 256-symbol kernel", i);
+                return SVX_E_INVALID;
+            }
+        again.clear();
+        for (uint32_t i : todo)
+            if (dist[i] & kUnproven) again.push_back(i);
+        if (!exact || again.empty()) break;
+        // exact request: widen the band of each unresolved pair.  Its result D' is an upper bound of
+        // the distance, so a band of D' is certain to resolve it; 4x the old band is tried first
+        // when that is narrower (the bound can be far above the distance)
+        for (uint32_t i : again) {
+            const uint32_t ub = dist[i] & ~kUnproven;
+            const uint32_t k4 = band_of[i] >= 0x10000000u ? 0x7FFFFFFFu : band_of[i] * 4;
+            band_of[i] = std::min(ub, k4);
         }
-        k = nk;
-        SVX_HIP(ctx, hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        a.sel = d_sel;
-        a.n = (uint32_t)sel.size();
+        todo = again;
+        big.clear();
+    }
+    rc = svx_timing_mark(ctx, 2);
+    if (rc != SVX_OK) return rc;
+    rc = svx_timing_end(ctx);
+    if (rc != SVX_OK) return rc;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        if (dist[i] & kUnproven) dist[i] = 0xFFFFFFFFu;          // only "> k_max" is known (threshold request)
+        else if (!exact && dist[i] > k_max) dist[i] = 0xFFFFFFFFu;
     }
     return SVX_OK;
 }

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "spawns_gpu_children: starts fresh processes that make their own first GPU "
+                                       "call; scheduled before any test that initialises the GPU in the pytest process")
+
+
+def pytest_collection_modifyitems(config, items):
+    # child processes must be started before the parent has touched the GPU (never fork/exec after GPU init)
+    first = [i for i in items if i.get_closest_marker("spawns_gpu_children")]
+    rest = [i for i in items if not i.get_closest_marker("spawns_gpu_children")]
+    items[:] = first + rest
 
 
 @pytest.fixture(scope="session")

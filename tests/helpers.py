@@ -271,3 +271,36 @@ def random_candidates(rng, names, lengths, seqs, n, hap_tag):
             p2 = max(0, min(lens[c2] - 1, anchor + int(rng.integers(-400, 400))))
             out.append(O.cand_bnd(contig, pos, rng.choice(["fwd", "rev"]), c2, p2, rng.choice(["fwd", "rev"]), reads, lens))
     return out
+
+
+def run_cli_ranks(argv, world_size, timeout=600):
+    """Run `svim-asm <argv>` as `world_size` fresh processes (one rank each, all on HIP device 0 — the
+    GPU box has one GPU), the way torch.distributed.run would start them.  Every child makes its own
+    first GPU call.  Returns [(returncode, combined output)] by rank."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    code = "import sys; sys.path.insert(0, %r); from svim_asm_amd import cli; cli.main(%r)" % (root, list(argv))
+    procs = []
+    for rank in range(world_size):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), WORLD_SIZE=str(world_size), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    out = []
+    for p in procs:
+        try:
+            text, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            text, _ = p.communicate()
+            text += "\n[timeout]"
+        out.append((p.returncode, text))
+    return out

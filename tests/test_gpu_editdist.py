@@ -1,4 +1,5 @@
-"""HIP banded Needleman-Wunsch (svx_edit_distance_batch) vs a textbook DP.
+"""HIP bit-vector edit distance (svx_edit_distance_batch) vs a textbook DP (and, for long
+sequences, the band-doubling DP pinned against it).
 
 Reference call sites: edlib.align(h1, h2)["editDistance"], SVIM_COMBINE.py:50,64,76,88,100.
 """
@@ -73,3 +74,126 @@ def test_edge_cases(svx_ctx):
         bo.append(o); bl.append(len(b)); o += len(b)
     got = svx_ctx.edit_distance_batch(np.frombuffer(pool, np.uint8), ao, al, bo, bl)
     assert list(got) == [0, 4, 4, 0, 1, 4, 0, 1000]
+
+
+def _pool(pairs):
+    pool = b"".join(a + b for a, b in pairs)
+    ao, al, bo, bl, o = [], [], [], [], 0
+    for a, b in pairs:
+        ao.append(o); al.append(len(a)); o += len(a)
+        bo.append(o); bl.append(len(b)); o += len(b)
+    return np.frombuffer(pool, np.uint8) if pool else np.zeros(0, np.uint8), ao, al, bo, bl
+
+
+def _rand_dna(rng, n):
+    return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].tobytes()
+
+
+def _edited(rng, s, n_sub, n_indel, max_indel):
+    """s with substitutions and a few insertions/deletions of up to max_indel bases (numpy, fast)."""
+    a = np.frombuffer(s, np.uint8).copy()
+    if n_sub and len(a):
+        a[rng.integers(0, len(a), n_sub)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_sub)]
+    parts, last = [], 0
+    for cut in sorted(rng.integers(0, len(a) + 1, n_indel).tolist()):
+        parts.append(a[last:cut])
+        ln = int(rng.integers(1, max_indel + 1))
+        if rng.random() < 0.5:
+            parts.append(np.frombuffer(_rand_dna(rng, ln), np.uint8))
+            last = cut
+        else:
+            last = min(len(a), cut + ln)
+    parts.append(a[last:])
+    return np.concatenate(parts).tobytes()
+
+
+@pytest.mark.parametrize("length", [1000, 10000, 100000])
+def test_long_sequences_every_mode(svx_ctx, length):
+    """Lengths 10^3..10^5 (1..25 strips of 4096 rows), thresholds 0 / 200 / exact; pairs that are
+    identical, within 200 edits, a few thousand edits apart (band widened per pair) and unrelated."""
+    rng = np.random.default_rng(length)
+    base = _rand_dna(rng, length)
+    pairs = [(base, base),
+             (base, _edited(rng, base, 40, 6, 20)),                       # within the default threshold
+             (_edited(rng, base, 90, 8, 12), base),                       # longer / shorter swapped
+             (base, _edited(rng, base, length // 50, 10, 300)),           # > 200, resolved by a wider band
+             (base[:length - length // 7], base),                         # length difference alone decides
+             (base, _rand_dna(rng, int(length * 0.9)))]                   # unrelated: the band grows to the full matrix
+    if length > 30000:
+        pairs = pairs[:5]  # the full-matrix oracle needs minutes for 10^5 x 10^5 unrelated bases (kept at 10^4)
+    exp = np.array([orc.edit_distance(a, b) if max(len(a), len(b)) <= 10000 else orc.edit_distance_banded(a, b)
+                    for a, b in pairs], dtype=np.int64)
+    pool, ao, al, bo, bl = _pool(pairs)
+    got = svx_ctx.edit_distance_batch(pool, ao, al, bo, bl).astype(np.int64)
+    assert np.array_equal(got, exp)
+    for k in (0, 200):
+        thr = svx_ctx.edit_distance_batch(pool, ao, al, bo, bl, k_max=k).astype(np.int64)
+        le = exp <= k
+        assert np.array_equal(thr[le], exp[le]) and np.all(thr[~le] > k)
+    assert exp[0] == 0 and 0 < exp[1] <= 200 and exp[3] > 200
+
+
+def test_unrelated_long_pair_exact(svx_ctx):
+    """3 x 10^4 unrelated bases on each side: every band falls short until the full matrix is visited."""
+    rng = np.random.default_rng(77)
+    a, b = _rand_dna(rng, 30000), _rand_dna(rng, 28000)
+    pool, ao, al, bo, bl = _pool([(a, b)])
+    assert int(svx_ctx.edit_distance_batch(pool, ao, al, bo, bl)[0]) == orc.edit_distance(a, b)
+
+
+def test_strip_and_block_boundaries(svx_ctx):
+    """Pattern lengths around 64-row blocks and 4096-row strips, text lengths around the 64-column
+    symbol chunks, with edits near both ends."""
+    rng = np.random.default_rng(5)
+    pairs = []
+    for m in (1, 2, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 8191, 8192, 8193, 12289):
+        a = _rand_dna(rng, m)
+        for b in (a, a[1:], a[:-1], b"T" + a, a + b"G", _edited(rng, a, min(m, 5), min(m, 3), 4)):
+            pairs.append((a, b))
+    for n in (1, 63, 64, 65, 128, 129):
+        a = _rand_dna(rng, 4200)
+        pairs.append((a, a[100:100 + n]))
+    exp = np.array([orc.edit_distance(a, b) for a, b in pairs], dtype=np.uint32)
+    pool, ao, al, bo, bl = _pool(pairs)
+    assert np.array_equal(svx_ctx.edit_distance_batch(pool, ao, al, bo, bl), exp)
+    got = svx_ctx.edit_distance_batch(pool, ao, al, bo, bl, k_max=3).astype(np.int64)
+    le = exp <= 3
+    assert np.array_equal(got[le], exp[le].astype(np.int64)) and np.all(got[~le] > 3)
+
+
+def test_rich_alphabets(svx_ctx):
+    """More than 16 distinct bytes in the pattern (IUPAC + lower case + arbitrary bytes, up to all 256):
+    the 256-symbol instantiation; mixed in one batch with plain DNA pairs."""
+    rng = np.random.default_rng(9)
+    pairs = []
+    for sigma, n in ((17, 300), (40, 900), (256, 700), (256, 5000), (200, 64)):
+        alpha = rng.permutation(256)[:sigma].astype(np.uint8)
+        a = alpha[rng.integers(0, sigma, n)].tobytes()
+        b = bytearray(a)
+        for _ in range(n // 20):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        del b[n // 3:n // 3 + 7]
+        pairs.append((a, bytes(b)))
+        pairs.append((_rand_dna(rng, n), _rand_dna(rng, n + 5)))
+    exp = np.array([orc.edit_distance(a, b) for a, b in pairs], dtype=np.uint32)
+    pool, ao, al, bo, bl = _pool(pairs)
+    assert np.array_equal(svx_ctx.edit_distance_batch(pool, ao, al, bo, bl), exp)
+
+
+def test_many_pairs_mixed_lengths(svx_ctx):
+    """A PAIR-sized batch (20 k haplotype pairs of 240..2500 bases plus a few long ones)."""
+    rng = np.random.default_rng(21)
+    pairs = []
+    for i in range(20000):
+        a = _rand_dna(rng, int(rng.integers(240, 2500)))
+        pairs.append((a, _edited(rng, a, int(rng.integers(0, 30)), int(rng.integers(0, 4)), 60)))
+    for L in (20000, 50000):
+        a = _rand_dna(rng, L)
+        pairs.append((a, _edited(rng, a, 100, 5, 50)))
+    pool, ao, al, bo, bl = _pool(pairs)
+    got = svx_ctx.edit_distance_batch(pool, ao, al, bo, bl, k_max=200).astype(np.int64)
+    pick = list(rng.integers(0, 20000, 400)) + [20000, 20001]
+    for i in pick:
+        a, b = pairs[i]
+        e = orc.edit_distance(a, b) if len(a) <= 3000 else orc.edit_distance_banded(a, b)
+        assert got[i] == e if e <= 200 else got[i] > 200

@@ -119,3 +119,40 @@ def test_collect_on_real_bam_matches_oracle_reader(svx_ctx):
     got = [helpers.candidate_tuple(c) for c in SVIM_COLLECT.analyze_alignment_file_coordsorted(bamio.AlignmentFile(path), o)]
     exp, _, _ = run_oracle.candidates_from_bam(path, o)
     assert got == exp and len(got) > 50
+
+
+def test_large_alleles_pair_like_the_oracle(svx_ctx):
+    """Partitions of 3+ members whose pairwise haplotype distances are far beyond any band that fits
+    in LDS (> 16 000 edits, the limit of the round-1 kernel): scipy's dendrogram above the cut, hence
+    the cluster label order and which member supplies the output coordinates, must be the reference's.
+    Also: thresholds of any size are accepted (SVIM_COMBINE.py:134-139)."""
+    rng = np.random.default_rng(31)
+    names, lengths = ["chrL", "chrM"], [260000, 90000]
+    seqs = {n: "".join(rng.choice(list("ACGT"), size=l)) for n, l in zip(names, lengths)}
+    lens = dict(zip(names, lengths))
+    ref, bam = helpers.FakeFasta(seqs), helpers.FakeBam(names, lengths, [])
+    from oracle import svim_oracle as O
+    c = 130000
+    t1 = [O.cand_del("chrL", c - 10000, c + 10000, ["a"], lens),             # same midpoint, very different sizes
+          O.cand_del("chrL", c - 2500, c + 2600, ["a2"], lens),
+          O.cand_tan("chrM", 30000, 36000, 3, True, ["t1"], lens),
+          O.cand_inv("chrM", 60000, 79000, ["i1"], True, lens)]
+    t2 = [O.cand_del("chrL", c - 19000, c + 19000, ["b"], lens),
+          O.cand_del("chrL", c - 14000, c + 14005, ["c"], lens),
+          O.cand_del("chrL", c - 2500, c + 2600, ["c2"], lens),
+          O.cand_tan("chrM", 30010, 36020, 1, True, ["t2"], lens),
+          O.cand_tan("chrM", 30000, 36000, 3, False, ["t3"], lens),
+          O.cand_inv("chrM", 60100, 78900, ["i2"], False, lens),
+          O.cand_inv("chrM", 59000, 80000, ["i3"], True, lens)]
+    for med in (200, 25000, 3_000_000_000):
+        o = helpers.options(max_edit_distance=med)
+        c1 = [helpers.build_candidate(t, bam, SVCandidate) for t in t1]
+        c2 = [helpers.build_candidate(t, bam, SVCandidate) for t in t2]
+        got = [helpers.candidate_tuple(x) for x in SVIM_COMBINE.pair_candidates(c1, c2, ref, bam, o)]
+        exp = svim_oracle.pair_candidates(t1, t2, ref.fetch, names, lengths, lens, o,
+                                          edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+        assert got == exp, med
+    # the compatibility seam returns a distance for any pair of haplotypes, however far apart
+    a, b = (1, helpers.build_candidate(t1[0], bam, SVCandidate)), (2, helpers.build_candidate(t2[0], bam, SVCandidate))
+    h = SVIM_COMBINE.haplotype_pair(a[1], b[1], ref)
+    assert SVIM_COMBINE.compute_distance(a, b, ref) == orc.edit_distance(h[0].encode(), h[1].encode()) > 16000

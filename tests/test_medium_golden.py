@@ -49,3 +49,29 @@ def test_cli_reproduces_reference_vcf_medium(svx_ctx, medium_dataset, tmp_path):
     cli.main(["diploid", str(tmp_path), bams[0], bams[1], fasta])
     got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
     assert got == expected_vcf()
+
+
+@pytest.mark.gpu
+@pytest.mark.spawns_gpu_children
+def test_two_rank_cli_reproduces_reference_vcf_medium(medium_dataset, tmp_path):
+    """BASELINE config 4 at the medium scale: two ranks (fresh processes, product kernels), contigs
+    LPT-packed by their share of the BAM; each rank inflates about half of what one process would."""
+    import glob
+    import re
+    from tests import helpers
+    fasta, bams = medium_dataset
+    res = helpers.run_cli_ranks(["diploid", str(tmp_path), bams[0], bams[1], fasta], 2)
+    for rank, (rc, text) in enumerate(res):
+        assert rc == 0, "rank %d failed:\n%s" % (rank, text)
+    got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == expected_vcf()
+    spanned = {}
+    for path in glob.glob(str(tmp_path / "SVIM_*.log")):
+        for m in re.finditer(r"INGEST: rank (\d+)/2 indexed (\d+) records \((\d+) of the (\d+) BGZF", open(path).read()):
+            spanned.setdefault(int(m.group(1)), []).append(int(m.group(4)))
+    from svim_asm_amd import bamio
+    whole = bamio.AlignmentFile(bams[0])
+    whole.load()
+    total = whole.blocks_spanned
+    for rank in (0, 1):
+        assert 0.35 * total < spanned[rank][0] < 0.65 * total, (rank, spanned, total)

@@ -149,3 +149,33 @@ def test_c_classify_and_partition_agree_with_python_oracle():
         flat = [e for p in parts for e in p]
         assert [sub[i] for i in perm] == flat
         assert list(part) == [pi for pi, p in enumerate(parts) for _ in p]
+
+
+def test_banded_oracle_equals_full_matrix_oracle():
+    """orc_edit_distance_banded (used to check long sequences on the GPU box) against the textbook
+    DP, including pairs whose optimal path leaves every narrow band (large indels)."""
+    import numpy as np
+    from oracle import orc
+    rng = np.random.default_rng(1)
+    dna = np.frombuffer(b"ACGT", np.uint8)
+    for it in range(150):
+        a = dna[rng.integers(0, 4, int(rng.integers(0, 700)))].tobytes()
+        if rng.random() < 0.3:
+            b = dna[rng.integers(0, 4, int(rng.integers(0, 700)))].tobytes()
+        else:
+            b = bytearray(a)
+            for _ in range(int(rng.integers(0, 120))):
+                pos = int(rng.integers(0, len(b) + 1))
+                kind = int(rng.integers(0, 3))
+                if kind == 0 and b:
+                    del b[min(pos, len(b) - 1)]
+                elif kind == 1:
+                    b.insert(pos, int(dna[rng.integers(0, 4)]))
+                elif b:
+                    b[min(pos, len(b) - 1)] = int(dna[rng.integers(0, 4)])
+            if rng.random() < 0.4:
+                pos = int(rng.integers(0, len(b) + 1))
+                b[pos:pos] = dna[rng.integers(0, 4, int(rng.integers(50, 400)))].tobytes()
+            b = bytes(b)
+        assert orc.edit_distance_banded(a, b) == orc.edit_distance(a, b)
+    assert orc.edit_distance_banded(b"", b"ACG") == 3 and orc.edit_distance_banded(b"ACG", b"") == 3

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--keep", default=None)
     ap.add_argument("--sv-per-mbp", type=float, default=8.0)
     ap.add_argument("--skip-oracle", action="store_true")
+    ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
+    ap.add_argument("--threads", type=int, default=0, help="ingest threads (0: one per hardware thread, at most 64)")
+    ap.add_argument("--repeat", type=int, default=1, help="repeat the product pipeline, report the best run too")
     args = ap.parse_args()
     from svim_asm_amd import synth, synth_bam
     contigs = tuple((n, max(60000, int(l * args.scale))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
@@ -38,9 +41,13 @@ def main():
     res = {"scale": args.scale, "genome_bp": int(sum(c[1] for c in contigs)), "dir": out}
 
     t0 = time.perf_counter()
-    n_shared = max(4, int(args.sv_per_mbp * max(c[1] for c in contigs) / 1e6))
-    fasta, bams = synth_bam.write_dataset(out, seed=3, contigs=contigs, diploid=True, n_shared=n_shared,
-                                          n_private=max(2, n_shared // 5), median_aln=300000, mean_m=2000)
+    if args.dataset:
+        out = args.dataset
+        fasta, bams = os.path.join(out, "ref.fa"), [os.path.join(out, "hap1.bam"), os.path.join(out, "hap2.bam")]
+    else:
+        n_shared = max(4, int(args.sv_per_mbp * max(c[1] for c in contigs) / 1e6))
+        fasta, bams = synth_bam.write_dataset(out, seed=3, contigs=contigs, diploid=True, n_shared=n_shared,
+                                              n_private=max(2, n_shared // 5), median_aln=300000, mean_m=2000)
     res["generate_s"] = time.perf_counter() - t0
     res["bam_bytes"] = [os.path.getsize(b) for b in bams]
 
@@ -55,17 +62,31 @@ def main():
     logging.getLogger().setLevel(logging.WARNING)
     from svim_asm_amd import _lib
     _lib.default_context(0)  # context creation / first-touch outside the timed region
-    t_all = time.perf_counter()
-    t = time.perf_counter(); f1 = bamio.AlignmentFile(bams[0]); f2 = bamio.AlignmentFile(bams[1]); res["open_inflate_s"] = time.perf_counter() - t
-    t = time.perf_counter(); c1 = shard.collect_sharded(f1, opts); c2 = shard.collect_sharded(f2, opts); res["collect_s"] = time.perf_counter() - t
-    ref = FastaFile(fasta)
-    t = time.perf_counter(); paired = shard.pair_sharded(c1, c2, ref, f1, opts); res["pair_s"] = time.perf_counter() - t
-    by = {k: [c for c in paired if c.type == k] for k, _ in cli.TYPE_LABELS}
-    t = time.perf_counter()
-    write_final_vcf(by["DUP_INT"], by["INV"], by["DUP_TAN"], by["DEL"], by["INS"], by["BND"], "1.0.3", f1.references,
-                    f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
-    res["vcf_s"] = time.perf_counter() - t
-    res["product_total_s"] = time.perf_counter() - t_all
+    runs = []
+    for _ in range(max(1, args.repeat)):
+        r = {}
+        t_all = time.perf_counter()
+        t = time.perf_counter()
+        f1 = bamio.AlignmentFile(bams[0], threads=args.threads, device=0).load()
+        f2 = bamio.AlignmentFile(bams[1], threads=args.threads, device=0).load()
+        r["open_index_s"] = time.perf_counter() - t
+        t = time.perf_counter(); c1 = shard.collect_sharded(f1, opts); c2 = shard.collect_sharded(f2, opts); r["collect_s"] = time.perf_counter() - t
+        ref = FastaFile(fasta)
+        t = time.perf_counter(); paired = shard.pair_sharded(c1, c2, ref, f1, opts); r["pair_s"] = time.perf_counter() - t
+        by = {k: [c for c in paired if c.type == k] for k, _ in cli.TYPE_LABELS}
+        t = time.perf_counter()
+        write_final_vcf(by["DUP_INT"], by["INV"], by["DUP_TAN"], by["DEL"], by["INS"], by["BND"], "1.0.3", f1.references,
+                        f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
+        r["vcf_s"] = time.perf_counter() - t
+        r["product_total_s"] = time.perf_counter() - t_all
+        runs.append(r)
+    res.update(runs[0])
+    if len(runs) > 1:
+        res["best_run"] = min(runs, key=lambda x: x["product_total_s"])
+    res["index_state"] = f1.index_state()
+    res["bgzf_members_inflated"] = [f1.blocks_inflated, f2.blocks_inflated]
+    res["bgzf_members_walked"] = [f1.blocks_spanned, f2.blocks_spanned]
+    res["ingest_threads"] = args.threads or min(64, os.cpu_count() or 1)
     res["candidates"] = [len(c1), len(c2), len(paired)]
     res["cigar_ops"] = [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]
     got = "".join(l for l in open(os.path.join(wd, "variants.vcf")) if not l.startswith("##fileDate="))
@@ -78,7 +99,7 @@ def main():
         res["oracle_total_s"] = time.perf_counter() - t
         res["vcf_identical"] = (got == exp)
         res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
-    if not args.keep:
+    if not args.keep and not args.dataset:
         shutil.rmtree(out)
     print(json.dumps(res))
 

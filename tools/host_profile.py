@@ -48,7 +48,7 @@ if __name__ == "__main__":
     fasta = os.path.join(d, "ref.fa")
     opts = parse_arguments("1.0.3", ["diploid", "/tmp/hp_wd", bams[0], bams[1], fasta])
     pr = cProfile.Profile()
-    t = time.time(); f1 = bamio.AlignmentFile(bams[0]); f2 = bamio.AlignmentFile(bams[1]); print("open", time.time() - t)
+    t = time.time(); f1 = bamio.AlignmentFile(bams[0]).load(); f2 = bamio.AlignmentFile(bams[1]).load(); print("open+index", time.time() - t, f1.index_state(), f1.blocks_inflated, f1.blocks_spanned)
     pr.enable()
     t = time.time(); c1 = shard.collect_sharded(f1, opts); c2 = shard.collect_sharded(f2, opts); print("collect", time.time() - t)
     ref = FastaFile(fasta)
