@@ -162,6 +162,37 @@ def make_medium():
     shutil.rmtree(d)
 
 
+LONGCIGAR = dict(seed=5, contigs=[["chr1", 1500000], ["chr2", 400000], ["chr3", 90000]], n_shared=30, n_private=6,
+                 median_aln=40000000, mean_m=12)
+
+
+def make_longcigar():
+    """Diploid sample whose contig-spanning alignments have CIGARs of > 65535 operations (chr1:
+    > 10^5), i.e. records stored with the `kSmN` placeholder + CG:B,I tag (SAM spec §4.2.2).  The
+    real reference reads them through the stub pysam, which restores the CIGAR the way htslib does.
+    Only the VCF and the input digests are committed; tests regenerate the inputs from the seeds."""
+    import gzip
+    import hashlib
+    from svim_asm_amd import bamio, synth_bam
+    d = tempfile.mkdtemp(prefix="svx_longcigar_")
+    contigs = tuple((n, l) for n, l in LONGCIGAR["contigs"])
+    fasta, bams = synth_bam.write_dataset(d, seed=LONGCIGAR["seed"], contigs=contigs, n_shared=LONGCIGAR["n_shared"],
+                                          n_private=LONGCIGAR["n_private"], median_aln=LONGCIGAR["median_aln"],
+                                          mean_m=LONGCIGAR["mean_m"])
+    n_ops = [int(bamio.AlignmentFile(b, reader="python")._cols["n_cig"].max()) for b in bams]
+    assert min(n_ops) > 100000, n_ops
+    wd = os.path.join(d, "wd")
+    run_reference_cli(["diploid", wd, bams[0], bams[1], fasta])
+    vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
+    with gzip.open(os.path.join(GOLD, "longcigar_diploid.vcf.gz"), "wb", compresslevel=9) as fh:
+        fh.write(vcf.encode())
+    digest = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in [fasta] + bams}
+    with open(os.path.join(GOLD, "longcigar_inputs.json"), "w") as fh:
+        json.dump({"params": LONGCIGAR, "sha256": digest, "max_cigar_ops": n_ops,
+                   "records": sum(1 for l in vcf.split("\n") if l and l[0] != "#")}, fh, indent=1)
+    shutil.rmtree(d)
+
+
 def make_function_vectors():
     import random
     ref = load_reference()
@@ -200,8 +231,16 @@ def make_function_vectors():
 
 
 def main():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     os.makedirs(GOLD, exist_ok=True)
     logging.getLogger().setLevel(logging.WARNING)
+    if len(sys.argv) > 1:   # regenerate selected fixtures only: functions / config1 / medium / longcigar
+        for what in sys.argv[1:]:
+            {"functions": make_function_vectors, "config1": make_config1, "medium": make_medium,
+             "longcigar": make_longcigar}[what]()
+        return
+    make_longcigar()
     make_function_vectors()
     out = make_config1()
     make_medium()
