@@ -40,7 +40,7 @@ def test_inputs_really_use_the_cg_tag(dataset):
     fasta, bams = dataset
     for path, n_ops in zip(bams, META["max_cigar_ops"]):
         raw = bamio.bgzf_decompress(path)
-        assert raw.count(b"CGBI") >= 2          # chr1 and chr2 alignments exceed 65535 operations
+        assert raw.count(b"CGBI") >= 1          # the chr1 alignment exceeds 65535 operations
         nat = bamio.AlignmentFile(path)
         assert int(nat._cols["n_cig"].max()) == n_ops > 100000
         py = bamio.AlignmentFile(path, reader="python")
