@@ -236,6 +236,14 @@ int svx_pair_partition(svx_ctx* ctx, const uint64_t* keys, uint32_t n, uint32_t 
                        uint32_t* perm, uint32_t* part_id, uint32_t* n_parts);
 int svx_pair_partition_dev(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist,
                            uint32_t* d_perm, uint32_t* d_part_id, uint32_t* d_n_parts);
+/* Same with the caller's knowledge of the key layout: key_bits has a 1 wherever some key may have
+ * one (the OR of all keys, or any superset such as `type bits | contig bits | position bits`).
+ * Only those bits are sorted on (P = ceil(live bits / 9) radix passes, P + 2 launches in total), and
+ * nothing is read back: fully asynchronous.  svx_pair_partition_dev derives the mask itself with one
+ * extra reduction and an 8-byte read-back, which synchronises the stream once. */
+int svx_pair_partition_dev_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist,
+                                uint64_t key_bits, uint32_t* d_perm, uint32_t* d_part_id,
+                                uint32_t* d_n_parts);
 
 /* ---------------------------------------------------------------- a7 ------- */
 /*

@@ -81,6 +81,7 @@ SYMBOLS = {
                                             C.POINTER(SegParams), _P]),
     "svx_pair_partition": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32)]),
     "svx_pair_partition_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "svx_pair_partition_dev_bits": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, _P]),
     "svx_edit_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_uint32,
                                           _P]),
     # native BAM ingest (include/svx_bam.h)

@@ -8,19 +8,31 @@
 // name under Python str order), pos = non-negative key position), so unsigned 64-bit
 // order == the reference's tuple order and ties keep input order (hap-1 list, then hap-2).
 //
-// Kernels (8 B key + 4 B index per candidate in HBM, ping-pong buffers):
-//   k_pair_init      copy keys, idx[i] = i, OR-reduce the keys (which 8-bit digits are live)
-//   per live digit:  k_radix_hist → k_radix_scan → k_radix_scatter  (LSD, 8 bits per pass;
-//                    one wave per 1024-key chunk; stable in-wave ranking with __ballot match
-//                    masks; dead digits exit immediately)
-//   k_partition      boundary flags + inclusive scan → partition ids, perm, n_parts
-// Integer/HBM-bound work, no MFMA.  Determinism: ranks come from prefix sums only.
+// Launch plan (P + 2 kernels; P = 4 for a human sample: 3 type + 5 contig + 28 position bits):
+//   the caller (or one reduction) tells which key bits can be set at all; those bits are
+//   squeezed into a dense key of L bits (up to four bit fields), sorted LSD with P = ceil(L / 9)
+//   digits of ceil(L / P) bits:
+//   k_pair_init      dense keys, idx[i] = i, per-chunk histogram of digit 0, zero the histograms
+//                    of the later digits;
+//   k_radix_pass × P one workgroup per 4 chunks of 1024 keys.  Column sums over the chunk
+//                    histograms give every chunk its global bucket offsets (no scan kernel, no
+//                    look-back: the table is 2 KiB per chunk and L2-resident); one wave per chunk
+//                    ranks its keys stably with __ballot match masks and scatters them, counting
+//                    on the way the NEXT digit into the histogram of the chunk each key lands in;
+//   k_partition      boundary flags (gathering the original keys through the permutation) +
+//                    inclusive scan → partition ids, perm, n_parts.  One workgroup up to 16 k
+//                    candidates; beyond that one workgroup per CU at most with one counter barrier.
+// Integer/HBM-bound work (20 B per candidate algorithmic), no MFMA.  Determinism: ranks come
+// from prefix sums only; the histogram atomics are commutative counts.
 #include "svx_internal.h"
 
 namespace {
 
 constexpr int kChunk = 1024;
 constexpr int kIters = kChunk / 64;
+constexpr int kMaxDigitBits = 9;
+constexpr int kBuckets = 1 << kMaxDigitBits;
+constexpr uint32_t kSingleBlockMax = 16384;
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -28,176 +40,362 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct PairBufs {
-    uint64_t* keys[2];
-    uint32_t* idx[2];
-    uint32_t* hist;     // [256 * n_chunks], digit-major
-    uint64_t* or_bits;  // OR of all keys
+struct KeyFields {  // dense = OR over f of ((key >> shift[f]) & mask[f]) << off[f]
     uint32_t n;
-    uint32_t n_chunks;
+    uint32_t shift[4], off[4];
+    uint64_t mask[4];
 };
 
-__device__ __forceinline__ bool pass_live(uint64_t orb, int d) { return ((orb >> (8 * d)) & 0xFFu) != 0; }
-// buffer holding the data BEFORE pass d (= number of live passes below d, mod 2)
-__device__ __forceinline__ int pass_src(uint64_t orb, int d) {
-    int c = 0;
-    for (int i = 0; i < d; ++i) c += pass_live(orb, i) ? 1 : 0;
-    return c & 1;
+struct PairBufs {
+    uint64_t* keys[2];  // dense keys, ping-pong
+    uint32_t* idx[2];
+    uint32_t* hist;     // [passes][n_chunks][kBuckets]
+    uint32_t n;
+    uint32_t n_chunks;
+    uint32_t passes;
+    uint32_t digit_bits;
+    KeyFields f;
+};
+
+__device__ __forceinline__ uint64_t dense_key(const KeyFields& f, uint64_t k) {
+    uint64_t d = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i)
+        if (i < f.n) d |= ((k >> f.shift[i]) & f.mask[i]) << f.off[i];
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_key_or(const uint64_t* __restrict__ keys, uint32_t n,
+                                                unsigned long long* __restrict__ out) {
+    uint64_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc |= keys[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        acc |= ((uint64_t)__shfl_xor((uint32_t)(acc >> 32), d) << 32) | __shfl_xor((uint32_t)acc, d);
+    if ((threadIdx.x & 63) == 0 && acc) atomicOr(out, (unsigned long long)acc);
 }
 
 __global__ __launch_bounds__(256) void k_pair_init(const uint64_t* __restrict__ keys, PairBufs b) {
-    uint64_t acc = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += gridDim.x * blockDim.x) {
-        const uint64_t k = keys[i];
-        b.keys[0][i] = k;
-        b.idx[0][i] = i;
-        acc |= k;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        acc |= ((uint64_t)__shfl_xor((uint32_t)(acc >> 32), d) << 32) | __shfl_xor((uint32_t)acc, d);
-    }
-    if ((threadIdx.x & 63) == 0 && acc) atomicOr((unsigned long long*)b.or_bits, (unsigned long long)acc);
-}
-
-__global__ __launch_bounds__(256) void k_radix_hist(PairBufs b, int d) {
-    __shared__ uint32_t s_h[4][256];
-    const uint64_t orb = *b.or_bits;
-    if (!pass_live(orb, d)) return;
+    __shared__ uint32_t s_h[4][kBuckets];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t* src = b.keys[pass_src(orb, d)];
+    const uint32_t dmask = (1u << b.digit_bits) - 1u;
     uint32_t* h = s_h[wave];
+    // zero the histograms of the later passes (counted into by the scatter of the pass before)
+    {
+        const size_t total = (size_t)(b.passes - 1) * b.n_chunks * kBuckets;
+        uint32_t* later = b.hist + (size_t)b.n_chunks * kBuckets;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            later[i] = 0;
+    }
     for (uint32_t chunk = blockIdx.x * 4 + wave; chunk < b.n_chunks; chunk += gridDim.x * 4) {
-        for (int i = lane; i < 256; i += 64) h[i] = 0;
+        for (int i = lane; i < kBuckets; i += 64) h[i] = 0;
         wave_lds_sync();
         const uint32_t base = chunk * kChunk;
         for (int it = 0; it < kIters; ++it) {
             const uint32_t i = base + it * 64 + lane;
-            if (i < b.n) atomicAdd(&h[(uint32_t)(src[i] >> (8 * d)) & 0xFFu], 1u);
+            if (i < b.n) {
+                const uint64_t d = dense_key(b.f, keys[i]);
+                b.keys[0][i] = d;
+                b.idx[0][i] = i;
+                atomicAdd(&h[(uint32_t)d & dmask], 1u);
+            }
         }
         wave_lds_sync();
-        for (int i = lane; i < 256; i += 64) b.hist[(size_t)i * b.n_chunks + chunk] = h[i];
+        for (int i = lane; i < kBuckets; i += 64) b.hist[(size_t)chunk * kBuckets + i] = h[i];
         wave_lds_sync();
     }
 }
 
-// exclusive scan of hist[256 * n_chunks] in place (single workgroup, chunked with carry)
-__global__ __launch_bounds__(1024) void k_radix_scan(PairBufs b, int d) {
-    __shared__ uint32_t s_w[16];
-    const uint64_t orb = *b.or_bits;
-    if (!pass_live(orb, d)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t total = (size_t)256 * b.n_chunks;
-    uint32_t carry = 0;
-    for (size_t base = 0; base < total; base += 1024) {
-        const size_t i = base + tid;
-        const uint32_t v = i < total ? b.hist[i] : 0u;
-        uint32_t s = v;
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) {
-            uint32_t t = __shfl_up(s, k);
-            if (lane >= k) s += t;
-        }
-        if (lane == 63) s_w[wave] = s;
-        __syncthreads();
-        uint32_t wp = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) wp += s_w[w];
-            tot += s_w[w];
-        }
-        if (i < total) b.hist[i] = carry + wp + s - v;
-        carry += tot;
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void k_radix_scatter(PairBufs b, int d) {
-    __shared__ uint32_t s_run[4][256];
-    const uint64_t orb = *b.or_bits;
-    if (!pass_live(orb, d)) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sb = pass_src(orb, d);
+__global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
+    __shared__ uint32_t s_run[4][kBuckets];  // running output position per (wave, digit)
+    __shared__ uint32_t s_tot[kBuckets];
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t shift = pass * b.digit_bits;
+    const uint32_t dmask = (1u << b.digit_bits) - 1u;
+    const uint32_t nb = 1u << b.digit_bits;
+    const int sb = pass & 1;
     const uint64_t* __restrict__ sk = b.keys[sb];
     const uint32_t* __restrict__ si = b.idx[sb];
     uint64_t* __restrict__ dk = b.keys[sb ^ 1];
     uint32_t* __restrict__ di = b.idx[sb ^ 1];
-    uint32_t* run = s_run[wave];
-    const uint64_t lt = (1ull << lane) - 1ull;
-    for (uint32_t chunk = blockIdx.x * 4 + wave; chunk < b.n_chunks; chunk += gridDim.x * 4) {
-        for (int i = lane; i < 256; i += 64) run[i] = b.hist[(size_t)i * b.n_chunks + chunk];
-        wave_lds_sync();
-        const uint32_t base = chunk * kChunk;
-        for (int it = 0; it < kIters; ++it) {
-            const uint32_t i = base + it * 64 + lane;
-            const bool valid = i < b.n;
-            uint64_t key = 0;
-            uint32_t id = 0;
-            if (valid) { key = sk[i]; id = si[i]; }
-            const uint32_t dig = (uint32_t)(key >> (8 * d)) & 0xFFu;
-            // lanes holding the same digit (match-any via 8 ballots)
-            uint64_t m = __ballot(valid);
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const uint64_t bal = __ballot((dig >> bit) & 1u);
-                m &= ((dig >> bit) & 1u) ? bal : ~bal;
-            }
-            const uint32_t rank = __popcll(m & lt);
-            uint32_t pos = 0;
-            if (valid) pos = run[dig] + rank;
-            wave_lds_sync();
-            if (valid && rank == 0) run[dig] += __popcll(m);
-            wave_lds_sync();
-            if (valid) { dk[pos] = key; di[pos] = id; }
-        }
-        wave_lds_sync();
-    }
-}
+    const uint32_t* __restrict__ hist = b.hist + (size_t)pass * b.n_chunks * kBuckets;
+    uint32_t* __restrict__ hnext = pass + 1 < b.passes ? b.hist + (size_t)(pass + 1) * b.n_chunks * kBuckets : nullptr;
+    const uint32_t chunk0 = blockIdx.x * 4;
 
-// boundary flags + inclusive scan (single workgroup, chunked with carry)
-__global__ __launch_bounds__(1024) void k_partition(PairBufs b, uint32_t max_dist,
-                                                    uint32_t* __restrict__ perm,
-                                                    uint32_t* __restrict__ part_id,
-                                                    uint32_t* __restrict__ n_parts) {
-    __shared__ uint32_t s_w[16];
-    const uint64_t orb = *b.or_bits;
-    const int fb = pass_src(orb, 8);
-    const uint64_t* __restrict__ sk = b.keys[fb];
-    const uint32_t* __restrict__ si = b.idx[fb];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < b.n; base += 1024) {
-        const uint32_t j = base + tid;
-        uint32_t flag = 0;
-        if (j < b.n && j > 0) {
-            const uint64_t a = sk[j - 1], c = sk[j];
-            const uint32_t pa = (uint32_t)a, pc = (uint32_t)c;
-            const uint32_t dist = pa > pc ? pa - pc : pc - pa;
-            flag = ((a >> 32) != (c >> 32) || dist > max_dist) ? 1u : 0u;  // SVIM_COMBINE.py:24-26
+    // ---- global bucket offsets of this workgroup's four chunks: column sums over the table
+    for (uint32_t v = tid; v < nb; v += 256) {
+        uint32_t before = 0, total = 0, mine[4] = {0, 0, 0, 0};
+        for (uint32_t c = 0; c < b.n_chunks; ++c) {
+            const uint32_t x = hist[(size_t)c * kBuckets + v];
+            total += x;
+            if (c < chunk0) before += x;
+            else if (c < chunk0 + 4) mine[c - chunk0] = x;
         }
-        uint32_t s = flag;
+        s_tot[v] = total;
+        uint32_t acc = before;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            s_run[w][v] = acc;
+            acc += mine[w];
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket totals (nb <= 512: two values per thread)
+    {
+        const uint32_t a0 = 2 * tid < nb ? s_tot[2 * tid] : 0u, a1 = 2 * tid + 1 < nb ? s_tot[2 * tid + 1] : 0u;
+        uint32_t s = a0 + a1;
 #pragma unroll
         for (int k = 1; k < 64; k <<= 1) {
-            uint32_t t = __shfl_up(s, k);
+            const uint32_t t = __shfl_up(s, k);
             if (lane >= k) s += t;
         }
         if (lane == 63) s_w[wave] = s;
         __syncthreads();
-        uint32_t wp = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) wp += s_w[w];
-            tot += s_w[w];
+        uint32_t wp = 0;
+        for (int w = 0; w < wave; ++w) wp += s_w[w];
+        const uint32_t ex = wp + s - (a0 + a1);
+        __syncthreads();
+        if (2 * tid < nb) s_tot[2 * tid] = ex;
+        if (2 * tid + 1 < nb) s_tot[2 * tid + 1] = ex + a0;
+    }
+    __syncthreads();
+    for (uint32_t v = tid; v < nb; v += 256) {
+        const uint32_t t = s_tot[v];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s_run[w][v] += t;
+    }
+    __syncthreads();
+
+    // ---- one wave per chunk: stable ranking with match masks, scatter, next digit's counts
+    const uint32_t chunk = chunk0 + wave;
+    if (chunk >= b.n_chunks) return;
+    uint32_t* run = s_run[wave];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t base = chunk * kChunk;
+    const uint32_t nshift = shift + b.digit_bits;
+    for (int it = 0; it < kIters; ++it) {
+        const uint32_t i = base + it * 64 + lane;
+        const bool valid = i < b.n;
+        uint64_t key = 0;
+        uint32_t id = 0;
+        if (valid) { key = sk[i]; id = si[i]; }
+        const uint32_t dig = (uint32_t)(key >> shift) & dmask;
+        uint64_t m = __ballot(valid);
+        for (uint32_t bit = 0; bit < b.digit_bits; ++bit) {
+            const uint64_t bal = __ballot((dig >> bit) & 1u);
+            m &= ((dig >> bit) & 1u) ? bal : ~bal;
         }
-        if (j < b.n) {
-            part_id[j] = carry + wp + s;
-            perm[j] = si[j];
+        const uint32_t rank = __popcll(m & lt);
+        uint32_t pos = 0;
+        if (valid) pos = run[dig] + rank;
+        wave_lds_sync();
+        if (valid && rank == 0) run[dig] += __popcll(m);
+        wave_lds_sync();
+        if (valid) {
+            dk[pos] = key;
+            di[pos] = id;
+            if (hnext) atomicAdd(&hnext[(size_t)(pos / kChunk) * kBuckets + ((uint32_t)(key >> nshift) & dmask)], 1u);
+        }
+    }
+}
+
+struct PartArgs {
+    const uint64_t* keys;     // original keys
+    const uint32_t* sorted;   // sorted permutation (idx buffer after the last pass)
+    uint32_t n;
+    uint32_t max_dist;
+    uint32_t* perm;
+    uint32_t* part_id;
+    uint32_t* n_parts;
+    uint32_t* block_tot;      // [gridDim.x] flags per workgroup (multi-block form)
+    uint32_t* counter;        // self-cleaning arrival counter (workspace header)
+};
+
+__device__ __forceinline__ uint32_t boundary_flag(const PartArgs& p, uint32_t j, uint32_t* perm_out) {
+    const uint32_t me = p.sorted[j];
+    *perm_out = me;
+    if (j == 0) return 0;
+    const uint64_t a = p.keys[p.sorted[j - 1]], c = p.keys[me];
+    const uint32_t pa = (uint32_t)a, pc = (uint32_t)c;
+    const uint32_t dist = pa > pc ? pa - pc : pc - pa;
+    return ((a >> 32) != (c >> 32) || dist > p.max_dist) ? 1u : 0u;  // SVIM_COMBINE.py:24-26
+}
+
+// inclusive scan of `flag` over a 1024-thread workgroup; returns the scanned value, *total the sum
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t flag, uint32_t* s_w, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t s = flag;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+        const uint32_t t = __shfl_up(s, k);
+        if (lane >= k) s += t;
+    }
+    if (lane == 63) s_w[wave] = s;
+    __syncthreads();
+    uint32_t wp = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wp += s_w[w];
+        tot += s_w[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return wp + s;
+}
+
+// Workgroup g owns the contiguous range [g * span, (g + 1) * span).  Pass 1 counts its flags;
+// after one arrival barrier (every workgroup is resident: the grid never exceeds one per CU) pass 2
+// re-walks the range with the exclusive sum of the earlier workgroups as carry-in.
+__global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t lo = blockIdx.x * span, hi = min(p.n, lo + span);
+    uint32_t carry = 0;
+    if (gridDim.x > 1) {
+        uint32_t cnt = 0;
+        for (uint32_t j = lo + threadIdx.x; j < hi; j += 1024) {
+            uint32_t dummy;
+            cnt += boundary_flag(p, j, &dummy);
+        }
+        uint32_t tot;
+        (void)block_scan_1024(cnt, s_w, &tot);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&p.block_tot[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+                __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            uint32_t c = 0;
+            for (uint32_t g = 0; g < blockIdx.x; ++g)
+                c += __hip_atomic_load(&p.block_tot[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_carry = c;
+            // the last workgroup to get here puts the counter back to zero for the next call
+            if (__hip_atomic_fetch_add(p.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+                __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        carry = s_carry;
+    }
+    for (uint32_t base = lo; base < hi; base += 1024) {
+        const uint32_t j = base + threadIdx.x;
+        uint32_t flag = 0, me = 0;
+        if (j < hi) flag = boundary_flag(p, j, &me);
+        uint32_t tot;
+        const uint32_t s = block_scan_1024(flag, s_w, &tot);
+        if (j < hi) {
+            p.part_id[j] = carry + s;
+            p.perm[j] = me;
         }
         carry += tot;
-        __syncthreads();
     }
-    if (tid == 0) *n_parts = b.n ? carry + 1 : 0;
+    if (threadIdx.x == 0 && hi == p.n) *p.n_parts = p.n ? carry + 1 : 0;
+}
+
+// bit fields of `bits` (set bits = key bits that can be non-zero), at most four: nearby runs are merged
+KeyFields fields_of(uint64_t bits, uint32_t* live) {
+    struct Run { uint32_t lo, hi; };  // [lo, hi)
+    std::vector<Run> runs;
+    for (uint32_t i = 0; i < 64;) {
+        if (!((bits >> i) & 1)) { ++i; continue; }
+        uint32_t j = i;
+        while (j < 64 && ((bits >> j) & 1)) ++j;
+        runs.push_back({i, j});
+        i = j;
+    }
+    while (runs.size() > 4) {  // merge the two runs separated by the smallest gap
+        size_t best = 0;
+        for (size_t r = 1; r + 1 < runs.size(); ++r)
+            if (runs[r + 1].lo - runs[r].hi < runs[best + 1].lo - runs[best].hi) best = r;
+        runs[best].hi = runs[best + 1].hi;
+        runs.erase(runs.begin() + best + 1);
+    }
+    KeyFields f;
+    memset(&f, 0, sizeof(f));
+    uint32_t off = 0;
+    for (const Run& r : runs) {
+        const uint32_t w = r.hi - r.lo;
+        f.shift[f.n] = r.lo;
+        f.off[f.n] = off;
+        f.mask[f.n] = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+        off += w;
+        ++f.n;
+    }
+    *live = off;
+    return f;
+}
+
+int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist, uint64_t key_bits,
+                        uint32_t* d_perm, uint32_t* d_part_id, uint32_t* d_n_parts) {
+    PairBufs b;
+    uint32_t live = 0;
+    b.f = fields_of(key_bits, &live);
+    if (live == 0) {  // every key is zero: one digit of one bit keeps the code path uniform
+        live = 1;
+        b.f.n = 1;
+        b.f.shift[0] = 0; b.f.off[0] = 0; b.f.mask[0] = 1;
+    }
+    b.passes = (live + kMaxDigitBits - 1) / kMaxDigitBits;
+    b.digit_bits = (live + b.passes - 1) / b.passes;
+    b.n = n;
+    b.n_chunks = (n + kChunk - 1) / kChunk;
+    const uint32_t part_grid = n <= kSingleBlockMax ? 1u
+        : std::min<uint32_t>((uint32_t)ctx->n_cu, (n + 4095) / 4096);
+    const size_t hist_words = (size_t)b.passes * b.n_chunks * kBuckets;
+    size_t need = 2 * svx_take_bytes(n, 8) + 2 * svx_take_bytes(n, 4) + svx_take_bytes(hist_words, 4) +
+                  svx_take_bytes(part_grid, 4);
+    int rc = svx_ws_reserve(ctx, need);
+    if (rc != SVX_OK) return rc;
+    b.keys[0] = svx_ws_take<uint64_t>(ctx, n);
+    b.keys[1] = svx_ws_take<uint64_t>(ctx, n);
+    b.idx[0] = svx_ws_take<uint32_t>(ctx, n);
+    b.idx[1] = svx_ws_take<uint32_t>(ctx, n);
+    b.hist = svx_ws_take<uint32_t>(ctx, hist_words);
+    uint32_t* block_tot = svx_ws_take<uint32_t>(ctx, part_grid);
+    rc = svx_timing_begin(ctx);
+    if (rc != SVX_OK) return rc;
+    const uint32_t g_chunk = (b.n_chunks + 3) / 4;
+    hipLaunchKernelGGL(k_pair_init, dim3(std::min<uint32_t>(g_chunk, (uint32_t)ctx->n_cu * 8u)), dim3(256), 0,
+                       ctx->stream, d_keys, b);
+    rc = svx_timing_mark(ctx, 1);
+    if (rc != SVX_OK) return rc;
+    for (uint32_t pass = 0; pass < b.passes; ++pass)
+        hipLaunchKernelGGL(k_radix_pass, dim3(g_chunk), dim3(256), 0, ctx->stream, b, pass);
+    rc = svx_timing_mark(ctx, 2);
+    if (rc != SVX_OK) return rc;
+    PartArgs pa;
+    pa.keys = d_keys;
+    pa.sorted = b.idx[b.passes & 1];
+    pa.n = n;
+    pa.max_dist = max_dist;
+    pa.perm = d_perm;
+    pa.part_id = d_part_id;
+    pa.n_parts = d_n_parts;
+    pa.block_tot = block_tot;
+    pa.counter = reinterpret_cast<uint32_t*>(ctx->ws) + 64;  // workspace header: zero between calls
+    const uint32_t span = ((n + part_grid - 1) / part_grid + 1023) / 1024 * 1024;
+    hipLaunchKernelGGL(k_partition, dim3((n + span - 1) / span), dim3(1024), 0, ctx->stream, pa, span);
+    SVX_HIP(ctx, hipGetLastError());
+    return svx_timing_end(ctx);
 }
 
 }  // namespace
+
+extern "C" int svx_pair_partition_dev_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist,
+                                           uint64_t key_bits, uint32_t* d_perm, uint32_t* d_part_id,
+                                           uint32_t* d_n_parts) {
+    if (!ctx || !d_n_parts) return SVX_E_INVALID;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) {
+        SVX_HIP(ctx, hipMemsetAsync(d_n_parts, 0, 4, ctx->stream));
+        return SVX_OK;
+    }
+    if (!d_keys || !d_perm || !d_part_id) return SVX_E_INVALID;
+    return pair_partition_bits(ctx, d_keys, n, max_dist, key_bits, d_perm, d_part_id, d_n_parts);
+}
 
 extern "C" int svx_pair_partition_dev(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n,
                                       uint32_t max_dist, uint32_t* d_perm, uint32_t* d_part_id,
@@ -209,39 +407,18 @@ extern "C" int svx_pair_partition_dev(svx_ctx* ctx, const uint64_t* d_keys, uint
         return SVX_OK;
     }
     if (!d_keys || !d_perm || !d_part_id) return SVX_E_INVALID;
-    PairBufs b;
-    b.n = n;
-    b.n_chunks = (n + kChunk - 1) / kChunk;
-    size_t need = 2 * svx_take_bytes(n, 8) + 2 * svx_take_bytes(n, 4) +
-                  svx_take_bytes((size_t)256 * b.n_chunks, 4) + svx_take_bytes(1, 8);
-    int rc = svx_ws_reserve(ctx, need);
+    // which key bits are used is not known here: one reduction and an 8-byte read-back (synchronises)
+    int rc = svx_ws_reserve(ctx, svx_take_bytes(1, 8));
     if (rc != SVX_OK) return rc;
-    b.keys[0] = svx_ws_take<uint64_t>(ctx, n);
-    b.keys[1] = svx_ws_take<uint64_t>(ctx, n);
-    b.idx[0] = svx_ws_take<uint32_t>(ctx, n);
-    b.idx[1] = svx_ws_take<uint32_t>(ctx, n);
-    b.hist = svx_ws_take<uint32_t>(ctx, (size_t)256 * b.n_chunks);
-    b.or_bits = svx_ws_take<uint64_t>(ctx, 1);
-    rc = svx_timing_begin(ctx);
-    if (rc != SVX_OK) return rc;
-    SVX_HIP(ctx, hipMemsetAsync(b.or_bits, 0, 8, ctx->stream));
-    const uint32_t cap = (uint32_t)ctx->n_cu * 8u;
-    uint32_t g_init = (n + 255) / 256;
-    if (g_init > cap) g_init = cap;
-    uint32_t g_chunk = (b.n_chunks + 3) / 4;
-    if (g_chunk > cap) g_chunk = cap;
-    hipLaunchKernelGGL(k_pair_init, dim3(g_init), dim3(256), 0, ctx->stream, d_keys, b);
-    svx_timing_mark(ctx, 1);
-    for (int d = 0; d < 8; ++d) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(g_chunk), dim3(256), 0, ctx->stream, b, d);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, ctx->stream, b, d);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(g_chunk), dim3(256), 0, ctx->stream, b, d);
-    }
-    svx_timing_mark(ctx, 2);
-    hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, ctx->stream, b, max_dist, d_perm,
-                       d_part_id, d_n_parts);
+    unsigned long long* d_or = reinterpret_cast<unsigned long long*>(svx_ws_take<uint64_t>(ctx, 1));
+    SVX_HIP(ctx, hipMemsetAsync(d_or, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_key_or, dim3(std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cu * 4u)), dim3(256), 0,
+                       ctx->stream, d_keys, n, d_or);
     SVX_HIP(ctx, hipGetLastError());
-    return svx_timing_end(ctx);
+    uint64_t bits = 0;
+    SVX_HIP(ctx, hipMemcpyAsync(&bits, d_or, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return pair_partition_bits(ctx, d_keys, n, max_dist, bits, d_perm, d_part_id, d_n_parts);
 }
 
 extern "C" int svx_pair_partition(svx_ctx* ctx, const uint64_t* keys, uint32_t n, uint32_t max_dist,
@@ -251,6 +428,8 @@ extern "C" int svx_pair_partition(svx_ctx* ctx, const uint64_t* keys, uint32_t n
     if (n == 0) return SVX_OK;
     if (!keys || !perm || !part_id) return SVX_E_INVALID;
     SVX_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t bits = 0;  // the keys are here: which bits are in use costs one pass over host memory
+    for (uint32_t i = 0; i < n; ++i) bits |= keys[i];
     size_t need = svx_take_bytes(n, 8) + 2 * svx_take_bytes(n, 4) + svx_take_bytes(1, 4);
     int rc = svx_stage_reserve(ctx, need);
     if (rc != SVX_OK) return rc;
@@ -259,7 +438,7 @@ extern "C" int svx_pair_partition(svx_ctx* ctx, const uint64_t* keys, uint32_t n
     uint32_t* d_id = svx_stage_take<uint32_t>(ctx, n);
     uint32_t* d_np = svx_stage_take<uint32_t>(ctx, 1);
     SVX_HIP(ctx, hipMemcpyAsync(d_k, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = svx_pair_partition_dev(ctx, d_k, n, max_dist, d_p, d_id, d_np);
+    rc = pair_partition_bits(ctx, d_k, n, max_dist, bits, d_p, d_id, d_np);
     if (rc != SVX_OK) return rc;
     SVX_HIP(ctx, hipMemcpyAsync(perm, d_p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(part_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -54,3 +54,65 @@ def test_properties_full_size(svx_ctx):
     # idempotence: sorting the sorted keys is the identity permutation
     perm2, part2, _ = svx_ctx.pair_partition(sk, 1000)
     assert np.array_equal(perm2, np.arange(n, dtype=np.uint32)) and np.array_equal(part2, part)
+
+
+@pytest.mark.parametrize("n", [1, 16384, 16385, 20000, 65536, 70001])
+def test_partition_kernel_forms(svx_ctx, n):
+    """Around the single-workgroup / multi-workgroup switch of the partition sweep (16 k), with dense
+    partitions (every other element opens one) and with a single partition."""
+    rng = np.random.default_rng(n)
+    for keys in (make_keys(rng, n, 3, 4 * n + 10), (np.arange(n, dtype=np.uint64) * np.uint64(5)),
+                 np.zeros(n, dtype=np.uint64), (np.arange(n, dtype=np.uint64)[::-1].copy() << np.uint64(32))):
+        for max_dist in (0, 3, 1000):
+            perm, part, n_parts = svx_ctx.pair_partition(keys, max_dist)
+            e_perm, e_part, e_n = orc.pair_partition(keys, max_dist)
+            assert n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
+
+
+def test_key_layouts(svx_ctx):
+    """Every digit plan: all 64 bits live (8 passes of 8 bits), scattered single bits (more than four
+    bit fields: merged), one live bit, the layout _pack_keys produces, keys equal in all but the top bit."""
+    rng = np.random.default_rng(3)
+    n = 5000
+    layouts = [rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64),
+               rng.integers(0, 1 << 62, n, dtype=np.uint64) & np.uint64(0x8040201008040201),
+               rng.integers(0, 2, n).astype(np.uint64) << np.uint64(40),
+               ((rng.integers(0, 6, n).astype(np.uint64) << np.uint64(24) | rng.integers(0, 24, n).astype(np.uint64))
+                << np.uint64(32)) | rng.integers(0, 250_000_000, n).astype(np.uint64),
+               (rng.integers(0, 2, n).astype(np.uint64) << np.uint64(63)) | np.uint64(12345)]
+    for keys in layouts:
+        perm, part, n_parts = svx_ctx.pair_partition(keys, 1000)
+        e_perm, e_part, e_n = orc.pair_partition(keys, 1000)
+        assert n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
+
+
+def test_device_entry_points(svx_ctx):
+    """svx_pair_partition_dev (derives the live key bits itself) and svx_pair_partition_dev_bits (the
+    caller names them; a superset is fine) on device buffers, repeated on one context."""
+    import torch
+    rng = np.random.default_rng(8)
+    dev = torch.device("cuda", 0)
+    for n in (3000, 70000):
+        keys = make_keys(rng, n, 6 * 24, 250_000_000)
+        d_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+        d_perm = torch.empty(n, dtype=torch.int32, device=dev)
+        d_part = torch.empty(n, dtype=torch.int32, device=dev)
+        d_np = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e_perm, e_part, e_n = orc.pair_partition(keys, 1000)
+        superset = (0xFF << 32) | 0xFFFFFFFF
+        for rep in range(3):
+            for bits in (None, int(np.bitwise_or.reduce(keys)), superset):
+                d_perm.zero_(); d_part.zero_()
+                torch.cuda.synchronize()
+                if bits is None:
+                    rc = svx_ctx.lib.svx_pair_partition_dev(svx_ctx.h, d_keys.data_ptr(), n, 1000, d_perm.data_ptr(),
+                                                            d_part.data_ptr(), d_np.data_ptr())
+                else:
+                    rc = svx_ctx.lib.svx_pair_partition_dev_bits(svx_ctx.h, d_keys.data_ptr(), n, 1000, bits,
+                                                                 d_perm.data_ptr(), d_part.data_ptr(), d_np.data_ptr())
+                assert rc == 0
+                svx_ctx.sync()
+                assert int(d_np.item()) == e_n
+                assert np.array_equal(d_perm.cpu().numpy().view(np.uint32), e_perm)
+                assert np.array_equal(d_part.cpu().numpy().view(np.uint32), e_part)
