@@ -61,6 +61,15 @@ const char* svx_version(void);
 /* Number of visible HIP devices (0 when none / no driver). Never fails. */
 int svx_device_count(void);
 
+/* Device buffers for callers that have no other owner of HBM (a ctypes binding without torch, the
+ * tests): plain hipMalloc / hipFree / hipMemcpyAsync on the context's device and stream.
+ * svx_dev_upload and svx_dev_download are ordered on the context's stream with the kernels of the
+ * *_dev entry points; svx_dev_download synchronises the stream before it returns. */
+int svx_dev_malloc(svx_ctx* ctx, size_t bytes, void** d_out);
+int svx_dev_free(svx_ctx* ctx, void* d_ptr);
+int svx_dev_upload(svx_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int svx_dev_download(svx_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
 /* Kernel timing with HIP events on the context's stream.  When enabled, every
  * *_dev entry point brackets its kernels with events; after svx_ctx_sync the
  * elapsed GPU time of the last call is returned in milliseconds. */

@@ -63,6 +63,10 @@ SYMBOLS = {
     "svx_last_error": (C.c_char_p, [_P]),
     "svx_version": (C.c_char_p, []),
     "svx_device_count": (C.c_int, []),
+    "svx_dev_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "svx_dev_free": (C.c_int, [_P, _P]),
+    "svx_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "svx_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "svx_ctx_set_timing": (C.c_int, [_P, C.c_int]),
     "svx_ctx_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "svx_ctx_wait_dominant": (C.c_int, [_P, _P]),
@@ -161,6 +165,11 @@ class Context:
 
     def sync(self):
         self._check(self.lib.svx_ctx_sync(self.h))
+
+    # ---------------------------------------------------------------- device buffers
+    def dev_array(self, host=None, nbytes=None):
+        """HBM buffer owned by this context (svx_dev_malloc); `host`: numpy array uploaded into it."""
+        return DeviceArray(self, host=host, nbytes=nbytes)
 
     def wait_dominant(self, other):
         """Order this context's next launches after `other`'s latest streaming kernel (pipelining)."""
@@ -270,6 +279,41 @@ class Context:
                                                          _ptr(a_len), _ptr(b_off), _ptr(b_len), n,
                                                          int(k_max) & 0xFFFFFFFF, _ptr(dist)))
         return dist
+
+
+class DeviceArray:
+    """A hipMalloc'ed buffer for the *_dev entry points (no torch needed): .ptr is the device address."""
+
+    def __init__(self, ctx, host=None, nbytes=None):
+        self.ctx = ctx
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            nbytes = host.nbytes
+        self.nbytes = int(nbytes)
+        p = _P()
+        ctx._check(ctx.lib.svx_dev_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        if host is not None and self.nbytes:
+            ctx._check(ctx.lib.svx_dev_upload(ctx.h, self.ptr, host.ctypes.data, self.nbytes))
+            ctx.sync()
+
+    def download(self, dtype, count=None):
+        dtype = np.dtype(dtype)
+        n = self.nbytes // dtype.itemsize if count is None else int(count)
+        out = np.empty(n, dtype)
+        self.ctx._check(self.ctx.lib.svx_dev_download(self.ctx.h, out.ctypes.data, self.ptr, n * dtype.itemsize))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.svx_dev_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 _default_ctx = {}

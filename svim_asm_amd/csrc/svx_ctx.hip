@@ -101,6 +101,45 @@ int svx_stage_reserve(svx_ctx* ctx, size_t total) {
     return grow(ctx, &ctx->stage, &ctx->stage_bytes, total);
 }
 
+extern "C" int svx_dev_malloc(svx_ctx* ctx, size_t bytes, void** d_out) {
+    if (!ctx || !d_out) return SVX_E_INVALID;
+    *d_out = nullptr;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        SVX_SET_ERR(ctx, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return SVX_E_NOMEM;
+    }
+    return SVX_OK;
+}
+
+extern "C" int svx_dev_free(svx_ctx* ctx, void* d_ptr) {
+    if (!ctx) return SVX_E_INVALID;
+    if (!d_ptr) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // kernels on the stream may still use it
+    SVX_HIP(ctx, hipFree(d_ptr));
+    return SVX_OK;
+}
+
+extern "C" int svx_dev_upload(svx_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !src))) return SVX_E_INVALID;
+    if (!bytes) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SVX_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // pageable source: the copy is staged before the call returns, `src` may be reused
+    return SVX_OK;
+}
+
+extern "C" int svx_dev_download(svx_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !d_src))) return SVX_E_INVALID;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) SVX_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SVX_OK;
+}
+
 extern "C" int svx_ctx_wait_dominant(svx_ctx* ctx, svx_ctx* other) {
     if (!ctx || !other) return SVX_E_INVALID;
     if (ctx->device != other->device) {

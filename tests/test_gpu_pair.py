@@ -89,30 +89,27 @@ def test_key_layouts(svx_ctx):
 def test_device_entry_points(svx_ctx):
     """svx_pair_partition_dev (derives the live key bits itself) and svx_pair_partition_dev_bits (the
     caller names them; a superset is fine) on device buffers, repeated on one context."""
-    import torch
     rng = np.random.default_rng(8)
-    dev = torch.device("cuda", 0)
     for n in (3000, 70000):
         keys = make_keys(rng, n, 6 * 24, 250_000_000)
-        d_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
-        d_perm = torch.empty(n, dtype=torch.int32, device=dev)
-        d_part = torch.empty(n, dtype=torch.int32, device=dev)
-        d_np = torch.zeros(1, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        d_keys = svx_ctx.dev_array(keys)
+        d_perm = svx_ctx.dev_array(nbytes=4 * n)
+        d_part = svx_ctx.dev_array(nbytes=4 * n)
+        d_np = svx_ctx.dev_array(np.zeros(1, np.uint32))
+        zeros = np.zeros(n, np.uint32)
         e_perm, e_part, e_n = orc.pair_partition(keys, 1000)
         superset = (0xFF << 32) | 0xFFFFFFFF
         for rep in range(3):
             for bits in (None, int(np.bitwise_or.reduce(keys)), superset):
-                d_perm.zero_(); d_part.zero_()
-                torch.cuda.synchronize()
+                for d in (d_perm, d_part):
+                    svx_ctx._check(svx_ctx.lib.svx_dev_upload(svx_ctx.h, d.ptr, zeros.ctypes.data, zeros.nbytes))
                 if bits is None:
-                    rc = svx_ctx.lib.svx_pair_partition_dev(svx_ctx.h, d_keys.data_ptr(), n, 1000, d_perm.data_ptr(),
-                                                            d_part.data_ptr(), d_np.data_ptr())
+                    rc = svx_ctx.lib.svx_pair_partition_dev(svx_ctx.h, d_keys.ptr, n, 1000, d_perm.ptr, d_part.ptr,
+                                                            d_np.ptr)
                 else:
-                    rc = svx_ctx.lib.svx_pair_partition_dev_bits(svx_ctx.h, d_keys.data_ptr(), n, 1000, bits,
-                                                                 d_perm.data_ptr(), d_part.data_ptr(), d_np.data_ptr())
+                    rc = svx_ctx.lib.svx_pair_partition_dev_bits(svx_ctx.h, d_keys.ptr, n, 1000, bits, d_perm.ptr,
+                                                                 d_part.ptr, d_np.ptr)
                 assert rc == 0
-                svx_ctx.sync()
-                assert int(d_np.item()) == e_n
-                assert np.array_equal(d_perm.cpu().numpy().view(np.uint32), e_perm)
-                assert np.array_equal(d_part.cpu().numpy().view(np.uint32), e_part)
+                assert int(d_np.download(np.uint32)[0]) == e_n
+                assert np.array_equal(d_perm.download(np.uint32), e_perm)
+                assert np.array_equal(d_part.download(np.uint32), e_part)
