@@ -44,6 +44,13 @@ def parse():
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to smoke-test the "
                          "multi-rank logic on a box with fewer GPUs than ranks, together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses device 0")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip latency_case / roofline_pair / roofline_editdist / e2e (N=1, rank 0 only, all outside "
+                         "the timed region of `value`)")
+    ap.add_argument("--e2e-scale", type=float, default=0.05,
+                    help="BAM->VCF wall-clock leg: fraction of the GRCh38 contig lengths of the synthetic diploid "
+                         "sample written as real BAM+FASTA files (1.0 = 3.1 Gbp; generation is single-threaded "
+                         "Python, ~20 min at 1.0); 0 skips the leg")
     ap.add_argument("--pipeline", action="store_true",
                     help="alternate two contexts between consecutive steps (independent batches overlap; "
                          "per-kernel durations then overlap too, so the default keeps one context)")
@@ -125,8 +132,251 @@ def cpu_baseline(batch, args):
     return out
 
 
+def _event_ms(ctx, fn, reps):
+    """HIP-event durations (total, dominant) of `reps` calls of fn() on ctx's stream, one at a time."""
+    ctx.set_timing(True)
+    tot, dom = [], []
+    for _ in range(reps):
+        fn()
+        ctx.sync()
+        t, d = ctx.last_kernel_ms()
+        tot.append(t)
+        dom.append(d)
+    ctx.set_timing(False)
+    return float(np.median(tot)), float(np.median(dom))
+
+
+def latency_case(args, local_rank, torch):
+    """The product CLI's operating point: ONE config-2 sample per launch (SVIM_COLLECT launches a1+a2
+    once per BAM).  Same step as the headline (a1+a2 on one stream, a3 on its own), wall-clock per step."""
+    from svim_asm_amd import _lib, synth
+    import ctypes as C
+    dev = torch.device("cuda", local_rank)
+    b = synth.synth_cigar_batch(seed=1000 + args.config * 100, mean_m=4000 if args.config == 2 else 400)
+    n_ops, n_aln = int(b["aln_off"][-1]), len(b["aln_off"]) - 1
+    d_cig = torch.from_numpy(b["cigar"].view(np.int32)).to(dev)
+    d_off = torch.from_numpy(b["aln_off"].astype(np.int64)).to(dev)
+    d_rs = torch.from_numpy(b["ref_start"]).to(dev)
+    cap = max(1024, n_ops // 16)
+    o = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)] + \
+        [torch.empty(cap, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)]
+    outs = tuple(t.data_ptr() for t in o[:5])
+    rng = np.random.default_rng(5)
+    n_reads = max(1, n_aln // 20)
+    k = rng.integers(2, 5, size=n_reads)
+    roff = np.concatenate(([0], np.cumsum(k))).astype(np.uint32)
+    n_segs = int(roff[-1])
+    segs = np.zeros(n_segs, dtype=_lib.SEG_DTYPE)
+    qs = rng.integers(0, 200000, size=n_segs)
+    segs["q_start"] = qs
+    segs["q_end"] = qs + rng.integers(500, 50000, size=n_segs)
+    segs["ref_id"] = rng.integers(0, 24, size=n_segs)
+    segs["ref_start"] = rng.integers(0, 50_000_000, size=n_segs)
+    segs["ref_end"] = segs["ref_start"] + rng.integers(500, 50000, size=n_segs)
+    d_segs = torch.from_numpy(segs.view(np.int32).reshape(-1, 6).copy()).to(dev)
+    d_roff = torch.from_numpy(roff.view(np.int32)).to(dev)
+    d_rl = torch.from_numpy(rng.integers(100000, 5000000, size=n_reads).astype(np.int32)).to(dev)
+    d_raw = torch.empty((n_segs, 8), dtype=torch.int32, device=dev)
+    prm = _lib.SegParams(args.min_sv_size, 100000, 50, 50, 50, 50)
+    c1, c2 = _lib.Context(local_rank), _lib.Context(local_rank)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        c1.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(), args.min_sv_size,
+                             outs, cap, o[5].data_ptr())
+        c2._check(c2.lib.svx_segments_classify_dev(c2.h, d_segs.data_ptr(), n_segs, d_roff.data_ptr(), n_reads,
+                                                   d_rl.data_ptr(), C.byref(prm), d_raw.data_ptr()))
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize(dev)
+    steps = 500
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    n_sig = int(o[5].item())
+    algo = 4 * n_ops + 16 * n_aln + 17 * n_sig
+    path_ms, dom_ms = _event_ms(c1, lambda: c1.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln,
+                                                                  d_rs.data_ptr(), args.min_sv_size, outs, cap,
+                                                                  o[5].data_ptr()), 20)
+    # same answer as the oracle (checker only)
+    from oracle import orc
+    exp = orc.cigar_extract(b["cigar"], b["aln_off"], b["ref_start"], args.min_sv_size)
+    ok = n_sig == len(exp["aln"]) and all(
+        np.array_equal(t[:n_sig].cpu().numpy().view(np.uint32 if key != "type" else np.uint8), exp[key])
+        for t, key in zip(o[:5], ("aln", "ref_pos", "read_pos", "len", "type")))
+    if not ok:
+        raise SystemExit("latency_case output differs from the oracle")
+    c1.close(); c2.close()
+    return {"workload": "BASELINE config %d, ONE sample per launch (%d ops, %d alignments, %d signatures): what "
+                        "`svim-asm haploid` launches per BAM" % (args.config, n_ops, n_aln, n_sig),
+            "ms_per_step": dt * 1e3, "value": n_ops / dt, "unit": "CIGAR ops/s",
+            "algorithmic_bytes": algo, "achieved": algo / dt / 1e9, "frac": algo / dt / 1e9 / HBM_PEAK_GBS,
+            "a1a2_path_ms_hip_events": path_ms, "dominant_kernel_ms": dom_ms, "bit_exact_vs_oracle": True}
+
+
+def roofline_pair(local_rank):
+    """a5+a6 (svx_pair_partition_dev_bits): 20 B per candidate over the HIP-event time of
+    all its kernels, at 60 k (one diploid human sample) and 600 k candidates."""
+    from svim_asm_amd import _lib
+    from oracle import orc
+    ctx = _lib.Context(local_rank)
+    out = []
+    for n in (60_000, 600_000):
+        rng = np.random.default_rng(n)
+        grp = (rng.integers(0, 6, n).astype(np.uint64) << np.uint64(8)) | rng.integers(0, 24, n).astype(np.uint64)
+        keys = (grp << np.uint64(32)) | rng.integers(0, 250_000_000, n).astype(np.uint64)
+        bits = int(np.bitwise_or.reduce(keys))
+        d_k, d_p, d_id = ctx.dev_array(keys), ctx.dev_array(nbytes=4 * n), ctx.dev_array(nbytes=4 * n)
+        d_np = ctx.dev_array(np.zeros(1, np.uint32))
+
+        def call():
+            ctx._check(ctx.lib.svx_pair_partition_dev_bits(ctx.h, d_k.ptr, n, 1000, bits, d_p.ptr, d_id.ptr, d_np.ptr))
+        for _ in range(5):
+            call()
+        ctx.sync()
+        tot_ms, radix_ms = _event_ms(ctx, call, 30)
+        e_perm, e_part, e_n = orc.pair_partition(keys, 1000)
+        if not (np.array_equal(d_p.download(np.uint32), e_perm) and np.array_equal(d_id.download(np.uint32), e_part)
+                and int(d_np.download(np.uint32)[0]) == e_n):
+            raise SystemExit("roofline_pair output differs from the oracle")
+        algo = 20 * n
+        out.append({"candidates": n, "ms": tot_ms, "radix_passes_ms": radix_ms, "algorithmic_bytes": algo,
+                    "achieved": algo / (tot_ms * 1e-3) / 1e9, "frac": algo / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        for d in (d_k, d_p, d_id, d_np):
+            d.free()
+    ctx.close()
+    return {"bound": "hbm", "kernel": "k_pair_init + k_radix_pass x P + k_partition", "unit": "GB/s",
+            "peak": HBM_PEAK_GBS, "bytes_per_candidate": 20, "cases": out, "bit_exact_vs_oracle": True}
+
+
+# VALU instructions per systolic step of k_edit_myers<16> (hot path of the inner loop in the gfx950 ISA,
+# `hipcc -S`; 64-bit logic counts as two): a step updates 64 lanes x 64 rows of the DP matrix
+EDIT_VALU_PER_STEP = 75
+
+
+def _edit_cells(la, lb, k):
+    """DP cells the kernel visits for one pair (strip of 4096 rows x the columns inside Ukkonen's band)."""
+    m, n = max(la, lb), min(la, lb)
+    if n == 0:
+        return 0
+    strips = (m + 4095) // 4096
+    if strips == 1:
+        return n * ((m + 63) // 64) * 64
+    cells = 0
+    for s in range(strips):
+        row_lo, row_hi = s * 4096 + 1, min(m, (s + 1) * 4096)
+        c_lo, c_hi = max(1, row_lo - k), min(n, row_hi + k)
+        if c_hi >= c_lo:
+            cells += (c_hi - c_lo + 1) * ((row_hi - row_lo + 64) // 64) * 64
+    return cells
+
+
+def roofline_editdist(local_rank, n_cu):
+    """a7 (svx_edit_distance_batch, Myers/Hyyro bit-vector kernel): DP cell updates per second against the VALU
+    issue ceiling of the formulation; two workloads: the PAIR step's typical haplotype pairs (threshold 200) and
+    contig-scale alleles (exact)."""
+    from svim_asm_amd import _lib
+    from oracle import orc
+    ctx = _lib.Context(local_rank)
+    rng = np.random.default_rng(11)
+    cases = []
+    for name, n_pairs, lo, hi, k in (("PAIR-like: 20000 haplotype pairs, 240-10200 bases, ~1 % divergence, threshold 200",
+                                      20000, 240, 10200, 200),
+                                     ("long alleles: 64 pairs of 100 kb, exact", 64, 100_000, 100_001, 0xFFFFFFFF)):
+        la = np.exp(rng.uniform(np.log(lo), np.log(hi), n_pairs)).astype(np.int64)
+        seqs, a_off, a_len, b_off, b_len, at = [], [], [], [], [], 0
+        for L in la.tolist():
+            a = rng.integers(0, 4, L).astype(np.uint8)
+            b = a.copy()
+            nm = max(1, L // 100)
+            b[rng.integers(0, L, nm)] = rng.integers(0, 4, nm)
+            cut = int(rng.integers(0, 20))
+            b = b[cut:]
+            a = np.frombuffer(b"ACGT", np.uint8)[a]
+            b = np.frombuffer(b"ACGT", np.uint8)[b]
+            seqs += [a, b]
+            a_off.append(at); a_len.append(len(a)); at += len(a)
+            b_off.append(at); b_len.append(len(b)); at += len(b)
+        pool = np.concatenate(seqs)
+        a_off, b_off = np.array(a_off, np.uint64), np.array(b_off, np.uint64)
+        a_len, b_len = np.array(a_len, np.uint32), np.array(b_len, np.uint32)
+        res = [None]
+
+        def call():
+            res[0] = ctx.edit_distance_batch(pool, a_off, a_len, b_off, b_len, k)
+        call()
+        tot_ms, _ = _event_ms(ctx, call, 5)
+        # checker: the C oracle on a bounded subset
+        idx = rng.choice(n_pairs, size=min(n_pairs, 200 if hi < 50000 else 4), replace=False)
+        for i in idx.tolist():
+            a = pool[int(a_off[i]):int(a_off[i]) + int(a_len[i])].tobytes()
+            b = pool[int(b_off[i]):int(b_off[i]) + int(b_len[i])].tobytes()
+            e = orc.edit_distance_banded(a, b)
+            g = int(res[0][i])
+            if not (g == e or (k != 0xFFFFFFFF and e > k and g > k)):
+                raise SystemExit("roofline_editdist: pair %d: %d != %d" % (i, g, e))
+        band = 200 if k != 0xFFFFFFFF else 256
+        cells = sum(_edit_cells(int(x), int(y), band) for x, y in zip(a_len, b_len))
+        cases.append({"workload": name, "pairs": n_pairs, "ms": tot_ms, "cells": cells,
+                      "achieved": cells / (tot_ms * 1e-3) / 1e9})
+    peak = n_cu * 4 * 2.4e9 / (EDIT_VALU_PER_STEP * 4) * 4096 / 1e9
+    for c in cases:
+        c["frac"] = c["achieved"] / peak
+    ctx.close()
+    return {"bound": "valu", "kernel": "k_edit_myers<16>", "unit": "G cell updates/s", "peak": peak,
+            "peak_basis": "%d CUs x 4 SIMDs x 2.4 GHz / (%d VALU x 4 clk per 64x64-cell step)" % (n_cu, EDIT_VALU_PER_STEP),
+            "cases": cases, "exact_vs_oracle_on_sample": True,
+            "note": "ms = HIP events around the launches of one svx_edit_distance_batch call (host-pointer entry: "
+                    "includes its small per-launch control copies and the result read-back; the exact case counts "
+                    "the cells of the first band only, retries with wider bands are extra work inside the same time)"}
+
+
+def e2e_leg(scale, local_rank):
+    """BAM -> VCF wall-clock of the product pipeline on a synthetic diploid sample (config 3) written as
+    real BAM + FASTA files, phase split, next to the CPU oracle pipeline; VCFs compared."""
+    from tools import e2e_bench
+    r = e2e_bench.run_e2e(scale=scale, repeat=2, device=local_rank)
+    best = r.get("best_run", r)
+    return {"workload": "svim-asm diploid, config 3 at %.3g x GRCh38 contig lengths (%d bp, 2 BAMs of %d / %d bytes)"
+                        % (scale, r["genome_bp"], r["bam_bytes"][0], r["bam_bytes"][1]),
+            "wall_s": best["product_total_s"], "first_run_wall_s": r["product_total_s"],
+            "phases_s": {k: best[k] for k in ("open_index_s", "collect_s", "pair_s", "vcf_s")},
+            "oracle_pipeline_wall_s": r.get("oracle_total_s"), "vcf_identical": r.get("vcf_identical"),
+            "vcf_records": r["vcf_records"], "cigar_ops": r["cigar_ops"], "candidates": r["candidates"],
+            "ingest_threads": r["ingest_threads"], "index_state": r["index_state"],
+            "generate_s": r["generate_s"],
+            "note": "outside the timed region of `value`; full scale (1.0) is run with tools/e2e_bench.py and kept "
+                    "under profiles/"}
+
+
+def relaunch_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run from this
+    process, which has not touched the GPU, and exit with its status (never exec after GPU init)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus <= 1 or world == args.gpus:
+        return
+    if world != 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port 29511 bench.py "
+                         "--gpus %d ...`" % (args.gpus, world, args.gpus, args.gpus))
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    relaunch_if_needed(args)
     import torch
     import torch.distributed as dist
 
@@ -268,8 +518,13 @@ def main():
     ctx.set_timing(False)
     k_avg = float(np.mean(k_ms)) * 1e-3
     p_avg = float(np.mean(p_ms)) * 1e-3
-    algo_bytes = 4 * n_ops + 16 * n_aln + 17 * n_sig
-    achieved = algo_bytes / k_avg / 1e9
+    algo_bytes = 4 * n_ops + 16 * n_aln + 17 * n_sig  # SURVEY.md §8(d), whole a1+a2 path
+    # what the dominant kernel itself moves of those: the op stream, aln_off, its slab records (16 B per
+    # signature) and one 16-B descriptor + one 4-B start index per tile; the 17-B final records are written by
+    # the finish kernel and only count for the path figure
+    n_tiles = (n_ops + 4095) // 4096
+    kernel_bytes = 4 * n_ops + 8 * n_aln + 16 * n_sig + 20 * n_tiles
+    achieved = kernel_bytes / k_avg / 1e9
 
     # measured device-copy ceiling of this box (SURVEY.md §8d asks for both denominators): 1 GiB
     # device-to-device copy, bytes read + written over its duration
@@ -301,6 +556,7 @@ def main():
         ok = (np.array_equal(o_ref[:k].cpu().numpy().view(np.uint32), exp["ref_pos"]) and
               np.array_equal(o_read[:k].cpu().numpy().view(np.uint32), exp["read_pos"]) and
               np.array_equal(o_aln[:k].cpu().numpy().view(np.uint32), exp["aln"]) and
+              np.array_equal(o_len[:k].cpu().numpy().view(np.uint32), exp["len"]) and
               np.array_equal(o_type[:k].cpu().numpy(), exp["type"]))
         if not ok and not os.environ.get("SVX_BENCH_NOCHECK"):  # (ablation builds of tools/ skip the check)
             raise SystemExit("bench output differs from the oracle on the checked prefix")
@@ -341,14 +597,26 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "k_cigar_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_avg * 1e3,
+                "kernel_bytes_per_launch": kernel_bytes, "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms": k_avg * 1e3,
                 "path_ms": p_avg * 1e3, "path_achieved": algo_bytes / p_avg / 1e9,
+                "path_frac": algo_bytes / p_avg / 1e9 / HBM_PEAK_GBS,
                 "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
             },
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             res["cpu_baseline"] = cpu_baseline(batch, args)
             res["speedup_vs_cpu_port"] = res["value"] / res["cpu_baseline"]["value"]
+        if not args.no_extras and world == 1:
+            for c in ctxs + [ctx2]:
+                c.sync()
+            del d_cig, d_op, out_sets  # the cohort is not needed any more
+            torch.cuda.empty_cache()
+            res["latency_case"] = latency_case(args, local_rank, torch)
+            res["roofline_pair"] = roofline_pair(local_rank)
+            res["roofline_editdist"] = roofline_editdist(local_rank, torch.cuda.get_device_properties(dev).multi_processor_count)
+            if args.e2e_scale > 0:
+                res["e2e"] = e2e_leg(args.e2e_scale, local_rank)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

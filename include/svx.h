@@ -61,6 +61,13 @@ const char* svx_version(void);
 /* Number of visible HIP devices (0 when none / no driver). Never fails. */
 int svx_device_count(void);
 
+/* svx_cigar_extract* run batches of at most `max_ops` CIGAR ops in TWO kernel launches (tiles of 1024
+ * ops; every workgroup of the second kernel scans all tile descriptors itself): the operating point of
+ * the svim-asm CLI, one BAM of an assembly per call (~1.5 M ops), where five dependent launches cost
+ * more than the work.  Larger batches take the streaming path (tiles of 4096 ops, five launches).
+ * Default and upper limit 2^21 ops; 0 disables the small-batch path.  Results are identical on both. */
+int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
+
 /* Device buffers for callers that have no other owner of HBM (a ctypes binding without torch, the
  * tests): plain hipMalloc / hipFree / hipMemcpyAsync on the context's device and stream.
  * svx_dev_upload and svx_dev_download are ordered on the context's stream with the kernels of the

@@ -354,14 +354,22 @@ __device__ uint32_t g_prof[kProfTiles * 8];  // 5 phase sums (shader clocks), li
 #define SVX_PROF_ADD(i, d)
 #endif
 
-// One tile (4096 ops) processed by one wave.  MODE_STAGE: signatures go to the tile's slab with
-// tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
-template <int MODE, bool SOA>
+// What a tile needs from outside.  MODE_STAGE: where a_lo (alignments that start before the tile)
+// comes from; MODE_DIRECT: a_lo, the carry-in and the output base, all known to the caller.
+enum { ALO_TABLE = 0, ALO_SEARCH = 1, ALO_GIVEN = 2 };
+struct TileIn {
+    uint32_t a_lo, carry_r, carry_d, obase;
+};
+
+// One tile (TILE_OPS <= 4096 ops) processed by one wave.  MODE_STAGE: signatures go to the tile's slab
+// with tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
+template <int MODE, bool SOA, int TILE_OPS, int ALO>
 __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t tile, const int lane, uint4* xp,
-                                             uint32_t* hmask, uint4* queue, uint4* stage) {
+                                             uint32_t* hmask, uint4* queue, uint4* stage, const TileIn& in) {
+    static_assert(TILE_OPS % kRoundOps == 0 && TILE_OPS <= kTileOps, "a tile is 1..kRounds whole rounds");
     uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
-    const uint64_t g0 = (uint64_t)tile * kTileOps;
-    const uint64_t tile_end = (g0 + kTileOps < p.n_ops) ? g0 + kTileOps : p.n_ops;
+    const uint64_t g0 = (uint64_t)tile * TILE_OPS;
+    const uint64_t tile_end = (g0 + TILE_OPS < p.n_ops) ? g0 + TILE_OPS : p.n_ops;
 
     // first round's loads go out before the (latency-bound) alignment-start lookup
     const uint32_t tile_len = (uint32_t)(tile_end - g0);
@@ -382,7 +390,9 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
 
     // ---- alignment starts inside this tile → 4096-bit mask in LDS; `dup` = two alignments start
     // at the same op (empty alignments), which disables the popcount shortcut for the index ----
-    const uint32_t a_lo = p.tile_alo[tile];  // wave-uniform: one scalar load instead of a 4-level search
+    // wave-uniform: one scalar load (start table of k_tile_alo), a 64-ary search (single-launch path), or given
+    const uint32_t a_lo = ALO == ALO_TABLE ? p.tile_alo[tile]
+                        : ALO == ALO_SEARCH ? (g0 ? wave_lower_bound(p.aln_off, p.n_aln, g0, lane) : 0u) : in.a_lo;
 #pragma unroll
     for (int i = lane; i < kTileOps / 32; i += 64) hmask[i] = 0;
     wave_lds_sync();
@@ -444,25 +454,19 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     auto drain = [&](uint32_t upto) {  // slab ranks [stage_base, upto) leave LDS
         const uint32_t n = upto - stage_base;
         if ((uint32_t)lane < n && stage_base + (uint32_t)lane < (uint32_t)kSlab) {
+            // streaming store: the slab is written once and read once by k_cigar_finish
             const uint4 v = stage[lane];
-#ifndef SVX_NO_NTSTORE  // streaming store: the slab is written once and read once by k_cigar_finish
             u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
             __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p.slab + (uint64_t)tile * kSlab + stage_base + lane));
-#else
-            p.slab[(uint64_t)tile * kSlab + stage_base + lane] = v;
-#endif
         }
         stage_base = upto;
     };
     uint32_t obase = 0;
     if (MODE == MODE_DIRECT) {
-        const uint4 bp = p.blk_prefix[tile / kScanBlock];
-        const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
-        const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
-        carry_r = local_head ? lr : lr + bp.y;
-        carry_d = local_head ? ld : ld + bp.z;
+        carry_r = in.carry_r;
+        carry_d = in.carry_d;
         seen = true;  // carry-in already holds "since the last start before the tile"
-        obase = (lb & 0x7FFFFFFFu) + bp.w;
+        obase = in.obase;
     }
 
     for (int round = 0; round < kRounds; ++round) {
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void k_tile_alo(const uint64_t* __restrict__ a
 }
 
 // ---- A: stream every tile once ----
-template <bool SOA>
+template <bool SOA, int TILE_OPS, int ALO>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kTileOps / 32];  // start mask, then the queue
@@ -649,8 +653,8 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves)
-        process_tile<MODE_STAGE, SOA>(p, tile, lane, s_xpose[wave], s_head[wave], reinterpret_cast<uint4*>(s_head[wave]),
-                                      s_stage[wave]);
+        process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
+                                                                  reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
 }
 
 // ---- B: segmented exclusive scan over tile descriptors ----
@@ -702,15 +706,19 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
             carry_read[t] = xf ? xd : pd_ + xd;
             out_base[t] = (pc + xc) | ((xf | pf) << 31);
         }
-        if (tid == 0) blk_agg[blockIdx.x] = make_uint4(af, ar, ad, ac);
+        // the aggregate is the only thing another workgroup of THIS launch reads: stored write-through
+        // (sc0 sc1) and read back with sc1 loads by the last workgroup, so no cache-wide release /
+        // acquire fence is needed (each costs microseconds: MI355X_MICROARCH.md, inter-workgroup visibility)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its dense-tile atomics have been performed
+        __syncthreads();
+        if (tid == 0) {
+            u32x4 w; w.x = af; w.y = ar; w.z = ad; w.w = ac;
+            __builtin_amdgcn_raw_buffer_store_b128(w, make_rsrc(blk_agg, n_blocks * 16u), (int)(blockIdx.x * 16u), 0, 17);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = (atomicAdd(ticket, 1u) == n_blocks - 1) ? 1u : 0u;
+        }
     }
-    // ---- last-arriving workgroup scans the block aggregates (one lane fences for the block) ----
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();  // release: this block's results are visible device-wide before the ticket
-        s_last = (atomicAdd(ticket, 1u) == n_blocks - 1) ? 1u : 0u;
-        if (s_last) __threadfence();  // acquire: drop stale lines before reading the other blocks' aggregates
-    }
+    // ---- last-arriving workgroup scans the block aggregates ----
     __syncthreads();
     if (!s_last) return;
     uint32_t cf = 0, cr = 0, cd = 0;
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
         const uint32_t b = base + tid;
         uint32_t f = 0, sr = 0, sd = 0, sc = 0;
         if (b < n_blocks) {
-            const uint4 v = blk_agg[b];
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(blk_agg, n_blocks * 16u), (int)(b * 16u), 0, 17);
             f = v.x; sr = v.y; sd = v.z; sc = v.w;
         }
         SVX_SEG_SCAN()
@@ -745,9 +753,8 @@ __global__ __launch_bounds__(kScanBlock) void k_desc_scan(const uint4* __restric
     if (tid == 0) {
         *n_out = cc;
         // publish the dense-tile count and leave the counters zeroed for the next call
-        n_dense[2] = n_dense[0];
-        n_dense[0] = 0;
-        *ticket = 0;
+        n_dense[2] = atomicExch(&n_dense[0], 0u);  // (read where the other workgroups' atomics were performed)
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -813,9 +820,144 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_dense
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t n_dense = p.n_dense[2];
-    for (uint32_t work = blockIdx.x * kWaves + wave; work < n_dense; work += gridDim.x * kWaves)
-        process_tile<MODE_DIRECT, SOA>(p, p.dense_list[work], lane, s_xpose[wave], s_head[wave],
-                                       reinterpret_cast<uint4*>(s_head[wave]), nullptr);
+    for (uint32_t work = blockIdx.x * kWaves + wave; work < n_dense; work += gridDim.x * kWaves) {
+        const uint32_t tile = p.dense_list[work];
+        const uint4 bp = p.blk_prefix[tile / kScanBlock];
+        const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
+        const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
+        TileIn in;
+        in.a_lo = p.tile_alo[tile];
+        in.carry_r = local_head ? lr : lr + bp.y;
+        in.carry_d = local_head ? ld : ld + bp.z;
+        in.obase = (lb & 0x7FFFFFFFu) + bp.w;
+        process_tile<MODE_DIRECT, SOA, kTileOps, ALO_GIVEN>(p, tile, lane, s_xpose[wave], s_head[wave],
+                                                                   reinterpret_cast<uint4*>(s_head[wave]), nullptr, in);
+    }
+}
+
+// ---- two-launch path for small batches (one BAM of a human assembly: ~1.5 M ops) ----
+// Five dependent launches cost more than the work itself below a chip-load of tiles, and a tile
+// of 4096 ops per wave leaves most of the chip idle.  Here: k_cigar_tiles with tiles of 1024 ops
+// (one round per wave: 4x the waves for the same batch) and the tile's start index from a 64-ary
+// search instead of a table kernel; then ONE kernel in which every workgroup scans ALL tile
+// descriptors itself (at most 2048 x 16 B, L2-resident: cheaper than a scan kernel plus a launch
+// gap, and no tickets, fences or waiting), copies the records of its own 16 tiles to the final SoA
+// and re-walks those of them that are dense.
+constexpr int kSmallTileOps = kRoundOps;            // 1024 ops
+constexpr uint32_t kSmallMaxTiles = 2048;           // batches up to 2 M ops take this path
+constexpr int kSmallPer = kSmallMaxTiles / 256;     // descriptors per thread in the scan
+
+template <bool SOA>
+__global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_t* __restrict__ n_out) {
+    __shared__ uint32_t s_cr[kSmallMaxTiles], s_cd[kSmallMaxTiles], s_ob[kSmallMaxTiles];
+    __shared__ uint4 s_xpose[kWaves][kXposeU4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kTileOps / 32];
+    __shared__ uint32_t s_f[4], s_r[4], s_d[4], s_c[4];
+    static_assert(kWaves == 4, "256 threads");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- the tile this thread's 16-lane group finishes: its records are requested before the scan
+    const uint32_t tile = blockIdx.x * (256u / kFinLanes) + tid / kFinLanes;
+    const uint32_t l = tid % kFinLanes;
+    const bool mine = tile < p.n_tiles;
+    uint4 spec[kFinSpec];
+#pragma unroll
+    for (int k = 0; k < kFinSpec; ++k)
+        spec[k] = mine ? p.slab[(uint64_t)tile * kSlab + l + k * kFinLanes] : make_uint4(0, 0, 0, 0);
+    const uint4 dsc = mine ? p.desc[tile] : make_uint4(0, 0, 0, 0);
+
+    // ---- segmented exclusive scan over all descriptors: kSmallPer consecutive ones per thread
+    uint32_t lr[kSmallPer], ld[kSmallPer], lc[kSmallPer], lf = 0;  // exclusive inside the thread; lf: bit i = a start before item i
+    uint32_t f = 0, sr = 0, sd = 0, sc = 0;
+    {
+        uint4 d[kSmallPer];
+#pragma unroll
+        for (int i = 0; i < kSmallPer; ++i) {
+            const uint32_t t = (uint32_t)tid * kSmallPer + i;
+            d[i] = t < p.n_tiles ? p.desc[t] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < kSmallPer; ++i) {
+            lr[i] = sr; ld[i] = sd; lc[i] = sc;
+            lf |= f << i;
+            if (d[i].x >> 31) { f = 1; sr = d[i].y; sd = d[i].z; }
+            else { sr += d[i].y; sd += d[i].z; }
+            sc += d[i].x & 0x3FFFFFFFu;
+        }
+    }
+    const uint32_t tf = f, tr = sr, td = sd, tc = sc;  // this thread's aggregate
+    SVX_SEG_SCAN()
+    if (lane == 63) { s_f[wave] = f; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
+    __syncthreads();
+    uint32_t pr_ = 0, pd_ = 0, pc = 0, ar = 0, ad = 0, ac = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+        if (w2 == wave) { pr_ = ar; pd_ = ad; pc = ac; }
+        if (s_f[w2]) { ar = s_r[w2]; ad = s_d[w2]; }
+        else { ar += s_r[w2]; ad += s_d[w2]; }
+        ac += s_c[w2];
+    }
+    const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
+                   xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
+    const uint32_t Tr = xf ? xr : pr_ + xr, Td = xf ? xd : pd_ + xd, Tc = pc + xc;  // exclusive over the threads before
+    (void)tf; (void)tr; (void)td; (void)tc;
+#pragma unroll
+    for (int i = 0; i < kSmallPer; ++i) {
+        const uint32_t t = (uint32_t)tid * kSmallPer + i;
+        const bool own = (lf >> i) & 1u;  // a start inside this thread's earlier items
+        s_cr[t] = own ? lr[i] : Tr + lr[i];
+        s_cd[t] = own ? ld[i] : Td + ld[i];
+        s_ob[t] = Tc + lc[i];
+    }
+    if (blockIdx.x == 0 && tid == 255) *n_out = (uint64_t)ac;
+    __syncthreads();
+
+    // ---- finish, sparse tiles (as k_cigar_finish): 16 lanes per tile
+    const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
+    const bool dense = cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense);
+    if (mine && cnt && !dense) {
+        const uint32_t cr = s_cr[tile], cd = s_cd[tile];
+        const uint64_t ob = s_ob[tile];
+        uint32_t rs[kFinSpec];
+#pragma unroll
+        for (int k = 0; k < kFinSpec; ++k)
+            rs[k] = (l + k * kFinLanes < cnt && p.ref_start) ? (uint32_t)p.ref_start[spec[k].x] : 0u;
+#pragma unroll
+        for (int k = 0; k < kFinSpec; ++k) {
+            const uint32_t r = l + k * kFinLanes;
+            if (r < cnt && ob + r < p.cap) {
+                const uint4 rec = spec[k];
+                const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+                p.out.aln[ob + r] = rec.x;
+                p.out.ref_pos[ob + r] = rec.y + (prec ? cr : 0u) + rs[k];
+                p.out.read_pos[ob + r] = rec.z + (prec ? cd : 0u);
+                p.out.len[ob + r] = len;
+                p.out.type[ob + r] = (uint8_t)type;
+            }
+        }
+        for (uint32_t r = l + kFinSpec * kFinLanes; r < cnt; r += kFinLanes) {
+            const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
+            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+            store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
+        }
+    }
+    // ---- dense tiles among this workgroup's 16 (rare): one wave each, re-walked with carry-in and
+    // output base known
+    const uint32_t t0 = blockIdx.x * (256u / kFinLanes);
+    for (uint32_t j = wave; j < 256u / kFinLanes; j += kWaves) {
+        const uint32_t t = t0 + j;
+        if (t >= p.n_tiles) break;
+        const uint4 dd = p.desc[t];  // wave-uniform
+        const uint32_t c = __builtin_amdgcn_readfirstlane(dd.x);
+        if ((c & 0x3FFFFFFFu) > (uint32_t)kSlab || (c & kDescForceDense)) {
+            TileIn in;
+            in.a_lo = __builtin_amdgcn_readfirstlane(dd.w);
+            in.carry_r = s_cr[t];
+            in.carry_d = s_cd[t];
+            in.obase = s_ob[t];
+            process_tile<MODE_DIRECT, SOA, kSmallTileOps, ALO_GIVEN>(p, t, lane, s_xpose[wave], s_head[wave],
+                                                                            reinterpret_cast<uint4*>(s_head[wave]), nullptr, in);
+        }
+    }
 }
 
 // ---- per-alignment CIGAR statistics: one wave per alignment ----
@@ -898,7 +1040,9 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
         SVX_SET_ERR(ctx, "device CIGAR buffers must be 16-byte aligned");
         return SVX_E_INVALID;
     }
-    const uint32_t n_tiles = (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
+    const bool small = n_ops <= (uint64_t)kSmallMaxTiles * kSmallTileOps && n_ops <= ctx->small_batch_ops;
+    const uint32_t n_tiles = small ? (uint32_t)((n_ops + kSmallTileOps - 1) / kSmallTileOps)
+                                   : (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
     size_t need = svx_take_bytes(n_tiles, sizeof(uint4)) +
                   svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
                   5 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
@@ -929,6 +1073,25 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     a.out = d_out;
     a.cap = cap;
 
+    if (small) {  // two launches: tiles of 1024 ops; scan + finish + dense tiles
+        rc = svx_timing_begin(ctx);
+        if (rc != SVX_OK) return rc;
+        rc = svx_timing_mark(ctx, 1);
+        if (rc != SVX_OK) return rc;
+        hipLaunchKernelGGL((k_cigar_tiles<SOA, kSmallTileOps, ALO_SEARCH>), dim3((n_tiles + kWaves - 1) / kWaves),
+                           dim3(64 * kWaves), 0, ctx->stream, a);
+        rc = svx_timing_mark(ctx, 2);
+        if (rc != SVX_OK) return rc;
+        if (ctx->want_dom) {
+            if (!ctx->ev_dom) SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dom, hipEventDisableTiming));
+            SVX_HIP(ctx, hipEventRecord(ctx->ev_dom, ctx->stream));
+            ctx->ev_dom_recorded = true;
+        }
+        hipLaunchKernelGGL((k_cigar_finish_small<SOA>), dim3((n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes)), dim3(256),
+                           0, ctx->stream, a, d_n_out);
+        SVX_HIP(ctx, hipGetLastError());
+        return svx_timing_end(ctx);
+    }
     const uint32_t blocks_all = (n_tiles + kWaves - 1) / kWaves;
     const uint32_t blocks_cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
@@ -937,7 +1100,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
                        a.tile_alo);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-    hipLaunchKernelGGL((k_cigar_tiles<SOA>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)

@@ -101,6 +101,12 @@ int svx_stage_reserve(svx_ctx* ctx, size_t total) {
     return grow(ctx, &ctx->stage, &ctx->stage_bytes, total);
 }
 
+extern "C" int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops) {
+    if (!ctx) return SVX_E_INVALID;
+    ctx->small_batch_ops = max_ops;
+    return SVX_OK;
+}
+
 extern "C" int svx_dev_malloc(svx_ctx* ctx, size_t bytes, void** d_out) {
     if (!ctx || !d_out) return SVX_E_INVALID;
     *d_out = nullptr;

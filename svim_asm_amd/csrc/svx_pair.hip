@@ -28,11 +28,10 @@
 
 namespace {
 
-constexpr int kChunk = 1024;
-constexpr int kIters = kChunk / 64;
 constexpr int kMaxDigitBits = 9;
 constexpr int kBuckets = 1 << kMaxDigitBits;
 constexpr uint32_t kSingleBlockMax = 16384;
+constexpr uint32_t kSmallSortMax = 131072;
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -49,9 +48,9 @@ struct KeyFields {  // dense = OR over f of ((key >> shift[f]) & mask[f]) << off
 struct PairBufs {
     uint64_t* keys[2];  // dense keys, ping-pong
     uint32_t* idx[2];
-    uint32_t* hist;     // [passes][n_chunks][kBuckets]
+    uint32_t* hist;     // [passes][n_blocks][kBuckets]
     uint32_t n;
-    uint32_t n_chunks;
+    uint32_t n_blocks;
     uint32_t passes;
     uint32_t digit_bits;
     KeyFields f;
@@ -75,39 +74,39 @@ __global__ __launch_bounds__(256) void k_key_or(const uint64_t* __restrict__ key
     if ((threadIdx.x & 63) == 0 && acc) atomicOr(out, (unsigned long long)acc);
 }
 
+// One workgroup (4 waves) per block of 256 * ITERS keys; wave w owns the w-th quarter of the block
+// (contiguous, so wave order == key order), 64 consecutive keys per iteration.
+template <int ITERS>
 __global__ __launch_bounds__(256) void k_pair_init(const uint64_t* __restrict__ keys, PairBufs b) {
-    __shared__ uint32_t s_h[4][kBuckets];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ uint32_t s_h[kBuckets];
+    const int tid = threadIdx.x;
     const uint32_t dmask = (1u << b.digit_bits) - 1u;
-    uint32_t* h = s_h[wave];
     // zero the histograms of the later passes (counted into by the scatter of the pass before)
     {
-        const size_t total = (size_t)(b.passes - 1) * b.n_chunks * kBuckets;
-        uint32_t* later = b.hist + (size_t)b.n_chunks * kBuckets;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-            later[i] = 0;
+        const size_t total = (size_t)(b.passes - 1) * b.n_blocks * kBuckets;
+        uint32_t* later = b.hist + (size_t)b.n_blocks * kBuckets;
+        for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) later[i] = 0;
     }
-    for (uint32_t chunk = blockIdx.x * 4 + wave; chunk < b.n_chunks; chunk += gridDim.x * 4) {
-        for (int i = lane; i < kBuckets; i += 64) h[i] = 0;
-        wave_lds_sync();
-        const uint32_t base = chunk * kChunk;
-        for (int it = 0; it < kIters; ++it) {
-            const uint32_t i = base + it * 64 + lane;
-            if (i < b.n) {
-                const uint64_t d = dense_key(b.f, keys[i]);
-                b.keys[0][i] = d;
-                b.idx[0][i] = i;
-                atomicAdd(&h[(uint32_t)d & dmask], 1u);
-            }
+    for (int v = tid; v < kBuckets; v += 256) s_h[v] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (256u * ITERS);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const uint32_t i = base + it * 256 + tid;
+        if (i < b.n) {
+            const uint64_t d = dense_key(b.f, keys[i]);
+            b.keys[0][i] = d;
+            b.idx[0][i] = i;
+            atomicAdd(&s_h[(uint32_t)d & dmask], 1u);
         }
-        wave_lds_sync();
-        for (int i = lane; i < kBuckets; i += 64) b.hist[(size_t)chunk * kBuckets + i] = h[i];
-        wave_lds_sync();
     }
+    __syncthreads();
+    for (int v = tid; v < kBuckets; v += 256) b.hist[(size_t)blockIdx.x * kBuckets + v] = s_h[v];
 }
 
+template <int ITERS>
 __global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
-    __shared__ uint32_t s_run[4][kBuckets];  // running output position per (wave, digit)
+    __shared__ uint32_t s_run[4][kBuckets];  // per (wave, digit): count, then running output position
     __shared__ uint32_t s_tot[kBuckets];
     __shared__ uint32_t s_w[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -119,69 +118,87 @@ __global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
     const uint32_t* __restrict__ si = b.idx[sb];
     uint64_t* __restrict__ dk = b.keys[sb ^ 1];
     uint32_t* __restrict__ di = b.idx[sb ^ 1];
-    const uint32_t* __restrict__ hist = b.hist + (size_t)pass * b.n_chunks * kBuckets;
-    uint32_t* __restrict__ hnext = pass + 1 < b.passes ? b.hist + (size_t)(pass + 1) * b.n_chunks * kBuckets : nullptr;
-    const uint32_t chunk0 = blockIdx.x * 4;
+    const uint32_t* __restrict__ hist = b.hist + (size_t)pass * b.n_blocks * kBuckets;
+    uint32_t* __restrict__ hnext = pass + 1 < b.passes ? b.hist + (size_t)(pass + 1) * b.n_blocks * kBuckets : nullptr;
+    constexpr uint32_t kBlockKeys = 256u * ITERS;
 
-    // ---- global bucket offsets of this workgroup's four chunks: column sums over the table
-    for (uint32_t v = tid; v < nb; v += 256) {
-        uint32_t before = 0, total = 0, mine[4] = {0, 0, 0, 0};
-        for (uint32_t c = 0; c < b.n_chunks; ++c) {
-            const uint32_t x = hist[(size_t)c * kBuckets + v];
-            total += x;
-            if (c < chunk0) before += x;
-            else if (c < chunk0 + 4) mine[c - chunk0] = x;
-        }
-        s_tot[v] = total;
-        uint32_t acc = before;
+    // ---- this wave's keys (registers) and its digit counts (LDS)
+    for (int v = tid; v < 4 * kBuckets; v += 256) (&s_run[0][0])[v] = 0;
+    uint64_t key[ITERS];
+    uint32_t id[ITERS];
+    const uint32_t base = blockIdx.x * kBlockKeys + wave * (64u * ITERS);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            s_run[w][v] = acc;
-            acc += mine[w];
+    for (int it = 0; it < ITERS; ++it) {
+        const uint32_t i = base + it * 64 + lane;
+        key[it] = 0;
+        id[it] = 0;
+        if (i < b.n) { key[it] = sk[i]; id[it] = si[i]; }
+    }
+    // ---- global bucket offsets of this block: column sums over the blocks' histograms (two buckets per
+    // thread, one 8-byte load per row, 16 rows in flight)
+    uint32_t before0 = 0, before1 = 0, total0 = 0, total1 = 0;
+    {
+        const uint2* __restrict__ col = reinterpret_cast<const uint2*>(hist) + tid;
+        uint32_t c = 0;
+        for (; c + 16 <= b.n_blocks; c += 16) {
+            uint2 x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = col[(size_t)(c + u) * (kBuckets / 2)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                total0 += x[u].x; total1 += x[u].y;
+                if (c + u < blockIdx.x) { before0 += x[u].x; before1 += x[u].y; }
+            }
+        }
+        for (; c < b.n_blocks; ++c) {
+            const uint2 x = col[(size_t)c * (kBuckets / 2)];
+            total0 += x.x; total1 += x.y;
+            if (c < blockIdx.x) { before0 += x.x; before1 += x.y; }
         }
     }
-    __syncthreads();
-    // exclusive scan of the bucket totals (nb <= 512: two values per thread)
+    __syncthreads();  // s_run zeroed
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+        if (base + it * 64 + lane < b.n) atomicAdd(&s_run[wave][(uint32_t)(key[it] >> shift) & dmask], 1u);
+    // exclusive scan of the bucket totals over the workgroup (thread t holds buckets 2t, 2t+1)
     {
-        const uint32_t a0 = 2 * tid < nb ? s_tot[2 * tid] : 0u, a1 = 2 * tid + 1 < nb ? s_tot[2 * tid + 1] : 0u;
-        uint32_t s = a0 + a1;
+        uint32_t s = total0 + total1;
 #pragma unroll
         for (int k = 1; k < 64; k <<= 1) {
             const uint32_t t = __shfl_up(s, k);
             if (lane >= k) s += t;
         }
         if (lane == 63) s_w[wave] = s;
-        __syncthreads();
+        __syncthreads();  // also: every wave's counts are in s_run
         uint32_t wp = 0;
         for (int w = 0; w < wave; ++w) wp += s_w[w];
-        const uint32_t ex = wp + s - (a0 + a1);
-        __syncthreads();
-        if (2 * tid < nb) s_tot[2 * tid] = ex;
-        if (2 * tid + 1 < nb) s_tot[2 * tid + 1] = ex + a0;
-    }
-    __syncthreads();
-    for (uint32_t v = tid; v < nb; v += 256) {
-        const uint32_t t = s_tot[v];
+        const uint32_t ex = wp + s - (total0 + total1);
+        // counts -> starting positions: global base of the bucket + this block's earlier waves
+        uint32_t acc0 = ex + before0, acc1 = ex + total0 + before1;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s_run[w][v] += t;
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c0 = s_run[w][2 * tid], c1 = s_run[w][2 * tid + 1];
+            s_run[w][2 * tid] = acc0;
+            s_run[w][2 * tid + 1] = acc1;
+            acc0 += c0;
+            acc1 += c1;
+        }
     }
     __syncthreads();
+    (void)nb;
+    (void)s_tot;
 
-    // ---- one wave per chunk: stable ranking with match masks, scatter, next digit's counts
-    const uint32_t chunk = chunk0 + wave;
-    if (chunk >= b.n_chunks) return;
+    // ---- one wave per quarter block: stable ranking with match masks, scatter, next digit's counts
     uint32_t* run = s_run[wave];
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t base = chunk * kChunk;
     const uint32_t nshift = shift + b.digit_bits;
-    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
         const uint32_t i = base + it * 64 + lane;
         const bool valid = i < b.n;
-        uint64_t key = 0;
-        uint32_t id = 0;
-        if (valid) { key = sk[i]; id = si[i]; }
-        const uint32_t dig = (uint32_t)(key >> shift) & dmask;
+        const uint32_t dig = (uint32_t)(key[it] >> shift) & dmask;
         uint64_t m = __ballot(valid);
+        if (m == 0) break;  // wave-uniform: nothing left in this quarter
         for (uint32_t bit = 0; bit < b.digit_bits; ++bit) {
             const uint64_t bal = __ballot((dig >> bit) & 1u);
             m &= ((dig >> bit) & 1u) ? bal : ~bal;
@@ -193,16 +210,17 @@ __global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
         if (valid && rank == 0) run[dig] += __popcll(m);
         wave_lds_sync();
         if (valid) {
-            dk[pos] = key;
-            di[pos] = id;
-            if (hnext) atomicAdd(&hnext[(size_t)(pos / kChunk) * kBuckets + ((uint32_t)(key >> nshift) & dmask)], 1u);
+            dk[pos] = key[it];
+            di[pos] = id[it];
+            if (hnext) atomicAdd(&hnext[(size_t)(pos / kBlockKeys) * kBuckets + ((uint32_t)(key[it] >> nshift) & dmask)], 1u);
         }
     }
 }
 
 struct PartArgs {
-    const uint64_t* keys;     // original keys
-    const uint32_t* sorted;   // sorted permutation (idx buffer after the last pass)
+    const uint64_t* sorted_keys;  // dense keys in sorted order (after the last pass)
+    const uint32_t* sorted;       // the permutation that goes with them
+    KeyFields f;                  // dense -> original key
     uint32_t n;
     uint32_t max_dist;
     uint32_t* perm;
@@ -212,11 +230,19 @@ struct PartArgs {
     uint32_t* counter;        // self-cleaning arrival counter (workspace header)
 };
 
-__device__ __forceinline__ uint32_t boundary_flag(const PartArgs& p, uint32_t j, uint32_t* perm_out) {
-    const uint32_t me = p.sorted[j];
-    *perm_out = me;
+// every set bit of an original key lies inside the fields (the caller's key_bits cover all keys), so the
+// dense key expands back to it exactly: the sweep reads the sorted keys contiguously, no gather
+__device__ __forceinline__ uint64_t original_key(const KeyFields& f, uint64_t d) {
+    uint64_t k = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i)
+        if (i < f.n) k |= ((d >> f.off[i]) & f.mask[i]) << f.shift[i];
+    return k;
+}
+
+__device__ __forceinline__ uint32_t boundary_flag(const PartArgs& p, uint32_t j) {
     if (j == 0) return 0;
-    const uint64_t a = p.keys[p.sorted[j - 1]], c = p.keys[me];
+    const uint64_t a = original_key(p.f, p.sorted_keys[j - 1]), c = original_key(p.f, p.sorted_keys[j]);
     const uint32_t pa = (uint32_t)a, pc = (uint32_t)c;
     const uint32_t dist = pa > pc ? pa - pc : pc - pa;
     return ((a >> 32) != (c >> 32) || dist > p.max_dist) ? 1u : 0u;  // SVIM_COMBINE.py:24-26
@@ -253,10 +279,7 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
     uint32_t carry = 0;
     if (gridDim.x > 1) {
         uint32_t cnt = 0;
-        for (uint32_t j = lo + threadIdx.x; j < hi; j += 1024) {
-            uint32_t dummy;
-            cnt += boundary_flag(p, j, &dummy);
-        }
+        for (uint32_t j = lo + threadIdx.x; j < hi; j += 1024) cnt += boundary_flag(p, j);
         uint32_t tot;
         (void)block_scan_1024(cnt, s_w, &tot);
         if (threadIdx.x == 0) {
@@ -282,13 +305,13 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
     }
     for (uint32_t base = lo; base < hi; base += 1024) {
         const uint32_t j = base + threadIdx.x;
-        uint32_t flag = 0, me = 0;
-        if (j < hi) flag = boundary_flag(p, j, &me);
+        uint32_t flag = 0;
+        if (j < hi) flag = boundary_flag(p, j);
         uint32_t tot;
         const uint32_t s = block_scan_1024(flag, s_w, &tot);
         if (j < hi) {
             p.part_id[j] = carry + s;
-            p.perm[j] = me;
+            p.perm[j] = p.sorted[j];
         }
         carry += tot;
     }
@@ -341,10 +364,14 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
     b.passes = (live + kMaxDigitBits - 1) / kMaxDigitBits;
     b.digit_bits = (live + b.passes - 1) / b.passes;
     b.n = n;
-    b.n_chunks = (n + kChunk - 1) / kChunk;
+    // keys per workgroup: 2048 up to 128 k keys (more workgroups for a batch that cannot fill the chip
+    // anyway), 4096 beyond (fewer histogram rows for every workgroup to sum)
+    const bool small = n <= kSmallSortMax;
+    const uint32_t block_keys = small ? 256u * 8 : 256u * 16;
+    b.n_blocks = (n + block_keys - 1) / block_keys;
     const uint32_t part_grid = n <= kSingleBlockMax ? 1u
         : std::min<uint32_t>((uint32_t)ctx->n_cu, (n + 4095) / 4096);
-    const size_t hist_words = (size_t)b.passes * b.n_chunks * kBuckets;
+    const size_t hist_words = (size_t)b.passes * b.n_blocks * kBuckets;
     size_t need = 2 * svx_take_bytes(n, 8) + 2 * svx_take_bytes(n, 4) + svx_take_bytes(hist_words, 4) +
                   svx_take_bytes(part_grid, 4);
     int rc = svx_ws_reserve(ctx, need);
@@ -357,18 +384,20 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
     uint32_t* block_tot = svx_ws_take<uint32_t>(ctx, part_grid);
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
-    const uint32_t g_chunk = (b.n_chunks + 3) / 4;
-    hipLaunchKernelGGL(k_pair_init, dim3(std::min<uint32_t>(g_chunk, (uint32_t)ctx->n_cu * 8u)), dim3(256), 0,
-                       ctx->stream, d_keys, b);
+    if (small) hipLaunchKernelGGL(k_pair_init<8>, dim3(b.n_blocks), dim3(256), 0, ctx->stream, d_keys, b);
+    else hipLaunchKernelGGL(k_pair_init<16>, dim3(b.n_blocks), dim3(256), 0, ctx->stream, d_keys, b);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-    for (uint32_t pass = 0; pass < b.passes; ++pass)
-        hipLaunchKernelGGL(k_radix_pass, dim3(g_chunk), dim3(256), 0, ctx->stream, b, pass);
+    for (uint32_t pass = 0; pass < b.passes; ++pass) {
+        if (small) hipLaunchKernelGGL(k_radix_pass<8>, dim3(b.n_blocks), dim3(256), 0, ctx->stream, b, pass);
+        else hipLaunchKernelGGL(k_radix_pass<16>, dim3(b.n_blocks), dim3(256), 0, ctx->stream, b, pass);
+    }
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     PartArgs pa;
-    pa.keys = d_keys;
+    pa.sorted_keys = b.keys[b.passes & 1];
     pa.sorted = b.idx[b.passes & 1];
+    pa.f = b.f;
     pa.n = n;
     pa.max_dist = max_dist;
     pa.perm = d_perm;

@@ -12,6 +12,16 @@ pytestmark = pytest.mark.gpu
 KEYS = ("aln", "ref_pos", "read_pos", "len", "type")
 
 
+@pytest.fixture(autouse=True, params=["small_batch", "streaming"])
+def cigar_path(request, svx_ctx):
+    """Every test of this module runs on both kernel paths: batches up to 2^21 ops in two launches
+    (tiles of 1024 ops, k_cigar_finish_small) and the five-launch streaming path (tiles of 4096 ops) that
+    larger batches take — forced here with svx_ctx_set_small_batch_ops(0)."""
+    svx_ctx.set_small_batch_ops(0 if request.param == "streaming" else 1 << 21)
+    yield request.param
+    svx_ctx.set_small_batch_ops(1 << 21)
+
+
 def pack(tuples):
     return np.array([(l << 4) | o for o, l in tuples], dtype=np.uint32)
 

@@ -25,27 +25,21 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--scale", type=float, default=0.1)
-    ap.add_argument("--keep", default=None)
-    ap.add_argument("--sv-per-mbp", type=float, default=8.0)
-    ap.add_argument("--skip-oracle", action="store_true")
-    ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
-    ap.add_argument("--threads", type=int, default=0, help="ingest threads (0: one per hardware thread, at most 64)")
-    ap.add_argument("--repeat", type=int, default=1, help="repeat the product pipeline, report the best run too")
-    args = ap.parse_args()
+def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, skip_oracle=False, dataset=None, threads=0, repeat=1,
+            device=0):
+    """Generate (or reuse) the dataset, run the product pipeline `repeat` times with phase clocks, then
+    the oracle pipeline once; returns the result dict."""
     from svim_asm_amd import synth, synth_bam
-    contigs = tuple((n, max(60000, int(l * args.scale))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
-    out = args.keep or tempfile.mkdtemp(prefix="svx_e2e_")
-    res = {"scale": args.scale, "genome_bp": int(sum(c[1] for c in contigs)), "dir": out}
+    contigs = tuple((n, max(60000, int(l * scale))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
+    out = keep or tempfile.mkdtemp(prefix="svx_e2e_")
+    res = {"scale": scale, "genome_bp": int(sum(c[1] for c in contigs)), "dir": out}
 
     t0 = time.perf_counter()
-    if args.dataset:
-        out = args.dataset
+    if dataset:
+        out = dataset
         fasta, bams = os.path.join(out, "ref.fa"), [os.path.join(out, "hap1.bam"), os.path.join(out, "hap2.bam")]
     else:
-        n_shared = max(4, int(args.sv_per_mbp * max(c[1] for c in contigs) / 1e6))
+        n_shared = max(4, int(sv_per_mbp * max(c[1] for c in contigs) / 1e6))
         fasta, bams = synth_bam.write_dataset(out, seed=3, contigs=contigs, diploid=True, n_shared=n_shared,
                                               n_private=max(2, n_shared // 5), median_aln=300000, mean_m=2000)
     res["generate_s"] = time.perf_counter() - t0
@@ -58,17 +52,19 @@ def main():
     from svim_asm_amd.SVIM_input_parsing import parse_arguments
     wd = os.path.join(out, "wd_product")
     opts = parse_arguments("1.0.3", ["diploid", wd, bams[0], bams[1], fasta])
+    opts.device = device
     os.makedirs(wd, exist_ok=True)
+    level = logging.getLogger().level
     logging.getLogger().setLevel(logging.WARNING)
     from svim_asm_amd import _lib
-    _lib.default_context(0)  # context creation / first-touch outside the timed region
+    _lib.default_context(device)  # context creation / first-touch outside the timed region
     runs = []
-    for _ in range(max(1, args.repeat)):
+    for _ in range(max(1, repeat)):
         r = {}
         t_all = time.perf_counter()
         t = time.perf_counter()
-        f1 = bamio.AlignmentFile(bams[0], threads=args.threads, device=0).load()
-        f2 = bamio.AlignmentFile(bams[1], threads=args.threads, device=0).load()
+        f1 = bamio.AlignmentFile(bams[0], threads=threads, device=device).load()
+        f2 = bamio.AlignmentFile(bams[1], threads=threads, device=device).load()
         r["open_index_s"] = time.perf_counter() - t
         t = time.perf_counter(); c1 = shard.collect_sharded(f1, opts); c2 = shard.collect_sharded(f2, opts); r["collect_s"] = time.perf_counter() - t
         ref = FastaFile(fasta)
@@ -86,22 +82,38 @@ def main():
     res["index_state"] = f1.index_state()
     res["bgzf_members_inflated"] = [f1.blocks_inflated, f2.blocks_inflated]
     res["bgzf_members_walked"] = [f1.blocks_spanned, f2.blocks_spanned]
-    res["ingest_threads"] = args.threads or min(64, os.cpu_count() or 1)
+    res["ingest_threads"] = threads or min(64, os.cpu_count() or 1)
     res["candidates"] = [len(c1), len(c2), len(paired)]
     res["cigar_ops"] = [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]
     got = "".join(l for l in open(os.path.join(wd, "variants.vcf")) if not l.startswith("##fileDate="))
+    res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
 
-    if not args.skip_oracle:
+    if not skip_oracle:
         from oracle import orc, run_oracle
         t = time.perf_counter()
         exp = run_oracle.vcf_from_files(bams, fasta, run_oracle.default_options(),
                                         edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
         res["oracle_total_s"] = time.perf_counter() - t
         res["vcf_identical"] = (got == exp)
-        res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
-    if not args.keep and not args.dataset:
+    logging.getLogger().setLevel(level)
+    if not keep and not dataset:
         shutil.rmtree(out)
-    print(json.dumps(res))
+        res.pop("dir")
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=0.1)
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("--sv-per-mbp", type=float, default=8.0)
+    ap.add_argument("--skip-oracle", action="store_true")
+    ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
+    ap.add_argument("--threads", type=int, default=0, help="ingest threads (0: one per hardware thread, at most 64)")
+    ap.add_argument("--repeat", type=int, default=1, help="repeat the product pipeline, report the best run too")
+    args = ap.parse_args()
+    print(json.dumps(run_e2e(args.scale, args.keep, args.sv_per_mbp, args.skip_oracle, args.dataset, args.threads,
+                             args.repeat)))
 
 
 if __name__ == "__main__":
