@@ -277,6 +277,21 @@ int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_t seq_bytes
                             const uint32_t* b_len, uint32_t n_pairs, uint32_t k_max,
                             uint32_t* dist);
 
+/*
+ * Batched complete linkage + flat cut: for every partition p (n_members[p] candidates, condensed
+ * distance vector of n(n-1)/2 doubles, partition after partition in `dist`)
+ *     fcluster(linkage(y, method="complete"), cutoff, criterion="distance")
+ * as the reference calls scipy at SVIM_COMBINE.py:134-135 (haplotype edit distances, cut at
+ * max_edit_distance), :155-156 (breakend span-position distance, cut at 0.3) and SVIM_inter.py:47-48
+ * (inversion breakpoints of one read, cut at 0.3).  labels (one per member, partition after
+ * partition) are scipy's 1-based flat-cluster labels IN SCIPY'S ORDER — the reference takes the
+ * coordinates of a paired call from cluster[0] (SVIM_COMBINE.py:184-363), so the order is part of the
+ * result.  Distances are compared exactly as doubles (scipy's float64).  Partitions of one member get
+ * label 1.  One lane per partition; any partition size is accepted.
+ */
+int svx_linkage_cut_batch(svx_ctx* ctx, const double* dist, const uint32_t* n_members, uint32_t n_parts,
+                          double cutoff, uint32_t* labels);
+
 #ifdef __cplusplus
 }
 #endif

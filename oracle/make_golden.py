@@ -11,9 +11,12 @@ replaced by an exact Levenshtein DP).  What is captured:
   * tests/golden/config1/          BAM + FASTA inputs (written by the build's own generator)
     and the reference's VCFs for `haploid` and `diploid` (##fileDate masked), default and
     alternative output options;
-  * tests/golden/functions.json    function-level vectors: analyze_cigar_indel,
-    retrieve_other_alignments on the reference's chimeric_read*.bam fixtures,
-    analyze_read_segments, form_partitions, pair_candidates.
+  * tests/golden/functions.json    function-level vectors: analyze_cigar_indel, is_similar,
+    retrieve_other_alignments on the reference's chimeric_read*.bam fixtures;
+  * tests/golden/pipeline_vectors.json.gz   function-level vectors of the callers either side of the
+    kernels: analyze_alignment_file_coordsorted (COLLECT), analyze_read_segments per read,
+    form_partitions, pair_candidates — inputs as plain records / candidate tuples, outputs as the
+    canonical candidate tuples of the REAL reference's objects.
 """
 import importlib.machinery
 import importlib.util
@@ -229,6 +232,121 @@ def make_function_vectors():
     with open(os.path.join(GOLD, "functions.json"), "w") as fh:
         json.dump(vec, fh, indent=0)
 
+PIPE_NAMES = ["chr1", "chr10", "chr2", "chrX"]
+PIPE_LENGTHS = [3_000_000, 1_500_000, 2_000_000, 800_000]
+
+
+def _ref_stub_bam(records, names, lengths):
+    import pysam  # the stub
+
+    class Bam(object):
+        references = tuple(names)
+
+        def __init__(self):
+            self.lengths = tuple(lengths)
+            self.recs = []
+            for r in records:
+                a = pysam.AlignedSegment()
+                a.query_name = r["qname"]
+                a.flag = r["flag"]
+                a.reference_id = r["tid"]
+                a.reference_start = r["pos"]
+                a.mapping_quality = r["mapq"]
+                a.cigartuples = [tuple(t) for t in r["cigar"]]
+                a.query_sequence = r["seq"]
+                if r.get("sa") is not None:
+                    a.set_tags([("SA", r["sa"], "Z")])
+                self.recs.append(a)
+
+        def fetch(self, contig=None):
+            tid = names.index(contig)
+            return iter([a for a in self.recs if a.reference_id == tid])
+
+        def get_tid(self, n):
+            return names.index(n) if n in names else -1
+
+        def get_reference_name(self, tid):
+            if tid < 0:
+                raise ValueError("bad tid")
+            return names[tid]
+
+        getrname = get_reference_name
+
+        def get_reference_length(self, n):
+            return lengths[names.index(n)]
+    return Bam()
+
+
+def make_pipeline_vectors():
+    """Function-level vectors of COLLECT / analyze_read_segments / form_partitions / pair_candidates from
+    the real reference.  Inputs come from the seeded generators of tests/helpers.py and are stored in
+    full, so the file is self-contained."""
+    import gzip
+    import numpy as np
+    ref = load_reference()
+    from tests import helpers
+    vec = {"names": PIPE_NAMES, "lengths": PIPE_LENGTHS}
+    # ---- COLLECT + per-read analyze_read_segments
+    option_sets = [dict(), dict(min_sv_size=30, max_sv_size=3000, min_mapq=0, query_gap_tolerance=500)]
+    collect = []
+    for seed, kw in enumerate(option_sets):
+        rng = np.random.default_rng(7000 + seed)
+        recs = helpers.random_records(rng, PIPE_NAMES, PIPE_LENGTHS, 10) + \
+            helpers.engineered_split_records(rng, PIPE_NAMES, PIPE_LENGTHS, 36)
+        recs.sort(key=lambda r: (r["tid"], r["pos"]))
+        o = helpers.options(**kw)
+        bam = _ref_stub_bam(recs, PIPE_NAMES, PIPE_LENGTHS)
+        out = [candidate_tuple(c) for c in ref["COLLECT"].analyze_alignment_file_coordsorted(bam, o)]
+        per_read = []
+        for i, aln in enumerate(bam.recs):
+            if aln.is_supplementary or aln.is_secondary or aln.is_unmapped or aln.mapping_quality < o.min_mapq:
+                continue
+            supp = [s for s in ref["COLLECT"].retrieve_other_alignments(aln, bam)
+                    if not s.is_unmapped and s.mapping_quality >= o.min_mapq]
+            if supp:
+                per_read.append({"record": i,
+                                 "out": [candidate_tuple(c) for c in ref["INTER"].analyze_read_segments(aln, supp, bam, o)]})
+        collect.append({"options": kw, "records": recs, "out": out, "analyze_read_segments": per_read})
+    vec["collect"] = collect
+    # ---- form_partitions + pair_candidates
+    pair = []
+    for seed, kw in enumerate([dict(), dict(max_edit_distance=10, partition_max_distance=100, query_names=True)]):
+        rng = np.random.default_rng(7100 + seed)
+        names = PIPE_NAMES
+        seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=25000)) for n in names}
+        lengths = [25000] * len(names)
+        fasta = helpers.FakeFasta(seqs)
+
+        class Bam(object):
+            references = tuple(names)
+
+            def get_reference_length(self, n):
+                return lengths[names.index(n)]
+        bam = Bam()
+        t1 = helpers.random_candidates(rng, names, lengths, seqs, 90, "h1")
+        t2 = helpers.random_candidates(rng, names, lengths, seqs, 90, "h2")
+        for c in t1[:50]:
+            if c[0] in ("DEL", "INS", "INV", "DUP_TAN"):
+                shift = int(rng.integers(-3, 4))
+                lst = list(c)
+                lst[2] = max(0, c[2] + shift)
+                lst[3] = max(lst[2], c[3] + shift)
+                lst[{"DEL": 4, "INS": 4, "INV": 4, "DUP_TAN": 6}[c[0]]] = ("h2_copy",)
+                t2.append(tuple(lst))
+        o = helpers.options(**kw)
+        c1 = [helpers.build_candidate(t, bam, ref["CAND"]) for t in t1]
+        c2 = [helpers.build_candidate(t, bam, ref["CAND"]) for t in t2]
+        parts = {}
+        for typ in ("DEL", "INV", "INS", "DUP_TAN", "DUP_INT", "BND"):
+            sub = [(1, c) for c in c1 if c.type == typ] + [(2, c) for c in c2 if c.type == typ]
+            where = {id(c): k for k, (_, c) in enumerate(sub)}
+            parts[typ] = [[where[id(c)] for _, c in p] for p in ref["COMBINE"].form_partitions(sub, o.partition_max_distance)]
+        out = [candidate_tuple(c) for c in ref["COMBINE"].pair_candidates(c1, c2, fasta, bam, o)]
+        pair.append({"options": kw, "seqs": seqs, "t1": t1, "t2": t2, "form_partitions": parts, "out": out})
+    vec["pair"] = pair
+    with gzip.open(os.path.join(GOLD, "pipeline_vectors.json.gz"), "wt", compresslevel=9) as fh:
+        json.dump(vec, fh)
+
 
 def main():
     if ROOT not in sys.path:
@@ -238,10 +356,11 @@ def main():
     if len(sys.argv) > 1:   # regenerate selected fixtures only: functions / config1 / medium / longcigar
         for what in sys.argv[1:]:
             {"functions": make_function_vectors, "config1": make_config1, "medium": make_medium,
-             "longcigar": make_longcigar}[what]()
+             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors}[what]()
         return
     make_longcigar()
     make_function_vectors()
+    make_pipeline_vectors()
     out = make_config1()
     make_medium()
     # the two reference BAM fixtures are data, not source: keep copies for the GPU box

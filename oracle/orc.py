@@ -48,6 +48,8 @@ def lib():
         l.orc_edit_distance.argtypes = [P, C.c_uint32, P, C.c_uint32]
         l.orc_edit_distance_banded.restype = C.c_uint32
         l.orc_edit_distance_banded.argtypes = [P, C.c_uint32, P, C.c_uint32]
+        l.orc_linkage_cut.restype = None
+        l.orc_linkage_cut.argtypes = [P, C.c_uint32, C.c_double, P]
         _lib = l
     return _lib
 
@@ -124,3 +126,12 @@ def edit_distance_banded(a: bytes, b: bytes):
     aa = np.frombuffer(a, np.uint8) if len(a) else np.zeros(0, np.uint8)
     bb = np.frombuffer(b, np.uint8) if len(b) else np.zeros(0, np.uint8)
     return int(lib().orc_edit_distance_banded(_p(aa), len(a), _p(bb), len(b)))
+
+
+def linkage_cut(condensed, n, cutoff):
+    """fcluster(linkage(condensed, "complete"), cutoff, "distance") — scipy's label order."""
+    cond = np.ascontiguousarray(condensed, np.float64)
+    assert len(cond) == n * (n - 1) // 2
+    labels = np.zeros(n, np.uint32)
+    lib().orc_linkage_cut(_p(cond), int(n), float(cutoff), _p(labels))
+    return labels

@@ -11,6 +11,7 @@
  * produced by importing the reference in the build container
  * (tests/golden/, generator oracle/make_golden.py).  See tests/test_oracle_pins.py.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -323,4 +324,130 @@ uint32_t orc_edit_distance_banded(const uint8_t* a, uint32_t la, const uint8_t* 
         if (d <= k) return d;
         if (k == longest) return d;
     }
+}
+
+/* ---- a7 / a3: complete linkage + flat cut, as scipy computes it ----------------------------------
+ * The reference clusters every partition of 2..10 candidates with
+ *     fcluster(linkage(distances, method="complete"), t, criterion="distance")
+ * (SVIM_COMBINE.py:134-135,155-156) and every group of overlapping inversion breakpoints of a read
+ * the same way (SVIM_inter.py:47-48).  Which member is cluster[0] — and supplies the coordinates of
+ * the paired call — follows from scipy's cluster LABEL order, so the restatement has to reproduce
+ * scipy's procedure, not just the set partition.  scipy (third-party, unpinned in the reference's
+ * setup.py; 1.15.3 installed here) does, for method "complete" on a condensed distance vector:
+ *   1. nearest-neighbour chain (Müllner): start the chain at the lowest live cluster; extend it with the
+ *      nearest live cluster (strict <, lowest index wins, the previous chain element is preferred on
+ *      ties); merge when two are mutual; the merged cluster keeps the larger index; Lance-Williams
+ *      update for complete linkage d(z,i) = max(d(x,i), d(y,i));
+ *   2. stable sort of the merges by distance;
+ *   3. relabelling with a union-find (new cluster ids n, n+1, ... in sorted order; smaller root first);
+ *   4. fcluster "distance": max distance in each subtree, then an explicit-stack traversal from the
+ *      root, left child first; a node whose max distance <= t becomes one flat cluster, remaining
+ *      leaves singletons; flat clusters are numbered in the order the traversal completes them.
+ * Pinned against scipy itself by tests/test_oracle_pins.py (exhaustive rank patterns incl. ties for
+ * n <= 6, random to n = 12).  labels[i] in 1..k.  n >= 1; scratch is heap-allocated. */
+static size_t cond_index(uint32_t n, uint32_t i, uint32_t j) {
+    if (i > j) { uint32_t t = i; i = j; j = t; }
+    return (size_t)n * i - (size_t)i * (i + 1) / 2 + (j - i - 1);
+}
+
+void orc_linkage_cut(const double* cond, uint32_t n, double cutoff, uint32_t* labels) {
+    if (n == 0) return;
+    if (n == 1) { labels[0] = 1; return; }
+    const size_t m = (size_t)n * (n - 1) / 2;
+    double* D = (double*)malloc(sizeof(double) * m);
+    memcpy(D, cond, sizeof(double) * m);
+    int* size = (int*)malloc(sizeof(int) * n);
+    int* chain = (int*)malloc(sizeof(int) * n);
+    int* zx = (int*)malloc(sizeof(int) * (n - 1));
+    int* zy = (int*)malloc(sizeof(int) * (n - 1));
+    double* zd = (double*)malloc(sizeof(double) * (n - 1));
+    for (uint32_t i = 0; i < n; ++i) size[i] = 1;
+    int chain_len = 0;
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+        int x = 0, y = 0;
+        double cur = 0;
+        if (chain_len == 0) {
+            chain_len = 1;
+            for (uint32_t i = 0; i < n; ++i)
+                if (size[i] > 0) { chain[0] = (int)i; break; }
+        }
+        for (;;) {
+            x = chain[chain_len - 1];
+            if (chain_len > 1) {
+                y = chain[chain_len - 2];
+                cur = D[cond_index(n, (uint32_t)x, (uint32_t)y)];
+            } else {
+                cur = (double)INFINITY;
+            }
+            for (uint32_t i = 0; i < n; ++i) {
+                if (size[i] == 0 || (int)i == x) continue;
+                const double d = D[cond_index(n, (uint32_t)x, i)];
+                if (d < cur) { cur = d; y = (int)i; }
+            }
+            if (chain_len > 1 && y == chain[chain_len - 2]) break;
+            chain[chain_len++] = y;
+        }
+        chain_len -= 2;
+        if (x > y) { int t = x; x = y; y = t; }
+        const int nx = size[x], ny = size[y];
+        zx[k] = x; zy[k] = y; zd[k] = cur;
+        size[x] = 0;
+        size[y] = nx + ny;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (size[i] == 0 || (int)i == y) continue;
+            const double a = D[cond_index(n, i, (uint32_t)x)], b = D[cond_index(n, i, (uint32_t)y)];
+            D[cond_index(n, i, (uint32_t)y)] = a > b ? a : b;
+        }
+    }
+    /* stable sort by distance (insertion sort) */
+    for (uint32_t i = 1; i + 1 < n; ++i) {
+        const int tx = zx[i], ty = zy[i];
+        const double td = zd[i];
+        uint32_t j = i;
+        while (j > 0 && zd[j - 1] > td) { zx[j] = zx[j - 1]; zy[j] = zy[j - 1]; zd[j] = zd[j - 1]; --j; }
+        zx[j] = tx; zy[j] = ty; zd[j] = td;
+    }
+    /* union-find relabelling */
+    int* parent = (int*)malloc(sizeof(int) * (2 * (size_t)n - 1));
+    for (uint32_t i = 0; i < 2 * n - 1; ++i) parent[i] = (int)i;
+    int next = (int)n;
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        int r[2] = {zx[i], zy[i]};
+        for (int s = 0; s < 2; ++s) {
+            int p = r[s], root = r[s];
+            while (parent[root] != root) root = parent[root];
+            while (parent[p] != root) { int q = parent[p]; parent[p] = root; p = q; }
+            r[s] = root;
+        }
+        zx[i] = r[0] < r[1] ? r[0] : r[1];
+        zy[i] = r[0] < r[1] ? r[1] : r[0];
+        parent[r[0]] = next;
+        parent[r[1]] = next;
+        ++next;
+    }
+    /* max distance below every internal node (children were created earlier: lower rows) */
+    double* md = (double*)malloc(sizeof(double) * (n - 1));
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        double v = zd[i];
+        if (zx[i] >= (int)n && md[zx[i] - (int)n] > v) v = md[zx[i] - (int)n];
+        if (zy[i] >= (int)n && md[zy[i] - (int)n] > v) v = md[zy[i] - (int)n];
+        md[i] = v;
+    }
+    /* flat clusters: explicit-stack traversal, left child first */
+    int* stack = (int*)malloc(sizeof(int) * n);
+    unsigned char* visited = (unsigned char*)calloc(2 * (size_t)n - 1, 1);
+    int kk = 0, n_cluster = 0, leader = -1;
+    stack[0] = 2 * (int)n - 2;
+    while (kk >= 0) {
+        const int root = stack[kk] - (int)n;
+        const int lc = zx[root], rc = zy[root];
+        if (leader == -1 && md[root] <= cutoff) { leader = root; ++n_cluster; }
+        if (lc >= (int)n && !visited[lc]) { visited[lc] = 1; stack[++kk] = lc; continue; }
+        if (rc >= (int)n && !visited[rc]) { visited[rc] = 1; stack[++kk] = rc; continue; }
+        if (lc < (int)n) { if (leader == -1) ++n_cluster; labels[lc] = (uint32_t)n_cluster; }
+        if (rc < (int)n) { if (leader == -1) ++n_cluster; labels[rc] = (uint32_t)n_cluster; }
+        if (leader == root) leader = -1;
+        --kk;
+    }
+    free(D); free(size); free(chain); free(zx); free(zy); free(zd); free(parent); free(md); free(stack); free(visited);
 }

@@ -9,7 +9,8 @@ GPU work: the stable sort by Candidate.get_key() + partition sweep is svx_pair_p
 launch for all six SV types: the type is the most significant key field, so partitions and
 their order are the ones the reference gets type by type); the pairwise haplotype edit
 distances (edlib in the reference) are svx_edit_distance_batch, one launch for all pairs.
-Complete linkage on the ≤10-member partitions uses scipy exactly as the reference does.
+Complete linkage + flat cut of the ≤10-member partitions (scipy in the reference) is
+svx_linkage_cut_batch, one launch for all partitions of a type, reproducing scipy's label order.
 """
 import logging
 import re
@@ -18,7 +19,6 @@ from collections import defaultdict
 from statistics import mean
 
 import numpy as np
-from scipy.cluster.hierarchy import fcluster, linkage
 
 from svim_asm_amd import _lib
 from svim_asm_amd.SVCandidate import (CandidateBreakend, CandidateDeletion, CandidateDuplicationInterspersed,
@@ -120,18 +120,35 @@ def span_position_distance_breakends(candidate1, candidate2):
     return 99999
 
 
+def _clusters_batch(partitions, condensed, threshold, ctx=None):
+    """Flat clusters of many partitions with ONE svx_linkage_cut_batch launch: complete linkage cut at
+    `threshold`, clusters in scipy's label order (= fcluster(linkage(d, "complete"), t, "distance"),
+    SVIM_COMBINE.py:134-139), members in partition order.  partitions[i] has the condensed distance list
+    condensed[i]."""
+    if not partitions:
+        return []
+    ctx = ctx or _lib.default_context()
+    sizes = np.array([len(p) for p in partitions], dtype=np.uint32)
+    flat = np.fromiter((d for c in condensed for d in c), dtype=np.float64, count=int((sizes.astype(np.int64) * (sizes.astype(np.int64) - 1) // 2).sum()))
+    labels = ctx.linkage_cut_batch(flat, sizes, float(threshold)).tolist()
+    out, at = [], 0
+    for partition in partitions:
+        lab = labels[at:at + len(partition)]
+        at += len(partition)
+        clusters = [[] for _ in range(max(lab))]
+        for member, l in zip(partition, lab):
+            clusters[l - 1].append(member)
+        out.append(clusters)
+    return out
+
+
 def _clusters_from_condensed(partition, distances, threshold):
-    labels = list(fcluster(linkage(np.array(distances, dtype=float), method="complete"), threshold,
-                           criterion="distance"))
-    clusters = [[] for _ in range(max(labels))]
-    for member, label in zip(partition, labels):
-        clusters[label - 1].append(member)
-    return clusters
+    return _clusters_batch([partition], [distances], threshold)[0]
 
 
 def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None):
     """Cluster each partition (2..10 members) by complete linkage over haplotype edit distances.
-    All distances of all partitions are computed in one GPU batch."""
+    All distances of all partitions are computed in one GPU batch, all linkage cuts in another."""
     jobs = []  # (partition index, i, j)
     strings = []
     for pi, partition in enumerate(partitions):
@@ -158,6 +175,13 @@ def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None)
             dist[jobs[k]] = 0 if strings[k][0] == strings[k][1] else 1  # only "> threshold" matters
     for k, d in zip(exa, edit_distances([strings[k] for k in exa], 0xFFFFFFFF, ctx)):
         dist[jobs[k]] = d
+    todo, condensed = [], []
+    for pi, partition in enumerate(partitions):
+        if 2 <= len(partition) <= 10:
+            todo.append(partition)
+            condensed.append([dist.get((pi, i, j), SAME_HAPLOTYPE_DISTANCE)
+                              for i in range(len(partition) - 1) for j in range(i + 1, len(partition))])
+    clustered = iter(_clusters_batch(todo, condensed, edit_distance_threshold, ctx))
     clusters_final = []
     for pi, partition in enumerate(partitions):
         if len(partition) < 2:
@@ -168,13 +192,20 @@ def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None)
                 len(partition), partition[0][1].get_key()[0],
                 ",".join("{0}:{1}".format(m[1].get_key()[1], m[1].get_key()[2]) for m in partition)))
         else:
-            condensed = [dist.get((pi, i, j), SAME_HAPLOTYPE_DISTANCE)
-                         for i in range(len(partition) - 1) for j in range(i + 1, len(partition))]
-            clusters_final.extend(_clusters_from_condensed(partition, condensed, edit_distance_threshold))
+            clusters_final.extend(next(clustered))
     return clusters_final
 
 
-def pair_haplotypes_breakends(partitions, span_position_distance_threshold=0.3):
+def pair_haplotypes_breakends(partitions, span_position_distance_threshold=0.3, ctx=None):
+    todo, condensed = [], []
+    for partition in partitions:
+        if 2 <= len(partition) <= 10:
+            rows = [(hap, c.get_source()[1], 1 if c.source_direction == "fwd" else 0, c.get_destination()[1],
+                     1 if c.dest_direction == "fwd" else 0) for hap, c in partition]
+            todo.append(partition)
+            condensed.append([span_position_distance_breakends(rows[i], rows[j])
+                              for i in range(len(rows) - 1) for j in range(i + 1, len(rows))])
+    clustered = iter(_clusters_batch(todo, condensed, span_position_distance_threshold, ctx))
     clusters_final = []
     for partition in partitions:
         if len(partition) < 2:
@@ -182,11 +213,7 @@ def pair_haplotypes_breakends(partitions, span_position_distance_threshold=0.3):
         elif len(partition) > 10:
             continue
         else:
-            rows = [(hap, c.get_source()[1], 1 if c.source_direction == "fwd" else 0, c.get_destination()[1],
-                     1 if c.dest_direction == "fwd" else 0) for hap, c in partition]
-            condensed = [span_position_distance_breakends(rows[i], rows[j])
-                         for i in range(len(rows) - 1) for j in range(i + 1, len(rows))]
-            clusters_final.extend(_clusters_from_condensed(partition, condensed, span_position_distance_threshold))
+            clusters_final.extend(next(clustered))
     return clusters_final
 
 

@@ -3,14 +3,14 @@
 Mirrors analyze_read_segments(primary, supplementaries, bam, options) (SVIM_inter.py:62-340).
 The adjacent-pair decision tree (:91-258) runs on the GPU (svx_segments_classify); the three
 per-read post-passes — tandem-duplication merge (:261-290), interspersed duplications from
-breakend pairs (:293-320) and inversion clustering (:323-338, scipy complete linkage exactly
-as the reference) — run here on the raw records of each read (a handful per read).
+breakend pairs (:293-320) and the inversion sweep (:323-338) — run here on the raw records of each
+read (a handful per read); the complete-linkage clustering of overlapping inversion breakpoints
+(:42-60, scipy in the reference) is svx_linkage_cut_batch, one launch for all reads.
 `analyze_read_segments_batch` is the entry COLLECT uses: one launch for all reads.
 """
 from fractions import Fraction
 
 import numpy as np
-from scipy.cluster.hierarchy import fcluster, linkage
 
 from svim_asm_amd import _lib
 from svim_asm_amd.SVCandidate import (CandidateBreakend, CandidateDeletion, CandidateDuplicationInterspersed,
@@ -34,18 +34,30 @@ def reciprocal_overlap_distance(inversion1, inversion2):
     return 1 - min(overlap / float(end1 - start1), overlap / float(end2 - start2))
 
 
-def process_overlapping_inversions(active_inversions, query_name, bam):
-    if len(active_inversions) < 2:
-        clusters = [active_inversions]
-    else:
-        data = np.array([[inv[1], inv[2], 0 if inv[3].split("_")[0] == "left" else 1] for inv in active_inversions])
-        labels = list(fcluster(linkage(data, method="complete", metric=reciprocal_overlap_distance), 0.3,
-                               criterion="distance"))
-        clusters = [[] for _ in range(max(labels))]
-        for inv, lab in zip(active_inversions, labels):
-            clusters[lab - 1].append(inv)
+def _inversion_condensed(active_inversions):
+    """Condensed distance vector scipy's pdist hands to linkage (:45-47): the metric on the float64 rows
+    [start, end, 0 (left) / 1 (right)]."""
+    rows = [(float(inv[1]), float(inv[2]), 0.0 if inv[3].split("_")[0] == "left" else 1.0) for inv in active_inversions]
+    return [reciprocal_overlap_distance(rows[i], rows[j]) for i in range(len(rows) - 1) for j in range(i + 1, len(rows))]
+
+
+def _inversion_candidates(active_inversions, labels, query_name, bam):
+    clusters = [[] for _ in range(max(labels))]
+    for inv, lab in zip(active_inversions, labels):
+        clusters[lab - 1].append(inv)
     return [CandidateInversion(cl[0][0], max(i[1] for i in cl), min(i[2] for i in cl), [query_name],
                                len(cl) > 1, bam) for cl in clusters]
+
+
+def process_overlapping_inversions(active_inversions, query_name, bam, ctx=None):
+    """Complete linkage over the breakpoints' reciprocal-overlap distance, cut at 0.3 (:42-60); the
+    clustering runs on the GPU (svx_linkage_cut_batch, scipy's label order)."""
+    if len(active_inversions) < 2:
+        labels = [1] * len(active_inversions)
+    else:
+        ctx = ctx or _lib.default_context()
+        labels = ctx.linkage_cut_batch(_inversion_condensed(active_inversions), [len(active_inversions)], 0.3).tolist()
+    return _inversion_candidates(active_inversions, labels, query_name, bam)
 
 
 def segment_row(alignment):
@@ -63,9 +75,11 @@ def _mean(values):
     return Fraction(sum(values), len(values))  # statistics.mean of ints is exact
 
 
-def candidates_from_raw(raw, primary, bam, options, sequence_slice):
+def candidates_from_raw(raw, primary, bam, options, sequence_slice, inversion_groups=None):
     """Raw records of ONE read (sorted-pair order) → candidates in the reference's order:
-    adjacency INS/DEL/BND, then DUP_TAN, then DUP_INT, then INV."""
+    adjacency INS/DEL/BND, then DUP_TAN, then DUP_INT, then INV.  With `inversion_groups` (a list) the
+    read's groups of overlapping inversion breakpoints are appended to it instead of being clustered
+    here: the caller clusters the groups of all reads with one launch and appends the INV candidates."""
     read_name = primary.query_name
     name = bam.get_reference_name
     sv_candidates, tandems, translocations, inversions = [], [], [], []
@@ -124,18 +138,23 @@ def candidates_from_raw(raw, primary, bam, options, sequence_slice):
                                                                           mid + length, [read_name], bam))
 
     # inversions: sweep over sorted breakpoints; the breakpoint that closes a group is dropped
-    # (reference quirk)
-    active = []
+    # (reference quirk).  The groups are clustered later, all reads in one launch.
+    groups, active = [], []
     for inv in sorted(inversions, key=lambda i: (i[0], i[1], i[2])):
         if not active:
             active.append(inv)
         elif inv[0] == active[-1][0] and inv[1] < max(i[2] for i in active):
             active.append(inv)
         else:
-            sv_candidates.extend(process_overlapping_inversions(active, read_name, bam))
+            groups.append(active)
             active = []
     if active:
-        sv_candidates.extend(process_overlapping_inversions(active, read_name, bam))
+        groups.append(active)
+    if inversion_groups is None:
+        for g in groups:
+            sv_candidates.extend(process_overlapping_inversions(g, read_name, bam))
+    else:
+        inversion_groups.extend(groups)
     return sv_candidates
 
 
@@ -172,9 +191,24 @@ def analyze_read_segments_batch(reads, bam, options, ctx=None, rows=None, read_l
     segs = np.array([t for r in rows for t in r], dtype=np.int32).reshape(-1, 6)
     segs = np.ascontiguousarray(segs).view(_lib.SEG_DTYPE).reshape(-1)
     raw = ctx.segments_classify(segs, read_off, np.asarray(read_lens, dtype=np.int32), seg_params(options))
-    out = []
+    out, pending = [], []  # pending: (read index, groups of that read)
     for i, (primary, _) in enumerate(reads):
-        out.append(candidates_from_raw(raw[read_off[i]:read_off[i + 1]], primary, bam, options, _slicer(primary)))
+        groups = []
+        out.append(candidates_from_raw(raw[read_off[i]:read_off[i + 1]], primary, bam, options, _slicer(primary), groups))
+        if groups:
+            pending.append((i, groups))
+    # inversion clustering of every read in one launch (single-member groups need none)
+    multi = [g for _, groups in pending for g in groups if len(g) > 1]
+    labels = iter(())
+    if multi:
+        flat = [d for g in multi for d in _inversion_condensed(g)]
+        lab = ctx.linkage_cut_batch(flat, [len(g) for g in multi], 0.3).tolist()
+        pos = np.concatenate(([0], np.cumsum([len(g) for g in multi]))).tolist()
+        labels = iter(lab[a:b] for a, b in zip(pos[:-1], pos[1:]))
+    for i, groups in pending:
+        name = reads[i][0].query_name
+        for g in groups:
+            out[i].extend(_inversion_candidates(g, next(labels) if len(g) > 1 else [1] * len(g), name, bam))
     return out
 
 

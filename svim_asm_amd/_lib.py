@@ -89,6 +89,7 @@ SYMBOLS = {
     "svx_pair_partition_dev_bits": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, _P]),
     "svx_edit_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_uint32,
                                           _P]),
+    "svx_linkage_cut_batch": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_double, _P]),
     # native BAM ingest (include/svx_bam.h)
     "svx_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "svx_bam_close": (None, [_P]),
@@ -284,6 +285,20 @@ class Context:
                                                          _ptr(a_len), _ptr(b_off), _ptr(b_len), n,
                                                          int(k_max) & 0xFFFFFFFF, _ptr(dist)))
         return dist
+
+    def linkage_cut_batch(self, dist, n_members, cutoff):
+        """scipy fcluster(linkage(y, "complete"), cutoff, "distance") for many partitions at once.
+        dist: condensed vectors back to back (float64); n_members: partition sizes.  Returns the
+        1-based labels, partition after partition (scipy's label order)."""
+        dist = _as(dist, np.float64)
+        n_members = _as(n_members, np.uint32)
+        if int((n_members.astype(np.int64) * (n_members.astype(np.int64) - 1) // 2).sum()) != len(dist):
+            raise SvxError(SVX_E_INVALID, "dist length does not match the partition sizes")
+        labels = np.zeros(int(n_members.sum()), np.uint32)
+        if len(n_members):
+            self._check(self.lib.svx_linkage_cut_batch(self.h, _ptr(dist), _ptr(n_members), len(n_members),
+                                                       float(cutoff), _ptr(labels)))
+        return labels
 
 
 class DeviceArray:

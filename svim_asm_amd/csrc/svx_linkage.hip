@@ -1,0 +1,224 @@
+// svx_linkage.hip — batched complete linkage + flat cut on gfx950, one thread per partition.
+//
+// Replaces, for every partition of the PAIR step and every group of overlapping inversion
+// breakpoints of a read,
+//     fcluster(linkage(distances, method="complete"), t, criterion="distance")
+// (reference SVIM_COMBINE.py:134-135,155-156 and SVIM_inter.py:47-48; scipy.cluster.hierarchy).
+// The flat-cluster LABELS decide which member is cluster[0], i.e. whose coordinates the paired call
+// carries (SVIM_COMBINE.py:184-363), so scipy's procedure is reproduced step by step:
+//   nearest-neighbour chain with its tie rules (strict <, lowest index, previous chain element
+//   preferred), merged cluster keeps the larger index, complete-linkage update max(d(x,i), d(y,i));
+//   stable sort of the merges by distance; union-find relabelling (smaller root first); maximum
+//   distance per subtree; explicit-stack traversal from the root, left child first, numbering flat
+//   clusters as the traversal completes them.
+// Partitions are tiny (2..10 members in PAIR) and there are thousands of them: the work is a short
+// sequential program per partition, so the mapping is one lane per partition with its whole state
+// (distance matrix, merge list, union-find, stack) in a private LDS slice — no global traffic besides
+// the input vector and the labels.  Partitions with more members than the LDS slice holds (inversion
+// groups of pathological reads) run the same code on a slice of the HBM workspace.
+// Double precision throughout (scipy computes in float64; the cut compares with <=): only
+// comparisons, max and copies — no arithmetic that could round differently.
+#include "svx_internal.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int kThreads = 64;
+constexpr uint32_t kLdsN = 10;  // partitions up to this size keep their state in LDS
+
+__host__ __device__ constexpr size_t link_bytes(uint32_t n) {
+    return n < 2 ? 0
+                 : 8 * ((size_t)n * (n - 1) / 2 + 2 * ((size_t)n - 1)) + 4 * (7 * (size_t)n - 3) + ((2 * (size_t)n - 1 + 7) / 8) * 8;
+}
+constexpr size_t kSlice = (link_bytes(kLdsN) + 15) / 16 * 16;
+
+struct LinkArgs {
+    const double* dist;          // condensed vectors, partition after partition
+    const uint64_t* dist_off;    // [n_parts] first element of partition p
+    const uint32_t* n_members;   // [n_parts]
+    const uint64_t* label_off;   // [n_parts] first label of partition p
+    const uint64_t* scratch_off; // [n_parts] byte offset into `scratch` (large partitions only)
+    char* scratch;
+    uint32_t n_parts;
+    double cutoff;
+    uint32_t* labels;
+};
+
+__device__ __forceinline__ size_t cidx(uint32_t n, uint32_t i, uint32_t j) {
+    if (i > j) { const uint32_t t = i; i = j; j = t; }
+    return (size_t)n * i - (size_t)i * (i + 1) / 2 + (j - i - 1);
+}
+
+__device__ void linkage_cut_one(const uint32_t n, const double* __restrict__ cond, const double cutoff,
+                                uint32_t* __restrict__ labels, char* mem) {
+    if (n == 0) return;
+    if (n == 1) { labels[0] = 1; return; }
+    const size_t m = (size_t)n * (n - 1) / 2;
+    double* D = reinterpret_cast<double*>(mem);
+    double* zd = D + m;
+    double* md = zd + (n - 1);
+    int* size = reinterpret_cast<int*>(md + (n - 1));
+    int* chain = size + n;
+    int* zx = chain + n;
+    int* zy = zx + (n - 1);
+    int* parent = zy + (n - 1);
+    int* stack = parent + (2 * n - 1);
+    unsigned char* visited = reinterpret_cast<unsigned char*>(stack + n);
+    for (size_t i = 0; i < m; ++i) D[i] = cond[i];
+    for (uint32_t i = 0; i < n; ++i) size[i] = 1;
+    // ---- nearest-neighbour chain
+    int chain_len = 0;
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+        int x = 0, y = 0;
+        double cur = 0;
+        if (chain_len == 0) {
+            chain_len = 1;
+            for (uint32_t i = 0; i < n; ++i)
+                if (size[i] > 0) { chain[0] = (int)i; break; }
+        }
+        for (;;) {
+            x = chain[chain_len - 1];
+            if (chain_len > 1) {
+                y = chain[chain_len - 2];
+                cur = D[cidx(n, (uint32_t)x, (uint32_t)y)];
+            } else {
+                cur = __builtin_huge_val();
+            }
+            for (uint32_t i = 0; i < n; ++i) {
+                if (size[i] == 0 || (int)i == x) continue;
+                const double d = D[cidx(n, (uint32_t)x, i)];
+                if (d < cur) { cur = d; y = (int)i; }
+            }
+            if (chain_len > 1 && y == chain[chain_len - 2]) break;
+            chain[chain_len++] = y;
+        }
+        chain_len -= 2;
+        if (x > y) { const int t = x; x = y; y = t; }
+        const int nx = size[x], ny = size[y];
+        zx[k] = x; zy[k] = y; zd[k] = cur;
+        size[x] = 0;
+        size[y] = nx + ny;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (size[i] == 0 || (int)i == y) continue;
+            const double a = D[cidx(n, i, (uint32_t)x)], b = D[cidx(n, i, (uint32_t)y)];
+            D[cidx(n, i, (uint32_t)y)] = a > b ? a : b;
+        }
+    }
+    // ---- stable sort of the merges by distance
+    for (uint32_t i = 1; i + 1 < n; ++i) {
+        const int tx = zx[i], ty = zy[i];
+        const double td = zd[i];
+        uint32_t j = i;
+        while (j > 0 && zd[j - 1] > td) { zx[j] = zx[j - 1]; zy[j] = zy[j - 1]; zd[j] = zd[j - 1]; --j; }
+        zx[j] = tx; zy[j] = ty; zd[j] = td;
+    }
+    // ---- union-find relabelling: cluster ids n, n+1, ... in sorted order
+    for (uint32_t i = 0; i < 2 * n - 1; ++i) { parent[i] = (int)i; visited[i] = 0; }
+    int next = (int)n;
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        int r0 = zx[i], r1 = zy[i];
+        {
+            int p = r0, root = r0;
+            while (parent[root] != root) root = parent[root];
+            while (parent[p] != root) { const int q = parent[p]; parent[p] = root; p = q; }
+            r0 = root;
+        }
+        {
+            int p = r1, root = r1;
+            while (parent[root] != root) root = parent[root];
+            while (parent[p] != root) { const int q = parent[p]; parent[p] = root; p = q; }
+            r1 = root;
+        }
+        zx[i] = r0 < r1 ? r0 : r1;
+        zy[i] = r0 < r1 ? r1 : r0;
+        parent[r0] = next;
+        parent[r1] = next;
+        ++next;
+    }
+    // ---- maximum distance below every internal node (children are earlier rows)
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        double v = zd[i];
+        if (zx[i] >= (int)n && md[zx[i] - (int)n] > v) v = md[zx[i] - (int)n];
+        if (zy[i] >= (int)n && md[zy[i] - (int)n] > v) v = md[zy[i] - (int)n];
+        md[i] = v;
+    }
+    // ---- flat clusters
+    int kk = 0, n_cluster = 0, leader = -1;
+    stack[0] = 2 * (int)n - 2;
+    while (kk >= 0) {
+        const int root = stack[kk] - (int)n;
+        const int lc = zx[root], rc = zy[root];
+        if (leader == -1 && md[root] <= cutoff) { leader = root; ++n_cluster; }
+        if (lc >= (int)n && !visited[lc]) { visited[lc] = 1; stack[++kk] = lc; continue; }
+        if (rc >= (int)n && !visited[rc]) { visited[rc] = 1; stack[++kk] = rc; continue; }
+        if (lc < (int)n) { if (leader == -1) ++n_cluster; labels[lc] = (uint32_t)n_cluster; }
+        if (rc < (int)n) { if (leader == -1) ++n_cluster; labels[rc] = (uint32_t)n_cluster; }
+        if (leader == root) leader = -1;
+        --kk;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_linkage_cut(LinkArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_mem[kThreads * kSlice];
+    const uint32_t p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= a.n_parts) return;
+    const uint32_t n = a.n_members[p];
+    char* mem = n <= kLdsN ? s_mem + (size_t)threadIdx.x * kSlice : a.scratch + a.scratch_off[p];
+    linkage_cut_one(n, a.dist + a.dist_off[p], a.cutoff, a.labels + a.label_off[p], mem);
+}
+
+}  // namespace
+
+extern "C" int svx_linkage_cut_batch(svx_ctx* ctx, const double* dist, const uint32_t* n_members, uint32_t n_parts,
+                                     double cutoff, uint32_t* labels) {
+    if (!ctx) return SVX_E_INVALID;
+    if (n_parts == 0) return SVX_OK;
+    if (!n_members || !labels) return SVX_E_INVALID;
+    std::vector<uint64_t> dist_off(n_parts), label_off(n_parts), scratch_off(n_parts);
+    uint64_t n_dist = 0, n_lab = 0, n_scratch = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const uint64_t n = n_members[p];
+        dist_off[p] = n_dist;
+        label_off[p] = n_lab;
+        scratch_off[p] = n_scratch;
+        n_dist += n * (n ? n - 1 : 0) / 2;
+        n_lab += n;
+        if (n > kLdsN) n_scratch += svx_align_up(link_bytes((uint32_t)n), 16);
+    }
+    if (n_dist && !dist) return SVX_E_INVALID;
+    if (n_lab == 0) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    size_t need = svx_take_bytes(n_dist ? n_dist : 1, 8) + 3 * svx_take_bytes(n_parts, 8) + svx_take_bytes(n_parts, 4) +
+                  svx_take_bytes(n_lab, 4) + svx_take_bytes(n_scratch ? n_scratch : 1, 1);
+    int rc = svx_stage_reserve(ctx, need);
+    if (rc != SVX_OK) return rc;
+    LinkArgs a;
+    double* d_dist = svx_stage_take<double>(ctx, n_dist ? n_dist : 1);
+    uint64_t* d_doff = svx_stage_take<uint64_t>(ctx, n_parts);
+    uint64_t* d_loff = svx_stage_take<uint64_t>(ctx, n_parts);
+    uint64_t* d_soff = svx_stage_take<uint64_t>(ctx, n_parts);
+    uint32_t* d_nm = svx_stage_take<uint32_t>(ctx, n_parts);
+    uint32_t* d_lab = svx_stage_take<uint32_t>(ctx, n_lab);
+    char* d_scratch = svx_stage_take<char>(ctx, n_scratch ? n_scratch : 1);
+    if (n_dist) SVX_HIP(ctx, hipMemcpyAsync(d_dist, dist, n_dist * 8, hipMemcpyHostToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(d_doff, dist_off.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(d_loff, label_off.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(d_soff, scratch_off.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(d_nm, n_members, (size_t)n_parts * 4, hipMemcpyHostToDevice, ctx->stream));
+    a.dist = d_dist; a.dist_off = d_doff; a.n_members = d_nm; a.label_off = d_loff; a.scratch_off = d_soff;
+    a.scratch = d_scratch; a.n_parts = n_parts; a.cutoff = cutoff; a.labels = d_lab;
+    rc = svx_timing_begin(ctx);
+    if (rc != SVX_OK) return rc;
+    rc = svx_timing_mark(ctx, 1);
+    if (rc != SVX_OK) return rc;
+    hipLaunchKernelGGL(k_linkage_cut, dim3((n_parts + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream, a);
+    SVX_HIP(ctx, hipGetLastError());
+    rc = svx_timing_mark(ctx, 2);
+    if (rc != SVX_OK) return rc;
+    rc = svx_timing_end(ctx);
+    if (rc != SVX_OK) return rc;
+    SVX_HIP(ctx, hipMemcpyAsync(labels, d_lab, n_lab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SVX_OK;
+}

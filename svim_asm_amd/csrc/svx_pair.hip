@@ -139,21 +139,18 @@ __global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
     uint32_t before0 = 0, before1 = 0, total0 = 0, total1 = 0;
     {
         const uint2* __restrict__ col = reinterpret_cast<const uint2*>(hist) + tid;
-        uint32_t c = 0;
-        for (; c + 16 <= b.n_blocks; c += 16) {
+        // (rows past the end read as zero through the predicate: the tail is a batch like the others,
+        // never one dependent load after another)
+        for (uint32_t c = 0; c < b.n_blocks; c += 16) {
             uint2 x[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = col[(size_t)(c + u) * (kBuckets / 2)];
+            for (int u = 0; u < 16; ++u)
+                x[u] = c + u < b.n_blocks ? col[(size_t)(c + u) * (kBuckets / 2)] : make_uint2(0u, 0u);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 total0 += x[u].x; total1 += x[u].y;
                 if (c + u < blockIdx.x) { before0 += x[u].x; before1 += x[u].y; }
             }
-        }
-        for (; c < b.n_blocks; ++c) {
-            const uint2 x = col[(size_t)c * (kBuckets / 2)];
-            total0 += x.x; total1 += x.y;
-            if (c < blockIdx.x) { before0 += x.x; before1 += x.y; }
         }
     }
     __syncthreads();  // s_run zeroed
@@ -210,9 +207,13 @@ __global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
         if (valid && rank == 0) run[dig] += __popcll(m);
         wave_lds_sync();
         if (valid) {
+#ifndef SVX_EXP_NOSCATTER  // (ablation builds only)
             dk[pos] = key[it];
             di[pos] = id[it];
+#endif
+#ifndef SVX_EXP_NOHNEXT  // (ablation builds only)
             if (hnext) atomicAdd(&hnext[(size_t)(pos / kBlockKeys) * kBuckets + ((uint32_t)(key[it] >> nshift) & dmask)], 1u);
+#endif
         }
     }
 }
@@ -274,7 +275,6 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t flag, uint32_t* s_w
 // re-walks the range with the exclusive sum of the earlier workgroups as carry-in.
 __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
     __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
     const uint32_t lo = blockIdx.x * span, hi = min(p.n, lo + span);
     uint32_t carry = 0;
     if (gridDim.x > 1) {
@@ -283,17 +283,13 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
         uint32_t tot;
         (void)block_scan_1024(cnt, s_w, &tot);
         if (threadIdx.x == 0) {
+            // block_tot is the only data another workgroup reads inside this launch: agent-scope atomic
+            // store and loads on both sides, no cache-wide release / acquire fences needed
             __hip_atomic_store(&p.block_tot[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
                 __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            uint32_t c = 0;
-            for (uint32_t g = 0; g < blockIdx.x; ++g)
-                c += __hip_atomic_load(&p.block_tot[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_carry = c;
             // the last workgroup to get here puts the counter back to zero for the next call
             if (__hip_atomic_fetch_add(p.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
                 __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -301,7 +297,15 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
             }
         }
         __syncthreads();
-        carry = s_carry;
+        // exclusive sum of the earlier workgroups' flags: one load per thread (the grid has at most one
+        // workgroup per CU, i.e. fewer than 1024), reduced over the workgroup
+        {
+            uint32_t v = threadIdx.x < blockIdx.x
+                             ? __hip_atomic_load(&p.block_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t tot2;
+            (void)block_scan_1024(v, s_w, &tot2);
+            carry = tot2;
+        }
     }
     for (uint32_t base = lo; base < hi; base += 1024) {
         const uint32_t j = base + threadIdx.x;

@@ -304,3 +304,30 @@ def run_cli_ranks(argv, world_size, timeout=600):
             text += "\n[timeout]"
         out.append((p.returncode, text))
     return out
+
+
+# ---- reference-generated function vectors (tests/golden/pipeline_vectors.json.gz) --------------
+def _tuplify(x):
+    return tuple(_tuplify(v) for v in x) if isinstance(x, list) else x
+
+
+def load_pipeline_vectors():
+    """COLLECT / analyze_read_segments / form_partitions / pair_candidates vectors written by the real
+    reference (oracle/make_golden.py pipeline).  JSON lists become the tuples the comparisons use."""
+    import gzip
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_vectors.json.gz")
+    with gzip.open(path, "rt") as fh:
+        vec = json.load(fh)
+    for c in vec["collect"]:
+        for r in c["records"]:
+            r["cigar"] = [tuple(t) for t in r["cigar"]]
+        c["out"] = [_tuplify(t) for t in c["out"]]
+        for pr in c["analyze_read_segments"]:
+            pr["out"] = [_tuplify(t) for t in pr["out"]]
+    for p in vec["pair"]:
+        p["t1"] = [_tuplify(t) for t in p["t1"]]
+        p["t2"] = [_tuplify(t) for t in p["t2"]]
+        p["out"] = [_tuplify(t) for t in p["out"]]
+    return vec

@@ -98,6 +98,39 @@ def test_pair_candidates_matches_oracle(svx_ctx, seed):
         assert gp == svim_oracle.form_partitions(osub, o.partition_max_distance)
 
 
+def test_pipeline_vectors_from_the_real_reference(svx_ctx):
+    """The product's COLLECT, analyze_read_segments, form_partitions and pair_candidates against vectors
+    the REAL reference produced in the build container (oracle/make_golden.py pipeline)."""
+    vec = helpers.load_pipeline_vectors()
+    names, lengths = vec["names"], vec["lengths"]
+    for case in vec["collect"]:
+        o = helpers.options(**case["options"])
+        bam = helpers.FakeBam(names, lengths, case["records"])
+        got = [helpers.candidate_tuple(c) for c in SVIM_COLLECT.analyze_alignment_file_coordsorted(bam, o)]
+        assert got == case["out"]
+        alns = list(bam.fetch())
+        for pr in case["analyze_read_segments"]:
+            aln = alns[pr["record"]]
+            supp = [s for s in SVIM_COLLECT.retrieve_other_alignments(aln, bam)
+                    if not s.is_unmapped and s.mapping_quality >= o.min_mapq]
+            got = [helpers.candidate_tuple(c) for c in SVIM_inter.analyze_read_segments(aln, supp, bam, o)]
+            assert got == pr["out"]
+    for case in vec["pair"]:
+        o = helpers.options(**case["options"])
+        seqs = case["seqs"]
+        plen = [len(seqs[n]) for n in names]
+        ref, bam = helpers.FakeFasta(seqs), helpers.FakeBam(names, plen, [])
+        c1 = [helpers.build_candidate(t, bam, SVCandidate) for t in case["t1"]]
+        c2 = [helpers.build_candidate(t, bam, SVCandidate) for t in case["t2"]]
+        for typ, parts in case["form_partitions"].items():
+            sub = [(1, c) for c in c1 if c.type == typ] + [(2, c) for c in c2 if c.type == typ]
+            where = {id(c): k for k, (_, c) in enumerate(sub)}
+            got = [[where[id(c)] for _, c in p] for p in SVIM_COMBINE.form_partitions(sub, o.partition_max_distance)]
+            assert got == parts
+        got = [helpers.candidate_tuple(c) for c in SVIM_COMBINE.pair_candidates(c1, c2, ref, bam, o)]
+        assert got == case["out"]
+
+
 @pytest.mark.parametrize("name", sorted(RUNS))
 def test_cli_reproduces_reference_vcf(svx_ctx, tmp_path, name):
     """`svim-asm haploid|diploid` on the config-1 BAMs == the VCF written by the real reference."""

@@ -108,8 +108,12 @@ def test_split_read_post_passes_match_oracle(seed):
         segs = np.array(rows, dtype=np.int32).view(orc.SEG_DTYPE).reshape(-1)
         raw = orc.segments_classify(segs, np.array([0, len(rows)], np.uint32),
                                     np.array([prim.infer_read_length()], np.int32), prm)
-        got = [helpers.candidate_tuple(c) for c in
-               SVIM_inter.candidates_from_raw(raw, prim, bam, o, lambda a, b: prim.query_sequence[a:b])]
+        groups = []  # the inversion groups are clustered on the GPU in the product: here by the C oracle
+        cands = SVIM_inter.candidates_from_raw(raw, prim, bam, o, lambda a, b: prim.query_sequence[a:b], groups)
+        for g in groups:
+            labels = [int(x) for x in orc.linkage_cut(SVIM_inter._inversion_condensed(g), len(g), 0.3)] if len(g) > 1 else [1]
+            cands.extend(SVIM_inter._inversion_candidates(g, labels, prim.query_name, bam))
+        got = [helpers.candidate_tuple(c) for c in cands]
         osupp = [s for s in svim_oracle.retrieve_other_alignments(rec, NAMES) if s["mapq"] >= o.min_mapq]
         exp = svim_oracle.analyze_read_segments(rec, osupp, NAMES, lens, o)
         assert got == exp

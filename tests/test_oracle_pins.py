@@ -179,3 +179,82 @@ def test_banded_oracle_equals_full_matrix_oracle():
             b = bytes(b)
         assert orc.edit_distance_banded(a, b) == orc.edit_distance(a, b)
     assert orc.edit_distance_banded(b"", b"ACG") == 3 and orc.edit_distance_banded(b"ACG", b"") == 3
+
+
+def test_pipeline_vectors_from_the_real_reference():
+    """COLLECT, per-read analyze_read_segments, form_partitions and pair_candidates of the oracle against
+    vectors the REAL reference produced (oracle/make_golden.py pipeline)."""
+    from tests import helpers
+    vec = helpers.load_pipeline_vectors()
+    names, lengths = vec["names"], vec["lengths"]
+    lens = dict(zip(names, lengths))
+    for case in vec["collect"]:
+        o = helpers.options(**case["options"])
+        recs = case["records"]
+        assert svim_oracle.collect(recs, names, lengths, o) == case["out"]
+        for pr in case["analyze_read_segments"]:
+            rec = recs[pr["record"]]
+            supp = [s for s in svim_oracle.retrieve_other_alignments(rec, names) if s["mapq"] >= o.min_mapq]
+            assert svim_oracle.analyze_read_segments(rec, supp, names, lens, o) == pr["out"]
+    for case in vec["pair"]:
+        o = helpers.options(**case["options"])
+        seqs = case["seqs"]
+        plen = [len(seqs[n]) for n in names]
+        fasta = helpers.FakeFasta(seqs)
+        t1, t2 = case["t1"], case["t2"]
+        for typ, parts in case["form_partitions"].items():
+            sub = [(1, t) for t in t1 if t[0] == typ] + [(2, t) for t in t2 if t[0] == typ]
+            got = svim_oracle.form_partitions(sub, o.partition_max_distance)
+            assert got == [[sub[k] for k in p] for p in parts]
+        got = svim_oracle.pair_candidates(t1, t2, fasta.fetch, names, plen, dict(zip(names, plen)), o,
+                                          edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+        assert got == case["out"]
+
+
+def _scipy_cut(cond, cutoff):
+    from scipy.cluster.hierarchy import fcluster, linkage
+    return list(fcluster(linkage(np.array(cond, dtype=float), method="complete"), cutoff, criterion="distance"))
+
+
+def linkage_cases():
+    """Condensed distance vectors that exercise scipy's tie-breaking: every rank pattern (with ties) for
+    n <= 4, a seeded sample of them for n = 5, 6, and random vectors with few distinct values to n = 12;
+    each with cut-offs below, between and above the values."""
+    import itertools
+    out = []
+    for n in (2, 3, 4):
+        m = n * (n - 1) // 2
+        for ranks in itertools.product(range(min(m, 4)), repeat=m):
+            out.append((n, [float(r) for r in ranks]))
+    rng = np.random.default_rng(5)
+    for n in (5, 6):
+        m = n * (n - 1) // 2
+        for _ in range(1500):
+            out.append((n, [float(x) for x in rng.integers(0, int(rng.integers(2, 6)), m)]))
+    for _ in range(1500):
+        n = int(rng.integers(2, 13))
+        m = n * (n - 1) // 2
+        kind = int(rng.integers(0, 3))
+        if kind == 0:    # edit-distance-like ints with same-haplotype sentinels (SVIM_COMBINE.py:37)
+            v = rng.integers(0, 400, m).astype(float)
+            v[rng.random(m) < 0.4] = 1000000000.0
+        elif kind == 1:  # breakend metric (d1 + d2) / 3000 and the 99999 sentinel (:105-117)
+            v = rng.integers(0, 2000, m) / 3000
+            v[rng.random(m) < 0.3] = 99999
+        else:            # inversion metric 1 - relative overlap, many exact 1.0 (SVIM_inter.py:19-39)
+            v = 1 - rng.integers(0, 11, m) / 10.0
+        out.append((n, [float(x) for x in v]))
+    return out
+
+
+def test_linkage_cut_matches_scipy():
+    """orc_linkage_cut == scipy's fcluster(linkage(y, "complete"), t, "distance") including the label
+    order (SVIM_COMBINE.py:134-139,155-160; SVIM_inter.py:47-52)."""
+    for n, cond in linkage_cases():
+        vals = sorted(set(cond))
+        cuts = {vals[0] - 0.5, vals[0], vals[-1], vals[-1] + 1, 0.3, 200.0}
+        if len(vals) > 1:
+            cuts.add((vals[0] + vals[1]) / 2)
+            cuts.add(vals[len(vals) // 2])
+        for t in sorted(cuts):
+            assert list(orc.linkage_cut(cond, n, t)) == _scipy_cut(cond, t), (n, cond, t)

@@ -37,6 +37,15 @@ class OracleCtx(object):
         return np.array(out, dtype=np.uint32)
 
 
+    def linkage_cut_batch(self, dist, n_members, cutoff):
+        out, at = [], 0
+        for n in n_members:
+            m = n * (n - 1) // 2
+            out.extend(orc.linkage_cut(dist[at:at + m], n, cutoff).tolist() if n > 1 else [1] * n)
+            at += m
+        return np.array(out, dtype=np.uint32)
+
+
 _lib.default_context = lambda device=0: OracleCtx()
 
 if __name__ == "__main__":
