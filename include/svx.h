@@ -233,6 +233,41 @@ int svx_segments_classify_dev(svx_ctx* ctx, const svx_seg* d_segs, uint32_t n_se
                               const int32_t* d_read_len, const svx_seg_params* params,
                               svx_raw* d_out);
 
+/*
+ * The three per-read post-passes of analyze_read_segments (SVIM_inter.py:260-338) over the raw records
+ * of svx_segments_classify: tandem-duplication merge (:261-290), interspersed duplications from pairs of
+ * breakends (:293-320), inversion sweep + complete-linkage clustering (:323-338, :42-60).  The INS / DEL /
+ * BND records of `raw` ARE candidates already (one each, in slot order); this call adds the derived ones.
+ *
+ *   raw, read_off   as written by / passed to svx_segments_classify (slot i of read r = raw[read_off[r] + i])
+ *   contig_rank     per reference id: rank of the contig NAME under Python str ordering — the inversion
+ *                   sweep sorts by (name, start, end) (:323); ids >= n_contigs rank as themselves
+ *   params          min_sv_size / max_sv_size bound the interspersed-duplication length (:309,:313)
+ *   out, out_off    derived candidates of read r at out[out_off[r] .. out_off[r] + out_cnt[r]), in the
+ *                   reference's order: tandem duplications, interspersed duplications, inversions;
+ *                   out_off[r+1] - out_off[r] must be at least svx_segments_postpass_bound(slots of r)
+ *                   (= s (s + 3) / 2: s tandems, s (s - 1) / 2 breakend pairs, s inversions), else
+ *                   SVX_E_CAPACITY
+ * Records (a0..a5):
+ *   SVX_POST_TANDEM   ref_id, start, end, copies, fully_covered        (CandidateDuplicationTandem)
+ *   SVX_POST_DUP_INT  src ref_id, src start, src end, dst ref_id, dst start, dst end
+ *   SVX_POST_INV      ref_id, start, end, complete                       (CandidateInversion)
+ */
+#define SVX_POST_TANDEM 1
+#define SVX_POST_DUP_INT 2
+#define SVX_POST_INV 3
+
+typedef struct svx_post {
+    int32_t kind;
+    int32_t a0, a1, a2, a3, a4, a5;
+    int32_t pad;
+} svx_post;
+
+uint64_t svx_segments_postpass_bound(uint32_t n_slots);
+int svx_segments_postpass(svx_ctx* ctx, const svx_raw* raw, const uint32_t* read_off, uint32_t n_reads,
+                          const int32_t* contig_rank, uint32_t n_contigs, const svx_seg_params* params,
+                          svx_post* out, const uint64_t* out_off, uint32_t* out_cnt);
+
 /* ------------------------------------------------------------ a5 + a6 ------ */
 /*
  * Pair sort + partition: form_partitions (SVIM_COMBINE.py:15-32).

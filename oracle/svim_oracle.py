@@ -360,6 +360,73 @@ def analyze_read_segments(primary, supplementaries, names, lens, o):
     return out
 
 
+def postpass_records(raw, contig_rank, min_sv_size, max_sv_size):
+    """Record-level restatement of the three post-passes (SVIM_inter.py:260-338) for ONE read: `raw` is
+    the read's adjacency records as (kind, a0..a5) tuples in sorted-pair order (kinds: 3 BND, 4 TANDEM,
+    5 INV — the layout of svx_raw in include/svx.h); contig_rank[ref_id] is the rank of the contig name
+    under Python str ordering (the inversion sort key, :323).  Returns the derived records in the
+    reference's order as tuples ("TANDEM", ref, start, end, copies, fully), ("DUP_INT", src_ref,
+    src_start, src_end, dst_ref, dst_start, dst_end), ("INV", ref, start, end, complete)."""
+    out = []
+    tandems = [(r[1], r[2], r[3], bool(r[4]), bool(r[5])) for r in raw if r[0] == 4]
+    transl = [(r[3], r[6], r[1], r[2], r[4], r[5]) for r in raw if r[0] == 3]   # (d1, d2, c1, p1, c2, p2)
+    inversions = [(r[1], r[2], r[3], r[4]) for r in raw if r[0] == 5]           # (ref, start, end, side 0..3)
+    cur_chr = None
+    for td in tandems:
+        if cur_chr is None:
+            cur_chr, starts, ends, copies, fully, direction = td[0], [td[1]], [td[2]], 1, [td[3]], td[4]
+        elif (cur_chr == td[0] and abs(_mean(starts) - td[1]) < 20 and abs(_mean(ends) - td[2]) < 20
+              and direction == td[4]):
+            starts.append(td[1]); ends.append(td[2]); copies += 1; fully.append(td[3])
+        else:
+            out.append(("TANDEM", cur_chr, int(_mean(starts)), int(_mean(ends)), copies, any(fully)))
+            cur_chr, starts, ends, copies, fully = td[0], [td[1]], [td[2]], 1, [td[3]]
+    if cur_chr is not None:
+        out.append(("TANDEM", cur_chr, int(_mean(starts)), int(_mean(ends)), copies, any(fully)))
+    for ti in range(len(transl)):
+        t_d1, t_d2, t_c1, t_p1, t_c2, t_p2 = transl[ti]
+        for b_d1, b_d2, b_c1, b_p1, b_c2, b_p2 in transl[:ti]:
+            if b_d1 == t_d2 and b_d2 == t_d1 and is_similar(b_c1, b_p1, 0, t_c2, t_p2, 0) \
+                    and b_c2 == t_c1 and b_d2 == b_d1:
+                if b_d1 == 0:
+                    length = t_p1 + 1 - b_p2
+                    if min_sv_size <= length <= max_sv_size:
+                        m = int(_mean([b_p1 + 1, t_p2]))
+                        out.append(("DUP_INT", b_c2, b_p2, t_p1 + 1, b_c1, m, m + length))
+                else:
+                    length = b_p2 + 1 - t_p1
+                    if min_sv_size <= length <= max_sv_size:
+                        m = int(_mean([b_p1, t_p2 + 1]))
+                        out.append(("DUP_INT", b_c2, t_p1, b_p2 + 1, b_c1, m, m + length))
+
+    def flush(active):
+        if len(active) < 2:
+            clusters = [active]
+        else:
+            rows = [(i[1], i[2], 0 if i[3] < 2 else 1) for i in active]
+            dist = [reciprocal_overlap_distance(rows[i], rows[j])
+                    for i in range(len(rows) - 1) for j in range(i + 1, len(rows))]
+            labels = _complete_linkage_labels(dist, len(rows), 0.3)
+            clusters = [[] for _ in range(max(labels))]
+            for idx, lab in enumerate(labels):
+                clusters[lab - 1].append(active[idx])
+        for cl in clusters:
+            out.append(("INV", cl[0][0], max(i[1] for i in cl), min(i[2] for i in cl), len(cl) > 1))
+
+    active = []
+    for inv in sorted(inversions, key=lambda i: (contig_rank[i[0]], i[1], i[2])):
+        if not active:
+            active.append(inv)
+        elif inv[0] == active[-1][0] and inv[1] < max(i[2] for i in active):
+            active.append(inv)
+        else:
+            flush(active)
+            active = []
+    if active:
+        flush(active)
+    return out
+
+
 # ----------------------------------------------------------------------------- a4
 _CIG_RE = re.compile(r"(\d+)([MIDNSHP=XB])")
 

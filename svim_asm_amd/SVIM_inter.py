@@ -1,15 +1,13 @@
 """Inter-alignment (split-segment) SV signatures.
 
 Mirrors analyze_read_segments(primary, supplementaries, bam, options) (SVIM_inter.py:62-340).
-The adjacent-pair decision tree (:91-258) runs on the GPU (svx_segments_classify); the three
-per-read post-passes — tandem-duplication merge (:261-290), interspersed duplications from
-breakend pairs (:293-320) and the inversion sweep (:323-338) — run here on the raw records of each
-read (a handful per read); the complete-linkage clustering of overlapping inversion breakpoints
-(:42-60, scipy in the reference) is svx_linkage_cut_batch, one launch for all reads.
-`analyze_read_segments_batch` is the entry COLLECT uses: one launch for all reads.
+The adjacent-pair decision tree (:91-258) runs on the GPU (svx_segments_classify) and so do the three
+per-read post-passes — tandem-duplication merge (:261-290), interspersed duplications from breakend
+pairs (:293-320), inversion sweep and complete-linkage clustering (:323-338, :42-60; scipy in the
+reference) — svx_segments_postpass, one lane per read.  The host turns the records of both kernels
+into Candidate objects.  `analyze_read_segments_batch` is the entry COLLECT uses: two launches for
+all reads of a BAM.
 """
-from fractions import Fraction
-
 import numpy as np
 
 from svim_asm_amd import _lib
@@ -71,96 +69,46 @@ def segment_row(alignment):
             1 if alignment.is_reverse else 0)
 
 
-def _mean(values):
-    return Fraction(sum(values), len(values))  # statistics.mean of ints is exact
-
-
-def candidates_from_raw(raw, primary, bam, options, sequence_slice, inversion_groups=None):
-    """Raw records of ONE read (sorted-pair order) → candidates in the reference's order:
-    adjacency INS/DEL/BND, then DUP_TAN, then DUP_INT, then INV.  With `inversion_groups` (a list) the
-    read's groups of overlapping inversion breakpoints are appended to it instead of being clustered
-    here: the caller clusters the groups of all reads with one launch and appends the INV candidates."""
+def candidates_from_records(raw, post, primary, bam, sequence_slice):
+    """Candidates of ONE read in the reference's order (SVIM_inter.py:91-338): the adjacency records of
+    svx_segments_classify (INS / DEL / BND, sorted-pair order), then the derived records of
+    svx_segments_postpass (tandem duplications, interspersed duplications, inversions)."""
     read_name = primary.query_name
     name = bam.get_reference_name
-    sv_candidates, tandems, translocations, inversions = [], [], [], []
+    sv_candidates = []
     for r in raw:
         kind = int(r["kind"])
-        if kind == _lib.RAW_NONE:
-            continue
-        a0, a1, a2, a3, a4, a5 = (int(r[k]) for k in ("a0", "a1", "a2", "a3", "a4", "a5"))
         if kind == _lib.RAW_INS:
-            sv_candidates.append(CandidateInsertion(name(a0), a1, a2, [read_name], sequence_slice(a3, a3 + a4), bam))
+            a3 = int(r["a3"])
+            sv_candidates.append(CandidateInsertion(name(int(r["a0"])), int(r["a1"]), int(r["a2"]), [read_name],
+                                                    sequence_slice(a3, a3 + int(r["a4"])), bam))
         elif kind == _lib.RAW_DEL:
-            sv_candidates.append(CandidateDeletion(name(a0), a1, a2, [read_name], bam))
+            sv_candidates.append(CandidateDeletion(name(int(r["a0"])), int(r["a1"]), int(r["a2"]), [read_name], bam))
         elif kind == _lib.RAW_BND:
-            c1, c2 = (name(a0), name(a3)) if a0 != a3 else (name(a0),) * 2
-            sv_candidates.append(CandidateBreakend(c1, a1, _DIR[a2], c2, a4, _DIR[a5], [read_name], bam))
-            translocations.append((_DIR[a2], _DIR[a5], c1, a1, c2, a4))
-        elif kind == _lib.RAW_TANDEM:
-            tandems.append((name(a0), a1, a2, bool(a3), bool(a4)))
-        elif kind == _lib.RAW_INV:
-            inversions.append((name(a0), a1, a2, _INV_SIDE[a3]))
-
-    # tandem duplications: merge consecutive similar tuples; the direction compared against stays
-    # that of the read's FIRST tuple (reference quirk, SURVEY.md A3.7)
-    run = None
-    for chrom, start, end, fully, direction in tandems:
-        if run is None:
-            run = dict(chrom=chrom, starts=[start], ends=[end], fully=[fully])
-            first_direction = direction
-        elif (run["chrom"] == chrom and abs(_mean(run["starts"]) - start) < 20 and
-              abs(_mean(run["ends"]) - end) < 20 and first_direction == direction):
-            run["starts"].append(start); run["ends"].append(end); run["fully"].append(fully)
-        else:
-            sv_candidates.append(_tandem_candidate(run, read_name, bam))
-            run = dict(chrom=chrom, starts=[start], ends=[end], fully=[fully])
-    if run is not None:
-        sv_candidates.append(_tandem_candidate(run, read_name, bam))
-
-    # interspersed duplications from pairs of breakends (:293-320)
-    lo, hi = options.min_sv_size, options.max_sv_size
-    for ti, (t_d1, t_d2, t_c1, t_p1, t_c2, t_p2) in enumerate(translocations):
-        for b_d1, b_d2, b_c1, b_p1, b_c2, b_p2 in translocations[:ti]:
-            if not (b_d1 == t_d2 and b_d2 == t_d1 and b_c1 == t_c2 and abs(b_p1 - t_p2) < 20 and
-                    b_c2 == t_c1 and b_d2 == b_d1):
-                continue
-            if b_d1 == "fwd":
-                length = t_p1 + 1 - b_p2
-                if lo <= length <= hi:
-                    mid = int(_mean([b_p1 + 1, t_p2]))
-                    sv_candidates.append(CandidateDuplicationInterspersed(b_c2, b_p2, t_p1 + 1, b_c1, mid,
-                                                                          mid + length, [read_name], bam))
-            elif b_d1 == "rev":
-                length = b_p2 + 1 - t_p1
-                if lo <= length <= hi:
-                    mid = int(_mean([b_p1, t_p2 + 1]))
-                    sv_candidates.append(CandidateDuplicationInterspersed(b_c2, t_p1, b_p2 + 1, b_c1, mid,
-                                                                          mid + length, [read_name], bam))
-
-    # inversions: sweep over sorted breakpoints; the breakpoint that closes a group is dropped
-    # (reference quirk, SURVEY.md A3.10).  The groups are clustered later, all reads in one launch.
-    groups, active = [], []
-    for inv in sorted(inversions, key=lambda i: (i[0], i[1], i[2])):
-        if not active:
-            active.append(inv)
-        elif inv[0] == active[-1][0] and inv[1] < max(i[2] for i in active):
-            active.append(inv)
-        else:
-            groups.append(active)
-            active = []
-    if active:
-        groups.append(active)
-    if inversion_groups is None:
-        for g in groups:
-            sv_candidates.extend(process_overlapping_inversions(g, read_name, bam))
-    else:
-        inversion_groups.extend(groups)
+            sv_candidates.append(CandidateBreakend(name(int(r["a0"])), int(r["a1"]), _DIR[int(r["a2"])], name(int(r["a3"])),
+                                                   int(r["a4"]), _DIR[int(r["a5"])], [read_name], bam))
+    for r in post:
+        kind = int(r["kind"])
+        if kind == _lib.POST_TANDEM:
+            sv_candidates.append(CandidateDuplicationTandem(name(int(r["a0"])), int(r["a1"]), int(r["a2"]), int(r["a3"]),
+                                                            bool(r["a4"]), [read_name], bam))
+        elif kind == _lib.POST_DUP_INT:
+            sv_candidates.append(CandidateDuplicationInterspersed(name(int(r["a0"])), int(r["a1"]), int(r["a2"]),
+                                                                  name(int(r["a3"])), int(r["a4"]), int(r["a5"]),
+                                                                  [read_name], bam))
+        elif kind == _lib.POST_INV:
+            sv_candidates.append(CandidateInversion(name(int(r["a0"])), int(r["a1"]), int(r["a2"]), [read_name],
+                                                    bool(r["a3"]), bam))
     return sv_candidates
 
 
-def _tandem_candidate(run, read_name, bam):
-    return CandidateDuplicationTandem(run["chrom"], int(_mean(run["starts"])), int(_mean(run["ends"])),
-                                      len(run["starts"]), any(run["fully"]), [read_name], bam)
+def contig_ranks(bam):
+    """Rank of every contig name under Python str ordering: the inversion sweep sorts by name (:323)."""
+    names = list(bam.references)
+    rank = np.zeros(len(names), dtype=np.int32)
+    for k, i in enumerate(sorted(range(len(names)), key=lambda i: names[i])):
+        rank[i] = k
+    return rank
 
 
 def seg_params(options):
@@ -190,26 +138,11 @@ def analyze_read_segments_batch(reads, bam, options, ctx=None, rows=None, read_l
     read_off = np.concatenate(([0], np.cumsum(counts))).astype(np.uint32)
     segs = np.array([t for r in rows for t in r], dtype=np.int32).reshape(-1, 6)
     segs = np.ascontiguousarray(segs).view(_lib.SEG_DTYPE).reshape(-1)
-    raw = ctx.segments_classify(segs, read_off, np.asarray(read_lens, dtype=np.int32), seg_params(options))
-    out, pending = [], []  # pending: (read index, groups of that read)
-    for i, (primary, _) in enumerate(reads):
-        groups = []
-        out.append(candidates_from_raw(raw[read_off[i]:read_off[i + 1]], primary, bam, options, _slicer(primary), groups))
-        if groups:
-            pending.append((i, groups))
-    # inversion clustering of every read in one launch (single-member groups need none)
-    multi = [g for _, groups in pending for g in groups if len(g) > 1]
-    labels = iter(())
-    if multi:
-        flat = [d for g in multi for d in _inversion_condensed(g)]
-        lab = ctx.linkage_cut_batch(flat, [len(g) for g in multi], 0.3).tolist()
-        pos = np.concatenate(([0], np.cumsum([len(g) for g in multi]))).tolist()
-        labels = iter(lab[a:b] for a, b in zip(pos[:-1], pos[1:]))
-    for i, groups in pending:
-        name = reads[i][0].query_name
-        for g in groups:
-            out[i].extend(_inversion_candidates(g, next(labels) if len(g) > 1 else [1] * len(g), name, bam))
-    return out
+    prm = seg_params(options)
+    raw = ctx.segments_classify(segs, read_off, np.asarray(read_lens, dtype=np.int32), prm)
+    post, first = ctx.segments_postpass(raw, read_off, contig_ranks(bam), prm)
+    return [candidates_from_records(raw[read_off[i]:read_off[i + 1]], post[first[i]:first[i + 1]], primary, bam,
+                                    _slicer(primary)) for i, (primary, _) in enumerate(reads)]
 
 
 def analyze_read_segments(primary, supplementaries, bam, options):

@@ -24,6 +24,7 @@ _STATUS = {0: "SVX_OK", -1: "SVX_E_INVALID", -2: "SVX_E_CAPACITY", -3: "SVX_E_HI
 
 SIG_INS, SIG_DEL = 0, 1
 RAW_NONE, RAW_INS, RAW_DEL, RAW_BND, RAW_TANDEM, RAW_INV = range(6)
+POST_TANDEM, POST_DUP_INT, POST_INV = 1, 2, 3
 
 
 class SvxError(RuntimeError):
@@ -84,6 +85,8 @@ SYMBOLS = {
     "svx_segments_classify": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.POINTER(SegParams), _P]),
     "svx_segments_classify_dev": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P,
                                             C.POINTER(SegParams), _P]),
+    "svx_segments_postpass_bound": (C.c_uint64, [C.c_uint32]),
+    "svx_segments_postpass": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(SegParams), _P, _P, _P]),
     "svx_pair_partition": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32)]),
     "svx_pair_partition_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "svx_pair_partition_dev_bits": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, _P]),
@@ -259,6 +262,31 @@ class Context:
         self._check(self.lib.svx_segments_classify(self.h, _ptr(segs), _ptr(read_off), n_reads,
                                                    _ptr(read_len), C.byref(p), _ptr(out)))
         return out
+
+    def segments_postpass(self, raw, read_off, contig_rank, params):
+        """Derived candidates (tandem / interspersed duplications, inversions) of every read from its raw
+        adjacency records.  Returns (post records, first record per read [n_reads + 1])."""
+        raw = np.ascontiguousarray(raw, dtype=RAW_DTYPE)
+        read_off = _as(read_off, np.uint32)
+        contig_rank = _as(contig_rank, np.int32)
+        n_reads = len(read_off) - 1 if len(read_off) else 0
+        if n_reads == 0:
+            return np.zeros(0, dtype=RAW_DTYPE), np.zeros(1, np.int64)
+        slots = np.diff(read_off.astype(np.int64))
+        out_off = np.concatenate(([0], np.cumsum(slots * (slots + 3) // 2))).astype(np.uint64)
+        out = np.zeros(int(out_off[-1]), dtype=RAW_DTYPE)  # svx_post has svx_raw's layout: kind, a0..a5, pad
+        cnt = np.zeros(n_reads, np.uint32)
+        p = params if isinstance(params, SegParams) else SegParams(*[int(x) for x in params])
+        self._check(self.lib.svx_segments_postpass(self.h, _ptr(raw), _ptr(read_off), n_reads, _ptr(contig_rank),
+                                                   len(contig_rank), C.byref(p), _ptr(out), _ptr(out_off), _ptr(cnt)))
+        # compact: records of read r at packed[first[r] : first[r + 1]]
+        first = np.concatenate(([0], np.cumsum(cnt.astype(np.int64))))
+        if int(first[-1]):
+            take = np.repeat(out_off[:-1].astype(np.int64) - first[:-1], cnt) + np.arange(int(first[-1]))
+            packed = out[take]
+        else:
+            packed = out[:0]
+        return packed, first
 
     # ---------------------------------------------------------------- a5 + a6
     def pair_partition(self, keys, max_dist):

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsvx.so")
-SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip", "svx_linkage.hip", "svx_bam.cpp"]
+SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip", "svx_linkage.hip", "svx_postpass.hip", "svx_bam.cpp"]
 
 
 def _hipcc():
@@ -30,7 +30,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "svx_internal.h"), os.path.join(ROOT, "include", "svx.h"),
+    deps = sources() + [os.path.join(CSRC, "svx_internal.h"), os.path.join(CSRC, "svx_linkage_dev.h"), os.path.join(ROOT, "include", "svx.h"),
                         os.path.join(ROOT, "include", "svx_bam.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 

@@ -2,6 +2,7 @@
 uses (svim-asm:124; SVIM_COMBINE.py:45-99,467; SVCandidate.py:57-58,105,155,210,301-302):
 0-based half-open `fetch`, `get_reference_length`, `close`, and the two error conditions
 main() distinguishes (missing file → IOError, missing index → ValueError)."""
+import mmap
 import os
 
 import numpy as np
@@ -25,7 +26,12 @@ class FastaFile(object):
                 self.references.append(f[0])
                 self.lengths.append(int(f[1]))
         self._fh = open(path, "rb")
-        self._cache = {}
+        # fetches are tens of thousands of short windows (haplotype flanks, VCF alleles): slices of a
+        # read-only mapping instead of a seek + read pair each
+        try:
+            self._map = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ) if os.path.getsize(path) else None
+        except (OSError, ValueError):
+            self._map = None
 
     def get_reference_length(self, name):
         return self._idx[name][0]
@@ -43,13 +49,19 @@ class FastaFile(object):
             return ""
         b0 = offset + (start // line_bases) * line_width + start % line_bases
         b1 = offset + ((end - 1) // line_bases) * line_width + (end - 1) % line_bases + 1
-        self._fh.seek(b0)
-        raw = self._fh.read(b1 - b0)
+        if self._map is not None:
+            raw = self._map[b0:b1]
+        else:
+            self._fh.seek(b0)
+            raw = self._fh.read(b1 - b0)
         if line_width != line_bases:
             raw = raw.replace(b"\n", b"").replace(b"\r", b"")
         return raw.decode("ascii")
 
     def close(self):
+        if getattr(self, "_map", None) is not None:
+            self._map.close()
+            self._map = None
         if self._fh:
             self._fh.close()
             self._fh = None

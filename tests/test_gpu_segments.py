@@ -5,7 +5,7 @@ Reference: adjacent-pair decision tree of analyze_read_segments (SVIM_inter.py:6
 import numpy as np
 import pytest
 
-from oracle import orc
+from oracle import orc, svim_oracle
 from svim_asm_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -76,3 +76,94 @@ def test_empty_and_single_segment_reads(svx_ctx):
     exp = orc.segments_classify(segs, off, rl, DEFAULT)
     assert np.array_equal(got, exp)
     assert svx_ctx.segments_classify(segs[:0], np.zeros(1, np.uint32), rl[:0], DEFAULT).shape == (0,)
+
+
+def _random_raw_read(rng, n_slots, n_contigs, crowded):
+    """Raw records of one read: TANDEM / BND / INV (and a few INS / DEL / NONE) with coordinates crowded enough
+    that tandem groups merge, breakend pairs mirror each other and inversion breakpoints overlap."""
+    rows = []
+    base = int(rng.integers(1000, 50000))
+    span = 60 if crowded else 5000
+    for _ in range(n_slots):
+        kind = int(rng.choice([0, 1, 2, 3, 3, 4, 4, 5, 5, 5]))
+        ref = int(rng.integers(0, n_contigs))
+        if kind == 4:
+            start = base + int(rng.integers(0, span))
+            rows.append((4, ref if not crowded else 0, start, start + int(rng.integers(40, 90)), int(rng.integers(0, 2)),
+                         int(rng.integers(0, 2)), 0))
+        elif kind == 3 and crowded and rng.random() < 0.5 and any(r[0] == 3 and r[3] == r[6] for r in rows):
+            # the mirror image of an earlier breakend: an interspersed-duplication pair (:293-320), or nearly
+            q = [r for r in rows if r[0] == 3 and r[3] == r[6]][-1]
+            delta = int(rng.integers(20, 500))
+            rows.append((3, q[4], q[5] + (delta if q[3] == 0 else -delta), q[3], q[1], q[2] + int(rng.integers(-25, 26)), q[3]))
+        elif kind == 3:
+            d = int(rng.integers(0, 2))
+            other = int(rng.integers(0, 2))
+            rows.append((3, ref if not crowded else int(rng.integers(0, 2)), base + int(rng.integers(0, span)), d,
+                         int(rng.integers(0, n_contigs)) if not crowded else int(rng.integers(0, 2)),
+                         base + 300 + int(rng.integers(0, span)), d if rng.random() < 0.7 else other))
+        elif kind == 5:
+            start = base + int(rng.integers(0, span * 4))
+            rows.append((5, ref if not crowded else int(rng.integers(0, 2)), start, start + int(rng.integers(40, 400)),
+                         int(rng.integers(0, 4)), 0, 0))
+        else:
+            rows.append((kind, ref, base, base + 50, 0, 50, 0))
+    return rows
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_postpass_matches_record_level_oracle(svx_ctx, seed):
+    """svx_segments_postpass vs oracle/svim_oracle.postpass_records (SVIM_inter.py:260-338) on random raw
+    records: merged and split tandem groups, mirrored breakend pairs, overlapping inversion breakpoints (groups of
+    more than 10 members included), contig names whose str order differs from the id order."""
+    rng = np.random.default_rng(40 + seed)
+    n_contigs = 12
+    names = ["chr%d" % (i + 1) for i in range(n_contigs)]  # str order: chr1 chr10 chr11 chr12 chr2 ...
+    rank = np.zeros(n_contigs, np.int32)
+    for k, i in enumerate(sorted(range(n_contigs), key=lambda i: names[i])):
+        rank[i] = k
+    reads = [_random_raw_read(rng, int(rng.integers(0, 9)), n_contigs, bool(rng.random() < 0.7)) for _ in range(600)]
+    reads += [_random_raw_read(rng, int(rng.integers(12, 40)), n_contigs, True) for _ in range(12)]
+    reads.append([])
+    read_off = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.uint32)
+    raw = np.zeros(int(read_off[-1]), dtype=_lib.RAW_DTYPE)
+    k = 0
+    for r in reads:
+        for row in r:
+            for name_, v in zip(("kind", "a0", "a1", "a2", "a3", "a4", "a5"), row):
+                raw[k][name_] = v
+            k += 1
+    prm = (40, 100000, 50, 50, 50, 50) if seed % 2 == 0 else (10, 300, 50, 50, 50, 50)
+    post, first = svx_ctx.segments_postpass(raw, read_off, rank, prm)
+    code = {1: "TANDEM", 2: "DUP_INT", 3: "INV"}
+    width = {"TANDEM": 5, "DUP_INT": 6, "INV": 4}
+    kinds = set()
+    for i, r in enumerate(reads):
+        exp = svim_oracle.postpass_records(r, rank.tolist(), prm[0], prm[1])
+        got = []
+        for rec in post[first[i]:first[i + 1]]:
+            kind = code[int(rec["kind"])]
+            vals = [int(rec[n]) for n in ("a0", "a1", "a2", "a3", "a4", "a5")][:width[kind]]
+            if kind == "TANDEM":
+                vals[4] = bool(vals[4])
+            if kind == "INV":
+                vals[3] = bool(vals[3])
+            got.append((kind,) + tuple(vals))
+        assert got == exp, (i, r)
+        kinds |= {(t[0], t[-1]) if t[0] == "INV" else (t[0],) for t in exp}
+    assert {("TANDEM",), ("DUP_INT",), ("INV", True), ("INV", False)} <= kinds
+
+
+def test_postpass_capacity_is_checked(svx_ctx):
+    import ctypes as C
+    raw = np.zeros(3, dtype=_lib.RAW_DTYPE)
+    read_off = np.array([0, 3], np.uint32)
+    out = np.zeros(2, dtype=_lib.RAW_DTYPE)
+    out_off = np.array([0, 2], np.uint64)  # needs svx_segments_postpass_bound(3) = 9
+    cnt = np.zeros(1, np.uint32)
+    rank = np.zeros(1, np.int32)
+    prm = _lib.SegParams(40, 100000, 50, 50, 50, 50)
+    assert svx_ctx.lib.svx_segments_postpass_bound(3) == 9
+    rc = svx_ctx.lib.svx_segments_postpass(svx_ctx.h, raw.ctypes.data, read_off.ctypes.data, 1, rank.ctypes.data, 1,
+                                           C.byref(prm), out.ctypes.data, out_off.ctypes.data, cnt.ctypes.data)
+    assert rc == _lib.SVX_E_CAPACITY

@@ -93,7 +93,8 @@ def test_candidate_model_clamps_keys_and_breakend_normalisation():
 
 @pytest.mark.parametrize("seed", range(4))
 def test_split_read_post_passes_match_oracle(seed):
-    """product post-passes over C-oracle raw records == pinned Python oracle, per read."""
+    """host candidate assembly over oracle records (C decision tree + record-level post-passes) == the pinned
+    Python oracle of analyze_read_segments, per read."""
     rng = np.random.default_rng(seed)
     recs = helpers.engineered_split_records(rng, NAMES, LENGTHS, 400)
     o = helpers.options(**([{}, dict(min_sv_size=30, max_sv_size=2000)][seed % 2]))
@@ -108,12 +109,19 @@ def test_split_read_post_passes_match_oracle(seed):
         segs = np.array(rows, dtype=np.int32).view(orc.SEG_DTYPE).reshape(-1)
         raw = orc.segments_classify(segs, np.array([0, len(rows)], np.uint32),
                                     np.array([prim.infer_read_length()], np.int32), prm)
-        groups = []  # the inversion groups are clustered on the GPU in the product: here by the C oracle
-        cands = SVIM_inter.candidates_from_raw(raw, prim, bam, o, lambda a, b: prim.query_sequence[a:b], groups)
-        for g in groups:
-            labels = [int(x) for x in orc.linkage_cut(SVIM_inter._inversion_condensed(g), len(g), 0.3)] if len(g) > 1 else [1]
-            cands.extend(SVIM_inter._inversion_candidates(g, labels, prim.query_name, bam))
-        got = [helpers.candidate_tuple(c) for c in cands]
+        # the post-passes run on the GPU in the product: here the record-level oracle produces the records
+        # the host turns into candidates
+        rank = SVIM_inter.contig_ranks(bam)
+        rows_ = [tuple(int(r[k]) for k in ("kind", "a0", "a1", "a2", "a3", "a4", "a5")) for r in raw]
+        post = np.zeros(64, dtype=orc.RAW_DTYPE)
+        code = {"TANDEM": 1, "DUP_INT": 2, "INV": 3}
+        recs_ = svim_oracle.postpass_records(rows_, rank.tolist(), o.min_sv_size, o.max_sv_size)
+        for k, t in enumerate(recs_):
+            vals = [code[t[0]]] + [int(v) for v in t[1:]]
+            for name_, v in zip(("kind", "a0", "a1", "a2", "a3", "a4", "a5"), vals + [0] * (7 - len(vals))):
+                post[k][name_] = v
+        got = [helpers.candidate_tuple(c) for c in
+               SVIM_inter.candidates_from_records(raw, post[:len(recs_)], prim, bam, lambda a, b: prim.query_sequence[a:b])]
         osupp = [s for s in svim_oracle.retrieve_other_alignments(rec, NAMES) if s["mapq"] >= o.min_mapq]
         exp = svim_oracle.analyze_read_segments(rec, osupp, NAMES, lens, o)
         assert got == exp

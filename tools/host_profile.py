@@ -37,6 +37,18 @@ class OracleCtx(object):
         return np.array(out, dtype=np.uint32)
 
 
+    def segments_postpass(self, raw, read_off, contig_rank, params):
+        from oracle import svim_oracle
+        prm = [getattr(params, f) for f, _ in params._fields_]
+        code = {"TANDEM": 1, "DUP_INT": 2, "INV": 3}
+        recs, first = [], [0]
+        for r in range(len(read_off) - 1):
+            rows = [tuple(int(x[k]) for k in ("kind", "a0", "a1", "a2", "a3", "a4", "a5")) for x in raw[read_off[r]:read_off[r + 1]]]
+            for t in svim_oracle.postpass_records(rows, list(contig_rank), prm[0], prm[1]):
+                recs.append(tuple([code[t[0]]] + [int(v) for v in t[1:]] + [0] * (8 - len(t))))
+            first.append(len(recs))
+        return np.array(recs, dtype=_lib.RAW_DTYPE) if recs else np.zeros(0, dtype=_lib.RAW_DTYPE), np.array(first, np.int64)
+
     def linkage_cut_batch(self, dist, n_members, cutoff):
         out, at = [], 0
         for n in n_members:
