@@ -47,10 +47,11 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip latency_case / roofline_pair / roofline_editdist / e2e (N=1, rank 0 only, all outside "
                          "the timed region of `value`)")
-    ap.add_argument("--e2e-scale", type=float, default=0.05,
+    ap.add_argument("--e2e-scale", type=float, default=0.25,
                     help="BAM->VCF wall-clock leg: fraction of the GRCh38 contig lengths of the synthetic diploid "
-                         "sample written as real BAM+FASTA files (1.0 = 3.1 Gbp; generation is single-threaded "
-                         "Python, ~20 min at 1.0); 0 skips the leg")
+                         "sample written as real BAM+FASTA files (1.0 = 3.1 Gbp: ~1 min of generation plus ~45 s "
+                         "of CPU oracle pipeline on the GPU box; the default keeps the whole bench near one minute); "
+                         "0 skips the leg")
     ap.add_argument("--pipeline", action="store_true",
                     help="alternate two contexts between consecutive steps (independent batches overlap; "
                          "per-kernel durations then overlap too, so the default keeps one context)")

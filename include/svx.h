@@ -136,12 +136,22 @@ int svx_cigar_extract(svx_ctx* ctx, const uint32_t* cigar, const uint64_t* aln_o
                       svx_sig_soa out, uint64_t cap, uint64_t* n_out);
 
 /* SoA input variant named by the north star: op codes and lengths in two arrays
- * (pysam cigartuples flattened as u8 op[], u32 len[]). Same output contract. */
+ * (pysam cigartuples flattened as u8 op[], u32 len[]). Same output contract.
+ * The PACKED layout above is the fast one: it is what a BAM record holds (no conversion on ingest),
+ * it moves 4 B per op instead of 5, and its walk decodes op and length from one word (8 VALU per op;
+ * the SoA walk takes the generic 11-VALU path: 0.62 vs 0.76 of HBM peak on the same batch, and
+ * assembling the packed word from the two SoA streams on the fly was measured slower still —
+ * profiles/README.md).  Callers that hold packed words should pass them as they are. */
 int svx_cigar_extract_soa(svx_ctx* ctx, const uint8_t* op, const uint32_t* len,
                           const uint64_t* aln_off, uint32_t n_aln, const int32_t* ref_start,
                           uint32_t min_len, svx_sig_soa out, uint64_t cap, uint64_t* n_out);
 
-/* Device-pointer variants.  n_ops must equal aln_off[n_aln] (the caller knows it;
+/* Device-pointer variants.  PRECONDITION (not checked: the offsets live in HBM and nothing is read
+ * back): d_aln_off[0] == 0, non-decreasing, d_aln_off[n_aln] == n_ops — the host-pointer entry points
+ * validate exactly this and return SVX_E_INVALID; with offsets that violate it the behaviour is
+ * undefined (alignment indices derived from them index d_ref_start).  A caller that cannot vouch
+ * for its offsets should validate them before the upload, as svx_cigar_extract does.
+ * n_ops must equal aln_off[n_aln] (the caller knows it;
  * the device copy is not read back).  d_cigar / d_len / d_op must be 16-byte aligned;
  * d_op is fetched as dwords, i.e. it must be readable up to the next multiple of 4 bytes
  * after n_ops (any hipMalloc'ed buffer is); the extra bytes are ignored.  d_n_out: one uint64 in device memory.
@@ -311,6 +321,31 @@ int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_t seq_bytes
                             const uint64_t* a_off, const uint32_t* a_len, const uint64_t* b_off,
                             const uint32_t* b_len, uint32_t n_pairs, uint32_t k_max,
                             uint32_t* dist);
+
+/*
+ * The same distances with the haplotype strings assembled on the device.  compute_distance
+ * (SVIM_COMBINE.py:43-100) aligns  reference[region_start : c.start] + MIDDLE + reference[c.end : region_end]
+ * of two candidates; MIDDLE is empty (DEL), the reverse complement of reference[c.start : c.end] (INV),
+ * that interval copies + 1 times (DUP_TAN), the inserted sequence (INS) or the source interval (DUP_INT);
+ * reference slices are upper-cased (:45-99 `.upper()`), inserted sequences are taken as they are.  Each
+ * haplotype is THREE pieces of one byte pool (reference windows — one per partition is enough — and the
+ * inserted sequences): bytes pool[off .. off + len), written `repeat` times (0: piece absent), with
+ * SVX_PIECE_UPPER (ASCII str.upper()) and / or SVX_PIECE_REVCOMP (read backwards; A<->T, C<->G after
+ * the upper-casing, every other byte unchanged — SVIM_COMBINE.py:63).  pieces holds 6 per pair: the
+ * three of haplotype a, then the three of b.  Result contract as svx_edit_distance_batch.
+ */
+#define SVX_PIECE_UPPER 1
+#define SVX_PIECE_REVCOMP 2
+
+typedef struct svx_hap_piece {
+    uint64_t off;
+    uint32_t len;
+    uint16_t repeat;
+    uint16_t flags;
+} svx_hap_piece;
+
+int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
+                                 const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist);
 
 /*
  * Batched complete linkage + flat cut: for every partition p (n_members[p] candidates, condensed

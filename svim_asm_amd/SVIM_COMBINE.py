@@ -146,35 +146,144 @@ def _clusters_from_condensed(partition, distances, threshold):
     return _clusters_batch([partition], [distances], threshold)[0]
 
 
+class _HaplotypePieces(object):
+    """Recipes of the haplotype strings compute_distance aligns (SVIM_COMBINE.py:43-100), for the device:
+    every haplotype is three pieces (offset, length, repeat, flags) of one byte pool that holds ONE
+    reference window per partition (all members lie within partition_max_distance of each other) plus the
+    inserted sequences / interspersed-duplication source intervals, once per candidate.  The strings
+    themselves are assembled by svx_haplotype_distance_batch on the GPU."""
+
+    _EMPTY = (0, 0, 0, 0)
+
+    def __init__(self, reference):
+        self.reference = reference
+        self.fetch_bytes = getattr(reference, "fetch_bytes", None)
+        self.chunks, self.size = [], 0
+        self.off, self.len, self.rep, self.flg = [], [], [], []
+        self._middle = {}  # id(candidate) -> piece of its INS sequence / DUP_INT source interval
+
+    def _add(self, data):
+        at = self.size
+        self.chunks.append(data)
+        self.size += len(data)
+        return at
+
+    def _window(self, contig, lo, hi):
+        if self.fetch_bytes is not None:
+            return self._add(self.fetch_bytes(contig, lo, hi))
+        return self._add(self.reference.fetch(contig, lo, hi).encode("latin-1"))
+
+    def partition_window(self, partition):
+        """(type, pool offset of the window, window start, contig length) of one partition."""
+        first = partition[0][1]
+        typ = first.type
+        if typ in ("DEL", "INV", "DUP_TAN"):
+            contig = first.source_contig
+            lo = min(c.source_start for _, c in partition)
+            hi = max(c.source_end for _, c in partition)
+        else:
+            contig = first.dest_contig
+            lo = min(c.dest_start for _, c in partition)
+            hi = max(c.dest_start for _, c in partition)
+        length = self.reference.get_reference_length(contig)
+        lo, hi = max(0, lo - 100), min(length, hi + 100)
+        return typ, self._window(contig, lo, hi), lo, length
+
+    def _middle_piece(self, typ, c):
+        m = self._middle.get(id(c))
+        if m is None:
+            if typ == "INS":  # the inserted sequence as it is: the reference does not fold its case (:74-75)
+                data = c.sequence.encode("latin-1")
+                m = (self._add(data), len(data), 1, 0)
+            else:             # DUP_INT: the source interval, upper-cased like every reference slice (:86-87)
+                n = max(0, min(c.source_end, self.reference.get_reference_length(c.source_contig)) - c.source_start)
+                m = (self._window(c.source_contig, c.source_start, c.source_end), n, 1, _lib.PIECE_UPPER) if n else self._EMPTY
+            self._middle[id(c)] = m
+        return m
+
+    def add_pair(self, window, c1, c2):
+        typ, base, lo, length = window
+        up = _lib.PIECE_UPPER
+
+        def ref(a, b, repeat=1, flags=up):
+            """reference[a:b] of the partition's contig, with fetch()'s clamping of the end (:45-99)."""
+            b = min(b, length)
+            return (base + a - lo, b - a, repeat, flags) if b > a else self._EMPTY
+
+        if typ in ("DEL", "INV", "DUP_TAN"):
+            region_start = max(0, min(c1.source_start, c2.source_start) - 100)
+            region_end = min(length, max(c1.source_end, c2.source_end) + 100)
+            for c in (c1, c2):
+                s, e = c.source_start, c.source_end
+                if typ == "DEL":
+                    mid = self._EMPTY
+                elif typ == "INV":
+                    mid = ref(s, e, 1, up | _lib.PIECE_REVCOMP)
+                else:
+                    if c.copies + 1 > 0xFFFF:
+                        raise ValueError("tandem duplication with %d copies" % c.copies)
+                    mid = ref(s, e, c.copies + 1)
+                self._emit((ref(region_start, s), mid, ref(e, region_end)))
+        else:
+            region_start = max(0, min(c1.dest_start, c2.dest_start) - 100)
+            region_end = min(length, max(c1.dest_start, c2.dest_start) + 100)
+            for c in (c1, c2):
+                d = c.dest_start
+                self._emit((ref(region_start, d), self._middle_piece(typ, c), ref(d, region_end)))
+
+    def _emit(self, three):
+        for off, ln, rep, flg in three:
+            if ln <= 0 or rep <= 0:
+                off, ln, rep, flg = self._EMPTY
+            self.off.append(off); self.len.append(ln); self.rep.append(rep); self.flg.append(flg)
+
+    def arrays(self, pair_indices):
+        """(pool bytes as uint8, HAP_PIECE_DTYPE array of the selected pairs)."""
+        pool = np.frombuffer(b"".join(self.chunks), dtype=np.uint8) if self.size else np.zeros(0, np.uint8)
+        pieces = np.empty(len(self.off), dtype=_lib.HAP_PIECE_DTYPE)
+        pieces["off"] = self.off
+        pieces["len"] = self.len
+        pieces["repeat"] = self.rep
+        pieces["flags"] = self.flg
+        idx = (np.asarray(pair_indices, dtype=np.int64)[:, None] * 6 + np.arange(6)).reshape(-1)
+        return pool, pieces[idx]
+
+
 def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None):
-    """Cluster each partition (2..10 members) by complete linkage over haplotype edit distances.
-    All distances of all partitions are computed in one GPU batch, all linkage cuts in another."""
+    """Cluster each partition (2..10 members) by complete linkage over haplotype edit distances.  The
+    haplotype strings of all cross-haplotype pairs are assembled on the GPU from one reference window per
+    partition, their distances come from one batch per mode, the linkage cuts from one more launch."""
+    ctx = ctx or _lib.default_context()
     jobs = []  # (partition index, i, j)
-    strings = []
+    recipes = _HaplotypePieces(reference)
     for pi, partition in enumerate(partitions):
         if len(partition) < 2 or len(partition) > 10:
             continue
+        window = None
         for i in range(len(partition) - 1):
             for j in range(i + 1, len(partition)):
                 if partition[i][0] != partition[j][0]:
+                    if window is None:
+                        window = recipes.partition_window(partition)
                     jobs.append((pi, i, j))
-                    strings.append(tuple(haplotype_pair(partition[i][1], partition[j][1], reference)))
+                    recipes.add_pair(window, partition[i][1], partition[j][1])
     # two-member partitions only need "<= threshold?"; larger ones get exact values so that the
     # dendrogram above the cut (hence scipy's cluster label order) is the reference's
-    exact = [len(partitions[pi]) > 2 for pi, _, _ in jobs]
     dist = {}
-    thr = [k for k, e in enumerate(exact) if not e]
-    exa = [k for k, e in enumerate(exact) if e]
+    thr = [k for k, (pi, _, _) in enumerate(jobs) if len(partitions[pi]) == 2]
+    exa = [k for k, (pi, _, _) in enumerate(jobs) if len(partitions[pi]) > 2]
     # any threshold the reference accepts: a negative one pairs nothing, one beyond 32 bits everything
     k_max = min(max(int(edit_distance_threshold), -1), 0xFFFFFFFE)
-    if thr and k_max >= 0:
-        for k, d in zip(thr, edit_distances([strings[k] for k in thr], k_max, ctx)):
-            dist[jobs[k]] = d if d != 0xFFFFFFFF else k_max + 1
-    elif thr:
-        for k in thr:
-            dist[jobs[k]] = 0 if strings[k][0] == strings[k][1] else 1  # only "> threshold" matters
-    for k, d in zip(exa, edit_distances([strings[k] for k in exa], 0xFFFFFFFF, ctx)):
-        dist[jobs[k]] = d
+    if thr:
+        # (a negative threshold: only "distance > threshold" matters, and every distance is >= 0)
+        pool, pieces = recipes.arrays(thr)
+        got = ctx.haplotype_distance_batch(pool, pieces, max(k_max, 0)).tolist()
+        for k, d in zip(thr, got):
+            dist[jobs[k]] = d if d != 0xFFFFFFFF else max(k_max, 0) + 1
+    if exa:
+        pool, pieces = recipes.arrays(exa)
+        for k, d in zip(exa, ctx.haplotype_distance_batch(pool, pieces, 0xFFFFFFFF).tolist()):
+            dist[jobs[k]] = d
     todo, condensed = [], []
     for pi, partition in enumerate(partitions):
         if 2 <= len(partition) <= 10:

@@ -51,6 +51,8 @@ class SegParams(C.Structure):
 
 SEG_DTYPE = np.dtype([("q_start", "<i4"), ("q_end", "<i4"), ("ref_id", "<i4"), ("ref_start", "<i4"),
                       ("ref_end", "<i4"), ("is_reverse", "<i4")])
+HAP_PIECE_DTYPE = np.dtype([("off", "<u8"), ("len", "<u4"), ("repeat", "<u2"), ("flags", "<u2")])  # svx_hap_piece
+PIECE_UPPER, PIECE_REVCOMP = 1, 2
 RAW_DTYPE = np.dtype([("kind", "<i4"), ("a0", "<i4"), ("a1", "<i4"), ("a2", "<i4"), ("a3", "<i4"),
                       ("a4", "<i4"), ("a5", "<i4"), ("pad", "<i4")])
 
@@ -92,6 +94,7 @@ SYMBOLS = {
     "svx_pair_partition_dev_bits": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, _P]),
     "svx_edit_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_uint32,
                                           _P]),
+    "svx_haplotype_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P]),
     "svx_linkage_cut_batch": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_double, _P]),
     # native BAM ingest (include/svx_bam.h)
     "svx_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P), C.c_char_p, C.c_size_t]),
@@ -312,6 +315,20 @@ class Context:
             self._check(self.lib.svx_edit_distance_batch(self.h, _ptr(seq), len(seq), _ptr(a_off),
                                                          _ptr(a_len), _ptr(b_off), _ptr(b_len), n,
                                                          int(k_max) & 0xFFFFFFFF, _ptr(dist)))
+        return dist
+
+    def haplotype_distance_batch(self, pool, pieces, k_max=0xFFFFFFFF):
+        """Edit distances of haplotype pairs assembled on the device from pieces of `pool` (bytes):
+        `pieces` is a HAP_PIECE_DTYPE array with 6 entries per pair (3 of haplotype a, 3 of b)."""
+        pool = _as(pool, np.uint8)
+        pieces = np.ascontiguousarray(pieces, dtype=HAP_PIECE_DTYPE)
+        if len(pieces) % 6:
+            raise SvxError(SVX_E_INVALID, "6 pieces per pair")
+        n = len(pieces) // 6
+        dist = np.zeros(n, np.uint32)
+        if n:
+            self._check(self.lib.svx_haplotype_distance_batch(self.h, _ptr(pool), len(pool), _ptr(pieces), n,
+                                                              int(k_max) & 0xFFFFFFFF, _ptr(dist)))
         return dist
 
     def linkage_cut_batch(self, dist, n_members, cutoff):

@@ -256,16 +256,63 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
 template <int CAP>
 constexpr size_t lds_bytes() { return (size_t)(CAP + 1) * 64 * 8 + 256 + 32; }
 
-}  // namespace
+// ---- haplotype strings on device -------------------------------------------------------------------
+// compute_distance (SVIM_COMBINE.py:43-100) aligns, for two candidates of one partition,
+//     reference[region_start : c.start] + MIDDLE + reference[c.end : region_end]
+// with MIDDLE = "" (DEL), the reverse complement of reference[c.start : c.end] (INV), that interval
+// repeated copies + 1 times (DUP_TAN), the inserted sequence (INS) or the source interval (DUP_INT);
+// every reference slice upper-cased, inserted sequences as they are.  A haplotype is therefore three
+// PIECES of a byte pool (reference windows fetched once per partition + the inserted sequences), each
+// {offset, length, repeat count, flags}.  k_hap_build writes the strings (one workgroup per string,
+// coalesced copies, upper-casing / complementing on the way) into the pool the edit-distance kernel
+// reads: the host never slices or concatenates a string.
+struct HapArgs {
+    const uint8_t* pool;
+    const svx_hap_piece* pieces;  // 3 per string, 6 per pair (a then b)
+    const uint64_t* str_off;      // [2 * n_pairs] where string w starts in `out`
+    uint8_t* out;
+    uint32_t n_strings;
+};
 
-extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_t seq_bytes,
-                                       const uint64_t* a_off, const uint32_t* a_len,
-                                       const uint64_t* b_off, const uint32_t* b_len, uint32_t n_pairs,
-                                       uint32_t k_max, uint32_t* dist) {
-    if (!ctx) return SVX_E_INVALID;
-    if (n_pairs == 0) return SVX_OK;
-    if (!a_off || !a_len || !b_off || !b_len || !dist || (seq_bytes && !seq)) return SVX_E_INVALID;
-    const bool exact = (k_max == 0xFFFFFFFFu);
+__device__ __forceinline__ uint8_t hap_byte(uint8_t c, uint32_t flags) {
+    if (flags & SVX_PIECE_UPPER) c = (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c;   // str.upper(), ASCII
+    if (flags & SVX_PIECE_REVCOMP) {  // SVIM_COMBINE.py:63: complement of A, C, G, T; anything else stays
+        c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_hap_build(HapArgs p) {
+    const uint32_t w = blockIdx.x;
+    if (w >= p.n_strings) return;
+    uint8_t* dst = p.out + p.str_off[w];
+    uint64_t at = 0;
+    for (int k = 0; k < 3; ++k) {
+        const svx_hap_piece pc = p.pieces[(size_t)w * 3 + k];
+        const uint8_t* src = p.pool + pc.off;
+        const uint64_t total = (uint64_t)pc.len * pc.repeat;
+        for (uint64_t i = threadIdx.x; i < total; i += 256) {
+            const uint32_t j = (uint32_t)(i % pc.len);
+            const uint8_t c = src[(pc.flags & SVX_PIECE_REVCOMP) ? pc.len - 1 - j : j];
+            dst[at + i] = hap_byte(c, pc.flags);
+        }
+        at += total;
+    }
+}
+
+// ---- host side of the batched distance: everything after the sequence pool is in HBM ---------------
+struct EdPlan {
+    std::vector<uint32_t> order;
+    uint64_t total_stream = 0;
+};
+
+static uint64_t ed_stream_words(uint32_t la, uint32_t lb) {
+    const uint64_t m = std::max(la, lb), n = std::min(la, lb);
+    return m > kStripRows ? 2 * ((n + 31) / 32) : 0;
+}
+
+static int ed_validate_and_plan(svx_ctx* ctx, uint64_t seq_bytes, const uint64_t* a_off, const uint32_t* a_len,
+                                const uint64_t* b_off, const uint32_t* b_len, uint32_t n_pairs, EdPlan* plan) {
     for (uint32_t i = 0; i < n_pairs; ++i) {
         if (a_off[i] + a_len[i] > seq_bytes || b_off[i] + b_len[i] > seq_bytes) {
             SVX_SET_ERR(ctx, "pair %u reads past the sequence pool", i);
@@ -276,32 +323,34 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
             return SVX_E_TOO_LARGE;
         }
     }
-    SVX_HIP(ctx, hipSetDevice(ctx->device));
     // launch order: most expensive pairs first (steps ~ strips * columns), so that the long tail of a
     // few contig-sized alleles overlaps the many small ones
-    std::vector<uint32_t> order(n_pairs);
-    std::iota(order.begin(), order.end(), 0u);
+    plan->order.resize(n_pairs);
+    std::iota(plan->order.begin(), plan->order.end(), 0u);
     auto cost = [&](uint32_t i) {
         const uint64_t m = std::max(a_len[i], b_len[i]), n = std::min(a_len[i], b_len[i]);
         return ((m + kStripRows - 1) / kStripRows) * (n + 64);
     };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost(x) > cost(y); });
-    auto stream_words = [&](uint32_t i) -> uint64_t {
-        const uint64_t m = std::max(a_len[i], b_len[i]), n = std::min(a_len[i], b_len[i]);
-        return m > kStripRows ? 2 * ((n + 31) / 32) : 0;
-    };
-    uint64_t total_stream = 0;
-    std::vector<uint64_t> soff(n_pairs);
-    for (uint32_t w = 0; w < n_pairs; ++w) {
-        soff[w] = total_stream;
-        total_stream += stream_words(order[w]);
-    }
-    size_t need = svx_take_bytes(seq_bytes ? seq_bytes : 1, 1) + 3 * svx_take_bytes(n_pairs, 8) +
-                  5 * svx_take_bytes(n_pairs, 4) + svx_take_bytes(total_stream ? total_stream : 1, 8);
-    int rc = svx_stage_reserve(ctx, need);
-    if (rc != SVX_OK) return rc;
+    std::stable_sort(plan->order.begin(), plan->order.end(), [&](uint32_t x, uint32_t y) { return cost(x) > cost(y); });
+    plan->total_stream = 0;
+    for (uint32_t w = 0; w < n_pairs; ++w) plan->total_stream += ed_stream_words(a_len[plan->order[w]], b_len[plan->order[w]]);
+    return SVX_OK;
+}
+
+static size_t ed_stage_need(uint32_t n_pairs, const EdPlan& plan) {
+    return 3 * svx_take_bytes(n_pairs, 8) + 5 * svx_take_bytes(n_pairs, 4) +
+           svx_take_bytes(plan.total_stream ? plan.total_stream : 1, 8);
+}
+
+// d_seq: the sequence pool in HBM (already uploaded / built on the context's stream); the stage region
+// must have been reserved with ed_stage_need() bytes still free
+static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, const uint32_t* a_len,
+                  const uint64_t* b_off, const uint32_t* b_len, uint32_t n_pairs, uint32_t k_max, uint32_t* dist,
+                  const EdPlan& plan) {
+    const bool exact = (k_max == 0xFFFFFFFFu);
+    const std::vector<uint32_t>& order = plan.order;
+    int rc;
     EdArgs a;
-    uint8_t* d_seq = svx_stage_take<uint8_t>(ctx, seq_bytes ? seq_bytes : 1);
     uint64_t* d_ao = svx_stage_take<uint64_t>(ctx, n_pairs);
     uint64_t* d_bo = svx_stage_take<uint64_t>(ctx, n_pairs);
     uint64_t* d_so = svx_stage_take<uint64_t>(ctx, n_pairs);
@@ -310,8 +359,7 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
     uint32_t* d_ord = svx_stage_take<uint32_t>(ctx, n_pairs);
     uint32_t* d_band = svx_stage_take<uint32_t>(ctx, n_pairs);
     uint32_t* d_dist = svx_stage_take<uint32_t>(ctx, n_pairs);
-    uint64_t* d_stream = svx_stage_take<uint64_t>(ctx, total_stream ? total_stream : 1);
-    if (seq_bytes) SVX_HIP(ctx, hipMemcpyAsync(d_seq, seq, seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t* d_stream = svx_stage_take<uint64_t>(ctx, plan.total_stream ? plan.total_stream : 1);
     SVX_HIP(ctx, hipMemcpyAsync(d_ao, a_off, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_bo, b_off, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_al, a_len, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -342,7 +390,7 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
             lst_band.resize(lst.size());
             for (size_t w2 = 0; w2 < lst.size(); ++w2) {
                 lst_soff[w2] = at;
-                at += stream_words(lst[w2]);
+                at += ed_stream_words(a_len[lst[w2]], b_len[lst[w2]]);
                 lst_band[w2] = band_of[lst[w2]];
             }
             SVX_HIP(ctx, hipMemcpyAsync(d_ord, lst.data(), lst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -391,4 +439,75 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
         else if (!exact && dist[i] > k_max) dist[i] = 0xFFFFFFFFu;
     }
     return SVX_OK;
+}
+
+}  // namespace
+
+extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_t seq_bytes,
+                                       const uint64_t* a_off, const uint32_t* a_len,
+                                       const uint64_t* b_off, const uint32_t* b_len, uint32_t n_pairs,
+                                       uint32_t k_max, uint32_t* dist) {
+    if (!ctx) return SVX_E_INVALID;
+    if (n_pairs == 0) return SVX_OK;
+    if (!a_off || !a_len || !b_off || !b_len || !dist || (seq_bytes && !seq)) return SVX_E_INVALID;
+    EdPlan plan;
+    int rc = ed_validate_and_plan(ctx, seq_bytes, a_off, a_len, b_off, b_len, n_pairs, &plan);
+    if (rc != SVX_OK) return rc;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    rc = svx_stage_reserve(ctx, svx_take_bytes(seq_bytes ? seq_bytes : 1, 1) + ed_stage_need(n_pairs, plan));
+    if (rc != SVX_OK) return rc;
+    uint8_t* d_seq = svx_stage_take<uint8_t>(ctx, seq_bytes ? seq_bytes : 1);
+    if (seq_bytes) SVX_HIP(ctx, hipMemcpyAsync(d_seq, seq, seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ed_run(ctx, d_seq, a_off, a_len, b_off, b_len, n_pairs, k_max, dist, plan);
+}
+
+extern "C" int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
+                                            const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max,
+                                            uint32_t* dist) {
+    if (!ctx) return SVX_E_INVALID;
+    if (n_pairs == 0) return SVX_OK;
+    if (!pieces || !dist || (pool_bytes && !pool)) return SVX_E_INVALID;
+    const uint32_t n_strings = 2 * n_pairs;
+    std::vector<uint64_t> str_off(n_strings), a_off(n_pairs), b_off(n_pairs);
+    std::vector<uint32_t> a_len(n_pairs), b_len(n_pairs);
+    uint64_t total = 0;
+    for (uint32_t w = 0; w < n_strings; ++w) {
+        uint64_t len = 0;
+        for (int k = 0; k < 3; ++k) {
+            const svx_hap_piece& pc = pieces[(size_t)w * 3 + k];
+            if (pc.len && (pc.off > pool_bytes || pc.len > pool_bytes - pc.off)) {
+                SVX_SET_ERR(ctx, "pair %u: a piece reads past the byte pool", w / 2);
+                return SVX_E_INVALID;
+            }
+            if (pc.flags & ~(SVX_PIECE_UPPER | SVX_PIECE_REVCOMP)) return SVX_E_INVALID;
+            len += (uint64_t)pc.len * pc.repeat;
+        }
+        if (len >= kUnproven) {
+            SVX_SET_ERR(ctx, "pair %u: haplotypes of 2^31 bytes or more are not supported", w / 2);
+            return SVX_E_TOO_LARGE;
+        }
+        str_off[w] = total;
+        if (w & 1) { b_off[w / 2] = total; b_len[w / 2] = (uint32_t)len; }
+        else { a_off[w / 2] = total; a_len[w / 2] = (uint32_t)len; }
+        total += len;
+    }
+    EdPlan plan;
+    int rc = ed_validate_and_plan(ctx, total, a_off.data(), a_len.data(), b_off.data(), b_len.data(), n_pairs, &plan);
+    if (rc != SVX_OK) return rc;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    rc = svx_stage_reserve(ctx, svx_take_bytes(pool_bytes ? pool_bytes : 1, 1) + svx_take_bytes((size_t)n_strings * 3, sizeof(svx_hap_piece)) +
+                                    svx_take_bytes(n_strings, 8) + svx_take_bytes(total ? total : 1, 1) + ed_stage_need(n_pairs, plan));
+    if (rc != SVX_OK) return rc;
+    HapArgs h;
+    uint8_t* d_pool = svx_stage_take<uint8_t>(ctx, pool_bytes ? pool_bytes : 1);
+    svx_hap_piece* d_pc = svx_stage_take<svx_hap_piece>(ctx, (size_t)n_strings * 3);
+    uint64_t* d_soff = svx_stage_take<uint64_t>(ctx, n_strings);
+    uint8_t* d_str = svx_stage_take<uint8_t>(ctx, total ? total : 1);
+    if (pool_bytes) SVX_HIP(ctx, hipMemcpyAsync(d_pool, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(d_pc, pieces, (size_t)n_strings * 3 * sizeof(svx_hap_piece), hipMemcpyHostToDevice, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(d_soff, str_off.data(), (size_t)n_strings * 8, hipMemcpyHostToDevice, ctx->stream));
+    h.pool = d_pool; h.pieces = d_pc; h.str_off = d_soff; h.out = d_str; h.n_strings = n_strings;
+    hipLaunchKernelGGL(k_hap_build, dim3(n_strings), dim3(256), 0, ctx->stream, h);
+    SVX_HIP(ctx, hipGetLastError());
+    return ed_run(ctx, d_str, a_off.data(), a_len.data(), b_off.data(), b_len.data(), n_pairs, k_max, dist, plan);
 }

@@ -228,9 +228,11 @@ extern "C" int svx_segments_classify_dev(svx_ctx* ctx, const svx_seg* d_segs, ui
     uint32_t cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
-    svx_timing_mark(ctx, 1);
+    rc = svx_timing_mark(ctx, 1);
+    if (rc != SVX_OK) return rc;
     hipLaunchKernelGGL(k_segments, dim3(blocks < cap ? blocks : cap), dim3(256), 0, ctx->stream, a);
-    svx_timing_mark(ctx, 2);
+    rc = svx_timing_mark(ctx, 2);
+    if (rc != SVX_OK) return rc;
     SVX_HIP(ctx, hipGetLastError());
     return svx_timing_end(ctx);
 }

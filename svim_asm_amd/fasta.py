@@ -37,6 +37,10 @@ class FastaFile(object):
         return self._idx[name][0]
 
     def fetch(self, reference, start=None, end=None):
+        return self.fetch_bytes(reference, start, end).decode("ascii")
+
+    def fetch_bytes(self, reference, start=None, end=None):
+        """fetch() without the str round trip (the GPU path uploads reference windows as bytes)."""
         length, offset, line_bases, line_width = self._idx[reference]
         start = 0 if start is None else start
         end = length if end is None else end
@@ -46,7 +50,7 @@ class FastaFile(object):
             raise ValueError("end out of range (%i)" % end)
         end = min(end, length)
         if start >= end:
-            return ""
+            return b""
         b0 = offset + (start // line_bases) * line_width + start % line_bases
         b1 = offset + ((end - 1) // line_bases) * line_width + (end - 1) % line_bases + 1
         if self._map is not None:
@@ -56,7 +60,7 @@ class FastaFile(object):
             raw = self._fh.read(b1 - b0)
         if line_width != line_bases:
             raw = raw.replace(b"\n", b"").replace(b"\r", b"")
-        return raw.decode("ascii")
+        return raw
 
     def close(self):
         if getattr(self, "_map", None) is not None:

@@ -197,3 +197,54 @@ def test_many_pairs_mixed_lengths(svx_ctx):
         a, b = pairs[i]
         e = orc.edit_distance(a, b) if len(a) <= 3000 else orc.edit_distance_banded(a, b)
         assert got[i] == e if e <= 200 else got[i] > 200
+
+
+def _assemble(pool, pieces):
+    """Python restatement of the piece semantics (include/svx.h): the string a haplotype recipe denotes."""
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    out = []
+    for off, ln, rep, flags in pieces:
+        s = bytes(pool[off:off + ln]).decode("latin-1")
+        if flags & 1:
+            s = s.upper()
+        if flags & 2:
+            s = "".join(comp.get(b, b) for b in reversed(s))
+        out.append(s * rep)
+    return "".join(out)
+
+
+def test_haplotype_distance_batch_assembles_like_the_reference(svx_ctx):
+    """svx_haplotype_distance_batch: three pieces per haplotype (prefix, middle, suffix) with upper-casing,
+    reverse complement and repeats == the strings compute_distance builds (SVIM_COMBINE.py:43-100) followed by
+    the exact edit distance."""
+    from svim_asm_amd import _lib
+    rng = np.random.default_rng(12)
+    pool = np.frombuffer("".join(rng.choice(list("ACGTacgtNnRy"), size=60000)).encode(), dtype=np.uint8)
+    n_pairs = 400
+    pieces = np.zeros(n_pairs * 6, dtype=_lib.HAP_PIECE_DTYPE)
+    for k in range(n_pairs * 6):
+        kind = k % 3
+        if kind == 1:  # middle: absent, reverse complement, repeated, or as it is
+            mode = int(rng.integers(0, 4))
+            ln = int(rng.integers(0, 900)) if mode else 0
+            rep = [0, 1, int(rng.integers(1, 5)), 1][mode]
+            flags = [0, 3, 1, 0][mode]
+        else:
+            ln, rep, flags = int(rng.integers(0, 300)), 1, 1
+        if ln == 0 or rep == 0:
+            ln = rep = flags = 0
+        pieces[k] = (int(rng.integers(0, len(pool) - 1000)) if ln else 0, ln, rep, flags)
+    exp = []
+    for p in range(n_pairs):
+        a = _assemble(pool, pieces[p * 6:p * 6 + 3].tolist())
+        b = _assemble(pool, pieces[p * 6 + 3:p * 6 + 6].tolist())
+        exp.append(orc.edit_distance(a.encode("latin-1"), b.encode("latin-1")))
+    got = svx_ctx.haplotype_distance_batch(pool, pieces, 0xFFFFFFFF)
+    assert got.tolist() == exp
+    thr = svx_ctx.haplotype_distance_batch(pool, pieces, 200)
+    assert all((g == e) if e <= 200 else g == 0xFFFFFFFF for g, e in zip(thr.tolist(), exp))
+    # a piece that reads past the pool is rejected, not read
+    bad = pieces[:6].copy()
+    bad[2] = (len(pool) - 10, 100, 1, 1)
+    with pytest.raises(_lib.SvxError):
+        svx_ctx.haplotype_distance_batch(pool, bad, 10)

@@ -49,6 +49,25 @@ class OracleCtx(object):
             first.append(len(recs))
         return np.array(recs, dtype=_lib.RAW_DTYPE) if recs else np.zeros(0, dtype=_lib.RAW_DTYPE), np.array(first, np.int64)
 
+    def haplotype_distance_batch(self, pool, pieces, k_max=0xFFFFFFFF):
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+        def build(three):
+            out = []
+            for off, ln, rep, flags in three:
+                s = bytes(pool[off:off + ln]).decode("latin-1")
+                if flags & 1:
+                    s = s.upper()
+                if flags & 2:
+                    s = "".join(comp.get(b, b) for b in reversed(s))
+                out.append(s * rep)
+            return "".join(out).encode("latin-1")
+        out = []
+        for p in range(len(pieces) // 6):
+            d = orc.edit_distance(build(pieces[p * 6:p * 6 + 3].tolist()), build(pieces[p * 6 + 3:p * 6 + 6].tolist()))
+            out.append(d if d <= k_max else 0xFFFFFFFF)
+        return np.array(out, dtype=np.uint32)
+
     def linkage_cut_batch(self, dist, n_members, cutoff):
         out, at = [], 0
         for n in n_members:

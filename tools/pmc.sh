@@ -9,7 +9,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out" -o pass$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > /dev/null 2>> "$out/err.txt"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out" -o pass$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > /dev/null 2>> "$out/err.txt"
 done
 python3 - "$out" <<'PY'
 import csv, collections, glob, json, re, sys
