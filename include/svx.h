@@ -238,6 +238,7 @@ typedef struct svx_raw {
 int svx_segments_classify(svx_ctx* ctx, const svx_seg* segs, const uint32_t* read_off,
                           uint32_t n_reads, const int32_t* read_len, const svx_seg_params* params,
                           svx_raw* out);
+/* _dev: d_segs 8-byte aligned, d_out 16-byte aligned (any hipMalloc'ed buffer is). */
 int svx_segments_classify_dev(svx_ctx* ctx, const svx_seg* d_segs, uint32_t n_segs,
                               const uint32_t* d_read_off, uint32_t n_reads,
                               const int32_t* d_read_len, const svx_seg_params* params,

@@ -165,6 +165,43 @@ def make_medium():
     shutil.rmtree(d)
 
 
+LARGE = dict(seed=3, scale=0.25, sv_per_mbp=8.0, median_aln=300000, mean_m=2000)
+
+
+def large_dataset_args():
+    """Arguments of synth_bam.write_dataset for the 772 Mbp diploid sample (config 3 at 1/4 of GRCh38: 24
+    contigs, 2 x 231 MB BAM, ~0.79 M CIGAR ops per haplotype) — the generator tools/e2e_bench.py uses."""
+    from svim_asm_amd import synth
+    contigs = tuple((n, max(60000, int(l * LARGE["scale"]))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
+    n_shared = max(4, int(LARGE["sv_per_mbp"] * max(c[1] for c in contigs) / 1e6))
+    return dict(seed=LARGE["seed"], contigs=contigs, diploid=True, n_shared=n_shared, n_private=max(2, n_shared // 5),
+                median_aln=LARGE["median_aln"], mean_m=LARGE["mean_m"])
+
+
+def make_large():
+    """`svim-asm diploid` of the REAL reference on the 772 Mbp sample.  The VCF is several MB: its SHA-256
+    (##fileDate masked), its size, the record counts and the first / last records are committed together
+    with the input digests; tests regenerate the inputs from the seeds and compare the digest of their VCF."""
+    import hashlib
+    from svim_asm_amd import synth_bam
+    d = tempfile.mkdtemp(prefix="svx_large_")
+    fasta, bams = synth_bam.write_dataset(d, **large_dataset_args())
+    wd = os.path.join(d, "wd")
+    run_reference_cli(["diploid", wd, bams[0], bams[1], fasta])
+    vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
+    digest = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in bams}
+    body = [l for l in vcf.split("\n") if l and l[0] != "#"]
+    kinds = {}
+    for l in body:
+        k = l.split("\t")[2].rsplit(".", 1)[0]
+        kinds[k] = kinds.get(k, 0) + 1
+    with open(os.path.join(GOLD, "large_inputs.json"), "w") as fh:
+        json.dump({"params": LARGE, "sha256": digest, "records": len(body), "records_by_id_prefix": kinds,
+                   "vcf_sha256": hashlib.sha256(vcf.encode()).hexdigest(), "vcf_bytes": len(vcf.encode()),
+                   "first_records": [l[:200] for l in body[:3]], "last_records": [l[:200] for l in body[-3:]]}, fh, indent=1)
+    shutil.rmtree(d)
+
+
 LONGCIGAR = dict(seed=5, contigs=[["chr1", 1500000], ["chr2", 400000], ["chr3", 90000]], n_shared=30, n_private=6,
                  median_aln=40000000, mean_m=12)
 
@@ -356,7 +393,7 @@ def main():
     if len(sys.argv) > 1:   # regenerate selected fixtures only: functions / config1 / medium / longcigar
         for what in sys.argv[1:]:
             {"functions": make_function_vectors, "config1": make_config1, "medium": make_medium,
-             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors}[what]()
+             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors, "large": make_large}[what]()
         return
     make_longcigar()
     make_function_vectors()

@@ -373,8 +373,11 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
     const bool small = n <= kSmallSortMax;
     const uint32_t block_keys = small ? 256u * 8 : 256u * 16;
     b.n_blocks = (n + block_keys - 1) / block_keys;
+    // the multi-workgroup sweep has one arrival barrier: its grid stays at half a workgroup per CU (a CU
+    // holds two of these 1024-thread workgroups), so that up to four such grids — other contexts or
+    // processes on the same device — are resident together and none can starve another's barrier
     const uint32_t part_grid = n <= kSingleBlockMax ? 1u
-        : std::min<uint32_t>((uint32_t)ctx->n_cu, (n + 4095) / 4096);
+        : std::min<uint32_t>(std::max<uint32_t>(1u, (uint32_t)ctx->n_cu / 2), (n + 4095) / 4096);
     const size_t hist_words = (size_t)b.passes * b.n_blocks * kBuckets;
     size_t need = 2 * svx_take_bytes(n, 8) + 2 * svx_take_bytes(n, 4) + svx_take_bytes(hist_words, 4) +
                   svx_take_bytes(part_grid, 4);

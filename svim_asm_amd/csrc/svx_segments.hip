@@ -171,7 +171,11 @@ __global__ __launch_bounds__(256) void k_segments(SegArgs p) {
         s.q_start = s.q_end = s.ref_id = s.ref_start = s.ref_end = s.is_reverse = 0;
         int32_t rl = 0;
         if (small && (uint32_t)gl < k) {
-            s = p.segs[b + gl];
+            // 24-byte records, 8-byte aligned: three 8-byte loads instead of six dwords
+            const uint2* q = reinterpret_cast<const uint2*>(p.segs + b + gl);
+            const uint2 w0 = q[0], w1 = q[1], w2 = q[2];
+            s.q_start = (int32_t)w0.x; s.q_end = (int32_t)w0.y; s.ref_id = (int32_t)w1.x;
+            s.ref_start = (int32_t)w1.y; s.ref_end = (int32_t)w2.x; s.is_reverse = (int32_t)w2.y;
             rl = p.read_len[r];
         }
         int rank = 0;
@@ -197,9 +201,12 @@ __global__ __launch_bounds__(256) void k_segments(SegArgs p) {
         n.ref_start = __shfl_down(t.ref_start, 1, kGroup);
         n.ref_end = __shfl_down(t.ref_end, 1, kGroup);
         n.is_reverse = __shfl_down(t.is_reverse, 1, kGroup);
-        if (small && k > 0) {
-            if ((uint32_t)gl + 1 < k) p.out[b + gl] = classify(t, n, rl, p.o);
-            else if ((uint32_t)gl + 1 == k) p.out[b + gl] = raw(SVX_RAW_NONE);
+        if (small && k > 0 && (uint32_t)gl < k) {
+            const svx_raw v = (uint32_t)gl + 1 < k ? classify(t, n, rl, p.o) : raw(SVX_RAW_NONE);
+            // 32-byte records, 16-byte aligned: two 16-byte stores
+            uint4* o = reinterpret_cast<uint4*>(p.out + b + gl);
+            o[0] = make_uint4((uint32_t)v.kind, (uint32_t)v.a0, (uint32_t)v.a1, (uint32_t)v.a2);
+            o[1] = make_uint4((uint32_t)v.a3, (uint32_t)v.a4, (uint32_t)v.a5, 0u);
         }
     }
 }
@@ -213,6 +220,10 @@ extern "C" int svx_segments_classify_dev(svx_ctx* ctx, const svx_seg* d_segs, ui
     if (!ctx || !params) return SVX_E_INVALID;
     if (n_reads == 0 || n_segs == 0) return SVX_OK;
     if (!d_segs || !d_read_off || !d_read_len || !d_out) return SVX_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(d_segs) & 7u) || (reinterpret_cast<uintptr_t>(d_out) & 15u)) {
+        SVX_SET_ERR(ctx, "d_segs must be 8-byte aligned and d_out 16-byte aligned");
+        return SVX_E_INVALID;
+    }
     SVX_HIP(ctx, hipSetDevice(ctx->device));
     int rc = svx_ws_reserve(ctx, svx_take_bytes(n_segs, sizeof(svx_seg)));
     if (rc != SVX_OK) return rc;

@@ -236,3 +236,30 @@ def test_index_builder_roundtrip(dataset, tmp_path):
     bamio.index_bam(p)
     assert open(p + ".bai", "rb").read() == open(bams[0] + ".bai", "rb").read()
     assert bamio.AlignmentFile(p).index_state() == 1
+
+
+@pytest.mark.parametrize("reader", ["native", "python"])
+def test_decoding_against_samtools_own_text_rendering(reader):
+    """chimeric_read_errors.sam is the SAM text of chimeric_read_errors.bam, both written by samtools and
+    both shipped with the reference's tests: every field our readers decode from the BAM bytes (name, flag,
+    contig, position, MAPQ, CIGAR, the 4-bit packed bases, the SA tag) must equal what samtools printed —
+    a pin of the ingest that does not go through this repository's own BAM writer."""
+    sam = [l.rstrip("\n").split("\t") for l in open(os.path.join(GOLD, "chimeric_read_errors.sam")) if not l.startswith("@")]
+    f = bamio.AlignmentFile(os.path.join(GOLD, "chimeric_read_errors.bam"), reader=reader)
+    header_names = [l.split("\t")[1][3:] for l in open(os.path.join(GOLD, "chimeric_read_errors.sam")) if l.startswith("@SQ")]
+    assert list(f.references) == header_names
+    assert len(f) == len(sam) > 0
+    for i, fields in enumerate(sam):
+        a = f.record(i)
+        qname, flag, rname, pos, mapq, cigar, _rnext, _pnext, _tlen, seq = fields[:10]
+        assert a.query_name == qname and a.flag == int(flag) and a.mapping_quality == int(mapq)
+        assert f.get_reference_name(a.reference_id) == rname and a.reference_start == int(pos) - 1
+        assert a.cigarstring == cigar
+        assert a.seq_slice(0, a._l_seq) == seq and a._l_seq == len(seq)
+        tags = dict((t[:2], t[5:]) for t in fields[11:])
+        if "SA" in tags:
+            assert a.get_tag("SA") == tags["SA"]
+        else:
+            assert not a.has_tag("SA")
+        if "NM" in tags:
+            assert int(a.get_tag("NM")) == int(tags["NM"])

@@ -58,14 +58,16 @@ def main():
         cig, off, rs, min_len = draw(rng)
         exp = orc.cigar_extract(cig, off, rs, min_len)
         soa = rng.random() < 0.3
+        streaming = rng.random() < 0.5  # both kernel paths: small-batch (two launches) and streaming (five)
+        ctx.set_small_batch_ops(0 if streaming else 1 << 21)
         if soa:
             got = ctx.cigar_extract((cig >> 4).astype(np.uint32), off, rs, min_len, op=(cig & 15).astype(np.uint8))
         else:
             got = ctx.cigar_extract(cig, off, rs, min_len)
         for k in KEYS:
             if len(got[k]) != len(exp[k]) or not np.array_equal(got[k], exp[k]):
-                print("MISMATCH seed %d key %s (n_aln %d n_ops %d min_len %d soa %s): got %d exp %d" % (
-                    seed, k, len(off) - 1, len(cig), min_len, soa, len(got[k]), len(exp[k])))
+                print("MISMATCH seed %d key %s (n_aln %d n_ops %d min_len %d soa %s streaming %s): got %d exp %d" % (
+                    seed, k, len(off) - 1, len(cig), min_len, soa, streaming, len(got[k]), len(exp[k])))
                 sys.exit(1)
         n_cases += 1; n_ops += len(cig); n_sig += len(exp["aln"])
         seed += 1

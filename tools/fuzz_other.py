@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential tests of the other C-ABI kernels against the C oracle:
-svx_segments_classify, svx_pair_partition, svx_edit_distance_batch, svx_cigar_stats.
+svx_segments_classify, svx_segments_postpass, svx_pair_partition, svx_edit_distance_batch,
+svx_haplotype_distance_batch, svx_linkage_cut_batch, svx_cigar_stats.
 
     python tools/fuzz_other.py [--seconds 120] [--seed 1]
 """
@@ -14,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
-from oracle import orc  # noqa: E402
+from oracle import orc, svim_oracle  # noqa: E402
 from svim_asm_amd import _lib, synth  # noqa: E402
 import test_gpu_segments as tseg  # noqa: E402  (random_reads)
 import test_gpu_pair as tpair  # noqa: E402  (make_keys)
@@ -98,13 +99,107 @@ def fuzz_stats(ctx, rng):
     return ok, "stats n_aln %d n_ops %d" % (n_aln, len(cig))
 
 
+def fuzz_linkage(ctx, rng):
+    n_parts = int(rng.choice([1, 7, 300, 3000]))
+    sizes, flat = [], []
+    for _ in range(n_parts):
+        n = int(rng.choice([1, 2, 2, 2, 3, 4, 5, 7, 10, 11, 14, 40]))
+        m = n * (n - 1) // 2
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            v = rng.integers(0, int(rng.choice([2, 5, 400])), m).astype(float)
+            v[rng.random(m) < 0.4] = 1000000000.0
+        elif kind == 1:
+            v = rng.integers(0, 2000, m) / 3000
+            v[rng.random(m) < 0.3] = 99999
+        elif kind == 2:
+            v = 1 - rng.integers(0, 11, m) / 10.0
+        else:
+            v = rng.random(m)
+        sizes.append(n)
+        flat.extend(v.tolist())
+    cutoff = float(rng.choice([0.3, 0.5, 1.0, 3.0, 200.0, -1.0]))
+    got = ctx.linkage_cut_batch(flat, sizes, cutoff)
+    at = fi = 0
+    ok = True
+    for n in sizes:
+        m = n * (n - 1) // 2
+        exp = orc.linkage_cut(flat[fi:fi + m], n, cutoff) if n > 1 else [1]
+        ok = ok and list(got[at:at + n]) == list(exp)
+        at += n
+        fi += m
+    return ok, "linkage n_parts %d cutoff %g" % (n_parts, cutoff)
+
+
+def fuzz_postpass(ctx, rng):
+    n_contigs = int(rng.choice([2, 3, 12]))
+    names = ["chr%d" % (i + 1) for i in range(n_contigs)]
+    rank = np.zeros(n_contigs, np.int32)
+    for k, i in enumerate(sorted(range(n_contigs), key=lambda i: names[i])):
+        rank[i] = k
+    reads = [tseg._random_raw_read(rng, int(rng.choice([0, 1, 2, 3, 5, 9, 25])), n_contigs, bool(rng.random() < 0.7))
+             for _ in range(int(rng.choice([1, 50, 800])))]
+    read_off = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.uint32)
+    raw = np.zeros(int(read_off[-1]), dtype=_lib.RAW_DTYPE)
+    k = 0
+    for r in reads:
+        for row in r:
+            for name_, v in zip(("kind", "a0", "a1", "a2", "a3", "a4", "a5"), row):
+                raw[k][name_] = v
+            k += 1
+    prm = (int(rng.choice([1, 10, 40])), int(rng.choice([300, 100000])), 50, 50, 50, 50)
+    post, first = ctx.segments_postpass(raw, read_off, rank, prm)
+    code = {1: "TANDEM", 2: "DUP_INT", 3: "INV"}
+    width = {"TANDEM": 5, "DUP_INT": 6, "INV": 4}
+    ok = True
+    for i, r in enumerate(reads):
+        exp = svim_oracle.postpass_records(r, rank.tolist(), prm[0], prm[1])
+        got = []
+        for rec in post[first[i]:first[i + 1]]:
+            kind = code[int(rec["kind"])]
+            vals = [int(rec[n]) for n in ("a0", "a1", "a2", "a3", "a4", "a5")][:width[kind]]
+            if kind != "DUP_INT":
+                vals[-1] = bool(vals[-1])
+            got.append((kind,) + tuple(vals))
+        ok = ok and got == exp
+    return ok, "postpass reads %d contigs %d prm %s" % (len(reads), n_contigs, prm)
+
+
+def fuzz_haplotypes(ctx, rng):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_editdist as ted
+    pool = np.frombuffer("".join(rng.choice(list("ACGTacgtNn"), size=int(rng.choice([200, 5000, 40000])))).encode(), dtype=np.uint8)
+    n_pairs = int(rng.choice([1, 9, 150]))
+    pieces = np.zeros(n_pairs * 6, dtype=_lib.HAP_PIECE_DTYPE)
+    for k in range(n_pairs * 6):
+        if k % 3 == 1:
+            mode = int(rng.integers(0, 4))
+            ln = int(rng.integers(0, min(4500, len(pool) // 2))) if mode else 0
+            rep = [0, 1, int(rng.integers(1, 4)), 1][mode]
+            flags = [0, 3, 1, 0][mode]
+        else:
+            ln, rep, flags = int(rng.integers(0, 150)), 1, 1
+        if ln == 0 or rep == 0:
+            ln = rep = flags = 0
+        pieces[k] = (int(rng.integers(0, len(pool) - ln)) if ln else 0, ln, rep, flags)
+    kmax = int(rng.choice([0, 200, 0xFFFFFFFF]))
+    got = ctx.haplotype_distance_batch(pool, pieces, kmax).tolist()
+    ok = True
+    for p in range(n_pairs):
+        a = ted._assemble(pool, pieces[p * 6:p * 6 + 3].tolist())
+        b = ted._assemble(pool, pieces[p * 6 + 3:p * 6 + 6].tolist())
+        e = orc.edit_distance_banded(a.encode("latin-1"), b.encode("latin-1"))
+        ok = ok and (got[p] == e if (kmax == 0xFFFFFFFF or e <= kmax) else got[p] == 0xFFFFFFFF)
+    return ok, "haplotypes pairs %d kmax %d" % (n_pairs, kmax)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     ctx = _lib.default_context(0)
-    fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats]
+    fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats, fuzz_linkage, fuzz_postpass, fuzz_haplotypes]
     counts = {f.__name__: 0 for f in fns}
     t0, seed = time.time(), a.seed
     while time.time() - t0 < a.seconds:

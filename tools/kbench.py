@@ -10,6 +10,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def segments_alone(n_reads=64580):
+    """a3 (svx_segments_classify_dev + postpass-free) alone at cohort scale: in bench.py it runs beside the
+    streaming kernel on a second stream, so its duration there includes the contention."""
+    import ctypes as C
+    import numpy as np
+    from svim_asm_amd import _lib
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(77)
+    k = rng.integers(2, 5, size=n_reads)
+    roff = np.concatenate(([0], np.cumsum(k))).astype(np.uint32)
+    n_segs = int(roff[-1])
+    segs = np.zeros(n_segs, dtype=_lib.SEG_DTYPE)
+    qs = rng.integers(0, 200000, size=n_segs)
+    segs["q_start"] = qs
+    segs["q_end"] = qs + rng.integers(500, 50000, size=n_segs)
+    segs["ref_id"] = rng.integers(0, 24, size=n_segs)
+    segs["ref_start"] = rng.integers(0, 50_000_000, size=n_segs)
+    segs["ref_end"] = segs["ref_start"] + rng.integers(500, 50000, size=n_segs)
+    d_segs, d_roff = ctx.dev_array(segs), ctx.dev_array(roff)
+    d_rl = ctx.dev_array(rng.integers(100000, 5000000, size=n_reads).astype(np.int32))
+    d_raw = ctx.dev_array(nbytes=32 * n_segs)
+    prm = _lib.SegParams(40, 100000, 50, 50, 50, 50)
+
+    def call():
+        ctx._check(ctx.lib.svx_segments_classify_dev(ctx.h, d_segs.ptr, n_segs, d_roff.ptr, n_reads, d_rl.ptr,
+                                                     C.byref(prm), d_raw.ptr))
+    for _ in range(5):
+        call()
+    ctx.sync()
+    import bench
+    tot, dom = bench._event_ms(ctx, call, 30)
+    return {"reads": n_reads, "segments": n_segs, "ms": dom, "bytes": 56 * n_segs, "GB/s": 56 * n_segs / (dom * 1e-3) / 1e9}
+
+
 def main():
     import argparse
     import torch
@@ -22,6 +56,8 @@ def main():
             print(json.dumps(bench.roofline_pair(0)))
         elif leg == "editdist":
             print(json.dumps(bench.roofline_editdist(0, torch.cuda.get_device_properties(0).multi_processor_count)))
+        elif leg == "segments":
+            print(json.dumps(segments_alone()))
         else:
             raise SystemExit("unknown leg " + leg)
 
