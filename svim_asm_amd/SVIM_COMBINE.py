@@ -368,17 +368,23 @@ _LOG_NAME = {"DEL": "deletions", "INV": "inversions", "INS": "insertions", "DUP_
 def pair_candidates(sv_candidates1, sv_candidates2, reference, bam, options):
     ctx = _lib.default_context(getattr(options, "device", 0) or 0)
     # one sort/partition launch for all types; the input order per type is hap-1 list then hap-2 list
+    per_type = {typ: ([], []) for typ in TYPE_ORDER}
+    for hap, cands in ((0, sv_candidates1), (1, sv_candidates2)):
+        for c in cands:
+            bucket = per_type.get(c.type)
+            if bucket is not None:
+                bucket[hap].append((hap + 1, c))
     tagged = []
     for typ in TYPE_ORDER:
-        tagged += [(1, c) for c in sv_candidates1 if c.type == typ]
-        tagged += [(2, c) for c in sv_candidates2 if c.type == typ]
+        tagged += per_type[typ][0]
+        tagged += per_type[typ][1]
     partitions = form_partitions(tagged, options.partition_max_distance, ctx=ctx)
     by_type = defaultdict(list)
     for part in partitions:
         by_type[part[0][1].type].append(part)
     paired_candidates = []
     for typ in TYPE_ORDER:
-        n = sum(1 for _, c in tagged if c.type == typ)
+        n = len(per_type[typ][0]) + len(per_type[typ][1])
         logging.info("Pairing {0} {1}...".format(n, _LOG_NAME[typ]))
         if typ == "BND":
             clusters = pair_haplotypes_breakends(by_type[typ])
@@ -395,8 +401,13 @@ def pair_candidates(sv_candidates1, sv_candidates2, reference, bam, options):
 # ------------------------------------------------------------------------------ output
 def sorted_nicely(vcf_entries):
     """Natural sort of ((contig, start, end), vcf_string, sv_type) entries: chr10 after chr2."""
+    natural = {}  # a sample has a few dozen contig names and tens of thousands of entries
+
     def key(entry):
-        contig = [int(tok) if tok.isdigit() else tok for tok in re.split("([0-9]+)", str(entry[0][0]))]
+        name = entry[0][0]
+        contig = natural.get(name)
+        if contig is None:
+            contig = natural[name] = [int(tok) if tok.isdigit() else tok for tok in re.split("([0-9]+)", str(name))]
         return (contig, entry[0][1], entry[0][2])
     return sorted(vcf_entries, key=key)
 

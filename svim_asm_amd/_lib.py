@@ -67,6 +67,7 @@ SYMBOLS = {
     "svx_version": (C.c_char_p, []),
     "svx_device_count": (C.c_int, []),
     "svx_ctx_set_small_batch_ops": (C.c_int, [_P, C.c_uint64]),
+    "svx_ctx_set_edit_wavefront_cap": (C.c_int, [_P, C.c_uint32]),
     "svx_dev_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "svx_dev_free": (C.c_int, [_P, _P]),
     "svx_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -177,6 +178,10 @@ class Context:
     def set_small_batch_ops(self, max_ops):
         """Largest batch (CIGAR ops) of the small-batch (two-launch) path; 0 forces the streaming path."""
         self._check(self.lib.svx_ctx_set_small_batch_ops(self.h, int(max_ops)))
+
+    def set_edit_wavefront_cap(self, max_edits):
+        """Edits the wavefront pass of the edit distance resolves (0: bit-vector kernel only)."""
+        self._check(self.lib.svx_ctx_set_edit_wavefront_cap(self.h, int(max_edits)))
 
     # ---------------------------------------------------------------- device buffers
     def dev_array(self, host=None, nbytes=None):

@@ -766,10 +766,13 @@ class AlignmentFile(object):
     getrname = get_reference_name
 
     def get_reference_length(self, name):
-        tid = self.get_tid(name)
-        if tid < 0:
+        by_name = self.__dict__.get("_len_by_name")
+        if by_name is None:  # called once or twice per candidate: one dict lookup instead of two calls
+            by_name = self.__dict__["_len_by_name"] = dict(zip(self.references, self.lengths))
+        try:
+            return by_name[name]
+        except KeyError:
             raise KeyError("unknown reference %s" % name)
-        return self.lengths[tid]
 
     def close(self):
         self._z = None

@@ -107,6 +107,12 @@ extern "C" int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops) {
     return SVX_OK;
 }
 
+extern "C" int svx_ctx_set_edit_wavefront_cap(svx_ctx* ctx, uint32_t max_edits) {
+    if (!ctx) return SVX_E_INVALID;
+    ctx->wfa_cap = max_edits > 4096u ? 4096u : max_edits;
+    return SVX_OK;
+}
+
 extern "C" int svx_dev_malloc(svx_ctx* ctx, size_t bytes, void** d_out) {
     if (!ctx || !d_out) return SVX_E_INVALID;
     *d_out = nullptr;

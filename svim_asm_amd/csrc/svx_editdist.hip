@@ -256,6 +256,138 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
 template <int CAP>
 constexpr size_t lds_bytes() { return (size_t)(CAP + 1) * 64 * 8 + 256 + 32; }
 
+// ---- wavefront (diagonal-transition) pass in front of the bit-vector kernel -------------------------
+// The haplotypes the PAIR step compares are long and nearly identical (two alleles of one variant plus
+// 100 bp flanks): the distance d is tiny next to the lengths.  Ukkonen / Landau-Vishkin / Myers'
+// O(n + d^2) scheme — the published algorithm behind WFA — computes exactly the unit-cost global distance
+// edlib returns: H_s[k] = furthest row i reachable on diagonal k = j - i with s edits,
+//     H_s[k] = extend(max(H_{s-1}[k-1], H_{s-1}[k] + 1, H_{s-1}[k+1] + 1)),   d = min{s : H_s[n - m] = m},
+// where extend() slides down the diagonal while the bytes match.  One wave per pair: lane = diagonal
+// (64 per iteration), the two live wavefronts in LDS; every lane first compares 8 bytes, runs that are
+// longer are finished by the whole wave 512 bytes per step.  Run for at most `cap` edits (the caller's
+// threshold, or a work bound); pairs that need more are left to the bit-vector kernel.
+struct WfaArgs {
+    const uint8_t* seq;
+    const uint64_t* a_off;
+    const uint32_t* a_len;
+    const uint64_t* b_off;
+    const uint32_t* b_len;
+    const uint32_t* order;
+    const uint32_t* cap;   // per launch slot: largest distance to resolve
+    uint32_t n;
+    uint32_t* dist;        // exact distance, or kUnproven | cap when it exceeds cap
+};
+
+constexpr int32_t kWfaNeg = -(1 << 30);
+
+// 8 bytes at an arbitrary address from two aligned 8-byte loads (reads up to 15 bytes past p: the pool
+// lives inside the staging block, what lies behind it is masked off by the caller's limit)
+__device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(a & ~(uintptr_t)7);
+    const uint32_t sh = (uint32_t)(a & 7u) * 8u;
+    const uint64_t lo = q[0], hi = q[1];
+    return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+}
+
+// number of leading equal bytes of pa[0..lim) and pb[0..lim), lim <= 8
+__device__ __forceinline__ uint32_t match8(const uint8_t* pa, const uint8_t* pb, uint32_t lim) {
+    const uint64_t x = load8_unaligned(pa) ^ load8_unaligned(pb);
+    const uint32_t e = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+    return e < lim ? e : lim;
+}
+
+__global__ __launch_bounds__(64) void k_edit_wfa(WfaArgs p, uint32_t lds_cap) {
+    extern __shared__ __attribute__((aligned(16))) int32_t wf[];
+    const int lane = threadIdx.x;
+    const uint32_t w = blockIdx.x;
+    const uint32_t pi = p.order[w];
+    const uint32_t m = p.a_len[pi], n = p.b_len[pi];
+    const uint8_t* A = p.seq + p.a_off[pi];
+    const uint8_t* B = p.seq + p.b_off[pi];
+    const uint32_t cap = p.cap[w] < lds_cap ? p.cap[w] : lds_cap;
+    if (m == 0 || n == 0) {
+        if (lane == 0) p.dist[pi] = m > n ? m : n;
+        return;
+    }
+    const int32_t kend = (int32_t)n - (int32_t)m;
+    if ((uint32_t)(kend < 0 ? -kend : kend) > cap) {  // at least |n - m| edits
+        if (lane == 0) p.dist[pi] = kUnproven | cap;
+        return;
+    }
+    const int32_t width = 2 * (int32_t)lds_cap + 3, zero = (int32_t)lds_cap + 1;
+    int32_t* cur = wf;
+    int32_t* prev = wf + width;
+    for (int32_t i = lane; i < 2 * width; i += 64) wf[i] = kWfaNeg;
+    wave_lds_fence();
+
+    // whole-wave extension along one diagonal: equal bytes of pa / pb, at most rem
+    auto coop_extend = [&](const uint8_t* pa, const uint8_t* pb, uint32_t rem) -> uint32_t {
+        uint32_t done = 0;
+        for (;;) {
+            const uint32_t off = done + 8u * (uint32_t)lane;
+            const uint32_t lim = off < rem ? (rem - off < 8u ? rem - off : 8u) : 0u;
+            const uint32_t e = lim ? match8(pa + off, pb + off, lim) : 0u;
+            const uint64_t stop = __ballot(e < 8u);
+            if (stop) {
+                const int f = __ffsll((unsigned long long)stop) - 1;
+                return done + 8u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e, f);
+            }
+            done += 512u;
+        }
+    };
+
+    {   // s = 0: the common prefix
+        const uint32_t i0 = coop_extend(A, B, m < n ? m : n);
+        if (kend == 0 && i0 == m) {
+            if (lane == 0) p.dist[pi] = 0;
+            return;
+        }
+        if (lane == 0) cur[zero] = (int32_t)i0;
+        wave_lds_fence();
+    }
+    for (uint32_t s = 1; s <= cap; ++s) {
+        int32_t* t = cur; cur = prev; prev = t;
+        const int32_t lo = -(int32_t)(s < m ? s : m), hi = (int32_t)(s < n ? s : n);
+        for (int32_t kbase = lo; kbase <= hi; kbase += 64) {
+            const int32_t k = kbase + lane;
+            const bool valid = k <= hi;
+            int32_t i = kWfaNeg;
+            uint32_t rem = 0;
+            if (valid) {
+                const int32_t x0 = prev[zero + k - 1], x1 = prev[zero + k] + 1, x2 = prev[zero + k + 1] + 1;
+                int32_t x = x0 > x1 ? x0 : x1;
+                x = x > x2 ? x : x2;
+                const int32_t bound = (int32_t)m < (int32_t)n - k ? (int32_t)m : (int32_t)n - k;  // i <= m, i + k <= n
+                if (x >= 0) {
+                    i = x < bound ? x : bound;
+                    rem = (uint32_t)(bound - i);
+                }
+            }
+            // every lane: the next 8 bytes of its diagonal; longer runs are finished by the whole wave
+            uint32_t e = 0;
+            if (rem) e = match8(A + i, B + i + k, rem < 8u ? rem : 8u);
+            i += (int32_t)e;
+            uint64_t more = __ballot(rem > 8u && e == 8u);
+            while (more) {
+                const int l = __ffsll((unsigned long long)more) - 1;
+                more &= more - 1;
+                const int32_t il = __builtin_amdgcn_readlane(i, l), kl = kbase + l;
+                const uint32_t reml = (uint32_t)__builtin_amdgcn_readlane((int)rem, l) - 8u;
+                const uint32_t run = coop_extend(A + il, B + il + kl, reml);
+                if (lane == l) i += (int32_t)run;
+            }
+            if (valid) cur[zero + k] = i;
+        }
+        wave_lds_fence();
+        if ((uint32_t)(kend < 0 ? -kend : kend) <= s && cur[zero + kend] >= (int32_t)m) {  // wave-uniform LDS read
+            if (lane == 0) p.dist[pi] = s;
+            return;
+        }
+    }
+    if (lane == 0) p.dist[pi] = kUnproven | cap;
+}
+
 // ---- haplotype strings on device -------------------------------------------------------------------
 // compute_distance (SVIM_COMBINE.py:43-100) aligns, for two candidates of one partition,
 //     reference[region_start : c.start] + MIDDLE + reference[c.end : region_end]
@@ -380,7 +512,41 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
     std::vector<uint32_t> band_of(n_pairs, exact ? 256u : k_max);
     std::vector<uint32_t> todo = order, big, again, lst_band;
     std::vector<uint64_t> lst_soff;
-    for (;;) {
+    // ---- wavefront pass: resolves every pair whose distance is small next to its length
+    if (ctx->wfa_cap > 0) {
+        lst_band.resize(n_pairs);
+        uint32_t lds_cap = 1;
+        for (uint32_t w = 0; w < n_pairs; ++w) {
+            const uint32_t i = order[w];
+            // at most the threshold; and no more edits than an eighth of the lengths (beyond that the
+            // d^2 / 64 wave steps of this pass cost more than the bit-vector kernel's strips)
+            uint64_t c = std::max<uint64_t>(64, ((uint64_t)a_len[i] + b_len[i]) / 8);
+            c = std::min<uint64_t>(c, ctx->wfa_cap);
+            if (!exact) c = std::min<uint64_t>(c, k_max);
+            lst_band[w] = (uint32_t)c;
+            lds_cap = std::max(lds_cap, (uint32_t)c);
+        }
+        SVX_HIP(ctx, hipMemcpyAsync(d_ord, order.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+        SVX_HIP(ctx, hipMemcpyAsync(d_band, lst_band.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+        WfaArgs wa;
+        wa.seq = d_seq; wa.a_off = d_ao; wa.a_len = d_al; wa.b_off = d_bo; wa.b_len = d_bl;
+        wa.order = d_ord; wa.cap = d_band; wa.n = n_pairs; wa.dist = d_dist;
+        const size_t lds = (size_t)2 * (2 * (size_t)lds_cap + 3) * sizeof(int32_t);
+        hipLaunchKernelGGL(k_edit_wfa, dim3(n_pairs), dim3(64), lds, ctx->stream, wa, lds_cap);
+        SVX_HIP(ctx, hipGetLastError());
+        SVX_HIP(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        todo.clear();
+        for (uint32_t w = 0; w < n_pairs; ++w) {
+            const uint32_t i = order[w];
+            if (!(dist[i] & kUnproven)) continue;                  // exact distance <= cap
+            if (!exact && lst_band[w] >= k_max) continue;          // distance > k_max: all the caller asked
+            band_of[i] = exact ? std::max<uint32_t>(256u, 2 * lst_band[w]) : k_max;   // distance > cap is known
+            todo.push_back(i);
+        }
+    }
+    // (pairs the rounds below do not visit keep what the wavefront pass wrote: d_dist holds it)
+    while (!todo.empty()) {
         // one round: fast instantiation over `todo`, then the 256-symbol one over what it rejected
         for (int pass = 0; pass < 2; ++pass) {
             const std::vector<uint32_t>& lst = pass == 0 ? todo : big;

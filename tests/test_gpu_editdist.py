@@ -11,6 +11,16 @@ from oracle import orc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["wavefront_1024", "wavefront_48", "bitvector_only"])
+def edit_stage(request, svx_ctx):
+    """Every test of this module runs with the default two-stage plan (wavefront pass up to 1024 edits, then
+    the bit-vector kernel), with a cap so small that most pairs fall through to the second stage, and with
+    the bit-vector kernel alone (svx_ctx_set_edit_wavefront_cap)."""
+    svx_ctx.set_edit_wavefront_cap({"wavefront_1024": 1024, "wavefront_48": 48, "bitvector_only": 0}[request.param])
+    yield request.param
+    svx_ctx.set_edit_wavefront_cap(1024)
+
+
 def mutate(rng, s, n_edits):
     s = bytearray(s)
     for _ in range(n_edits):
@@ -248,3 +258,18 @@ def test_haplotype_distance_batch_assembles_like_the_reference(svx_ctx):
     bad[2] = (len(pool) - 10, 100, 1, 1)
     with pytest.raises(_lib.SvxError):
         svx_ctx.haplotype_distance_batch(pool, bad, 10)
+
+
+@pytest.mark.parametrize("k", [0, 2, 100])
+def test_threshold_applies_to_pairs_with_an_empty_side(svx_ctx, k):
+    """Pairs the first stage settles on its own (one side empty: the distance is the other side's length) still
+    obey the threshold contract: > k comes back as 0xFFFFFFFF (regression: fuzz seed 20036)."""
+    pairs = [(b"", b"ACGT"), (b"ACGT" * 20, b""), (b"A", b"A"), (b"", b""), (b"AC", b"")]
+    pool = np.frombuffer(b"".join(a + b for a, b in pairs), np.uint8)
+    ao, al, bo, bl, o = [], [], [], [], 0
+    for a, b in pairs:
+        ao.append(o); al.append(len(a)); o += len(a)
+        bo.append(o); bl.append(len(b)); o += len(b)
+    got = svx_ctx.edit_distance_batch(pool, ao, al, bo, bl, k_max=k).tolist()
+    exp = [max(len(a), len(b)) if (not a or not b) else 0 for a, b in pairs]
+    assert got == [e if e <= k else 0xFFFFFFFF for e in exp]

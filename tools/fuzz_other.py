@@ -75,6 +75,7 @@ def fuzz_edit(ctx, rng):
             seqs.append(arr); offs.append(pos); lens.append(len(arr)); pos += len(arr)
     pool = np.concatenate(seqs) if pos else np.zeros(0, np.uint8)
     k = int(rng.choice([0, 1, 5, 200, 5000, 0xFFFFFFFF]))
+    ctx.set_edit_wavefront_cap(int(rng.choice([0, 3, 48, 1024, 4096])))
     got = ctx.edit_distance_batch(pool, np.array(a_off, np.uint64), np.array(a_len, np.uint32),
                                   np.array(b_off, np.uint64), np.array(b_len, np.uint32), k)
     ok = True
@@ -183,6 +184,7 @@ def fuzz_haplotypes(ctx, rng):
             ln = rep = flags = 0
         pieces[k] = (int(rng.integers(0, len(pool) - ln)) if ln else 0, ln, rep, flags)
     kmax = int(rng.choice([0, 200, 0xFFFFFFFF]))
+    ctx.set_edit_wavefront_cap(int(rng.choice([0, 48, 1024])))
     got = ctx.haplotype_distance_batch(pool, pieces, kmax).tolist()
     ok = True
     for p in range(n_pairs):
