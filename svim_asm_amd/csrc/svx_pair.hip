@@ -12,18 +12,22 @@
 //   the caller (or one reduction) tells which key bits can be set at all; those bits are
 //   squeezed into a dense key of L bits (up to four bit fields), sorted LSD with P = ceil(L / 9)
 //   digits of ceil(L / P) bits:
-//   k_pair_init      dense keys, idx[i] = i, per-chunk histogram of digit 0, zero the histograms
-//                    of the later digits;
-//   k_radix_pass × P one workgroup per 4 chunks of 1024 keys.  Column sums over the chunk
-//                    histograms give every chunk its global bucket offsets (no scan kernel, no
-//                    look-back: the table is 2 KiB per chunk and L2-resident); one wave per chunk
-//                    ranks its keys stably with __ballot match masks and scatters them, counting
-//                    on the way the NEXT digit into the histogram of the chunk each key lands in;
-//   k_partition      boundary flags (gathering the original keys through the permutation) +
-//                    inclusive scan → partition ids, perm, n_parts.  One workgroup up to 16 k
-//                    candidates; beyond that one workgroup per CU at most with one counter barrier.
-// Integer/HBM-bound work (20 B per candidate algorithmic), no MFMA.  Determinism: ranks come
-// from prefix sums only; the histogram atomics are commutative counts.
+//   k_pair_init      dense keys, idx[i] = i, per-workgroup histogram of digit 0 (one workgroup = one
+//                    block of 2048 keys up to 128 k keys, 4096 beyond), zero the histograms of the later
+//                    digits;
+//   k_radix_pass × P one workgroup per block, its keys in registers.  Every workgroup sums the histogram
+//                    rows of ALL blocks itself (two buckets per thread, 16 rows in flight) — no scan
+//                    kernel, no look-back; the table is 2 KiB per block and L2-resident —, its four waves
+//                    count their quarter's digits in LDS, rank the keys stably with __ballot match masks
+//                    and scatter them, counting on the way the NEXT digit into the histogram row of the
+//                    block each key lands in;
+//   k_partition      boundary flags straight from the sorted dense keys (they expand back to the original
+//                    keys: no gather) + inclusive scan → partition ids, perm, n_parts.  One workgroup up
+//                    to 16 k candidates; beyond that at most half a workgroup per CU with one arrival
+//                    counter (every workgroup of the grid is resident).
+// Integer work, 20 B per candidate algorithmic, no MFMA; at the product's 60 k candidates it is bound by
+// the six dependent launches (≈ 9 µs per pass even with no output), not by bytes.  Determinism: ranks
+// come from prefix sums only; the histogram atomics are commutative counts.
 #include "svx_internal.h"
 
 namespace {
@@ -107,12 +111,10 @@ __global__ __launch_bounds__(256) void k_pair_init(const uint64_t* __restrict__ 
 template <int ITERS>
 __global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
     __shared__ uint32_t s_run[4][kBuckets];  // per (wave, digit): count, then running output position
-    __shared__ uint32_t s_tot[kBuckets];
     __shared__ uint32_t s_w[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t shift = pass * b.digit_bits;
     const uint32_t dmask = (1u << b.digit_bits) - 1u;
-    const uint32_t nb = 1u << b.digit_bits;
     const int sb = pass & 1;
     const uint64_t* __restrict__ sk = b.keys[sb];
     const uint32_t* __restrict__ si = b.idx[sb];
@@ -182,8 +184,6 @@ __global__ __launch_bounds__(256) void k_radix_pass(PairBufs b, uint32_t pass) {
         }
     }
     __syncthreads();
-    (void)nb;
-    (void)s_tot;
 
     // ---- one wave per quarter block: stable ranking with match masks, scatter, next digit's counts
     uint32_t* run = s_run[wave];
