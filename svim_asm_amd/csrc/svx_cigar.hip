@@ -8,12 +8,13 @@
 //   aln_off[n_aln+1]  u64 offsets; ref_start[n_aln] i32
 //   out SoA           aln u32, ref_pos u32, read_pos u32, len u32, type u8 (17 B/signature)
 //
-// Pipeline (no inter-workgroup waiting anywhere, so no dispatch-order assumption):
+// Pipeline, streaming path (no inter-workgroup waiting anywhere, so no dispatch-order assumption):
+//   0  k_tile_alo             per tile, the number of alignments that start before it.
 //   A  k_cigar_tiles          one WAVE per tile of 4096 ops; 4 rounds of 1024 ops; per round:
 //                             coalesced dwordx4 loads (1 KiB/wave-instr) → wave-private XOR-swizzled LDS
 //                             transpose → 16 consecutive ops per lane → lane-local segmented walk →
 //                             wave scans (DPP row_shr/row_bcast) → signatures staged into the tile's
-//                             slab (256 x 16 B) with tile-local cursors; tile descriptor
+//                             slab (128 x 16 B) with tile-local cursors; tile descriptor
 //                             {count, seen_head, ref_tail, read_tail, a_lo} written at the end.
 //   B  k_desc_scan            segmented exclusive scan over the tile descriptors: per-tile carry-in
 //                             (cursor sums since the last alignment start before the tile), output
@@ -21,9 +22,13 @@
 //   C  k_cigar_finish         16 lanes per sparse tile: slab → final SoA at out_base, adding the
 //                             carry to signatures that precede the tile's first alignment start
 //                             and ref_start of the alignment.
-//   D  k_cigar_dense          dense tiles (> 256 signatures, e.g. adversarial all-indel CIGARs) are
+//   D  k_cigar_dense          dense tiles (> 128 signatures, e.g. adversarial all-indel CIGARs) are
 //                             re-walked with carry-in and output base known (process_tile<DIRECT>),
 //                             writing final SoA; an empty launch in the common case.
+// Batches of at most 2 M ops (one BAM of an assembly: what the svim-asm CLI launches) take a two-launch
+// variant of the same code: k_cigar_tiles with tiles of 1024 ops and the tile's start index from a wave
+// search, then k_cigar_finish_small, in which every workgroup scans all descriptors itself, finishes its
+// own 16 tiles and re-walks the dense ones (see the comment above that kernel).
 // Output order = (alignment, op) order by construction (prefix sums, no atomically-ordered appends).
 #include "svx_internal.h"
 
