@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kMaxDigitBits = 9;
 constexpr int kBuckets = 1 << kMaxDigitBits;
-constexpr uint32_t kSingleBlockMax = 16384;
+constexpr uint32_t kSingleBlockMax = 16384;  // one workgroup sweeps up to two chunks itself
 constexpr uint32_t kSmallSortMax = 131072;
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -241,18 +241,10 @@ __device__ __forceinline__ uint64_t original_key(const KeyFields& f, uint64_t d)
     return k;
 }
 
-__device__ __forceinline__ uint32_t boundary_flag(const PartArgs& p, uint32_t j) {
-    if (j == 0) return 0;
-    const uint64_t a = original_key(p.f, p.sorted_keys[j - 1]), c = original_key(p.f, p.sorted_keys[j]);
-    const uint32_t pa = (uint32_t)a, pc = (uint32_t)c;
-    const uint32_t dist = pa > pc ? pa - pc : pc - pa;
-    return ((a >> 32) != (c >> 32) || dist > p.max_dist) ? 1u : 0u;  // SVIM_COMBINE.py:24-26
-}
-
-// inclusive scan of `flag` over a 1024-thread workgroup; returns the scanned value, *total the sum
-__device__ __forceinline__ uint32_t block_scan_1024(uint32_t flag, uint32_t* s_w, uint32_t* total) {
+// inclusive scan of `v` over a 1024-thread workgroup; returns the scanned value, *total the sum
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_w, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t s = flag;
+    uint32_t s = v;
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) {
         const uint32_t t = __shfl_up(s, k);
@@ -270,16 +262,46 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t flag, uint32_t* s_w
     return wp + s;
 }
 
-// Workgroup g owns the contiguous range [g * span, (g + 1) * span).  Pass 1 counts its flags;
-// after one arrival barrier (every workgroup is resident: the grid never exceeds one per CU) pass 2
-// re-walks the range with the exclusive sum of the earlier workgroups as carry-in.
+constexpr int kPartPer = 8;                       // consecutive sorted keys per thread and chunk
+constexpr uint32_t kPartChunk = 1024u * kPartPer; // keys one workgroup sweeps per scan
+
+// Boundary flags of the thread's kPartPer consecutive positions of chunk [base, base + kPartChunk) ∩ [.., hi):
+// bit i of the result = position base + tid * kPartPer + i opens a partition (SVIM_COMBINE.py:24-26).
+__device__ __forceinline__ uint32_t chunk_flags(const PartArgs& p, uint32_t base, uint32_t hi) {
+    const uint32_t j0 = base + threadIdx.x * kPartPer;
+    if (j0 >= hi) return 0;
+    uint64_t prev = j0 ? original_key(p.f, p.sorted_keys[j0 - 1]) : 0;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < kPartPer; ++i) {
+        const uint32_t j = j0 + i;
+        if (j < hi) {
+            const uint64_t c = original_key(p.f, p.sorted_keys[j]);
+            const uint32_t pa = (uint32_t)prev, pc = (uint32_t)c;
+            const uint32_t dist = pa > pc ? pa - pc : pc - pa;
+            if (j && ((prev >> 32) != (c >> 32) || dist > p.max_dist)) bits |= 1u << i;
+            prev = c;
+        }
+    }
+    return bits;
+}
+
+// Workgroup g owns the contiguous range [g * span, (g + 1) * span) of the sorted keys, swept in chunks of
+// 8192 (eight consecutive keys per thread: one scan of the thread counts per chunk).  With several
+// workgroups, each first counts its flags, publishes the count and meets the others at one arrival
+// counter (every workgroup is resident: the grid never exceeds half a workgroup per CU); its carry-in
+// is the sum of the earlier workgroups' counts.  A range of one chunk keeps its flags in registers.
 __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
     __shared__ uint32_t s_w[16];
     const uint32_t lo = blockIdx.x * span, hi = min(p.n, lo + span);
-    uint32_t carry = 0;
+    const bool one_chunk = hi - lo <= kPartChunk;
+    uint32_t carry = 0, kept = 0;
     if (gridDim.x > 1) {
         uint32_t cnt = 0;
-        for (uint32_t j = lo + threadIdx.x; j < hi; j += 1024) cnt += boundary_flag(p, j);
+        for (uint32_t base = lo; base < hi; base += kPartChunk) {
+            kept = chunk_flags(p, base, hi);
+            cnt += __popc(kept);
+        }
         uint32_t tot;
         (void)block_scan_1024(cnt, s_w, &tot);
         if (threadIdx.x == 0) {
@@ -297,25 +319,24 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
             }
         }
         __syncthreads();
-        // exclusive sum of the earlier workgroups' flags: one load per thread (the grid has at most one
-        // workgroup per CU, i.e. fewer than 1024), reduced over the workgroup
-        {
-            uint32_t v = threadIdx.x < blockIdx.x
-                             ? __hip_atomic_load(&p.block_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            uint32_t tot2;
-            (void)block_scan_1024(v, s_w, &tot2);
-            carry = tot2;
-        }
+        // exclusive sum of the earlier workgroups' flags: one load per thread (fewer than 1024 workgroups)
+        const uint32_t v = threadIdx.x < blockIdx.x
+                               ? __hip_atomic_load(&p.block_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        (void)block_scan_1024(v, s_w, &carry);
     }
-    for (uint32_t base = lo; base < hi; base += 1024) {
-        const uint32_t j = base + threadIdx.x;
-        uint32_t flag = 0;
-        if (j < hi) flag = boundary_flag(p, j);
+    for (uint32_t base = lo; base < hi; base += kPartChunk) {
+        const uint32_t bits = (one_chunk && gridDim.x > 1) ? kept : chunk_flags(p, base, hi);
         uint32_t tot;
-        const uint32_t s = block_scan_1024(flag, s_w, &tot);
-        if (j < hi) {
-            p.part_id[j] = carry + s;
-            p.perm[j] = p.sorted[j];
+        uint32_t id = carry + block_scan_1024(__popc(bits), s_w, &tot) - __popc(bits);  // partitions opened before this thread
+        const uint32_t j0 = base + threadIdx.x * kPartPer;
+#pragma unroll
+        for (int i = 0; i < kPartPer; ++i) {
+            const uint32_t j = j0 + i;
+            if (j < hi) {
+                id += (bits >> i) & 1u;
+                p.part_id[j] = id;
+                p.perm[j] = p.sorted[j];
+            }
         }
         carry += tot;
     }
