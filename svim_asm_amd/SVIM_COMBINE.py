@@ -249,6 +249,69 @@ class _HaplotypePieces(object):
         return pool, pieces[idx]
 
 
+def _pair_two_member_partitions(partitions, which, reference, edit_distance_threshold, ctx):
+    """The bulk of a sample: deletion / insertion partitions of exactly two members, one per haplotype.
+    Their haplotype recipes (SVIM_COMBINE.py:43-77) are built with array arithmetic — for two members the
+    pair's region IS the partition's window — and complete linkage of two points is one comparison:
+    fcluster(linkage([d]), t, "distance") puts them in one cluster iff d <= t, else member 0 gets label 1
+    and member 1 label 2 (:134-139).  Returns {partition index: paired?}."""
+    if not which:
+        return {}
+    first = [partitions[pi][0][1] for pi in which]
+    second = [partitions[pi][1][1] for pi in which]
+    typ = first[0].type
+    n = len(which)
+    up = _lib.PIECE_UPPER
+    fetch = getattr(reference, "fetch_bytes", None) or (lambda c, a, b: reference.fetch(c, a, b).encode("latin-1"))
+    lengths = {}
+    if typ == "DEL":
+        contigs = [c.source_contig for c in first]
+        s = np.array([[a.source_start, b.source_start] for a, b in zip(first, second)], dtype=np.int64)
+        e = np.array([[a.source_end, b.source_end] for a, b in zip(first, second)], dtype=np.int64)
+    else:
+        contigs = [c.dest_contig for c in first]
+        s = np.array([[a.dest_start, b.dest_start] for a, b in zip(first, second)], dtype=np.int64)
+        e = s
+    for c in contigs:
+        if c not in lengths:
+            lengths[c] = reference.get_reference_length(c)
+    L = np.array([lengths[c] for c in contigs], dtype=np.int64)
+    lo = np.maximum(0, s.min(axis=1) - 100)
+    hi = np.minimum(L, e.max(axis=1) + 100)
+    chunks = [fetch(c, a, b) for c, a, b in zip(contigs, lo.tolist(), hi.tolist())]
+    wlen = np.array([len(w) for w in chunks], dtype=np.int64)
+    if not np.array_equal(wlen, np.maximum(hi - lo, 0)):
+        raise ValueError("reference windows shorter than the index says")
+    base = np.concatenate(([0], np.cumsum(wlen)))[:-1]
+    pieces = np.zeros((n, 2, 3), dtype=_lib.HAP_PIECE_DTYPE)
+    for h in (0, 1):
+        # prefix reference[region_start : start] and suffix reference[end : region_end], fetch()'s clamping
+        pre = np.maximum(np.minimum(s[:, h], L) - lo, 0)
+        suf = np.maximum(hi - e[:, h], 0)
+        pieces["off"][:, h, 0] = np.where(pre > 0, base, 0)
+        pieces["len"][:, h, 0] = pre
+        pieces["repeat"][:, h, 0] = pre > 0
+        pieces["flags"][:, h, 0] = np.where(pre > 0, up, 0)
+        pieces["off"][:, h, 2] = np.where(suf > 0, base + e[:, h] - lo, 0)
+        pieces["len"][:, h, 2] = suf
+        pieces["repeat"][:, h, 2] = suf > 0
+        pieces["flags"][:, h, 2] = np.where(suf > 0, up, 0)
+    if typ == "INS":  # the inserted sequences as they are (:74-75), behind the windows in the pool
+        seqs = [c.sequence.encode("latin-1") for pair in zip(first, second) for c in pair]
+        slen = np.array([len(x) for x in seqs], dtype=np.int64).reshape(n, 2)
+        soff = (int(wlen.sum()) + np.concatenate(([0], np.cumsum(slen.reshape(-1))))[:-1]).reshape(n, 2)
+        pieces["off"][:, :, 1] = np.where(slen > 0, soff, 0)
+        pieces["len"][:, :, 1] = slen
+        pieces["repeat"][:, :, 1] = slen > 0
+        chunks += seqs
+    pool = np.frombuffer(b"".join(chunks), dtype=np.uint8) if chunks else np.zeros(0, np.uint8)
+    k_max = max(min(max(int(edit_distance_threshold), -1), 0xFFFFFFFE), 0)
+    d = ctx.haplotype_distance_batch(pool, pieces.reshape(-1), k_max).astype(np.float64)
+    d[d == float(0xFFFFFFFF)] = k_max + 1  # "more than the threshold" is all that is known, and all that matters
+    paired = d <= float(edit_distance_threshold)
+    return dict(zip(which, paired.tolist()))
+
+
 def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None):
     """Cluster each partition (2..10 members) by complete linkage over haplotype edit distances.  The
     haplotype strings of all cross-haplotype pairs are assembled on the GPU from one reference window per
@@ -256,8 +319,11 @@ def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None)
     ctx = ctx or _lib.default_context()
     jobs = []  # (partition index, i, j)
     recipes = _HaplotypePieces(reference)
+    two = [pi for pi, p in enumerate(partitions)
+           if len(p) == 2 and p[0][0] != p[1][0] and p[0][1].type in ("DEL", "INS")]
+    settled = _pair_two_member_partitions(partitions, two, reference, edit_distance_threshold, ctx)
     for pi, partition in enumerate(partitions):
-        if len(partition) < 2 or len(partition) > 10:
+        if len(partition) < 2 or len(partition) > 10 or pi in settled:
             continue
         window = None
         for i in range(len(partition) - 1):
@@ -286,7 +352,7 @@ def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None)
             dist[jobs[k]] = d
     todo, condensed = [], []
     for pi, partition in enumerate(partitions):
-        if 2 <= len(partition) <= 10:
+        if 2 <= len(partition) <= 10 and pi not in settled:
             todo.append(partition)
             condensed.append([dist.get((pi, i, j), SAME_HAPLOTYPE_DISTANCE)
                               for i in range(len(partition) - 1) for j in range(i + 1, len(partition))])
@@ -295,6 +361,12 @@ def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None)
     for pi, partition in enumerate(partitions):
         if len(partition) < 2:
             clusters_final.append(partition)
+        elif pi in settled:
+            if settled[pi]:
+                clusters_final.append(partition)
+            else:
+                clusters_final.append([partition[0]])
+                clusters_final.append([partition[1]])
         elif len(partition) > 10:
             # very large partitions tend to be in difficult regions: dropped (SVIM_COMBINE.py:126-128)
             logging.debug("Ignored partition of size {0} and type {1}: {2}".format(
@@ -339,14 +411,26 @@ def _rebuild(typ, cluster, bam):
         second = cluster[1][1]
         reads = first.reads + second.reads
     if typ == "DEL":
-        return CandidateDeletion(first.source_contig, first.source_start, first.source_end, reads, bam, genotype)
+        # the constructor would clamp coordinates that are clamped already: same object state from a copy
+        assert first.source_end >= first.source_start, \
+            "Deletion end ({0}:{1}) is smaller than its start ({0}:{2}). From read {3}".format(
+                first.source_contig, first.source_end, first.source_start, reads)
+        new = CandidateDeletion.__new__(CandidateDeletion)
+        new.__dict__.update(first.__dict__)
+        new.reads, new.genotype = reads, genotype
+        return new
     if typ == "INV":
         complete = first.complete if second is None else (first.complete or second.complete)
         return CandidateInversion(first.source_contig, first.source_start, first.source_end, reads, complete, bam,
                                   genotype)
     if typ == "INS":
-        return CandidateInsertion(first.dest_contig, first.dest_start, first.dest_end, reads, first.sequence, bam,
-                                  genotype)
+        assert first.dest_end >= first.dest_start, \
+            "Insertion end ({0}:{1}) is smaller than its start ({0}:{2}). From read {3}".format(
+                first.dest_contig, first.dest_end, first.dest_start, reads)
+        new = CandidateInsertion.__new__(CandidateInsertion)
+        new.__dict__.update(first.__dict__)
+        new.reads, new.genotype = reads, genotype
+        return new
     if typ == "DUP_TAN":
         copies = first.copies if second is None else round(mean([first.copies, second.copies]))
         fully = first.fully_covered if second is None else (first.fully_covered or second.fully_covered)
