@@ -121,7 +121,7 @@ def analyze_alignment_file_coordsorted(bam, options):
     sig_ref = sig["ref_pos"].astype(np.int64)
     # the inserted alleles are the only bases COLLECT needs: decode exactly those ranges, all at once
     # (native reader: its threads inflate just the BGZF members that hold them)
-    ins_seq = None
+    ins_seq, slices_job = None, None
     batch_slices = getattr(bam, "sequence_slices", None)
     ins = np.nonzero(sig["type"] == _lib.SIG_INS)[0]
     if len(ins):
@@ -129,8 +129,18 @@ def analyze_alignment_file_coordsorted(bam, options):
         lo = sig["read_pos"][ins].astype(np.int64)
         hi = lo + sig["len"][ins]
         if batch_slices is not None and (rec_index >= 0).all():
-            ins_seq = np.empty(len(sig["aln"]), dtype=object)
-            ins_seq[ins] = batch_slices(rec_index, lo, hi)
+            # the reader's threads inflate and decode while this thread parses SA tags and runs the segment
+            # kernels (the native call releases the GIL); joined before the candidates are assembled
+            import threading
+            box = {}
+
+            def decode():
+                try:
+                    box["seq"] = batch_slices(rec_index, lo, hi)
+                except BaseException as e:  # noqa: BLE001 — re-raised on the calling thread below
+                    box["error"] = e
+            slices_job = threading.Thread(target=decode)
+            slices_job.start()
         else:
             prefetch = getattr(bam, "prefetch_sequence", None)
             if prefetch is not None:
@@ -160,14 +170,20 @@ def analyze_alignment_file_coordsorted(bam, options):
         seg_cands = SVIM_inter.analyze_read_segments_batch(reads, bam, options, ctx=ctx, rows=rows,
                                                            read_lens=read_lens)
 
-    # ---- assemble in the reference's order
+    if slices_job is not None:
+        slices_job.join()
+        if "error" in box:
+            raise box["error"]
+        ins_seq = np.empty(len(sig["aln"]), dtype=object)
+        ins_seq[ins] = box["seq"]
+
+    # ---- assemble in the reference's order: per alignment its indels (CIGAR order), then its segment candidates
+    indels = SVIM_intra.candidates_from_signature_arrays(kept, bam, sig, sig_ref, ins_seq)
     sv_candidates = []
-    for k, aln in enumerate(kept):
-        lo, hi = int(sig_lo[k]), int(sig_lo[k + 1])
-        if hi > lo:
-            sv_candidates.extend(SVIM_intra.candidates_from_signatures(
-                aln, bam, aln.query_name, bam.getrname(aln.reference_id), sig_ref[lo:hi], sig["read_pos"][lo:hi],
-                sig["len"][lo:hi], sig["type"][lo:hi], None if ins_seq is None else ins_seq[lo:hi]))
+    lows = sig_lo.tolist()
+    for k in range(len(kept)):
+        if lows[k + 1] > lows[k]:
+            sv_candidates.extend(indels[lows[k]:lows[k + 1]])
         r = read_index.get(k)
         if r is not None:
             sv_candidates.extend(seg_cands[r])
