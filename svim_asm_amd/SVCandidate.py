@@ -79,7 +79,8 @@ class CandidateDeletion(Candidate):
         contig, start, end = self.get_source()
         if sequence_alleles:
             ref = reference.fetch(contig, max(0, start - 1), end).upper()
-            alt = reference.fetch(contig, max(0, start - 1), start).upper()
+            # reference.fetch(contig, max(0, start - 1), start): the first base of `ref` (nothing when start is 0)
+            alt = ref[:start - max(0, start - 1)]
         else:
             ref, alt = "N", "<DEL>"
         info = "SVTYPE=DEL;END={0};SVLEN={1}".format(end, start - end) + self._reads_info(read_names)

@@ -582,7 +582,10 @@ def write_final_vcf(int_duplication_candidates, inversion_candidates, tandem_dup
         if not options.symbolic_alleles:
             reference.close()
         counter = defaultdict(int)
+        lines = []
         for _, entry, svtype in sorted_nicely(entries):
             counter[svtype] += 1
-            print(entry.replace("PLACEHOLDERFORID", "svim_asm.{0}.{1}".format(svtype, counter[svtype]), 1),
-                  file=vcf_output)
+            lines.append(entry.replace("PLACEHOLDERFORID", "svim_asm.{0}.{1}".format(svtype, counter[svtype]), 1))
+        if lines:
+            vcf_output.write("\n".join(lines))
+            vcf_output.write("\n")

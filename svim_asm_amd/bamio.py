@@ -219,7 +219,7 @@ class AlignedRecord(object):
     """One BAM record (or an SA-derived pseudo record) with pysam-compatible attribute names."""
     __slots__ = ("query_name", "flag", "reference_id", "reference_start", "mapping_quality",
                  "cigar_words", "_seq_packed", "_l_seq", "_seq_str", "_tags_raw", "_tags", "index", "_sa",
-                 "_seq_fetch")
+                 "_sa_absent", "_seq_fetch")
 
     def __init__(self):
         self.query_name = None
@@ -235,6 +235,7 @@ class AlignedRecord(object):
         self._tags = None
         self.index = -1
         self._sa = None          # SA:Z string located by the native reader (None: parse the aux bytes)
+        self._sa_absent = False  # the native reader looked for an SA tag and found none
         self._seq_fetch = None   # callable (a, b) -> str decoding bases straight from the BGZF stream
 
     is_unmapped = property(lambda s: bool(s.flag & 0x4))
@@ -376,8 +377,11 @@ class AlignedRecord(object):
         return tags
 
     def get_tag(self, name):
-        if name == "SA" and self._sa is not None:
-            return self._sa
+        if name == "SA":
+            if self._sa is not None:
+                return self._sa
+            if self._sa_absent:
+                raise KeyError("tag 'SA' not present")
         tags = self._parse_tags()
         if name not in tags:
             raise KeyError("tag '%s' not present" % name)
@@ -680,6 +684,8 @@ class AlignmentFile(object):
             so = int(self._sa_off[i])
             if so >= 0:
                 r._sa = self._aux_pool[so:so + int(self._sa_len[i])].decode()
+            else:
+                r._sa_absent = True
             r._seq_fetch = lambda a, b, _i=i: self.sequence_slices([_i], [a], [b])[0]
         else:
             r.query_name = self._names[i]

@@ -79,6 +79,7 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, skip_oracle=False, dataset=Non
     res.update(runs[0])
     if len(runs) > 1:
         res["best_run"] = min(runs, key=lambda x: x["product_total_s"])
+        res["all_runs_total_s"] = [r["product_total_s"] for r in runs]
     res["index_state"] = f1.index_state()
     res["bgzf_members_inflated"] = [f1.blocks_inflated, f2.blocks_inflated]
     res["bgzf_members_walked"] = [f1.blocks_spanned, f2.blocks_spanned]
