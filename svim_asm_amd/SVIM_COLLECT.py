@@ -139,7 +139,7 @@ def analyze_alignment_file_coordsorted(bam, options):
                     box["seq"] = batch_slices(rec_index, lo, hi)
                 except BaseException as e:  # noqa: BLE001 — re-raised on the calling thread below
                     box["error"] = e
-            slices_job = threading.Thread(target=decode)
+            slices_job = threading.Thread(target=decode, daemon=True)  # (never outlives a failing run)
             slices_job.start()
         else:
             prefetch = getattr(bam, "prefetch_sequence", None)
