@@ -89,6 +89,19 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, skip_oracle=False, dataset=Non
     got = "".join(l for l in open(os.path.join(wd, "variants.vcf")) if not l.startswith("##fileDate="))
     res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
 
+    # ---- the command line itself, as a fresh process: interpreter start, imports, HIP initialisation and
+    # log writing included — what `time svim-asm diploid ...` shows
+    import subprocess
+    wd_cli = os.path.join(out, "wd_cli")
+    t = time.perf_counter()
+    rc = subprocess.call([sys.executable, os.path.join(ROOT, "bin", "svim-asm"), "diploid", wd_cli, bams[0], bams[1], fasta],
+                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res["cli_wall_s"] = time.perf_counter() - t
+    res["cli_rc"] = rc
+    if rc == 0:
+        cli_vcf = "".join(l for l in open(os.path.join(wd_cli, "variants.vcf")) if not l.startswith("##fileDate="))
+        res["cli_vcf_identical_to_in_process"] = (cli_vcf == got)
+
     if not skip_oracle:
         from oracle import orc, run_oracle
         t = time.perf_counter()
