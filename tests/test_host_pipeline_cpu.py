@@ -1,0 +1,104 @@
+"""The HOST logic of the product path — COLLECT gathering and assembly, split-read candidates, PAIR recipes and
+clustering glue, the CLI and the VCF writer — with the device answered by the CPU oracle
+(tests/helpers.OracleBackedContext), so that it is checked in the CPU-only suite as well: against the pinned Python
+oracle on seeded inputs, against the function vectors the REAL reference produced, and through the `svim-asm`
+command line against the real reference's golden VCFs.  The -m gpu suite makes the same comparisons with the
+real kernels."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc, svim_oracle
+from svim_asm_amd import SVCandidate, SVIM_COLLECT, SVIM_COMBINE, SVIM_inter
+from tests import helpers
+from tests.test_oracle_pins import RUNS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+NAMES = ["chr1", "chr10", "chr2", "chrX"]
+LENGTHS = [3_000_000, 1_500_000, 2_000_000, 800_000]
+
+
+@pytest.fixture(autouse=True)
+def device_is_the_oracle(monkeypatch):
+    helpers.oracle_backed_device(monkeypatch)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_collect_matches_oracle(seed):
+    rng = np.random.default_rng(seed)
+    recs = helpers.random_records(rng, NAMES, LENGTHS, 60) + helpers.engineered_split_records(rng, NAMES, LENGTHS, 120)
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    o = helpers.options(**[dict(), dict(min_sv_size=30, max_sv_size=3000), dict(min_mapq=0, query_gap_tolerance=500)][seed])
+    got = [helpers.candidate_tuple(c) for c in
+           SVIM_COLLECT.analyze_alignment_file_coordsorted(helpers.FakeBam(NAMES, LENGTHS, recs), o)]
+    assert got == svim_oracle.collect(recs, NAMES, LENGTHS, o)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_pair_candidates_matches_oracle(seed):
+    rng = np.random.default_rng(300 + seed)
+    seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=30000)) for n in NAMES}
+    lengths = [30000] * len(NAMES)
+    ref, bam = helpers.FakeFasta(seqs), helpers.FakeBam(NAMES, lengths, [])
+    t1 = helpers.random_candidates(rng, NAMES, lengths, seqs, 120, "h1")
+    t2 = helpers.random_candidates(rng, NAMES, lengths, seqs, 120, "h2")
+    for c in t1[:70]:  # near-copies on the other haplotype: two-member partitions on both sides of the threshold
+        if c[0] in ("DEL", "INS", "INV", "DUP_TAN"):
+            shift = int(rng.integers(-3, 4))
+            lst = list(c)
+            lst[2] = max(0, c[2] + shift)
+            lst[3] = max(lst[2], c[3] + shift)
+            lst[{"DEL": 4, "INS": 4, "INV": 4, "DUP_TAN": 6}[c[0]]] = ("h2_copy",)
+            t2.append(tuple(lst))
+    o = helpers.options(max_edit_distance=[200, 10, -1][seed], partition_max_distance=[1000, 100, 1000][seed])
+    c1 = [helpers.build_candidate(t, bam, SVCandidate) for t in t1]
+    c2 = [helpers.build_candidate(t, bam, SVCandidate) for t in t2]
+    got = [helpers.candidate_tuple(c) for c in SVIM_COMBINE.pair_candidates(c1, c2, ref, bam, o)]
+    exp = svim_oracle.pair_candidates(t1, t2, ref.fetch, NAMES, lengths, dict(zip(NAMES, lengths)), o,
+                                      edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+    assert got == exp
+
+
+def test_function_vectors_from_the_real_reference():
+    vec = helpers.load_pipeline_vectors()
+    names, lengths = vec["names"], vec["lengths"]
+    for case in vec["collect"]:
+        o = helpers.options(**case["options"])
+        bam = helpers.FakeBam(names, lengths, case["records"])
+        got = [helpers.candidate_tuple(c) for c in SVIM_COLLECT.analyze_alignment_file_coordsorted(bam, o)]
+        assert got == case["out"]
+        alns = list(bam.fetch())
+        for pr in case["analyze_read_segments"]:
+            aln = alns[pr["record"]]
+            supp = [s for s in SVIM_COLLECT.retrieve_other_alignments(aln, bam)
+                    if not s.is_unmapped and s.mapping_quality >= o.min_mapq]
+            assert [helpers.candidate_tuple(c) for c in SVIM_inter.analyze_read_segments(aln, supp, bam, o)] == pr["out"]
+    for case in vec["pair"]:
+        o = helpers.options(**case["options"])
+        seqs = case["seqs"]
+        plen = [len(seqs[n]) for n in names]
+        ref, bam = helpers.FakeFasta(seqs), helpers.FakeBam(names, plen, [])
+        c1 = [helpers.build_candidate(t, bam, SVCandidate) for t in case["t1"]]
+        c2 = [helpers.build_candidate(t, bam, SVCandidate) for t in case["t2"]]
+        for typ, parts in case["form_partitions"].items():
+            sub = [(1, c) for c in c1 if c.type == typ] + [(2, c) for c in c2 if c.type == typ]
+            where = {id(c): k for k, (_, c) in enumerate(sub)}
+            assert [[where[id(c)] for _, c in p] for p in SVIM_COMBINE.form_partitions(sub, o.partition_max_distance)] == parts
+        assert [helpers.candidate_tuple(c) for c in SVIM_COMBINE.pair_candidates(c1, c2, ref, bam, o)] == case["out"]
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_cli_reproduces_reference_vcf_config1(tmp_path, name):
+    """`svim-asm haploid|diploid` (native BAM reader, host logic, VCF writer) on the config-1 BAMs == the VCF the
+    real reference wrote, the kernels answered by the oracle."""
+    from svim_asm_amd import cli
+    argv = list(RUNS[name])
+    argv[1] = str(tmp_path)
+    for i, a in enumerate(argv):
+        if a.endswith(".bam") or a.endswith(".fa"):
+            argv[i] = os.path.join(GOLD, "config1", a)
+    cli.main(argv)
+    got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == open(os.path.join(GOLD, "config1", name + ".vcf")).read()
