@@ -96,7 +96,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict__ a, uint32_t n,
                                                      uint64_t key, int lane) {
     uint32_t lo = 0, hi = n;
-    while (hi - lo > 64) {
+    while (hi - lo > 128) {
         uint32_t step = (hi - lo + 63) / 64;
         uint64_t idx = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
         bool less = (idx < hi) ? (a[idx] < key) : false;
@@ -106,9 +106,12 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
         lo = (uint32_t)(nlo < hi ? nlo : hi);
         hi = (uint32_t)(nhi < hi ? nhi : hi);
     }
-    uint32_t idx = lo + lane;
-    bool less = (idx < hi) ? (a[idx] < key) : false;
-    return lo + __popcll(__ballot(less));
+    // last level: up to 128 candidates, two per lane, both loads in flight together (for the ~5 k
+    // alignments of a human assembly the whole search is two dependent rounds of loads)
+    const uint32_t i0 = lo + lane, i1 = lo + 64 + lane;
+    const uint64_t v0 = i0 < hi ? a[i0] : ~0ull, v1 = i1 < hi ? a[i1] : ~0ull;
+    const bool less0 = i0 < hi && v0 < key, less1 = i1 < hi && v1 < key;
+    return lo + __popcll(__ballot(less0)) + __popcll(__ballot(less1));
 }
 
 // largest a in [0, n_aln) with aln_off[a] <= g, given aln_off[a] < tile_start for all a < a_lo

@@ -261,3 +261,42 @@ def test_cigar_stats(svx_ctx):
     c = pack([(5, 3)] + [(4, 2)] * 150 + [(0, 10), (4, 7)])
     got = svx_ctx.cigar_stats(c, [0, len(c)])
     assert (int(got["q_start"][0]), int(got["q_end"][0]), int(got["read_len"][0]), int(got["n_hard"][0])) == (300, 310, 320, 3)
+
+
+def test_device_pointer_entry_points(svx_ctx):
+    """svx_cigar_extract_dev / svx_cigar_extract_soa_dev / svx_cigar_stats_dev on buffers the caller owns in HBM
+    (svx_dev_malloc: no torch involved), capacity protocol included: exactly min(count, cap) rows are written."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    cig, off, rs = synth.random_cigar_case(rng, 700, max_ops=400)
+    n_ops, n_aln = len(cig), len(off) - 1
+    exp = orc.cigar_extract(cig, off, rs, 40)
+    n_exp = len(exp["aln"])
+    assert n_exp > 10
+    d_cig, d_off, d_rs = svx_ctx.dev_array(cig), svx_ctx.dev_array(off.astype(np.uint64)), svx_ctx.dev_array(rs)
+    d_len = svx_ctx.dev_array((cig >> 4).astype(np.uint32))
+    d_op = svx_ctx.dev_array(np.concatenate(((cig & 15).astype(np.uint8), np.zeros(16, np.uint8))))
+    for cap in (n_exp + 5, n_exp // 2):
+        outs = [svx_ctx.dev_array(nbytes=4 * max(cap, 1)) for _ in range(4)] + [svx_ctx.dev_array(nbytes=max(cap, 1))]
+        d_n = svx_ctx.dev_array(np.zeros(1, np.uint64))
+        for soa in (False, True):
+            sig = _lib.SigSoa(*[o.ptr for o in outs])
+            if soa:
+                rc = svx_ctx.lib.svx_cigar_extract_soa_dev(svx_ctx.h, d_op.ptr, d_len.ptr, n_ops, d_off.ptr, n_aln, d_rs.ptr,
+                                                           40, sig, cap, d_n.ptr)
+            else:
+                rc = svx_ctx.lib.svx_cigar_extract_dev(svx_ctx.h, d_cig.ptr, n_ops, d_off.ptr, n_aln, d_rs.ptr, 40, sig,
+                                                       cap, d_n.ptr)
+            assert rc == 0
+            assert int(d_n.download(np.uint64)[0]) == n_exp  # the full count, whatever the capacity
+            k = min(cap, n_exp)
+            for o, key in zip(outs, KEYS):
+                got = o.download(np.uint8 if key == "type" else np.uint32, k)
+                assert np.array_equal(got, exp[key][:k]), (key, cap, soa)
+    # per-alignment statistics on device buffers
+    st = {k: svx_ctx.dev_array(nbytes=4 * n_aln) for k in ("ref_len", "q_start", "q_end", "read_len", "n_hard")}
+    stats = _lib.AlnStats(*[st[k].ptr for k in ("ref_len", "q_start", "q_end", "read_len", "n_hard")])
+    assert svx_ctx.lib.svx_cigar_stats_dev(svx_ctx.h, d_cig.ptr, n_ops, d_off.ptr, n_aln, stats) == 0
+    e = orc.cigar_stats(cig, off)
+    for k in st:
+        assert np.array_equal(st[k].download(np.uint32), e[k]), k
