@@ -532,6 +532,9 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
         wa.seq = d_seq; wa.a_off = d_ao; wa.a_len = d_al; wa.b_off = d_bo; wa.b_len = d_bl;
         wa.order = d_ord; wa.cap = d_band; wa.n = n_pairs; wa.dist = d_dist;
         const size_t lds = (size_t)2 * (2 * (size_t)lds_cap + 3) * sizeof(int32_t);
+        if (lds > 32768)  // (the largest cap, 4096 edits, needs 65 560 bytes of dynamic LDS: above the default limit)
+            SVX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_edit_wfa),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_edit_wfa, dim3(n_pairs), dim3(64), lds, ctx->stream, wa, lds_cap);
         SVX_HIP(ctx, hipGetLastError());
         SVX_HIP(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));

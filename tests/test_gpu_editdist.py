@@ -273,3 +273,18 @@ def test_threshold_applies_to_pairs_with_an_empty_side(svx_ctx, k):
     got = svx_ctx.edit_distance_batch(pool, ao, al, bo, bl, k_max=k).tolist()
     exp = [max(len(a), len(b)) if (not a or not b) else 0 for a, b in pairs]
     assert got == [e if e <= k else 0xFFFFFFFF for e in exp]
+
+
+def test_largest_wavefront_cap(svx_ctx):
+    """svx_ctx_set_edit_wavefront_cap(4096): the first stage then needs more dynamic LDS than the default launch
+    limit; distances between 1024 and 4096 edits are resolved by it."""
+    rng = np.random.default_rng(77)
+    a = bytes(rng.choice(list(b"ACGT"), size=60000).astype(np.uint8))
+    b = mutate(rng, a, 3000)
+    pool = np.frombuffer(a + b, np.uint8)
+    svx_ctx.set_edit_wavefront_cap(4096)
+    try:
+        got = int(svx_ctx.edit_distance_batch(pool, [0], [len(a)], [len(a)], [len(b)])[0])
+    finally:
+        svx_ctx.set_edit_wavefront_cap(1024)
+    assert got == orc.edit_distance_banded(a, b) and got > 1024
