@@ -22,7 +22,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
 
 
 def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, skip_oracle=False, dataset=None, threads=0, repeat=1,

@@ -9,8 +9,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
-from oracle import orc
 from svim_asm_amd import _lib
 
 
