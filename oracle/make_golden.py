@@ -122,6 +122,18 @@ def make_config1():
         "diploid_default": ["diploid", "{wd}", bams[0], bams[1], fasta],
         "diploid_options": ["diploid", "{wd}", bams[0], bams[1], fasta, "--query_names", "--max_edit_distance", "20",
                             "--partition_max_distance", "300", "--min_mapq", "0"],
+        "diploid_symbolic_dup_as_ins": ["diploid", "{wd}", bams[0], bams[1], fasta, "--symbolic_alleles",
+                                        "--tandem_duplications_as_insertions",
+                                        "--interspersed_duplications_as_insertions", "--sample", "D2"],
+        "diploid_tolerances": ["diploid", "{wd}", bams[0], bams[1], fasta, "--query_gap_tolerance", "0",
+                               "--query_overlap_tolerance", "0", "--reference_gap_tolerance", "500",
+                               "--reference_overlap_tolerance", "1000", "--min_sv_size", "50"],
+        "diploid_strict_pairing": ["diploid", "{wd}", bams[0], bams[1], fasta, "--max_edit_distance", "0",
+                                   "--partition_max_distance", "0"],
+        "diploid_types_small": ["diploid", "{wd}", bams[1], bams[0], fasta, "--types", "DEL,DUP:TANDEM,INV",
+                                "--max_sv_size", "500"],
+        "haploid_mapq_overlap": ["haploid", "{wd}", bams[1], fasta, "--min_mapq", "30",
+                                 "--reference_overlap_tolerance", "0", "--query_overlap_tolerance", "500"],
     }
     for name, argv in runs.items():
         wd = tempfile.mkdtemp(prefix="svimref_")
