@@ -358,6 +358,7 @@ def e2e_leg(scale, local_rank):
             "wall_s": best["product_total_s"], "first_run_wall_s": r["product_total_s"],
             "phases_s": {k: best[k] for k in ("open_index_s", "collect_s", "pair_s", "vcf_s")},
             "oracle_pipeline_wall_s": r.get("oracle_total_s"), "vcf_identical": r.get("vcf_identical"),
+            "vcf_matches_real_reference_digest": r.get("vcf_matches_real_reference_digest"),
             "vcf_records": r["vcf_records"], "cigar_ops": r["cigar_ops"], "candidates": r["candidates"],
             "ingest_threads": r["ingest_threads"], "index_state": r["index_state"],
             "generate_s": r["generate_s"],

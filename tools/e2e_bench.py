@@ -87,6 +87,19 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, skip_oracle=False, dataset=Non
     res["cigar_ops"] = [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]
     got = "".join(l for l in open(os.path.join(wd, "variants.vcf")) if not l.startswith("##fileDate="))
     res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
+    # at the scale of tests/golden/large_inputs.json the inputs are the ones the REAL reference was run on in the
+    # build container (same generator arguments): compare with the digest of its VCF
+    try:
+        import hashlib
+        meta = json.load(open(os.path.join(ROOT, "tests", "golden", "large_inputs.json")))
+        prm = meta["params"]
+        if not dataset and abs(scale - prm["scale"]) < 1e-12 and sv_per_mbp == prm["sv_per_mbp"]:
+            same_inputs = all(hashlib.sha256(open(b, "rb").read()).hexdigest() == meta["sha256"][os.path.basename(b)] for b in bams)
+            res["inputs_match_real_reference_run"] = same_inputs
+            if same_inputs:
+                res["vcf_matches_real_reference_digest"] = hashlib.sha256(got.encode()).hexdigest() == meta["vcf_sha256"]
+    except Exception as e:  # noqa: BLE001 — informative only
+        res["real_reference_digest_error"] = repr(e)
 
     # ---- the command line itself, as a fresh process: interpreter start, imports, HIP initialisation and
     # log writing included — what `time svim-asm diploid ...` shows
