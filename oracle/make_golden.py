@@ -169,7 +169,7 @@ def make_medium():
     wd = os.path.join(d, "wd")
     run_reference_cli(["diploid", wd, bams[0], bams[1], fasta])
     vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
-    with gzip.open(os.path.join(GOLD, "medium_diploid.vcf.gz"), "wb", compresslevel=9) as fh:
+    with gzip.GzipFile(os.path.join(GOLD, "medium_diploid.vcf.gz"), "wb", compresslevel=9, mtime=0) as fh:
         fh.write(vcf.encode())
     digest = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in [fasta] + bams}
     with open(os.path.join(GOLD, "medium_inputs.json"), "w") as fh:
@@ -236,7 +236,7 @@ def make_longcigar():
     wd = os.path.join(d, "wd")
     run_reference_cli(["diploid", wd, bams[0], bams[1], fasta])
     vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
-    with gzip.open(os.path.join(GOLD, "longcigar_diploid.vcf.gz"), "wb", compresslevel=9) as fh:
+    with gzip.GzipFile(os.path.join(GOLD, "longcigar_diploid.vcf.gz"), "wb", compresslevel=9, mtime=0) as fh:
         fh.write(vcf.encode())
     digest = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in [fasta] + bams}
     with open(os.path.join(GOLD, "longcigar_inputs.json"), "w") as fh:
@@ -393,8 +393,8 @@ def make_pipeline_vectors():
         out = [candidate_tuple(c) for c in ref["COMBINE"].pair_candidates(c1, c2, fasta, bam, o)]
         pair.append({"options": kw, "seqs": seqs, "t1": t1, "t2": t2, "form_partitions": parts, "out": out})
     vec["pair"] = pair
-    with gzip.open(os.path.join(GOLD, "pipeline_vectors.json.gz"), "wt", compresslevel=9) as fh:
-        json.dump(vec, fh)
+    with gzip.GzipFile(os.path.join(GOLD, "pipeline_vectors.json.gz"), "wb", compresslevel=9, mtime=0) as fh:
+        fh.write(json.dumps(vec).encode())  # (mtime 0: regenerating the fixture leaves the bytes unchanged)
 
 
 def main():
