@@ -395,22 +395,10 @@ def default_context(device=0):
     """Process-wide context per device (created on first use; raises without a GPU)."""
     ctx = _default_ctx.get(device)
     if ctx is None:
-        with _default_ctx_lock:  # (the CLI warms the context up on a thread while the BAM is being opened)
+        with _default_ctx_lock:
             ctx = _default_ctx.get(device)
             if ctx is None:
                 ctx = Context(device)
                 _default_ctx[device] = ctx
     return ctx
 
-
-def warm_up(device=0):
-    """Start creating the process-wide context (HIP runtime initialisation, ~0.15 s) in the background; a
-    failure is not reported here — the first real use raises it."""
-    def run():
-        try:
-            default_context(device)
-        except Exception:  # noqa: BLE001
-            pass
-    t = threading.Thread(target=run, daemon=True)
-    t.start()
-    return t

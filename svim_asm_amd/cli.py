@@ -107,25 +107,19 @@ def _run(options):
     # pure overhead (10-15 % of the wall-clock at human scale)
     import gc
     gc.disable()
-    warm = []
     try:
-        return _run_steps(options, warm)
+        return _run_steps(options)
     finally:
         gc.enable()
-        for t in warm:  # never leave the process while the HIP runtime is still coming up on the other thread
-            t.join()
 
 
-def _run_steps(options, warm):
+def _run_steps(options):
     logging.info("****************** Start SVIM-asm, version {0} ******************".format(__version__))
     logging.info("CMD: python3 {0}".format(" ".join(sys.argv)))
     logging.info("WORKING DIR: {0}".format(os.path.abspath(options.working_dir)))
     for arg in vars(options):
         logging.info("PARAMETER: {0}, VALUE: {1}".format(arg, getattr(options, arg)))
 
-    # HIP runtime initialisation overlaps opening and indexing the first BAM
-    from svim_asm_amd import _lib
-    warm.append(_lib.warm_up(getattr(options, "device", 0) or 0))
     logging.info("****************** STEP 1: COLLECT ******************")
     if options.sub == "haploid":
         logging.info("MODE: haploid")
