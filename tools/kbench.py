@@ -44,6 +44,30 @@ def segments_alone(n_reads=64580):
     return {"reads": n_reads, "segments": n_segs, "ms": dom, "bytes": 56 * n_segs, "GB/s": 56 * n_segs / (dom * 1e-3) / 1e9}
 
 
+def host_pointer_rate():
+    """PCIe-inclusive rate of the host-pointer entry (svx_cigar_extract: H2D of 4 B/op + offsets, kernels, D2H of the
+    17 B/signature, synchronous): one config-2 sample (what the CLI hands over per BAM) and a 64-sample cohort."""
+    import time
+    import numpy as np
+    from svim_asm_amd import _lib, synth
+    ctx = _lib.Context(0)
+    out = []
+    for samples in (1, 64):
+        base = [synth.synth_cigar_batch(seed=1200 + i, mean_m=4000) for i in range(min(samples, 8))]
+        b = synth.concat_batches([base[i % len(base)] for i in range(samples)])
+        n_ops = int(b["aln_off"][-1])
+        for _ in range(3):
+            ctx.cigar_extract(b["cigar"], b["aln_off"], b["ref_start"], 40)
+        reps = 50 if samples == 1 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sig = ctx.cigar_extract(b["cigar"], b["aln_off"], b["ref_start"], 40)
+        dt = (time.perf_counter() - t0) / reps
+        out.append({"samples": samples, "ops": n_ops, "signatures": len(sig["aln"]), "ms_per_call": dt * 1e3,
+                    "ops_per_s": n_ops / dt, "host_bytes_per_call": 4 * n_ops + 12 * (len(b["aln_off"]) - 1) + 17 * len(sig["aln"])})
+    return {"entry": "svx_cigar_extract (host pointers, pageable numpy arrays)", "cases": out}
+
+
 def main():
     import argparse
     import torch
@@ -56,6 +80,8 @@ def main():
             print(json.dumps(bench.roofline_pair(0)))
         elif leg == "editdist":
             print(json.dumps(bench.roofline_editdist(0, torch.cuda.get_device_properties(0).multi_processor_count)))
+        elif leg == "hostptr":
+            print(json.dumps(host_pointer_rate()))
         elif leg == "segments":
             print(json.dumps(segments_alone()))
         else:
