@@ -50,8 +50,7 @@ class Candidate(object):
         return (self.source_contig, self.source_start, self.source_end)
 
     def get_key(self):
-        contig, start, end = self.get_source()
-        return (self.type, contig, (start + end) // 2)
+        return (self.type, self.source_contig, (self.source_start + self.source_end) // 2)
 
     def position_distance_to(self, other):
         c1, s1, e1 = self.get_source()
@@ -76,15 +75,17 @@ class CandidateDeletion(Candidate):
         self.genotype = genotype
 
     def get_vcf_entry(self, sequence_alleles=False, reference=None, read_names=False):
-        contig, start, end = self.get_source()
+        contig, start, end = self.source_contig, self.source_start, self.source_end
         if sequence_alleles:
-            ref = reference.fetch(contig, max(0, start - 1), end).upper()
+            first = start - 1 if start > 0 else 0
+            ref = reference.fetch(contig, first, end).upper()
             # reference.fetch(contig, max(0, start - 1), start): the first base of `ref` (nothing when start is 0)
-            alt = ref[:start - max(0, start - 1)]
+            alt = ref[:start - first]
         else:
             ref, alt = "N", "<DEL>"
-        info = "SVTYPE=DEL;END={0};SVLEN={1}".format(end, start - end) + self._reads_info(read_names)
-        return _vcf_line(contig, max(1, start), ref, alt, [], info, "GT", self.genotype)
+        reads = self._reads_info(read_names) if read_names else ""
+        return (f"{contig}\t{start if start > 1 else 1}\tPLACEHOLDERFORID\t{ref}\t{alt}\t.\tPASS\t"
+                f"SVTYPE=DEL;END={end};SVLEN={start - end}{reads}\tGT\t{self.genotype}")
 
 
 class CandidateInversion(Candidate):
@@ -124,14 +125,15 @@ class CandidateInsertion(Candidate):
         return (self.type, self.dest_contig, self.dest_start)
 
     def get_vcf_entry(self, sequence_alleles=False, reference=None, read_names=False):
-        contig, start, end = self.get_destination()
+        contig, start, end = self.dest_contig, self.dest_start, self.dest_end
         if sequence_alleles:
-            ref = reference.fetch(contig, max(0, start - 1), start).upper()
+            ref = reference.fetch(contig, start - 1 if start > 0 else 0, start).upper()
             alt = ref + self.sequence
         else:
             ref, alt = "N", "<INS>"
-        info = "SVTYPE=INS;END={0};SVLEN={1}".format(start, end - start) + self._reads_info(read_names)
-        return _vcf_line(contig, max(1, start), ref, alt, [], info, "GT", self.genotype)
+        reads = self._reads_info(read_names) if read_names else ""
+        return (f"{contig}\t{start if start > 1 else 1}\tPLACEHOLDERFORID\t{ref}\t{alt}\t.\tPASS\t"
+                f"SVTYPE=INS;END={start};SVLEN={end - start}{reads}\tGT\t{self.genotype}")
 
 
 class CandidateDuplicationTandem(Candidate):

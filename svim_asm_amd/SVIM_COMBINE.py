@@ -33,13 +33,21 @@ SAME_HAPLOTYPE_DISTANCE = 1000000000
 def _pack_keys(candidates_with_haplotype):
     """get_key() tuples → u64 `(type rank, contig rank under str order) << 32 | pos`."""
     keys = [c.get_key() for _, c in candidates_with_haplotype]
-    contig_rank = {name: i for i, name in enumerate(sorted(set(k[1] for k in keys)))}
-    packed = np.empty(len(keys), dtype=np.uint64)
-    for i, (typ, contig, pos) in enumerate(keys):
-        if pos < 0 or pos >= (1 << 32):
-            raise ValueError("key position out of range: %r" % (pos,))
-        packed[i] = ((_TYPE_RANK.get(typ, len(TYPE_ORDER)) << 24 | contig_rank[contig]) << 32) | pos
-    return packed
+    if not keys:
+        return np.empty(0, dtype=np.uint64)
+    types = [k[0] for k in keys]
+    contigs = [k[1] for k in keys]
+    positions = [k[2] for k in keys]
+    contig_rank = {name: i for i, name in enumerate(sorted(set(contigs)))}
+    type_rank = {t: _TYPE_RANK.get(t, len(TYPE_ORDER)) for t in set(types)}
+    pos = np.array(positions, dtype=object if max(positions) >= (1 << 62) else np.int64)
+    bad = np.flatnonzero((pos < 0) | (pos >= (1 << 32)))
+    if len(bad):
+        raise ValueError("key position out of range: %r" % (positions[int(bad[0])],))
+    n = len(keys)
+    high = (np.fromiter(map(type_rank.__getitem__, types), dtype=np.uint64, count=n) << np.uint64(24)) | \
+        np.fromiter(map(contig_rank.__getitem__, contigs), dtype=np.uint64, count=n)
+    return (high << np.uint64(32)) | pos.astype(np.uint64)
 
 
 def form_partitions(sv_candidates_with_haplotype, max_distance, ctx=None):

@@ -152,7 +152,11 @@ def _run_steps(options):
     if options.sub == "diploid":
         logging.info("****************** STEP 2: PAIR ******************")
         sv_candidates = shard.pair_sharded(sv_candidates1, sv_candidates2, reference, aln_file1, options)
-    by_type = {key: [c for c in sv_candidates if c.type == key] for key, _ in TYPE_LABELS}
+    by_type = {key: [] for key, _ in TYPE_LABELS}
+    for candidate in sv_candidates:
+        bucket = by_type.get(candidate.type)
+        if bucket is not None:
+            bucket.append(candidate)
 
     logging.info("****************** STEP {0}: OUTPUT ******************".format(2 if options.sub == "haploid" else 3))
     for key, label in (TYPE_LABELS[0], TYPE_LABELS[1], TYPE_LABELS[2], TYPE_LABELS[3], TYPE_LABELS[4], TYPE_LABELS[5]):
