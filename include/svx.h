@@ -67,6 +67,12 @@ int svx_device_count(void);
  * more than the work.  Larger batches take the streaming path (tiles of 4096 ops, five launches).
  * Default and upper limit 2^21 ops; 0 disables the small-batch path.  Results are identical on both. */
 int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
+/* svx_pair_partition* sort batches of at most `max_candidates` keys in ONE kernel launch (buckets by the
+ * leading key bits, every window of buckets sorted inside one workgroup's LDS, two arrival barriers inside
+ * the launch): the PAIR step of one diploid sample is 60-90 k candidates.  Larger batches take the radix
+ * path (P + 2 launches).  Default and upper limit 131072; 0 disables the one-launch path.  Results are
+ * identical on both. */
+int svx_ctx_set_pair_single_launch_max(svx_ctx* ctx, uint32_t max_candidates);
 
 /* Device buffers for callers that have no other owner of HBM (a ctypes binding without torch, the
  * tests): plain hipMalloc / hipFree / hipMemcpyAsync on the context's device and stream.

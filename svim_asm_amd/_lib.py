@@ -68,6 +68,7 @@ SYMBOLS = {
     "svx_version": (C.c_char_p, []),
     "svx_device_count": (C.c_int, []),
     "svx_ctx_set_small_batch_ops": (C.c_int, [_P, C.c_uint64]),
+    "svx_ctx_set_pair_single_launch_max": (C.c_int, [_P, C.c_uint32]),
     "svx_ctx_set_edit_wavefront_cap": (C.c_int, [_P, C.c_uint32]),
     "svx_dev_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "svx_dev_free": (C.c_int, [_P, _P]),
@@ -179,6 +180,10 @@ class Context:
     def set_small_batch_ops(self, max_ops):
         """Largest batch (CIGAR ops) of the small-batch (two-launch) path; 0 forces the streaming path."""
         self._check(self.lib.svx_ctx_set_small_batch_ops(self.h, int(max_ops)))
+
+    def set_pair_single_launch_max(self, max_candidates):
+        """Largest batch (candidates) of the one-launch pair sort; 0 forces the radix path."""
+        self._check(self.lib.svx_ctx_set_pair_single_launch_max(self.h, int(max_candidates)))
 
     def set_edit_wavefront_cap(self, max_edits):
         """Edits the wavefront pass of the edit distance resolves (0: bit-vector kernel only)."""

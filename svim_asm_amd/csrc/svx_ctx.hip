@@ -107,6 +107,12 @@ extern "C" int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops) {
     return SVX_OK;
 }
 
+extern "C" int svx_ctx_set_pair_single_launch_max(svx_ctx* ctx, uint32_t max_candidates) {
+    if (!ctx) return SVX_E_INVALID;
+    ctx->pair_single_max = max_candidates > 131072u ? 131072u : max_candidates;
+    return SVX_OK;
+}
+
 extern "C" int svx_ctx_set_edit_wavefront_cap(svx_ctx* ctx, uint32_t max_edits) {
     if (!ctx) return SVX_E_INVALID;
     ctx->wfa_cap = max_edits > 4096u ? 4096u : max_edits;

@@ -8,13 +8,20 @@
 // name under Python str order), pos = non-negative key position), so unsigned 64-bit
 // order == the reference's tuple order and ties keep input order (hap-1 list, then hap-2).
 //
-// Launch plan (P + 2 kernels; P = 4 for a human sample: 3 type + 5 contig + 28 position bits):
+// Two plans, same results (tests run every case on both):
+//
+// * up to 131072 candidates (one diploid sample is 60-90 k): ONE launch, k_pair_single — slices of the
+//   input are turned into dense keys and counted per bucket of the leading 9 key bits, the bucket sequence
+//   is cut into windows of about n / grid keys, every workgroup gathers its window into LDS, sorts it there
+//   with stable 9-bit counting passes, flags the partition borders and, after the second of two arrival
+//   barriers, adds the partitions opened in earlier windows (see the comment at the kernel);
+//
+// * beyond that: P + 2 launches (P = 4 for a human sample: 3 type + 5 contig + 28 position bits):
 //   the caller (or one reduction) tells which key bits can be set at all; those bits are
 //   squeezed into a dense key of L bits (up to four bit fields), sorted LSD with P = ceil(L / 9)
 //   digits of ceil(L / P) bits:
 //   k_pair_init      dense keys, idx[i] = i, per-workgroup histogram of digit 0 (one workgroup = one
-//                    block of 2048 keys up to 128 k keys, 4096 beyond), zero the histograms of the later
-//                    digits;
+//                    block of 4096 keys), zero the histograms of the later digits;
 //   k_radix_pass × P one workgroup per block, its keys in registers.  Every workgroup sums the histogram
 //                    rows of ALL blocks itself (two buckets per thread, 16 rows in flight) — no scan
 //                    kernel, no look-back; the table is 2 KiB per block and L2-resident —, its four waves
@@ -22,11 +29,10 @@
 //                    and scatter them, counting on the way the NEXT digit into the histogram row of the
 //                    block each key lands in;
 //   k_partition      boundary flags straight from the sorted dense keys (they expand back to the original
-//                    keys: no gather) + inclusive scan → partition ids, perm, n_parts.  One workgroup up
-//                    to 16 k candidates; beyond that at most half a workgroup per CU with one arrival
-//                    counter (every workgroup of the grid is resident).
+//                    keys: no gather) + inclusive scan → partition ids, perm, n_parts.  At most half a
+//                    workgroup per CU with one arrival counter (every workgroup of the grid is resident).
 // Integer work, 20 B per candidate algorithmic, no MFMA; at the product's 60 k candidates it is bound by
-// the six dependent launches (≈ 9 µs per pass even with no output), not by bytes.  Determinism: ranks
+// dependent latencies (launches, grid barriers, LDS passes), not by bytes.  Determinism: ranks
 // come from prefix sums only; the histogram atomics are commutative counts.
 #include "svx_internal.h"
 
@@ -241,23 +247,38 @@ __device__ __forceinline__ uint64_t original_key(const KeyFields& f, uint64_t d)
     return k;
 }
 
-// inclusive scan of `v` over a 1024-thread workgroup; returns the scanned value, *total the sum
+// DPP lane movement (gfx9 family): 0 flows into lanes without a source
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive sum over the wave: shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 / lane 31 broadcasts
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += dpp0<0x111, 0xF>(v);
+    v += dpp0<0x112, 0xF>(v);
+    v += dpp0<0x114, 0xF>(v);
+    v += dpp0<0x118, 0xF>(v);
+    v += dpp0<0x142, 0xA>(v);
+    v += dpp0<0x143, 0xC>(v);
+    return v;
+}
+
+// inclusive scan of `v` over a 1024-thread workgroup; returns the scanned value, *total the sum.
+// TAIL_SYNC = false: the caller has a barrier of its own before s_w is written again.
+template <bool TAIL_SYNC = true>
 __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_w, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t s = v;
-#pragma unroll
-    for (int k = 1; k < 64; k <<= 1) {
-        const uint32_t t = __shfl_up(s, k);
-        if (lane >= k) s += t;
-    }
+    const uint32_t s = wave_scan_incl(v);
     if (lane == 63) s_w[wave] = s;
     __syncthreads();
     uint32_t wp = 0, tot = 0;
+#pragma unroll
     for (int w = 0; w < 16; ++w) {
-        if (w < wave) wp += s_w[w];
-        tot += s_w[w];
+        const uint32_t x = s_w[w];
+        if (w < wave) wp += x;
+        tot += x;
     }
-    __syncthreads();
+    if (TAIL_SYNC) __syncthreads();
     *total = tot;
     return wp + s;
 }
@@ -343,6 +364,392 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
     if (threadIdx.x == 0 && hi == p.n) *p.n_parts = p.n ? carry + 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch for up to 128 k candidates (a diploid human sample has 60-90 k): bucket by the leading
+// bits, then sort every window of buckets inside one workgroup's LDS.
+//
+//   slice pass   workgroup g turns slice g of the input into dense keys (written once) and counts the
+//                slice's keys per fine bucket (the leading kFineBits of the dense key) into row g;
+//   barrier A    (arrival counter; the grid is at most a quarter of the CUs, every workgroup resident)
+//   windows      every workgroup sums the rows itself: bucket totals, their prefix, and from it the same
+//                split of the bucket sequence into windows of about n / grid keys everywhere; workgroup g
+//                owns window g: position `start` of the sorted order, M keys;
+//   gather       the window's keys are collected in input order: a slice's share of the window and where
+//                it goes follow from the rows, slices without a share are never read;
+//   window sort  stable LSD passes of 9-bit digits over the low bits, one over the bucket number, in LDS
+//                (M <= kWinCap) — a window that does not fit (a single crowded bucket) runs the same
+//                passes on a private stretch of HBM scratch: slower, same result, no second code path
+//                for the caller;
+//   flags        boundary flags between neighbours inside the window, local partition numbers;
+//   barrier B    the windows publish their flag count and their first and last key; everybody derives the
+//                flag between windows and the carry-in from that table;
+//   output       perm / part_id at start .. start + M.
+// Ranks come from prefix sums and match masks only: the result does not depend on scheduling.
+constexpr uint32_t kFineBits = 9;
+constexpr uint32_t kFine = 1u << kFineBits;
+constexpr uint32_t kWinCap = 5120;          // keys of a window sorted in LDS: five per thread
+constexpr uint32_t kSingleGridMax = 64;     // one wave tabulates the windows
+constexpr int kGatherBatch = 16;
+constexpr uint32_t kSingleDynLds = 2 * kWinCap * 8 + 2 * kWinCap * 4;  // beside 32 KiB of static counters
+
+struct SingleArgs {
+    const uint64_t* keys;
+    uint64_t* dense;      // [n]
+    uint32_t* rows;       // [grid][kFine]
+    uint64_t* gkey;       // [2][n], windows that do not fit LDS
+    uint32_t* gidx;       // [2][n]
+    uint32_t* win;        // [grid][2]: flags inside the window, keys in the window
+    uint64_t* win_keys;   // [grid][2]: first and last key of the sorted window
+    KeyFields f;
+    uint32_t n, live, max_dist, target, slice_len;
+    uint32_t* perm;
+    uint32_t* part_id;
+    uint32_t* n_parts;
+    uint32_t* counter;    // workspace header: two self-cleaning arrival barriers, two words each
+};
+
+#ifdef SVX_EXP_PAIRCLK  // (timeline builds only: 100 MHz clock stamps of thread 0 of every workgroup)
+__device__ unsigned long long g_pair_clk[64 * 16];
+#define PAIR_CLK(k) do { if (threadIdx.x == 0) g_pair_clk[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define PAIR_CLK(k)
+#endif
+
+template <typename T>
+__device__ __forceinline__ void agent_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T agent_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all threads: the workgroup's earlier agent-scope stores are out, then one thread meets the other
+// workgroups at counter c (c + 1 counts the leavers; the last one puts both back to zero)
+__device__ __forceinline__ void grid_barrier(uint32_t* c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (agent_load(c) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+        if (__hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            agent_store(c, 0u);
+            agent_store(c + 1, 0u);
+        }
+    }
+    __syncthreads();
+}
+
+// hist[dig] += length of every run of equal digits among the wave's valid lanes (the valid lanes are a
+// prefix of the wave): one LDS atomic per run instead of one per key — keys arrive nearly sorted
+__device__ __forceinline__ void count_runs(uint32_t* hist, uint32_t dig, bool valid, int lane) {
+    const uint32_t prev = __shfl_up(dig, 1);
+    const bool head = lane == 0 || dig != prev;
+    const uint64_t heads = __ballot(head);
+    if (head && valid) {
+        const uint64_t nxt = (heads >> lane) >> 1;
+        atomicAdd(&hist[dig], nxt ? (uint32_t)__ffsll((unsigned long long)nxt) : 64u - (uint32_t)lane);
+    }
+}
+
+__device__ __forceinline__ bool opens_partition(const KeyFields& f, uint64_t prev_dense, uint64_t cur_dense, uint32_t max_dist) {
+    const uint64_t a = original_key(f, prev_dense), c = original_key(f, cur_dense);
+    const uint32_t pa = (uint32_t)a, pc = (uint32_t)c;
+    const uint32_t dist = pa > pc ? pa - pc : pc - pa;
+    return (a >> 32) != (c >> 32) || dist > max_dist;
+}
+
+// One stable counting pass over the window: digit(key) = ((key >> shift) & mask) - sub, `bits` wide.
+// Wave w owns the w-th sixteenth of the window, 64 consecutive keys per iteration.
+__device__ __forceinline__ void window_pass(const uint64_t* sk, const uint32_t* si, uint64_t* dk, uint32_t* di, uint32_t M,
+                                            uint32_t* s_cnt, uint32_t* s_w, uint32_t shift, uint32_t mask, uint32_t sub,
+                                            uint32_t bits) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t per = (M + 1023) >> 10, wbase = wave * 64u * per;
+    for (int v = tid; v < 16 * (int)kFine; v += 1024) s_cnt[v] = 0;
+    __syncthreads();
+    for (uint32_t it = 0; it < per; ++it) {
+        const uint32_t j = wbase + it * 64 + lane;
+        const bool valid = j < M;
+        const uint32_t dig = valid ? ((uint32_t)(sk[j] >> shift) & mask) - sub : ~0u;
+        if (__ballot(valid) == 0) break;
+        count_runs(s_cnt + wave * kFine, dig, valid, lane);
+    }
+    __syncthreads();
+    uint32_t c[16], tot = 0;
+    if (tid < (int)kFine) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { c[w] = s_cnt[w * kFine + tid]; tot += c[w]; }
+    }
+    uint32_t all;
+    uint32_t base = block_scan_1024<false>(tot, s_w, &all) - tot;
+    if (tid < (int)kFine) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { s_cnt[w * kFine + tid] = base; base += c[w]; }
+    }
+    __syncthreads();
+    uint32_t* run = s_cnt + wave * kFine;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (uint32_t it = 0; it < per; ++it) {
+        const uint32_t j = wbase + it * 64 + lane;
+        const bool valid = j < M;
+        uint64_t m = __ballot(valid);
+        if (m == 0) break;
+        uint64_t key = 0;
+        uint32_t id = 0;
+        if (valid) { key = sk[j]; id = si[j]; }
+        const uint32_t dig = ((uint32_t)(key >> shift) & mask) - sub;
+        for (uint32_t bit = 0; bit < bits; ++bit) {
+            const uint64_t bal = __ballot((dig >> bit) & 1u);
+            m &= ((dig >> bit) & 1u) ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(m & lt);
+        uint32_t pos = 0;
+        if (valid) pos = run[dig] + rank;
+        wave_lds_sync();
+        if (valid && rank == 0) run[dig] += __popcll(m);
+        wave_lds_sync();
+        if (valid) { dk[pos] = key; di[pos] = id; }
+    }
+    __syncthreads();
+}
+
+template <bool LDS>
+__device__ __forceinline__ void window_work(const SingleArgs& a, char* s_dyn, uint32_t* s_cnt, uint32_t* s_w,
+                                            const uint32_t* s_soff, const uint32_t* s_scnt, uint32_t lo, uint32_t hi,
+                                            uint32_t start, uint32_t M, uint32_t low_bits) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // both halves of a ping-pong pair hang off one base pointer (LDS or HBM scratch): half h is base + h * stride
+    uint64_t* kbase;
+    uint32_t* ibase;
+    uint32_t stride;
+    if constexpr (LDS) {
+        kbase = reinterpret_cast<uint64_t*>(s_dyn);
+        ibase = reinterpret_cast<uint32_t*>(s_dyn + 2 * kWinCap * 8);
+        stride = kWinCap;
+    } else {
+        kbase = a.gkey + start;
+        ibase = a.gidx + start;
+        stride = a.n;
+    }
+    auto K = [&](int h) { return kbase + (size_t)h * stride; };
+    auto I = [&](int h) { return ibase + (size_t)h * stride; };
+    // ---- gather, input order: slice s puts its share at s_soff[s]
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (uint32_t s = wave; s < gridDim.x; s += 16) {
+        const uint32_t share = s_scnt[s];
+        if (!share) continue;
+        uint32_t run = s_soff[s];
+        const uint32_t end = run + share;
+        const uint32_t sl = s * a.slice_len, sh = min(a.n, sl + a.slice_len);
+        for (uint32_t base = sl; base < sh && run < end; base += 64 * kGatherBatch) {
+            uint64_t d[kGatherBatch];  // all loads of the batch in flight before the first is looked at
+#pragma unroll
+            for (int u = 0; u < kGatherBatch; ++u) {
+                const uint32_t i = base + u * 64 + lane;
+                d[u] = i < sh ? agent_load(a.dense + i) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherBatch; ++u) {
+                const uint32_t i = base + u * 64 + lane;
+                const uint32_t fine = (uint32_t)(d[u] >> low_bits);
+                const bool in = i < sh && fine >= lo && fine < hi;
+                const uint64_t bal = __ballot(in);
+                if (in) {
+                    const uint32_t pos = run + __popcll(bal & lt);
+                    K(0)[pos] = d[u];
+                    I(0)[pos] = i;
+                }
+                run += __popcll(bal);
+            }
+        }
+    }
+    __syncthreads();
+    PAIR_CLK(5);
+    // ---- stable LSD passes: the low bits in digits of at most 9, then the bucket number
+    int src = 0;
+    if (low_bits) {
+        const uint32_t passes = (low_bits + kFineBits - 1) / kFineBits;
+        const uint32_t db = (low_bits + passes - 1) / passes;
+        for (uint32_t p = 0; p < passes; ++p) {
+            window_pass(K(src), I(src), K(src ^ 1), I(src ^ 1), M, s_cnt, s_w, p * db, (1u << db) - 1u, 0u, db);
+            src ^= 1;
+        }
+    }
+    if (hi - lo > 1) {
+        window_pass(K(src), I(src), K(src ^ 1), I(src ^ 1), M, s_cnt, s_w, low_bits, kFine - 1u, lo,
+                    32u - (uint32_t)__clz((int)(hi - lo - 1)));
+        src ^= 1;
+    }
+    PAIR_CLK(6);
+    // ---- flags between neighbours, local partition numbers (into the free index buffer)
+    uint32_t carry = 0;
+    uint32_t* ID = I(src ^ 1);
+    if constexpr (LDS) {  // at most five consecutive keys per thread: one scan for the whole window
+        const uint32_t per = (M + 1023) >> 10, j0 = tid * per;
+        uint32_t bits = 0;
+        if (j0 < M) {
+            uint64_t prev = j0 ? original_key(a.f, K(src)[j0 - 1]) : 0ull;
+#pragma unroll
+            for (uint32_t i = 0; i < kWinCap / 1024; ++i) {
+                const uint32_t j = j0 + i;
+                if (i < per && j < M) {
+                    const uint64_t c = original_key(a.f, K(src)[j]);
+                    const uint32_t pa = (uint32_t)prev, pc = (uint32_t)c;
+                    const uint32_t dist = pa > pc ? pa - pc : pc - pa;
+                    if (j && ((prev >> 32) != (c >> 32) || dist > a.max_dist)) bits |= 1u << i;
+                    prev = c;
+                }
+            }
+        }
+        uint32_t id = block_scan_1024<false>(__popc(bits), s_w, &carry) - __popc(bits);
+#pragma unroll
+        for (uint32_t i = 0; i < kWinCap / 1024; ++i) {
+            const uint32_t j = j0 + i;
+            if (i < per && j < M) {
+                id += (bits >> i) & 1u;
+                ID[j] = id;
+            }
+        }
+    } else {
+        for (uint32_t base = 0; base < M; base += 1024) {
+            const uint32_t j = base + tid;
+            uint32_t flag = 0;
+            if (j < M && j) flag = opens_partition(a.f, K(src)[j - 1], K(src)[j], a.max_dist) ? 1u : 0u;
+            uint32_t tot;
+            const uint32_t incl = block_scan_1024(flag, s_w, &tot);
+            if (j < M) ID[j] = carry + incl;
+            carry += tot;
+        }
+    }
+    if (tid == 0) {
+        agent_store(a.win + 2 * blockIdx.x, carry);
+        agent_store(a.win + 2 * blockIdx.x + 1, M);
+        agent_store(a.win_keys + 2 * blockIdx.x, K(src)[0]);
+        agent_store(a.win_keys + 2 * blockIdx.x + 1, K(src)[M - 1]);
+    }
+    PAIR_CLK(7);
+    grid_barrier(a.counter + 2);
+    PAIR_CLK(8);
+    // ---- the table of windows: flag between windows, carry-in
+    __shared__ uint32_t s_in[2];
+    if (wave == 0) {
+        const bool have = (uint32_t)lane < gridDim.x;
+        const uint32_t cnt = have ? agent_load(a.win + 2 * lane) : 0u;
+        const uint32_t m = have ? agent_load(a.win + 2 * lane + 1) : 0u;
+        const uint64_t first = (have && m) ? agent_load(a.win_keys + 2 * lane) : 0ull;
+        const uint64_t last = (have && m) ? agent_load(a.win_keys + 2 * lane + 1) : 0ull;
+        const uint64_t filled = __ballot(m != 0) & lt;
+        const int pred = filled ? 63 - __clzll((long long)filled) : 0;
+        const uint64_t pl = ((uint64_t)__shfl((uint32_t)(last >> 32), pred) << 32) | __shfl((uint32_t)last, pred);
+        const uint32_t f0 = (m && filled && opens_partition(a.f, pl, first, a.max_dist)) ? 1u : 0u;
+        uint32_t sc = cnt + f0;
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            const uint32_t t = __shfl_up(sc, k);
+            if (lane >= k) sc += t;
+        }
+        if ((uint32_t)lane == blockIdx.x) { s_in[0] = sc - cnt; s_in[1] = 0; }  // earlier windows + own leading flag
+        if (lane == 63 && blockIdx.x == 0) *a.n_parts = sc + 1;
+    }
+    __syncthreads();
+    const uint32_t add = s_in[0];
+    PAIR_CLK(9);
+    for (uint32_t j = tid; j < M; j += 1024) {
+        a.part_id[start + j] = add + ID[j];
+        a.perm[start + j] = I(src)[j];
+    }
+    PAIR_CLK(10);
+}
+
+__global__ __launch_bounds__(1024) void k_pair_single(SingleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    __shared__ uint32_t s_cnt[16 * kFine];
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_rng[4];
+    __shared__ uint32_t s_soff[kSingleGridMax], s_scnt[kSingleGridMax];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t g = blockIdx.x, G = gridDim.x;
+    const uint32_t fine_bits = a.live < kFineBits ? a.live : kFineBits, low_bits = a.live - fine_bits;
+    for (int v = tid; v < (int)kFine; v += 1024) s_cnt[v] = 0;
+    if (tid == 0) { s_rng[0] = 0; s_rng[1] = 0; s_rng[2] = 0; s_rng[3] = 0; }
+    __syncthreads();
+    PAIR_CLK(0);
+    // ---- slice pass
+    {
+        const uint32_t sl = g * a.slice_len, sh = min(a.n, sl + a.slice_len);
+        for (uint32_t base = sl + wave * 64; base < sh; base += 1024) {
+            const uint32_t i = base + lane;
+            const bool valid = i < sh;
+            uint32_t fine = ~0u;
+            if (valid) {
+                const uint64_t d = dense_key(a.f, a.keys[i]);
+                agent_store(a.dense + i, d);
+                fine = (uint32_t)(d >> low_bits);
+            }
+            count_runs(s_cnt, fine, valid, lane);
+        }
+        __syncthreads();
+        // the row is stored as its inclusive prefix over the buckets: a stretch of buckets is two loads
+        uint32_t all;
+        const uint32_t incl = block_scan_1024(tid < (int)kFine ? s_cnt[tid] : 0u, s_w, &all);
+        if (tid < (int)kFine) agent_store(a.rows + (size_t)g * kFine + tid, incl);
+    }
+    PAIR_CLK(1);
+    grid_barrier(a.counter);
+    PAIR_CLK(2);
+    // ---- windows: column sums of the prefix rows = keys in buckets 0..b over all slices (every load of a
+    // thread in flight at once: thread t sums bucket t % 512 over one half of the slices)
+    {
+        const uint32_t b = tid & (kFine - 1), s0 = (tid >> 9) * 32;
+        uint32_t x[32], cp = 0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) x[u] = s0 + u < G ? agent_load(a.rows + (size_t)(s0 + u) * kFine + b) : 0u;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) cp += x[u];
+        s_cnt[tid] = cp;
+    }
+    __syncthreads();
+    // bucket b belongs to window (keys before b) / target: the buckets of a window are consecutive, the
+    // first and the last one announce themselves (empty buckets at the edges count as members)
+    if (tid < (int)kFine) {
+        const uint32_t w_lo = g * a.target, w_hi = w_lo + a.target;  // (no overflow: g * target < n + target)
+        const uint32_t cp = s_cnt[tid] + s_cnt[kFine + tid];                          // keys in buckets 0..tid
+        const uint32_t ex = tid ? s_cnt[tid - 1] + s_cnt[kFine + tid - 1] : 0u;       // keys before bucket tid
+        const uint32_t ex_prev = tid > 1 ? s_cnt[tid - 2] + s_cnt[kFine + tid - 2] : 0u;
+        const bool mine = ex >= w_lo && ex < w_hi;
+        const bool prev_mine = tid > 0 && ex_prev >= w_lo && ex_prev < w_hi;
+        const bool next_mine = tid + 1 < (int)kFine && cp >= w_lo && cp < w_hi;
+        if (mine && !prev_mine) { s_rng[0] = (uint32_t)tid; s_rng[2] = ex; }
+        if (mine && !next_mine) { s_rng[1] = (uint32_t)tid + 1u; s_rng[3] = cp; }
+    }
+    __syncthreads();
+    const uint32_t lo = s_rng[0], hi = s_rng[1], start = s_rng[2], M = s_rng[3] - s_rng[2];
+    PAIR_CLK(3);
+    if (M == 0) {  // no bucket starts inside this window's stretch
+        if (tid == 0) { agent_store(a.win + 2 * g, 0u); agent_store(a.win + 2 * g + 1, 0u); }
+        grid_barrier(a.counter + 2);
+        return;
+    }
+    // every slice's share of the window and where it goes
+    if (wave == 0) {
+        uint32_t c = 0;
+        if ((uint32_t)lane < G) {
+            const uint32_t upto = agent_load(a.rows + (size_t)lane * kFine + hi - 1);
+            const uint32_t below = lo ? agent_load(a.rows + (size_t)lane * kFine + lo - 1) : 0u;
+            c = upto - below;
+        }
+        uint32_t sc = c;
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            const uint32_t t = __shfl_up(sc, k);
+            if (lane >= k) sc += t;
+        }
+        s_soff[lane] = sc - c;
+        s_scnt[lane] = c;
+    }
+    __syncthreads();
+    PAIR_CLK(4);
+    if (M <= kWinCap) window_work<true>(a, s_dyn, s_cnt, s_w, s_soff, s_scnt, lo, hi, start, M, low_bits);
+    else window_work<false>(a, s_dyn, s_cnt, s_w, s_soff, s_scnt, lo, hi, start, M, low_bits);
+}
+
 // bit fields of `bits` (set bits = key bits that can be non-zero), at most four: nearby runs are merged
 KeyFields fields_of(uint64_t bits, uint32_t* live) {
     struct Run { uint32_t lo, hi; };  // [lo, hi)
@@ -376,6 +783,52 @@ KeyFields fields_of(uint64_t bits, uint32_t* live) {
     return f;
 }
 
+int pair_single_launch(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist, const KeyFields& f,
+                       uint32_t live, uint32_t* d_perm, uint32_t* d_part_id, uint32_t* d_n_parts) {
+    static bool lds_set = false;  // (the attribute belongs to the function, not to a context)
+    if (!lds_set) {
+        SVX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_single),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSingleDynLds));
+        lds_set = true;
+    }
+    SingleArgs a;
+    // two arrival barriers: the grid stays at a quarter of the CUs (one of these workgroups fills a CU's
+    // LDS), so that four such grids are resident together and none can starve another's barrier
+    const uint32_t grid_max = std::min<uint32_t>(kSingleGridMax, std::max<uint32_t>(1u, (uint32_t)ctx->n_cu / 4));
+    a.target = std::max<uint32_t>((n + grid_max - 1) / grid_max, 1024u);
+    const uint32_t grid = (n + a.target - 1) / a.target;
+    a.slice_len = ((n + grid - 1) / grid + 63) / 64 * 64;
+    size_t need = svx_take_bytes(n, 8) + svx_take_bytes(2 * (size_t)n, 8) + svx_take_bytes(2 * (size_t)n, 4) +
+                  svx_take_bytes((size_t)grid * kFine, 4) +
+                  svx_take_bytes(2 * grid, 4) + svx_take_bytes(2 * grid, 8);
+    int rc = svx_ws_reserve(ctx, need);
+    if (rc != SVX_OK) return rc;
+    a.keys = d_keys;
+    a.dense = svx_ws_take<uint64_t>(ctx, n);
+    a.gkey = svx_ws_take<uint64_t>(ctx, 2 * (size_t)n);
+    a.gidx = svx_ws_take<uint32_t>(ctx, 2 * (size_t)n);
+    a.rows = svx_ws_take<uint32_t>(ctx, (size_t)grid * kFine);
+    a.win = svx_ws_take<uint32_t>(ctx, 2 * grid);
+    a.win_keys = svx_ws_take<uint64_t>(ctx, 2 * grid);
+    a.f = f;
+    a.n = n;
+    a.live = live;
+    a.max_dist = max_dist;
+    a.perm = d_perm;
+    a.part_id = d_part_id;
+    a.n_parts = d_n_parts;
+    a.counter = reinterpret_cast<uint32_t*>(ctx->ws) + 68;  // workspace header: zero between calls
+    rc = svx_timing_begin(ctx);
+    if (rc != SVX_OK) return rc;
+    rc = svx_timing_mark(ctx, 1);
+    if (rc != SVX_OK) return rc;
+    hipLaunchKernelGGL(k_pair_single, dim3(grid), dim3(1024), kSingleDynLds, ctx->stream, a);
+    SVX_HIP(ctx, hipGetLastError());
+    rc = svx_timing_mark(ctx, 2);
+    if (rc != SVX_OK) return rc;
+    return svx_timing_end(ctx);
+}
+
 int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist, uint64_t key_bits,
                         uint32_t* d_perm, uint32_t* d_part_id, uint32_t* d_n_parts) {
     PairBufs b;
@@ -386,6 +839,7 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
         b.f.n = 1;
         b.f.shift[0] = 0; b.f.off[0] = 0; b.f.mask[0] = 1;
     }
+    if (n <= ctx->pair_single_max) return pair_single_launch(ctx, d_keys, n, max_dist, b.f, live, d_perm, d_part_id, d_n_parts);
     b.passes = (live + kMaxDigitBits - 1) / kMaxDigitBits;
     b.digit_bits = (live + b.passes - 1) / b.passes;
     b.n = n;
@@ -440,6 +894,12 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
 }
 
 }  // namespace
+
+#ifdef SVX_EXP_PAIRCLK
+extern "C" int svx_debug_pair_clk(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_clk), sizeof(g_pair_clk));
+}
+#endif
 
 extern "C" int svx_pair_partition_dev_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist,
                                            uint64_t key_bits, uint32_t* d_perm, uint32_t* d_part_id,

@@ -10,6 +10,16 @@ from oracle import orc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["single_launch", "radix"])
+def pair_path(request, svx_ctx):
+    """Every test of this module runs on both sort paths: batches up to 131072 candidates in one launch
+    (k_pair_single: windows of buckets sorted in LDS) and the radix path (P + 2 launches) that larger
+    batches take — forced here with svx_ctx_set_pair_single_launch_max(0)."""
+    svx_ctx.set_pair_single_launch_max(0 if request.param == "radix" else 131072)
+    yield request.param
+    svx_ctx.set_pair_single_launch_max(131072)
+
+
 def make_keys(rng, n, n_groups, pos_max, dup_frac=0.3):
     grp = rng.integers(0, n_groups, size=n).astype(np.uint64)
     pos = rng.integers(0, pos_max, size=n).astype(np.uint64)
@@ -113,3 +123,56 @@ def test_device_entry_points(svx_ctx):
                 assert int(d_np.download(np.uint32)[0]) == e_n
                 assert np.array_equal(d_perm.download(np.uint32), e_perm)
                 assert np.array_equal(d_part.download(np.uint32), e_part)
+
+
+def _check(svx_ctx, keys, max_dist):
+    perm, part, n_parts = svx_ctx.pair_partition(keys, max_dist)
+    e_perm, e_part, e_n = orc.pair_partition(keys, max_dist)
+    assert n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
+
+
+def test_sample_shaped_input(svx_ctx):
+    """The order PAIR hands over: the haplotype-1 list, then the haplotype-2 list, each grouped by type and
+    ordered along the genome (svim-asm:133-148) — long runs of one bucket per slice; plus the same keys shuffled."""
+    rng = np.random.default_rng(21)
+    for n_hap in (30_000, 44_000, 65_536):
+        haps = []
+        for _ in range(2):
+            typ = np.sort(rng.choice(6, n_hap, p=[0.45, 0.45, 0.04, 0.03, 0.02, 0.01])).astype(np.uint64)
+            contig = rng.integers(0, 24, n_hap).astype(np.uint64)
+            pos = rng.integers(0, 248_000_000, n_hap).astype(np.uint64)
+            order = np.lexsort((pos, contig, typ))
+            haps.append(((typ[order] << np.uint64(24) | contig[order]) << np.uint64(32)) | pos[order])
+        keys = np.concatenate(haps)
+        _check(svx_ctx, keys, 1000)
+        _check(svx_ctx, rng.permutation(keys), 1000)
+
+
+@pytest.mark.parametrize("n", [5120, 5121, 9000, 131072, 131073])
+def test_crowded_buckets(svx_ctx, n):
+    """Windows at and beyond what one workgroup sorts in LDS: all keys in one bucket (equal leading bits),
+    two crowded buckets beside sparse ones, equal keys only; and the largest one-launch batch."""
+    rng = np.random.default_rng(n)
+    low = rng.integers(0, 1 << 12, n).astype(np.uint64)
+    one_bucket = (np.uint64(5) << np.uint64(32)) | low
+    two = np.where(rng.random(n) < 0.5, np.uint64(3) << np.uint64(40), np.uint64(4) << np.uint64(40)) | low
+    two[:50] = (rng.integers(0, 1 << 10, 50).astype(np.uint64) << np.uint64(33)) | low[:50]
+    # 99 % of the keys below 2^12 under a 30-bit key range: one leading-bits bucket holds nearly everything
+    skewed = np.where(rng.random(n) < 0.99, low, rng.integers(0, 1 << 30, n).astype(np.uint64))
+    skewed_groups = skewed | (rng.integers(0, 3, n).astype(np.uint64) << np.uint64(32))
+    for keys in (one_bucket, two, np.full(n, 7, dtype=np.uint64), skewed, skewed_groups):
+        for max_dist in (0, 1000):
+            _check(svx_ctx, keys, max_dist)
+
+
+def test_boundaries_between_windows(svx_ctx):
+    """Partitions that continue across bucket and window borders: one group, positions a few apart over
+    the whole 28-bit range, so that every border between windows lies inside a partition or opens one
+    depending on max_dist alone."""
+    rng = np.random.default_rng(5)
+    for n in (3000, 40_000, 100_000):
+        pos = np.cumsum(rng.integers(1, 7, n)).astype(np.uint64) * np.uint64((1 << 28) // (7 * n))
+        keys = rng.permutation((np.uint64(2) << np.uint64(32)) | pos)
+        step = int((1 << 28) // (7 * n))
+        for max_dist in (0, step, 3 * step, 6 * step, 1 << 28):
+            _check(svx_ctx, keys, max_dist)
