@@ -68,10 +68,12 @@ int svx_device_count(void);
  * Default and upper limit 2^21 ops; 0 disables the small-batch path.  Results are identical on both. */
 int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
 /* svx_pair_partition* sort batches of at most `max_candidates` keys in ONE kernel launch (buckets by the
- * leading key bits, every window of buckets sorted inside one workgroup's LDS, two arrival barriers inside
- * the launch): the PAIR step of one diploid sample is 60-90 k candidates.  Larger batches take the radix
- * path (P + 2 launches).  Default and upper limit 131072; 0 disables the one-launch path.  Results are
- * identical on both. */
+ * leading key bits, every window of buckets sorted inside one workgroup's LDS — merged when the window
+ * arrives as a few sorted runs, as PAIR's two haplotype lists do, counted otherwise —, two arrival barriers
+ * inside the launch): the PAIR step of one diploid sample is 60-90 k candidates.  Larger batches take the
+ * radix path (P + 2 launches).  Default and upper limit 131072; 0 disables the one-launch path.  Results
+ * are identical on both.  The launch holds at most min(64, CUs / 4) workgroups, all resident: up to four
+ * contexts may run it on one device at the same time. */
 int svx_ctx_set_pair_single_launch_max(svx_ctx* ctx, uint32_t max_candidates);
 
 /* Device buffers for callers that have no other owner of HBM (a ctypes binding without torch, the
@@ -306,8 +308,9 @@ int svx_pair_partition_dev(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uin
                            uint32_t* d_perm, uint32_t* d_part_id, uint32_t* d_n_parts);
 /* Same with the caller's knowledge of the key layout: key_bits has a 1 wherever some key may have
  * one (the OR of all keys, or any superset such as `type bits | contig bits | position bits`).
- * Only those bits are sorted on (P = ceil(live bits / 9) radix passes, P + 2 launches in total), and
- * nothing is read back: fully asynchronous.  svx_pair_partition_dev derives the mask itself with one
+ * Only those bits are sorted on (one launch up to svx_ctx_set_pair_single_launch_max candidates; beyond
+ * that P = ceil(live bits / 9) radix passes, P + 2 launches in total), and nothing is read back: fully
+ * asynchronous.  svx_pair_partition_dev derives the mask itself with one
  * extra reduction and an 8-byte read-back, which synchronises the stream once. */
 int svx_pair_partition_dev_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist,
                                 uint64_t key_bits, uint32_t* d_perm, uint32_t* d_part_id,

@@ -30,6 +30,7 @@ struct svx_ctx {
     bool want_dom = false;
     int n_cu = 256;
     uint32_t wfa_cap = 1024;  // svx_ctx_set_edit_wavefront_cap: edits the wavefront pass of the edit distance resolves
+    uint32_t pair_launches = 0;        // launches of k_pair_single so far: which set of arrival counters is next
     uint32_t pair_single_max = 131072;  // svx_ctx_set_pair_single_launch_max: largest batch of the one-launch pair sort
     uint64_t small_batch_ops = 1ull << 21;  // svx_ctx_set_small_batch_ops: largest batch of the single-launch CIGAR path
     char err[512] = {0};

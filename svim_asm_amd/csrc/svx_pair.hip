@@ -376,8 +376,10 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
 //                owns window g: position `start` of the sorted order, M keys;
 //   gather       the window's keys are collected in input order: a slice's share of the window and where
 //                it goes follow from the rows, slices without a share are never read;
-//   window sort  stable LSD passes of 9-bit digits over the low bits, one over the bucket number, in LDS
-//                (M <= kWinCap) — a window that does not fit (a single crowded bucket) runs the same
+//   window sort  in LDS (M <= kWinCap): a window that arrives as at most kMergeRuns sorted runs — PAIR hands
+//                over two lists ordered along the genome — is merged pairwise, one binary search per key
+//                and round; otherwise stable LSD passes of 9-bit digits over the low bits and one over the
+//                bucket number.  A window that does not fit (a single crowded bucket) runs the same
 //                passes on a private stretch of HBM scratch: slower, same result, no second code path
 //                for the caller;
 //   flags        boundary flags between neighbours inside the window, local partition numbers;
@@ -389,7 +391,8 @@ constexpr uint32_t kFineBits = 9;
 constexpr uint32_t kFine = 1u << kFineBits;
 constexpr uint32_t kWinCap = 5120;          // keys of a window sorted in LDS: five per thread
 constexpr uint32_t kSingleGridMax = 64;     // one wave tabulates the windows
-constexpr int kGatherBatch = 16;
+constexpr int kGatherBatch = 8;            // groups of 128 keys in flight per wave
+constexpr uint32_t kMergeRuns = 32;       // presorted windows: merged instead of counted (at most five rounds)
 constexpr uint32_t kSingleDynLds = 2 * kWinCap * 8 + 2 * kWinCap * 4;  // beside 32 KiB of static counters
 
 struct SingleArgs {
@@ -405,7 +408,8 @@ struct SingleArgs {
     uint32_t* perm;
     uint32_t* part_id;
     uint32_t* n_parts;
-    uint32_t* counter;    // workspace header: two self-cleaning arrival barriers, two words each
+    uint32_t* counter;        // workspace header: this launch's two arrival counters
+    uint32_t* counter_stale;  // the two of the launch before
 };
 
 #ifdef SVX_EXP_PAIRCLK  // (timeline builds only: 100 MHz clock stamps of thread 0 of every workgroup)
@@ -415,23 +419,28 @@ __device__ unsigned long long g_pair_clk[64 * 16];
 #define PAIR_CLK(k)
 #endif
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T>
 __device__ __forceinline__ void agent_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T>
 __device__ __forceinline__ T agent_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // all threads: the workgroup's earlier agent-scope stores are out, then one thread meets the other
-// workgroups at counter c (c + 1 counts the leavers; the last one puts both back to zero)
-__device__ __forceinline__ void grid_barrier(uint32_t* c) {
+// workgroups at counter c.  Nobody counts the leavers: the counters come in two sets used by alternate
+// launches of a context, and the last workgroup to arrive at the FIRST barrier of a launch puts the set of
+// the launch before (long finished: same stream) back to zero — one round trip less per barrier.
+__device__ __forceinline__ void grid_barrier(uint32_t* c, uint32_t* stale) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (agent_load(c) < gridDim.x) __builtin_amdgcn_s_sleep(2);
-        if (__hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            agent_store(c, 0u);
-            agent_store(c + 1, 0u);
+        const uint32_t before = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stale && before == gridDim.x - 1) {
+            agent_store(stale, 0u);
+            agent_store(stale + 1, 0u);
         }
+        if (before != gridDim.x - 1)
+            while (agent_load(c) < gridDim.x) __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
 }
@@ -530,41 +539,120 @@ __device__ __forceinline__ void window_work(const SingleArgs& a, char* s_dyn, ui
     }
     auto K = [&](int h) { return kbase + (size_t)h * stride; };
     auto I = [&](int h) { return ibase + (size_t)h * stride; };
-    // ---- gather, input order: slice s puts its share at s_soff[s]
+    // ---- gather, input order: slice s puts its share at s_soff[s].  One 16-byte sc1 load per lane and group
+    // of 128 keys (keys 2 * lane and 2 * lane + 1 of the group), a batch of groups in flight before the first
+    // is looked at; a slice is left as soon as its share has been found
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (uint32_t s = wave; s < gridDim.x; s += 16) {
-        const uint32_t share = s_scnt[s];
-        if (!share) continue;
-        uint32_t run = s_soff[s];
-        const uint32_t end = run + share;
-        const uint32_t sl = s * a.slice_len, sh = min(a.n, sl + a.slice_len);
-        for (uint32_t base = sl; base < sh && run < end; base += 64 * kGatherBatch) {
-            uint64_t d[kGatherBatch];  // all loads of the batch in flight before the first is looked at
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.dense, 0, (int)(a.n * 8u), 0x00020000);
+        for (uint32_t s = wave; s < gridDim.x; s += 16) {
+            const uint32_t share = s_scnt[s];
+            if (!share) continue;
+            uint32_t run = s_soff[s];
+            const uint32_t end = run + share;
+            const uint32_t sl = s * a.slice_len, sh = min(a.n, sl + a.slice_len);
+            for (uint32_t base = sl; base < sh && run < end; base += 128 * kGatherBatch) {
+                u32x4 d[kGatherBatch];
 #pragma unroll
-            for (int u = 0; u < kGatherBatch; ++u) {
-                const uint32_t i = base + u * 64 + lane;
-                d[u] = i < sh ? agent_load(a.dense + i) : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < kGatherBatch; ++u) {
-                const uint32_t i = base + u * 64 + lane;
-                const uint32_t fine = (uint32_t)(d[u] >> low_bits);
-                const bool in = i < sh && fine >= lo && fine < hi;
-                const uint64_t bal = __ballot(in);
-                if (in) {
-                    const uint32_t pos = run + __popcll(bal & lt);
-                    K(0)[pos] = d[u];
-                    I(0)[pos] = i;
+                for (int u = 0; u < kGatherBatch; ++u) {
+                    const uint32_t i0 = base + u * 128 + 2 * lane;
+                    d[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (i0 < sh) d[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 8u, 0, 16);
                 }
-                run += __popcll(bal);
+#pragma unroll
+                for (int u = 0; u < kGatherBatch; ++u) {
+                    const uint32_t i0 = base + u * 128 + 2 * lane;
+                    const uint64_t k0 = ((uint64_t)d[u].y << 32) | d[u].x, k1 = ((uint64_t)d[u].w << 32) | d[u].z;
+                    const uint32_t f0 = (uint32_t)(k0 >> low_bits), f1 = (uint32_t)(k1 >> low_bits);
+                    const bool in0 = i0 < sh && f0 >= lo && f0 < hi, in1 = i0 + 1 < sh && f1 >= lo && f1 < hi;
+                    const uint64_t b0 = __ballot(in0), b1 = __ballot(in1);
+                    const uint32_t below = run + __popcll(b0 & lt) + __popcll(b1 & lt);
+                    if (in0) { K(0)[below] = k0; I(0)[below] = i0; }
+                    if (in1) { K(0)[below + (in0 ? 1u : 0u)] = k1; I(0)[below + (in0 ? 1u : 0u)] = i0 + 1; }
+                    run += __popcll(b0) + __popcll(b1);
+                }
             }
         }
     }
     __syncthreads();
     PAIR_CLK(5);
-    // ---- stable LSD passes: the low bits in digits of at most 9, then the bucket number
+    // ---- the window as it was gathered is a few sorted runs when the caller's lists were ordered (PAIR
+    // hands over the haplotype-1 list, then the haplotype-2 list, each along the genome: two runs, a few more
+    // where alignments overlap): up to kMergeRuns runs are merged pairwise, one binary search per key and
+    // round; equal keys: the earlier run first, so input order is kept.  More runs: counting passes.
     int src = 0;
-    if (low_bits) {
+    bool sorted = false;
+    if constexpr (LDS) {
+        __shared__ uint32_t s_run[kMergeRuns + 2];
+        const uint32_t per = (M + 1023) >> 10, j0 = tid * per;
+        uint32_t bits = 0;
+        if (j0 < M) {
+            uint64_t prev = j0 ? K(0)[j0 - 1] : 0ull;
+#pragma unroll
+            for (uint32_t i = 0; i < kWinCap / 1024; ++i) {
+                const uint32_t j = j0 + i;
+                if (i < per && j < M) {
+                    const uint64_t c = K(0)[j];
+                    if (c < prev) bits |= 1u << i;  // (never at j = 0: prev = 0)
+                    prev = c;
+                }
+            }
+        }
+        uint32_t descents;
+        uint32_t r = block_scan_1024(__popc(bits), s_w, &descents) - __popc(bits);  // descents before this thread
+        uint32_t runs = descents + 1;
+        if (runs <= kMergeRuns) {
+            sorted = true;
+            if (tid == 0) { s_run[0] = 0; s_run[runs] = M; }
+#pragma unroll
+            for (uint32_t i = 0; i < kWinCap / 1024; ++i)
+                if ((bits >> i) & 1u) s_run[++r] = j0 + i;
+            __syncthreads();
+            while (runs > 1) {
+                const uint64_t* sk = K(src);
+                const uint32_t* si = I(src);
+                uint64_t* dk = K(src ^ 1);
+                uint32_t* di = I(src ^ 1);
+                for (uint32_t j = tid; j < M; j += 1024) {
+                    const uint64_t x = sk[j];
+                    uint32_t q = 0;  // the run of position j
+                    for (uint32_t t = 1; t < runs; ++t) q += s_run[t] <= j ? 1u : 0u;
+                    uint32_t out = j;
+                    if ((q & 1u) == 0u && q + 1 < runs) {        // left run of a pair: keys of the right run below x
+                        uint32_t lo = s_run[q + 1], hi = s_run[q + 2];
+                        const uint32_t first = lo;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (sk[mid] < x) lo = mid + 1; else hi = mid;
+                        }
+                        out = j + (lo - first);
+                    } else if (q & 1u) {                          // right run: keys of the left run up to x
+                        uint32_t lo = s_run[q - 1], hi = s_run[q];
+                        const uint32_t last = hi;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (sk[mid] <= x) lo = mid + 1; else hi = mid;
+                        }
+                        out = j - (last - lo);
+                    }
+                    dk[out] = x;
+                    di[out] = si[j];
+                }
+                __syncthreads();
+                const uint32_t merged = (runs + 1) >> 1;
+                if (tid < 64) {  // run q of the next round starts where run 2q started
+                    const uint32_t v = (uint32_t)tid <= merged ? ((uint32_t)tid == merged ? M : s_run[2 * tid]) : 0u;
+                    wave_lds_sync();
+                    if ((uint32_t)tid <= merged) s_run[tid] = v;
+                }
+                __syncthreads();
+                runs = merged;
+                src ^= 1;
+            }
+        }
+    }
+    // ---- stable LSD passes: the low bits in digits of at most 9, then the bucket number
+    if (!sorted && low_bits) {
         const uint32_t passes = (low_bits + kFineBits - 1) / kFineBits;
         const uint32_t db = (low_bits + passes - 1) / passes;
         for (uint32_t p = 0; p < passes; ++p) {
@@ -572,7 +660,7 @@ __device__ __forceinline__ void window_work(const SingleArgs& a, char* s_dyn, ui
             src ^= 1;
         }
     }
-    if (hi - lo > 1) {
+    if (!sorted && hi - lo > 1) {
         window_pass(K(src), I(src), K(src ^ 1), I(src ^ 1), M, s_cnt, s_w, low_bits, kFine - 1u, lo,
                     32u - (uint32_t)__clz((int)(hi - lo - 1)));
         src ^= 1;
@@ -625,7 +713,7 @@ __device__ __forceinline__ void window_work(const SingleArgs& a, char* s_dyn, ui
         agent_store(a.win_keys + 2 * blockIdx.x + 1, K(src)[M - 1]);
     }
     PAIR_CLK(7);
-    grid_barrier(a.counter + 2);
+    grid_barrier(a.counter + 1, nullptr);
     PAIR_CLK(8);
     // ---- the table of windows: flag between windows, carry-in
     __shared__ uint32_t s_in[2];
@@ -692,7 +780,7 @@ __global__ __launch_bounds__(1024) void k_pair_single(SingleArgs a) {
         if (tid < (int)kFine) agent_store(a.rows + (size_t)g * kFine + tid, incl);
     }
     PAIR_CLK(1);
-    grid_barrier(a.counter);
+    grid_barrier(a.counter, a.counter_stale);
     PAIR_CLK(2);
     // ---- windows: column sums of the prefix rows = keys in buckets 0..b over all slices (every load of a
     // thread in flight at once: thread t sums bucket t % 512 over one half of the slices)
@@ -724,7 +812,7 @@ __global__ __launch_bounds__(1024) void k_pair_single(SingleArgs a) {
     PAIR_CLK(3);
     if (M == 0) {  // no bucket starts inside this window's stretch
         if (tid == 0) { agent_store(a.win + 2 * g, 0u); agent_store(a.win + 2 * g + 1, 0u); }
-        grid_barrier(a.counter + 2);
+        grid_barrier(a.counter + 1, nullptr);
         return;
     }
     // every slice's share of the window and where it goes
@@ -817,13 +905,16 @@ int pair_single_launch(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_
     a.perm = d_perm;
     a.part_id = d_part_id;
     a.n_parts = d_n_parts;
-    a.counter = reinterpret_cast<uint32_t*>(ctx->ws) + 68;  // workspace header: zero between calls
+    // workspace header, words 68..71: two sets of two arrival counters, alternate launches alternate sets
+    a.counter = reinterpret_cast<uint32_t*>(ctx->ws) + 68 + 2 * (ctx->pair_launches & 1u);
+    a.counter_stale = reinterpret_cast<uint32_t*>(ctx->ws) + 68 + 2 * ((ctx->pair_launches & 1u) ^ 1u);
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
     hipLaunchKernelGGL(k_pair_single, dim3(grid), dim3(1024), kSingleDynLds, ctx->stream, a);
     SVX_HIP(ctx, hipGetLastError());
+    ++ctx->pair_launches;  // (only a launch that went out used its set of counters)
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     return svx_timing_end(ctx);

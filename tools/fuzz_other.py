@@ -33,17 +33,29 @@ def fuzz_segments(ctx, rng):
 
 
 def fuzz_pair(ctx, rng):
-    n = int(rng.choice([0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 5000, 70000, 400000]))
+    n = int(rng.choice([0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 5000, 5121, 20000, 70000, 131072, 131073, 400000]))
     groups = int(rng.choice([1, 2, 24, 144, 5000]))
     pos_max = int(rng.choice([1, 5, 1000, 250_000_000, (1 << 32) - 1]))
     keys = tpair.make_keys(rng, n, groups, pos_max, dup_frac=float(rng.choice([0.0, 0.3, 0.9])))
+    shape = str(rng.choice(["as is", "skewed", "runs", "two lists"]))
+    if n and shape == "skewed":     # most keys in one bucket of the leading bits
+        crowd = rng.random(n) < float(rng.choice([0.5, 0.9, 0.999]))
+        keys = np.where(crowd, keys & np.uint64(0xFFF), keys)
+    elif n and shape == "runs":     # a few sorted runs one after the other (the run-merging form of the window sort)
+        cuts = np.sort(rng.integers(0, n + 1, int(rng.choice([1, 2, 5, 31, 32, 40, 200]))))
+        keys = np.concatenate([np.sort(part) for part in np.split(keys, cuts)])
+    elif n and shape == "two lists":
+        keys = np.concatenate([np.sort(keys[:n // 2]), np.sort(keys[n // 2:])])
     if rng.random() < 0.2 and n:
         keys |= np.uint64(int(rng.integers(0, 1 << 20))) << np.uint64(44)  # high group bits in use
     md = int(rng.choice([0, 1, 1000, 1 << 20, (1 << 32) - 1]))
+    single = bool(rng.random() < 0.8)
+    ctx.set_pair_single_launch_max(131072 if single else 0)
     perm, part, n_parts = ctx.pair_partition(keys, md)
+    ctx.set_pair_single_launch_max(131072)
     e_perm, e_part, e_n = orc.pair_partition(keys, md)
     ok = n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
-    return ok, "pair n %d groups %d pos_max %d max_dist %d" % (n, groups, pos_max, md)
+    return ok, "pair n %d groups %d pos_max %d max_dist %d shape %s one-launch %s" % (n, groups, pos_max, md, shape, single)
 
 
 def fuzz_edit(ctx, rng):
@@ -199,9 +211,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", default="", help="one of the fuzz_* functions, e.g. pair")
     a = ap.parse_args()
     ctx = _lib.default_context(0)
     fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats, fuzz_linkage, fuzz_postpass, fuzz_haplotypes]
+    if a.only:
+        fns = [f for f in fns if f.__name__ == "fuzz_" + a.only]
     counts = {f.__name__: 0 for f in fns}
     t0, seed = time.time(), a.seed
     while time.time() - t0 < a.seconds:
