@@ -493,15 +493,17 @@ def pair_candidates(sv_candidates1, sv_candidates2, reference, bam, options):
 # ------------------------------------------------------------------------------ output
 def sorted_nicely(vcf_entries):
     """Natural sort of ((contig, start, end), vcf_string, sv_type) entries: chr10 after chr2."""
-    natural = {}  # a sample has a few dozen contig names and tens of thousands of entries
-
-    def key(entry):
-        name = entry[0][0]
-        contig = natural.get(name)
-        if contig is None:
-            contig = natural[name] = [int(tok) if tok.isdigit() else tok for tok in re.split("([0-9]+)", str(name))]
-        return (contig, entry[0][1], entry[0][2])
-    return sorted(vcf_entries, key=key)
+    # a sample has a few dozen contig names and tens of thousands of entries: the names are ranked once under
+    # the natural key (equal keys — "chr01" and "chr1" — share a rank), the entries sort on integers
+    names = set(entry[0][0] for entry in vcf_entries)
+    natural = {name: [int(tok) if tok.isdigit() else tok for tok in re.split("([0-9]+)", str(name))] for name in names}
+    rank, last = {}, None
+    for name in sorted(names, key=natural.__getitem__):
+        if last is None or natural[name] != natural[last]:
+            r = len(rank)
+        rank[name] = r
+        last = name
+    return sorted(vcf_entries, key=lambda entry: (rank[entry[0][0]], entry[0][1], entry[0][2]))
 
 
 def _header_lines(version, contig_names, contig_lengths, types_to_output, options):
