@@ -73,7 +73,10 @@ int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
  * inside the launch): the PAIR step of one diploid sample is 60-90 k candidates.  Larger batches take the
  * radix path (P + 2 launches).  Default and upper limit 131072; 0 disables the one-launch path.  Results
  * are identical on both.  The launch holds at most min(64, CUs / 4) workgroups, all resident: up to four
- * contexts may run it on one device at the same time. */
+ * contexts may run it on one device at the same time.  Should its workgroups (or those of the radix path's
+ * partition sweep) ever wait for each other longer than 20 s, they give up: the call — for the asynchronous
+ * entry points the next svx_ctx_sync — returns SVX_E_HIP, the outputs of that call are invalid, the context
+ * stays usable. */
 int svx_ctx_set_pair_single_launch_max(svx_ctx* ctx, uint32_t max_candidates);
 
 /* Device buffers for callers that have no other owner of HBM (a ctypes binding without torch, the

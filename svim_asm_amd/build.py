@@ -35,12 +35,19 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 into svim_asm_amd/libsvx.so."""
+def build_lib(force=False, verbose=False, out=None, defines=()):
+    """Compile every HIP translation unit for gfx950 into svim_asm_amd/libsvx.so (or into `out`, with extra
+    `defines` such as the SVX_EXP_* macros of the ablation / test builds)."""
+    if out is not None:
+        return _compile(out, list(defines), verbose)
     if not force and not is_stale():
         return LIB
+    return _compile(LIB, [], verbose)
+
+
+def _compile(LIB, defines, verbose):
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
+           "-Wall", "-Wno-unused-function"] + defines + [
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB + ".tmp"] + sources() + \
           ["-lz", "-ldl", "-lpthread"]
     if verbose:

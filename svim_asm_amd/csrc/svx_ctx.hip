@@ -60,7 +60,20 @@ extern "C" int svx_ctx_sync(svx_ctx* ctx) {
     if (!ctx) return SVX_E_INVALID;
     SVX_HIP(ctx, hipSetDevice(ctx->device));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return SVX_OK;
+    return svx_barrier_check(ctx);
+}
+
+int svx_barrier_check(svx_ctx* ctx) {
+    if (!ctx->barrier_pending || !ctx->ws) return SVX_OK;
+    ctx->barrier_pending = false;
+    uint32_t note = 0;
+    SVX_HIP(ctx, hipMemcpy(&note, ctx->ws + 4 * SVX_WS_BARRIER_NOTE_WORD, 4, hipMemcpyDeviceToHost));
+    if (!note) return SVX_OK;
+    SVX_HIP(ctx, hipMemset(ctx->ws, 0, 4096));  // counters of the broken launch included
+    ctx->pair_launches = 0;
+    SVX_SET_ERR(ctx, "svx_pair_partition: a wait between workgroups ran out (more than four contexts sorting on one "
+                     "device?); the results of that call are invalid");
+    return SVX_E_HIP;
 }
 
 extern "C" const char* svx_last_error(const svx_ctx* ctx) { return ctx ? ctx->err : "null context"; }
@@ -91,6 +104,12 @@ static int grow(svx_ctx* ctx, char** buf, size_t* have, size_t want) {
 }
 
 int svx_ws_reserve(svx_ctx* ctx, size_t total) {
+    if (ctx->barrier_pending && total + 4096 > ctx->ws_bytes) {  // the note would go away with the old buffer
+        SVX_HIP(ctx, hipSetDevice(ctx->device));
+        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = svx_barrier_check(ctx);
+        if (rc != SVX_OK) return rc;
+    }
     // the first 4 KiB of the workspace are a header of self-cleaning counters (zeroed at
     // allocation, left at zero by the kernels that use them); per-call scratch starts after it
     ctx->ws_used = 4096;

@@ -30,6 +30,8 @@ struct svx_ctx {
     bool want_dom = false;
     int n_cu = 256;
     uint32_t wfa_cap = 1024;  // svx_ctx_set_edit_wavefront_cap: edits the wavefront pass of the edit distance resolves
+    bool barrier_pending = false;      // a kernel with a grid barrier went out since the last svx_barrier_check
+    bool pair_lds_set = false;         // k_pair_single's dynamic-LDS limit raised on this context's device
     uint32_t pair_launches = 0;        // launches of k_pair_single so far: which set of arrival counters is next
     uint32_t pair_single_max = 131072;  // svx_ctx_set_pair_single_launch_max: largest batch of the one-launch pair sort
     uint64_t small_batch_ops = 1ull << 21;  // svx_ctx_set_small_batch_ops: largest batch of the single-launch CIGAR path
@@ -56,6 +58,10 @@ static inline size_t svx_align_up(size_t x, size_t a) { return (x + a - 1) / a *
 // Reserve `total` bytes of workspace for this call (may reallocate; synchronises the
 // stream first when it has to, so earlier kernels never lose their scratch).
 int svx_ws_reserve(svx_ctx* ctx, size_t total);
+// Word of the workspace header where a kernel notes that a wait for other workgroups ran out; to be called
+// with the stream synchronised: SVX_OK, or SVX_E_HIP after clearing the header for the calls to come.
+#define SVX_WS_BARRIER_NOTE_WORD 80
+int svx_barrier_check(svx_ctx* ctx);
 int svx_stage_reserve(svx_ctx* ctx, size_t total);
 
 template <typename T>

@@ -38,6 +38,7 @@
 
 namespace {
 
+constexpr int kBarrierNoteWord = SVX_WS_BARRIER_NOTE_WORD;
 constexpr int kMaxDigitBits = 9;
 constexpr int kBuckets = 1 << kMaxDigitBits;
 constexpr uint32_t kSingleBlockMax = 16384;  // one workgroup sweeps up to two chunks itself
@@ -47,6 +48,26 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Waiting for the other workgroups of a launch is bounded: after kBarrierTicks of the 100 MHz clock (20 s —
+// every workgroup of these grids is resident unless more than four contexts run them on one device) the
+// workgroup notes it in the workspace header and leaves the kernel (what the others would have published is
+// not there: nothing may be computed from it); the host finds the note at its next synchronisation
+// (svx_barrier_check) and reports the call as failed instead of the device hanging.
+#ifndef SVX_EXP_BARRIER_TICKS
+#define SVX_EXP_BARRIER_TICKS 2000000000ull
+#endif
+__device__ __forceinline__ bool spin_until(const uint32_t* c, uint32_t want, uint32_t* timed_out) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > SVX_EXP_BARRIER_TICKS) {
+            __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
 }
 
 struct KeyFields {  // dense = OR over f of ((key >> shift[f]) & mask[f]) << off[f]
@@ -331,8 +352,8 @@ __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
             __hip_atomic_store(&p.block_tot[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
-                __builtin_amdgcn_s_sleep(2);
+            // (after a wait that ran out the carry-in is wrong, every store stays inside the outputs)
+            (void)spin_until(p.counter, gridDim.x, p.counter + (kBarrierNoteWord - 64));
             // the last workgroup to get here puts the counter back to zero for the next call
             if (__hip_atomic_fetch_add(p.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
                 __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -410,6 +431,7 @@ struct SingleArgs {
     uint32_t* n_parts;
     uint32_t* counter;        // workspace header: this launch's two arrival counters
     uint32_t* counter_stale;  // the two of the launch before
+    uint32_t* note;           // set when a wait ran out (svx_barrier_check)
 };
 
 #ifdef SVX_EXP_PAIRCLK  // (timeline builds only: 100 MHz clock stamps of thread 0 of every workgroup)
@@ -430,7 +452,8 @@ __device__ __forceinline__ T agent_load(const T* p) { return __hip_atomic_load(p
 // workgroups at counter c.  Nobody counts the leavers: the counters come in two sets used by alternate
 // launches of a context, and the last workgroup to arrive at the FIRST barrier of a launch puts the set of
 // the launch before (long finished: same stream) back to zero — one round trip less per barrier.
-__device__ __forceinline__ void grid_barrier(uint32_t* c, uint32_t* stale) {
+__device__ __forceinline__ bool grid_barrier(uint32_t* c, uint32_t* stale, uint32_t* note) {
+    __shared__ uint32_t s_met;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -439,10 +462,10 @@ __device__ __forceinline__ void grid_barrier(uint32_t* c, uint32_t* stale) {
             agent_store(stale, 0u);
             agent_store(stale + 1, 0u);
         }
-        if (before != gridDim.x - 1)
-            while (agent_load(c) < gridDim.x) __builtin_amdgcn_s_sleep(1);
+        s_met = (before == gridDim.x - 1 || spin_until(c, gridDim.x, note)) ? 1u : 0u;
     }
     __syncthreads();
+    return s_met != 0;  // false: the wait ran out, the caller leaves the kernel
 }
 
 // hist[dig] += length of every run of equal digits among the wave's valid lanes (the valid lanes are a
@@ -713,7 +736,7 @@ __device__ __forceinline__ void window_work(const SingleArgs& a, char* s_dyn, ui
         agent_store(a.win_keys + 2 * blockIdx.x + 1, K(src)[M - 1]);
     }
     PAIR_CLK(7);
-    grid_barrier(a.counter + 1, nullptr);
+    if (!grid_barrier(a.counter + 1, nullptr, a.note)) return;
     PAIR_CLK(8);
     // ---- the table of windows: flag between windows, carry-in
     __shared__ uint32_t s_in[2];
@@ -780,7 +803,7 @@ __global__ __launch_bounds__(1024) void k_pair_single(SingleArgs a) {
         if (tid < (int)kFine) agent_store(a.rows + (size_t)g * kFine + tid, incl);
     }
     PAIR_CLK(1);
-    grid_barrier(a.counter, a.counter_stale);
+    if (!grid_barrier(a.counter, a.counter_stale, a.note)) return;
     PAIR_CLK(2);
     // ---- windows: column sums of the prefix rows = keys in buckets 0..b over all slices (every load of a
     // thread in flight at once: thread t sums bucket t % 512 over one half of the slices)
@@ -812,7 +835,7 @@ __global__ __launch_bounds__(1024) void k_pair_single(SingleArgs a) {
     PAIR_CLK(3);
     if (M == 0) {  // no bucket starts inside this window's stretch
         if (tid == 0) { agent_store(a.win + 2 * g, 0u); agent_store(a.win + 2 * g + 1, 0u); }
-        grid_barrier(a.counter + 1, nullptr);
+        (void)grid_barrier(a.counter + 1, nullptr, a.note);
         return;
     }
     // every slice's share of the window and where it goes
@@ -873,11 +896,10 @@ KeyFields fields_of(uint64_t bits, uint32_t* live) {
 
 int pair_single_launch(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_t max_dist, const KeyFields& f,
                        uint32_t live, uint32_t* d_perm, uint32_t* d_part_id, uint32_t* d_n_parts) {
-    static bool lds_set = false;  // (the attribute belongs to the function, not to a context)
-    if (!lds_set) {
+    if (!ctx->pair_lds_set) {  // once per context: the attribute is kept per device
         SVX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_single),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSingleDynLds));
-        lds_set = true;
+        ctx->pair_lds_set = true;
     }
     SingleArgs a;
     // two arrival barriers: the grid stays at a quarter of the CUs (one of these workgroups fills a CU's
@@ -908,6 +930,7 @@ int pair_single_launch(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_
     // workspace header, words 68..71: two sets of two arrival counters, alternate launches alternate sets
     a.counter = reinterpret_cast<uint32_t*>(ctx->ws) + 68 + 2 * (ctx->pair_launches & 1u);
     a.counter_stale = reinterpret_cast<uint32_t*>(ctx->ws) + 68 + 2 * ((ctx->pair_launches & 1u) ^ 1u);
+    a.note = reinterpret_cast<uint32_t*>(ctx->ws) + kBarrierNoteWord;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
     rc = svx_timing_mark(ctx, 1);
@@ -915,6 +938,7 @@ int pair_single_launch(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32_
     hipLaunchKernelGGL(k_pair_single, dim3(grid), dim3(1024), kSingleDynLds, ctx->stream, a);
     SVX_HIP(ctx, hipGetLastError());
     ++ctx->pair_launches;  // (only a launch that went out used its set of counters)
+    ctx->barrier_pending = true;
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     return svx_timing_end(ctx);
@@ -981,6 +1005,7 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
     const uint32_t span = ((n + part_grid - 1) / part_grid + 1023) / 1024 * 1024;
     hipLaunchKernelGGL(k_partition, dim3((n + span - 1) / span), dim3(1024), 0, ctx->stream, pa, span);
     SVX_HIP(ctx, hipGetLastError());
+    ctx->barrier_pending = true;
     return svx_timing_end(ctx);
 }
 
@@ -1052,5 +1077,5 @@ extern "C" int svx_pair_partition(svx_ctx* ctx, const uint64_t* keys, uint32_t n
     SVX_HIP(ctx, hipMemcpyAsync(part_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(n_parts, d_np, 4, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return SVX_OK;
+    return svx_barrier_check(ctx);
 }

@@ -103,3 +103,54 @@ def test_device_buffers_round_trip(svx_ctx):
     assert svx_ctx.lib.svx_dev_free(svx_ctx.h, p) == 0
     assert svx_ctx.lib.svx_dev_free(svx_ctx.h, None) == 0
     assert svx_ctx.lib.svx_dev_upload(svx_ctx.h, None, x.ctypes.data, 16) == _lib.SVX_E_INVALID
+
+
+_BARRIER_CHILD = r'''
+import numpy as np
+from oracle import orc
+from svim_asm_amd import _lib
+ctx = _lib.Context(0)
+rng = np.random.default_rng(4)
+big = (rng.integers(0, 100, 70_000).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 28, 70_000).astype(np.uint64)
+small = big[:700]
+for limit in (131072, 0):                       # one-launch plan (59 workgroups), radix plan (k_partition: 18)
+    ctx.set_pair_single_launch_max(limit)
+    for rep in range(2):                        # the context recovers: the second failure looks like the first
+        try:
+            ctx.pair_partition(big, 1000)
+            raise SystemExit("no error from a launch whose waits cannot succeed")
+        except _lib.SvxError as e:
+            assert "ran out" in str(e), str(e)
+        perm, part, n_parts = ctx.pair_partition(small, 1000)   # one workgroup: nobody to wait for
+        e_perm, e_part, e_n = orc.pair_partition(small, 1000)
+        assert n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
+# the asynchronous entry reports at the next synchronisation
+d_k, d_p, d_id = ctx.dev_array(big), ctx.dev_array(nbytes=4 * len(big)), ctx.dev_array(nbytes=4 * len(big))
+d_np = ctx.dev_array(np.zeros(1, np.uint32))
+ctx.set_pair_single_launch_max(131072)
+ctx._check(ctx.lib.svx_pair_partition_dev_bits(ctx.h, d_k.ptr, len(big), 1000, int(np.bitwise_or.reduce(big)), d_p.ptr,
+                                               d_id.ptr, d_np.ptr))
+try:
+    ctx.sync()
+    raise SystemExit("svx_ctx_sync did not report the failed launch")
+except _lib.SvxError as e:
+    assert "ran out" in str(e), str(e)
+ctx.sync()
+print("barrier child ok")
+'''
+
+
+def test_a_wait_between_workgroups_that_runs_out_is_an_error_not_a_hang(tmp_path):
+    """The kernels that wait for their other workgroups inside a launch (k_pair_single, k_partition) bound the
+    wait; a build whose bound is zero turns every such wait into the failure: the call (or the next
+    svx_ctx_sync after an asynchronous one) returns SVX_E_HIP with a text, nothing hangs, the context works
+    on."""
+    import os
+    import subprocess
+    import sys
+    from svim_asm_amd import build
+    lib = build.build_lib(out=str(tmp_path / "libsvx_wait0.so"), defines=["-DSVX_EXP_BARRIER_TICKS=0ull"])
+    env = dict(os.environ, SVX_LIB=lib, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", _BARRIER_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and "barrier child ok" in res.stdout, res.stdout
