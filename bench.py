@@ -548,12 +548,13 @@ def main():
     ctx.set_timing(False)
     k_avg = float(np.mean(k_ms)) * 1e-3
     p_avg = float(np.mean(p_ms)) * 1e-3
-    algo_bytes = 4 * n_ops + 16 * n_aln + 17 * n_sig  # SURVEY.md §8(d), whole a1+a2 path
+    op_bytes = 5 if args.layout == "soa" else 4  # packed u32 per op; SoA: a u8 op code next to the u32 length
+    algo_bytes = op_bytes * n_ops + 16 * n_aln + 17 * n_sig  # SURVEY.md §8(d), whole a1+a2 path
     # what the dominant kernel itself moves of those: the op stream, aln_off, its slab records (16 B per
     # signature) and one 16-B descriptor + one 4-B start index per tile; the 17-B final records are written by
     # the finish kernel and only count for the path figure
     n_tiles = (n_ops + 4095) // 4096
-    kernel_bytes = 4 * n_ops + 8 * n_aln + 16 * n_sig + 20 * n_tiles
+    kernel_bytes = op_bytes * n_ops + 8 * n_aln + 16 * n_sig + 20 * n_tiles
     achieved = kernel_bytes / k_avg / 1e9
 
     # measured device-copy ceiling of this box (SURVEY.md §8d asks for both denominators): 1 GiB
