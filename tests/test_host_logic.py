@@ -154,6 +154,61 @@ def test_sorted_nicely_is_natural_and_stable():
     assert [x[1] for x in SVIM_COMBINE.sorted_nicely(e)] == ["d", "b", "c", "a"]
 
 
+def test_sorted_nicely_follows_the_reference_rule_on_awkward_names():
+    """The reference's key (SVIM_COMBINE.py:367-373): the contig name split at digit runs, the runs as
+    integers, then start and end — "chr01" and "chr1" compare equal there and fall through to the positions."""
+    import random
+    import re
+
+    def reference_order(entries):
+        convert = lambda text: int(text) if text.isdigit() else text  # noqa: E731
+        return sorted(entries, key=lambda e: ([convert(c) for c in re.split("([0-9]+)", str(e[0][0]))], e[0][1], e[0][2]))
+    rnd = random.Random(3)
+    names = ["chr1", "chr01", "chr10", "chr2", "chrX", "chrUn_KI270", "chr2_random", "1", "10", "2", "MT", "chr001", "a1b2", "a1b10"]
+    for _ in range(300):
+        e = [((rnd.choice(names), rnd.randrange(4), rnd.randrange(4)), "line%d" % i, "DEL") for i in range(rnd.randrange(0, 50))]
+        assert SVIM_COMBINE.sorted_nicely(e) == reference_order(e)
+
+
+def test_pack_keys_orders_like_the_get_key_tuples():
+    """_pack_keys: u64 order == order of the (type, contig, position) tuples of get_key() with the contigs under
+    Python's str order (SVIM_COMBINE.py:17) — for every candidate class, and out-of-range positions are refused."""
+    bam = helpers.FakeBam(NAMES, LENGTHS, [])
+    rng = np.random.default_rng(11)
+    items = []
+    for i in range(600):
+        c, s = NAMES[int(rng.integers(len(NAMES)))], int(rng.integers(0, 900_000))
+        kind = i % 6
+        if kind == 0:
+            cand = SVCandidate.CandidateDeletion(c, s, s + 50, ["r"], bam)
+        elif kind == 1:
+            cand = SVCandidate.CandidateInsertion(c, s, s + 50, ["r"], "A" * 50, bam)
+        elif kind == 2:
+            cand = SVCandidate.CandidateInversion(c, s, s + 500, ["r"], True, bam)
+        elif kind == 3:
+            cand = SVCandidate.CandidateDuplicationTandem(c, s, s + 100, 2, True, ["r"], bam)
+        elif kind == 4:
+            cand = SVCandidate.CandidateDuplicationInterspersed(c, s, s + 100, NAMES[0], s + 5, s + 105, ["r"], bam)
+        else:
+            cand = SVCandidate.CandidateBreakend(c, s, "fwd", NAMES[1], s + 7, "rev", ["r"], bam)
+        items.append((1 + i % 2, cand))
+    packed = SVIM_COMBINE._pack_keys(items)
+    tuples = [(SVIM_COMBINE.TYPE_ORDER.index(c.get_key()[0]), c.get_key()[1], c.get_key()[2]) for _, c in items]
+    by_tuple = sorted(range(len(items)), key=lambda i: tuples[i])
+    by_packed = sorted(range(len(items)), key=lambda i: int(packed[i]))
+    assert by_tuple == by_packed  # both sorts are stable: equal keys keep input order in both
+    for i, j in zip(by_tuple, by_tuple[1:]):
+        assert (tuples[i] == tuples[j]) == (packed[i] == packed[j])
+    assert SVIM_COMBINE._pack_keys([]).dtype == np.uint64 and len(SVIM_COMBINE._pack_keys([])) == 0
+    far = SVCandidate.CandidateInsertion("chr1", 10, 20, ["r"], "A", bam)
+    far.dest_start = 1 << 32
+    with pytest.raises(ValueError):
+        SVIM_COMBINE._pack_keys([(1, far)])
+    far.dest_start = -1
+    with pytest.raises(ValueError):
+        SVIM_COMBINE._pack_keys([(1, far)])
+
+
 def test_cli_rejects_unsorted_bam_without_touching_the_gpu(tmp_path, caplog):
     from svim_asm_amd import cli
     wd = tmp_path / "wd"
