@@ -149,6 +149,10 @@ def test_a_wait_between_workgroups_that_runs_out_is_an_error_not_a_hang(tmp_path
     import subprocess
     import sys
     from svim_asm_amd import build
+    try:
+        build._hipcc()
+    except RuntimeError:
+        pytest.skip("no hipcc on this box: the zero-bound build cannot be made")
     lib = build.build_lib(out=str(tmp_path / "libsvx_wait0.so"), defines=["-DSVX_EXP_BARRIER_TICKS=0ull"])
     env = dict(os.environ, SVX_LIB=lib, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = subprocess.run([sys.executable, "-c", _BARRIER_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
