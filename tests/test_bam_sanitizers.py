@@ -2,7 +2,8 @@
 every entry point on the reference's own fixtures, the config-1 goldens and a sample with CG-tag long CIGARs,
 then on hundreds of damaged copies (flipped bytes, truncations, overwritten length fields, damaged or missing
 .bai).  A damaged file may be refused or read as what it now says; any out-of-bounds access, use after free,
-signed overflow or leak fails the test.  (GPU sanitizers are not available on the pool; this is the host side of
+signed overflow or leak fails the test; a second build runs the same under ThreadSanitizer (the reader inflates,
+indexes and decodes on its own threads).  (GPU sanitizers are not available on the pool; this is the host side of
 the ingest, which parses untrusted input.)"""
 import json
 import os
@@ -15,13 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-@pytest.fixture(scope="module")
-def driver(tmp_path_factory):
+@pytest.fixture(scope="module", params=["address,undefined", "thread"])
+def driver(request, tmp_path_factory):
     gxx = shutil.which("g++")
     if not gxx or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
         pytest.skip("g++ or the HIP headers are not here")
     exe = str(tmp_path_factory.mktemp("san") / "bam_sanitize")
-    cmd = [gxx, "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    cmd = [gxx, "-std=c++17", "-g", "-O1", "-fsanitize=" + request.param, "-fno-sanitize-recover=all",
            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
            "-I", os.path.join(ROOT, "svim_asm_amd", "csrc"), os.path.join(ROOT, "tests", "native", "bam_sanitize.cpp"),
            os.path.join(ROOT, "svim_asm_amd", "csrc", "svx_bam.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-lz", "-lpthread",
@@ -33,10 +34,12 @@ def driver(tmp_path_factory):
 
 
 def _run(exe, scratch, mutations, files):
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               TSAN_OPTIONS="halt_on_error=1")
     res = subprocess.run([exe, str(scratch), str(mutations)] + files, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, env=env, timeout=900)
-    assert res.returncode == 0 and "bam_sanitize ok" in res.stdout, res.stdout[-4000:]
+    assert res.returncode == 0 and "bam_sanitize ok" in res.stdout and "WARNING: ThreadSanitizer" not in res.stdout, \
+        res.stdout[-4000:]
     return res.stdout
 
 
