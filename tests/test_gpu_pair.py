@@ -176,3 +176,37 @@ def test_boundaries_between_windows(svx_ctx):
         step = int((1 << 28) // (7 * n))
         for max_dist in (0, step, 3 * step, 6 * step, 1 << 28):
             _check(svx_ctx, keys, max_dist)
+
+
+def test_four_contexts_sort_at_the_same_time():
+    """svx.h: up to four contexts may run the one-launch sort on one device at the same time (each launch keeps
+    min(64, CUs / 4) workgroups resident behind its barriers).  Four contexts on four host threads, thirty calls
+    each, sizes that fill the grid; every result is checked."""
+    import threading
+    from svim_asm_amd import _lib
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (60_000, 88_000, 131_072, 45_000):
+        keys = make_keys(rng, n, 6 * 24, 250_000_000)
+        cases.append((keys, orc.pair_partition(keys, 1000)))
+    ctxs = [_lib.Context(0) for _ in range(4)]
+    errors = []
+
+    def work(i):
+        try:
+            keys, (e_perm, e_part, e_n) = cases[i]
+            for _ in range(30):
+                perm, part, n_parts = ctxs[i].pair_partition(keys, 1000)
+                if not (n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)):
+                    errors.append("context %d: wrong result" % i)
+                    return
+        except Exception as e:  # noqa: BLE001 — reported below
+            errors.append("context %d: %r" % (i, e))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in ctxs:
+        c.close()
+    assert not errors, errors
