@@ -214,6 +214,94 @@ def make_large():
     shutil.rmtree(d)
 
 
+FULL = dict(seed=3, scale=1.0, sv_per_mbp=8.0, median_aln=300000, mean_m=2000)
+
+
+def full_dataset_args(prm=None):
+    """synth_bam.write_dataset arguments of the full-size diploid sample (BASELINE config 3 as the metric quotes it:
+    GRCh38 contig lengths, 3.1 Gbp, 2 x 924 MB BAM, ~3.2 M CIGAR ops per haplotype) — what bench.py's e2e leg and
+    tools/e2e_bench.py generate at --scale 1.0."""
+    from svim_asm_amd import synth
+    prm = prm or FULL
+    contigs = tuple((n, max(60000, int(l * prm["scale"]))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
+    n_shared = max(4, int(prm["sv_per_mbp"] * max(c[1] for c in contigs) / 1e6))
+    return dict(seed=prm["seed"], contigs=contigs, diploid=True, n_shared=n_shared, n_private=max(2, n_shared // 5),
+                median_aln=prm["median_aln"], mean_m=prm["mean_m"])
+
+
+def _vcf_summary(vcf):
+    import hashlib
+    body = [l for l in vcf.split("\n") if l and l[0] != "#"]
+    kinds = {}
+    for l in body:
+        k = l.split("\t")[2].rsplit(".", 1)[0]
+        kinds[k] = kinds.get(k, 0) + 1
+    return {"records": len(body), "records_by_id_prefix": kinds, "vcf_sha256": hashlib.sha256(vcf.encode()).hexdigest(),
+            "vcf_bytes": len(vcf.encode()), "first_records": [l[:200] for l in body[:3]],
+            "last_records": [l[:200] for l in body[-3:]]}
+
+
+def make_full(keep=None):
+    """`svim-asm diploid` of the REAL reference on the full-size sample (the configuration BASELINE's BAM->VCF
+    wall-clock is quoted on).  Committed: digest / size / counts / first and last records of its VCF, the
+    reference's own wall-clock in this container, and the digests of the inputs' UNCOMPRESSED content
+    (synth_bam.payload_digest — independent of the zlib build) so that bench.py and the tests can tell, on any
+    box, that they regenerated the same inputs."""
+    import time
+    from svim_asm_amd import synth_bam
+    keep = keep or os.environ.get("SVX_KEEP_FULL")
+    d = keep or tempfile.mkdtemp(prefix="svx_full_")
+    t0 = time.time()
+    fasta, bams = synth_bam.write_dataset(d, **full_dataset_args())
+    t_gen = time.time() - t0
+    wd = os.path.join(d, "wd_reference")
+    t0 = time.time()
+    run_reference_cli(["diploid", wd, bams[0], bams[1], fasta])
+    t_ref = time.time() - t0
+    vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
+    meta = {"params": FULL,
+            "payload_sha256": dict([(os.path.basename(f), synth_bam.payload_digest(f)) for f in bams] +
+                                   [(os.path.basename(fasta), synth_bam.file_digest(fasta))]),
+            "bam_bytes_here": [os.path.getsize(b) for b in bams],
+            "reference_wall_s_build_container": round(t_ref, 1), "generate_s_build_container": round(t_gen, 1),
+            "reference_note": "the real reference (pure Python, /root/reference) with oracle/refstub pysam and edlib "
+                              "(edlib = the C oracle's exact Levenshtein), 1 core of the build container"}
+    meta.update(_vcf_summary(vcf))
+    with open(os.path.join(GOLD, "full_inputs.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    if not keep:
+        shutil.rmtree(d)
+
+
+def refresh_payload_digests():
+    """Add `payload_sha256` (uncompressed-content digests) to medium / large / longcigar metadata: the inputs are
+    regenerated here, checked byte for byte against the compressed-file digests taken when the reference ran on
+    them (same container, same zlib), and the zlib-independent digests of exactly those inputs are stored."""
+    import hashlib
+    from svim_asm_amd import synth_bam
+    jobs = [("medium_inputs.json", dict(seed=MEDIUM["seed"], contigs=medium_contigs(), n_shared=MEDIUM["n_shared"],
+                                        n_private=MEDIUM["n_private"], median_aln=MEDIUM["median_aln"], mean_m=MEDIUM["mean_m"])),
+            ("large_inputs.json", large_dataset_args()),
+            ("longcigar_inputs.json", dict(seed=LONGCIGAR["seed"], contigs=tuple((n, l) for n, l in LONGCIGAR["contigs"]),
+                                           n_shared=LONGCIGAR["n_shared"], n_private=LONGCIGAR["n_private"],
+                                           median_aln=LONGCIGAR["median_aln"], mean_m=LONGCIGAR["mean_m"]))]
+    for name, kw in jobs:
+        path = os.path.join(GOLD, name)
+        meta = json.load(open(path))
+        d = tempfile.mkdtemp(prefix="svx_digest_")
+        fasta, bams = synth_bam.write_dataset(d, **kw)
+        for f in [fasta] + bams:
+            want = meta["sha256"].get(os.path.basename(f))
+            if want is not None and hashlib.sha256(open(f, "rb").read()).hexdigest() != want:
+                raise SystemExit("%s: regenerated %s differs from the file the golden was made from" % (name, f))
+        meta["payload_sha256"] = dict([(os.path.basename(f), synth_bam.payload_digest(f)) for f in bams] +
+                                      [(os.path.basename(fasta), synth_bam.file_digest(fasta))])
+        with open(path, "w") as fh:
+            json.dump(meta, fh, indent=1)
+        shutil.rmtree(d)
+        print(name, "ok")
+
+
 LONGCIGAR = dict(seed=5, contigs=[["chr1", 1500000], ["chr2", 400000], ["chr3", 90000]], n_shared=30, n_private=6,
                  median_aln=40000000, mean_m=12)
 
@@ -405,7 +493,8 @@ def main():
     if len(sys.argv) > 1:   # regenerate selected fixtures only: functions / config1 / medium / longcigar
         for what in sys.argv[1:]:
             {"functions": make_function_vectors, "config1": make_config1, "medium": make_medium,
-             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors, "large": make_large}[what]()
+             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors, "large": make_large, "full": make_full,
+             "digests": refresh_payload_digests}[what]()
         return
     make_longcigar()
     make_function_vectors()

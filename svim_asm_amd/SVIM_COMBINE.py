@@ -1,53 +1,79 @@
-"""PAIR (diploid) + VCF output.
+"""PAIR (diploid) + VCF output, columnar.
 
 Mirrors form_partitions (SVIM_COMBINE.py:15-32), compute_distance (:35-102),
 span_position_distance_breakends (:105-117), pair_haplotypes (:120-140),
 pair_haplotypes_breakends (:143-161), pair_candidates (:164-366), sorted_nicely (:369-376) and
 write_final_vcf (:379-477).
 
-GPU work: the stable sort by Candidate.get_key() + partition sweep is svx_pair_partition (one
-launch for all six SV types: the type is the most significant key field, so partitions and
-their order are the ones the reference gets type by type); the pairwise haplotype edit
-distances (edlib in the reference) are svx_edit_distance_batch, one launch for all pairs.
-Complete linkage + flat cut of the ≤10-member partitions (scipy in the reference) is
-svx_linkage_cut_batch, one launch for all partitions of a type, reproducing scipy's label order.
+The reference keeps (haplotype, Candidate) tuples in Python lists, sorts them with `sorted`, loops over the
+partitions and builds a new object per output candidate.  Here the candidates are rows of a CandidateTable
+(svim_asm_amd/table.py) from COLLECT to the VCF:
+  * keys are packed from the columns; the stable sort by Candidate.get_key() + partition sweep is ONE
+    svx_pair_partition launch for all six SV types (the type is the most significant key field, so
+    partitions and their order are the ones the reference gets type by type);
+  * the cross-haplotype pairs of every partition of 2..10 members are enumerated with array arithmetic (one
+    index template per partition size), their haplotype strings are described as three pieces each of one byte
+    pool (one reference window per partition, fetched in one native batch) and assembled + aligned on the GPU
+    (svx_haplotype_distance_batch; edlib in the reference);
+  * complete linkage + flat cut of the partitions with 3..10 members (scipy in the reference) is one
+    svx_linkage_cut_batch launch per kind of distance, in scipy's label order; two members need no
+    dendrogram: one cluster iff d <= t;
+  * the paired candidates are a row selection plus the merged columns (reads concatenated, flags OR-ed,
+    copies averaged with banker's rounding, constructors re-applied, :184-363);
+  * the VCF record lines are formatted, naturally sorted and numbered by svx_vcf_format (include/svx_text.h).
+The reference's seams (`form_partitions`, `pair_candidates`, `write_final_vcf`, ...) keep their signatures;
+lists of Candidate objects are converted to a table on the way in, `pair_candidates` returns a CandidateList.
 """
+import ctypes as C
 import logging
 import re
 import time
-from collections import defaultdict
-from statistics import mean
 
 import numpy as np
 
 from svim_asm_amd import _lib
-from svim_asm_amd.SVCandidate import (CandidateBreakend, CandidateDeletion, CandidateDuplicationInterspersed,
-                                      CandidateDuplicationTandem, CandidateInsertion, CandidateInversion)
+from svim_asm_amd.SVIM_COLLECT import _apply_constructors
+from svim_asm_amd.table import (CandidateList, CandidateTable, F_BOOL, F_DST_REV, F_SRC_REV, GENOTYPES, T_BND, T_DEL,
+                                T_DUP_INT, T_DUP_TAN, T_INS, T_INV, TYPE_ORDER, _ranges, as_table)
 
-TYPE_ORDER = ("DEL", "INV", "INS", "DUP_TAN", "DUP_INT", "BND")  # processing order of pair_candidates
 _TYPE_RANK = {t: i for i, t in enumerate(TYPE_ORDER)}
 _COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A"}
 SAME_HAPLOTYPE_DISTANCE = 1000000000
+BREAKEND_MISMATCH_DISTANCE = 99999
+
+
+class _NoBam(object):
+    references = ()
+
+    def get_reference_length(self, name):
+        raise KeyError(name)
+
+
+def _str_rank(names):
+    """Rank of every name under Python str ordering; equal names share a rank."""
+    uniq = {name: k for k, name in enumerate(sorted(set(names)))}
+    return np.array([uniq[name] for name in names], dtype=np.int64).reshape(len(names))
+
+
+def _keys_of_table(t):
+    """get_key() of every row → u64 `(type rank << 24 | contig rank under str order) << 32 | pos`."""
+    if len(t) == 0:
+        return np.empty(0, dtype=np.uint64)
+    pos = t.key_position()
+    bad = np.flatnonzero((pos < 0) | (pos >= (1 << 32)))
+    if len(bad):
+        raise ValueError("key position out of range: %r" % (int(pos[int(bad[0])]),))
+    rank = _str_rank(t.contigs)
+    high = (t.type.astype(np.uint64) << np.uint64(24)) | rank[t.key_contig()].astype(np.uint64)
+    return (high << np.uint64(32)) | pos.astype(np.uint64)
 
 
 def _pack_keys(candidates_with_haplotype):
-    """get_key() tuples → u64 `(type rank, contig rank under str order) << 32 | pos`."""
-    keys = [c.get_key() for _, c in candidates_with_haplotype]
-    if not keys:
+    """get_key() tuples of (haplotype, candidate) items → the u64 keys above."""
+    items = list(candidates_with_haplotype)
+    if not items:
         return np.empty(0, dtype=np.uint64)
-    types = [k[0] for k in keys]
-    contigs = [k[1] for k in keys]
-    positions = [k[2] for k in keys]
-    contig_rank = {name: i for i, name in enumerate(sorted(set(contigs)))}
-    type_rank = {t: _TYPE_RANK.get(t, len(TYPE_ORDER)) for t in set(types)}
-    pos = np.array(positions, dtype=object if max(positions) >= (1 << 62) else np.int64)
-    bad = np.flatnonzero((pos < 0) | (pos >= (1 << 32)))
-    if len(bad):
-        raise ValueError("key position out of range: %r" % (positions[int(bad[0])],))
-    n = len(keys)
-    high = (np.fromiter(map(type_rank.__getitem__, types), dtype=np.uint64, count=n) << np.uint64(24)) | \
-        np.fromiter(map(contig_rank.__getitem__, contigs), dtype=np.uint64, count=n)
-    return (high << np.uint64(32)) | pos.astype(np.uint64)
+    return _keys_of_table(CandidateTable.from_objects([c for _, c in items], _NoBam()))
 
 
 def form_partitions(sv_candidates_with_haplotype, max_distance, ctx=None):
@@ -125,332 +151,307 @@ def span_position_distance_breakends(candidate1, candidate2):
     hap2, pos2a, dir2a, pos2b, dir2b = candidate2
     if hap1 != hap2 and dir1a == dir2a and dir1b == dir2b:
         return (abs(pos1a - pos2a) + abs(pos1b - pos2b)) / 3000
-    return 99999
+    return BREAKEND_MISMATCH_DISTANCE
 
 
-def _clusters_batch(partitions, condensed, threshold, ctx=None):
-    """Flat clusters of many partitions with ONE svx_linkage_cut_batch launch: complete linkage cut at
-    `threshold`, clusters in scipy's label order (= fcluster(linkage(d, "complete"), t, "distance"),
-    SVIM_COMBINE.py:134-139), members in partition order.  partitions[i] has the condensed distance list
-    condensed[i]."""
-    if not partitions:
-        return []
-    ctx = ctx or _lib.default_context()
-    sizes = np.array([len(p) for p in partitions], dtype=np.uint32)
-    flat = np.fromiter((d for c in condensed for d in c), dtype=np.float64, count=int((sizes.astype(np.int64) * (sizes.astype(np.int64) - 1) // 2).sum()))
-    labels = ctx.linkage_cut_batch(flat, sizes, float(threshold)).tolist()
-    out, at = [], 0
-    for partition in partitions:
-        lab = labels[at:at + len(partition)]
-        at += len(partition)
-        clusters = [[] for _ in range(max(lab))]
-        for member, l in zip(partition, lab):
-            clusters[l - 1].append(member)
-        out.append(clusters)
+# ------------------------------------------------------------------------------ reference windows
+def _fetch_windows(reference, contigs, lo, hi, upper):
+    """reference.fetch(contigs[i], lo[i], hi[i]) for all i: (uint8 pool, int64 offsets).  One native batch
+    for the product's FastaFile; any object with pysam's fetch() otherwise."""
+    batch = getattr(reference, "fetch_batch", None)
+    if batch is not None:
+        return batch(contigs, lo, hi, upper=upper)
+    parts = []
+    for c, a, b in zip(contigs, np.asarray(lo).tolist(), np.asarray(hi).tolist()):
+        s = reference.fetch(c, a, b)
+        parts.append((s.upper() if upper else s).encode("latin-1"))
+    off = np.zeros(len(parts) + 1, np.int64)
+    if parts:
+        np.cumsum([len(p) for p in parts], out=off[1:])
+    return (np.frombuffer(b"".join(parts), dtype=np.uint8) if parts else np.zeros(0, np.uint8)), off
+
+
+def _reference_lengths(reference, names, used):
+    """reference.get_reference_length of the contig ids in `used` (others -1)."""
+    out = np.full(len(names), -1, np.int64)
+    for cid in np.unique(used).tolist():
+        if cid >= 0:
+            out[cid] = reference.get_reference_length(names[cid])
     return out
 
 
-def _clusters_from_condensed(partition, distances, threshold):
-    return _clusters_batch([partition], [distances], threshold)[0]
+# ------------------------------------------------------------------------------ pairing on columns
+class _Clusters(object):
+    """Output clusters as columns: partition number, scipy label inside it, first / second member row."""
+
+    def __init__(self):
+        self.part, self.label, self.first, self.second, self.size = [], [], [], [], []
+
+    def add(self, part, label, first, second, size):
+        self.part.append(np.asarray(part, dtype=np.int64))
+        self.label.append(np.asarray(label, dtype=np.int64))
+        self.first.append(np.asarray(first, dtype=np.int64))
+        self.second.append(np.asarray(second, dtype=np.int64))
+        self.size.append(np.asarray(size, dtype=np.int64))
+
+    def ordered(self):
+        if not self.part:
+            z = np.zeros(0, np.int64)
+            return z, z, z, z
+        part, label = np.concatenate(self.part), np.concatenate(self.label)
+        o = np.lexsort((label, part))  # partitions in sorted-key order, clusters in label order (:136-139)
+        return part[o], np.concatenate(self.first)[o], np.concatenate(self.second)[o], np.concatenate(self.size)[o]
 
 
-class _HaplotypePieces(object):
-    """Recipes of the haplotype strings compute_distance aligns (SVIM_COMBINE.py:43-100), for the device:
-    every haplotype is three pieces (offset, length, repeat, flags) of one byte pool that holds ONE
-    reference window per partition (all members lie within partition_max_distance of each other) plus the
-    inserted sequences / interspersed-duplication source intervals, once per candidate.  The strings
-    themselves are assembled by svx_haplotype_distance_batch on the GPU."""
-
-    _EMPTY = (0, 0, 0, 0)
-
-    def __init__(self, reference):
-        self.reference = reference
-        self.fetch_bytes = getattr(reference, "fetch_bytes", None)
-        self.chunks, self.size = [], 0
-        self.off, self.len, self.rep, self.flg = [], [], [], []
-        self._middle = {}  # id(candidate) -> piece of its INS sequence / DUP_INT source interval
-
-    def _add(self, data):
-        at = self.size
-        self.chunks.append(data)
-        self.size += len(data)
-        return at
-
-    def _window(self, contig, lo, hi):
-        if self.fetch_bytes is not None:
-            return self._add(self.fetch_bytes(contig, lo, hi))
-        return self._add(self.reference.fetch(contig, lo, hi).encode("latin-1"))
-
-    def partition_window(self, partition):
-        """(type, pool offset of the window, window start, contig length) of one partition."""
-        first = partition[0][1]
-        typ = first.type
-        if typ in ("DEL", "INV", "DUP_TAN"):
-            contig = first.source_contig
-            lo = min(c.source_start for _, c in partition)
-            hi = max(c.source_end for _, c in partition)
-        else:
-            contig = first.dest_contig
-            lo = min(c.dest_start for _, c in partition)
-            hi = max(c.dest_start for _, c in partition)
-        length = self.reference.get_reference_length(contig)
-        lo, hi = max(0, lo - 100), min(length, hi + 100)
-        return typ, self._window(contig, lo, hi), lo, length
-
-    def _middle_piece(self, typ, c):
-        m = self._middle.get(id(c))
-        if m is None:
-            if typ == "INS":  # the inserted sequence as it is: the reference does not fold its case (:74-75)
-                data = c.sequence.encode("latin-1")
-                m = (self._add(data), len(data), 1, 0)
-            else:             # DUP_INT: the source interval, upper-cased like every reference slice (:86-87)
-                n = max(0, min(c.source_end, self.reference.get_reference_length(c.source_contig)) - c.source_start)
-                m = (self._window(c.source_contig, c.source_start, c.source_end), n, 1, _lib.PIECE_UPPER) if n else self._EMPTY
-            self._middle[id(c)] = m
-        return m
-
-    def add_pair(self, window, c1, c2):
-        typ, base, lo, length = window
-        up = _lib.PIECE_UPPER
-
-        def ref(a, b, repeat=1, flags=up):
-            """reference[a:b] of the partition's contig, with fetch()'s clamping of the end (:45-99)."""
-            b = min(b, length)
-            return (base + a - lo, b - a, repeat, flags) if b > a else self._EMPTY
-
-        if typ in ("DEL", "INV", "DUP_TAN"):
-            region_start = max(0, min(c1.source_start, c2.source_start) - 100)
-            region_end = min(length, max(c1.source_end, c2.source_end) + 100)
-            for c in (c1, c2):
-                s, e = c.source_start, c.source_end
-                if typ == "DEL":
-                    mid = self._EMPTY
-                elif typ == "INV":
-                    mid = ref(s, e, 1, up | _lib.PIECE_REVCOMP)
-                else:
-                    if c.copies + 1 > 0xFFFF:
-                        raise ValueError("tandem duplication with %d copies" % c.copies)
-                    mid = ref(s, e, c.copies + 1)
-                self._emit((ref(region_start, s), mid, ref(e, region_end)))
-        else:
-            region_start = max(0, min(c1.dest_start, c2.dest_start) - 100)
-            region_end = min(length, max(c1.dest_start, c2.dest_start) + 100)
-            for c in (c1, c2):
-                d = c.dest_start
-                self._emit((ref(region_start, d), self._middle_piece(typ, c), ref(d, region_end)))
-
-    def _emit(self, three):
-        for off, ln, rep, flg in three:
-            if ln <= 0 or rep <= 0:
-                off, ln, rep, flg = self._EMPTY
-            self.off.append(off); self.len.append(ln); self.rep.append(rep); self.flg.append(flg)
-
-    def arrays(self, pair_indices):
-        """(pool bytes as uint8, HAP_PIECE_DTYPE array of the selected pairs)."""
-        pool = np.frombuffer(b"".join(self.chunks), dtype=np.uint8) if self.size else np.zeros(0, np.uint8)
-        pieces = np.empty(len(self.off), dtype=_lib.HAP_PIECE_DTYPE)
-        pieces["off"] = self.off
-        pieces["len"] = self.len
-        pieces["repeat"] = self.rep
-        pieces["flags"] = self.flg
-        idx = (np.asarray(pair_indices, dtype=np.int64)[:, None] * 6 + np.arange(6)).reshape(-1)
-        return pool, pieces[idx]
-
-
-def _pair_two_member_partitions(partitions, which, reference, edit_distance_threshold, ctx):
-    """The bulk of a sample: deletion / insertion partitions of exactly two members, one per haplotype.
-    Their haplotype recipes (SVIM_COMBINE.py:43-77) are built with array arithmetic — for two members the
-    pair's region IS the partition's window — and complete linkage of two points is one comparison:
-    fcluster(linkage([d]), t, "distance") puts them in one cluster iff d <= t, else member 0 gets label 1
-    and member 1 label 2 (:134-139).  Returns {partition index: paired?}."""
-    if not which:
-        return {}
-    first = [partitions[pi][0][1] for pi in which]
-    second = [partitions[pi][1][1] for pi in which]
-    typ = first[0].type
-    n = len(which)
+def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig, win_base, win_lo, L_part, reference):
+    """svx_hap_piece recipes (3 per haplotype, 6 per job) of the strings compute_distance aligns
+    (SVIM_COMBINE.py:43-100) for jobs (candidate rows a, b of partition job_part).  Returns (pieces [J, 2, 3],
+    extra pool parts appended behind the windows: interspersed-duplication source intervals, inserted sequences)."""
+    J = len(job_a)
     up = _lib.PIECE_UPPER
-    fetch = getattr(reference, "fetch_bytes", None) or (lambda c, a, b: reference.fetch(c, a, b).encode("latin-1"))
-    lengths = {}
-    if typ == "DEL":
-        contigs = [c.source_contig for c in first]
-        s = np.array([[a.source_start, b.source_start] for a, b in zip(first, second)], dtype=np.int64)
-        e = np.array([[a.source_end, b.source_end] for a, b in zip(first, second)], dtype=np.int64)
-    else:
-        contigs = [c.dest_contig for c in first]
-        s = np.array([[a.dest_start, b.dest_start] for a, b in zip(first, second)], dtype=np.int64)
-        e = s
-    for c in contigs:
-        if c not in lengths:
-            lengths[c] = reference.get_reference_length(c)
-    L = np.array([lengths[c] for c in contigs], dtype=np.int64)
-    lo = np.maximum(0, s.min(axis=1) - 100)
-    hi = np.minimum(L, e.max(axis=1) + 100)
-    chunks = [fetch(c, a, b) for c, a, b in zip(contigs, lo.tolist(), hi.tolist())]
-    wlen = np.array([len(w) for w in chunks], dtype=np.int64)
-    if not np.array_equal(wlen, np.maximum(hi - lo, 0)):
-        raise ValueError("reference windows shorter than the index says")
-    base = np.concatenate(([0], np.cumsum(wlen)))[:-1]
-    pieces = np.zeros((n, 2, 3), dtype=_lib.HAP_PIECE_DTYPE)
+    pieces = np.zeros((J, 2, 3), dtype=_lib.HAP_PIECE_DTYPE)
+    typ = p_type[job_part]
+    L = L_part[job_part]
+    base, lo = win_base[job_part], win_lo[job_part]
+    rows = (job_a, job_b)
+    s = (kstart[job_a], kstart[job_b])
+    e = (kend[job_a], kend[job_b])
+    rs = np.maximum(0, np.minimum(s[0], s[1]) - 100)
+    re_ = np.minimum(L, np.maximum(e[0], e[1]) + 100)
+    windows_bytes = int(win_base[-1]) if len(win_base) else 0
+
+    def put(h, k, off, ln, rep, flags):
+        ok = (ln > 0) & (rep > 0)
+        pieces["off"][:, h, k] = np.where(ok, off, 0)
+        pieces["len"][:, h, k] = np.where(ok, ln, 0)
+        pieces["repeat"][:, h, k] = np.where(ok, rep, 0)
+        pieces["flags"][:, h, k] = np.where(ok, flags, 0)
+
+    # the middle pieces that are not slices of the partition's window live behind the windows in the pool
+    extra_parts, extra_at = [], windows_bytes
+    dint = np.flatnonzero(typ == T_DUP_INT)
+    mid_off = np.zeros((J, 2), np.int64)
+    mid_len = np.zeros((J, 2), np.int64)
+    if len(dint):
+        # DUP_INT: the source interval, upper-cased like every reference slice (:86-87); one fetch per candidate
+        cand = np.unique(np.concatenate((job_a[dint], job_b[dint])))
+        Ls = _reference_lengths(reference, T.contigs, T.sc[cand])[T.sc[cand]]
+        n_src = np.maximum(0, np.minimum(T.se[cand], Ls) - T.ss[cand])
+        pool, off = _fetch_windows(reference, [T.contigs[c] for c in T.sc[cand].tolist()], T.ss[cand], T.se[cand], False)
+        if not np.array_equal(off[1:] - off[:-1], n_src):
+            raise ValueError("reference windows shorter than the index says")
+        extra_parts.append(pool)
+        for h in (0, 1):
+            where = np.searchsorted(cand, rows[h][dint])
+            mid_off[dint, h] = extra_at + off[:-1][where]
+            mid_len[dint, h] = n_src[where]
+        extra_at += len(pool)
+    ins = typ == T_INS
+    if bool(ins.any()):
+        # INS: the inserted sequence as it is — the reference does not fold its case (:74-75)
+        extra_parts.append(np.asarray(T.seqs, dtype=np.uint8))
+        for h in (0, 1):
+            mid_off[:, h] = np.where(ins, extra_at + T.q_off[rows[h]], mid_off[:, h])
+            mid_len[:, h] = np.where(ins, T.q_len[rows[h]], mid_len[:, h])
+    tan = typ == T_DUP_TAN
+    if bool(tan.any()):
+        worst = int(max(T.copies[job_a[tan]].max(), T.copies[job_b[tan]].max()))
+        if worst + 1 > 0xFFFF:
+            raise ValueError("tandem duplication with %d copies" % worst)
+    one = np.ones(J, np.int64)
     for h in (0, 1):
-        # prefix reference[region_start : start] and suffix reference[end : region_end], fetch()'s clamping
-        pre = np.maximum(np.minimum(s[:, h], L) - lo, 0)
-        suf = np.maximum(hi - e[:, h], 0)
-        pieces["off"][:, h, 0] = np.where(pre > 0, base, 0)
-        pieces["len"][:, h, 0] = pre
-        pieces["repeat"][:, h, 0] = pre > 0
-        pieces["flags"][:, h, 0] = np.where(pre > 0, up, 0)
-        pieces["off"][:, h, 2] = np.where(suf > 0, base + e[:, h] - lo, 0)
-        pieces["len"][:, h, 2] = suf
-        pieces["repeat"][:, h, 2] = suf > 0
-        pieces["flags"][:, h, 2] = np.where(suf > 0, up, 0)
-    if typ == "INS":  # the inserted sequences as they are (:74-75), behind the windows in the pool
-        seqs = [c.sequence.encode("latin-1") for pair in zip(first, second) for c in pair]
-        slen = np.array([len(x) for x in seqs], dtype=np.int64).reshape(n, 2)
-        soff = (int(wlen.sum()) + np.concatenate(([0], np.cumsum(slen.reshape(-1))))[:-1]).reshape(n, 2)
-        pieces["off"][:, :, 1] = np.where(slen > 0, soff, 0)
-        pieces["len"][:, :, 1] = slen
-        pieces["repeat"][:, :, 1] = slen > 0
-        chunks += seqs
-    pool = np.frombuffer(b"".join(chunks), dtype=np.uint8) if chunks else np.zeros(0, np.uint8)
-    k_max = max(min(max(int(edit_distance_threshold), -1), 0xFFFFFFFE), 0)
-    d = ctx.haplotype_distance_batch(pool, pieces.reshape(-1), k_max).astype(np.float64)
-    d[d == float(0xFFFFFFFF)] = k_max + 1  # "more than the threshold" is all that is known, and all that matters
-    paired = d <= float(edit_distance_threshold)
-    return dict(zip(which, paired.tolist()))
+        sh, eh = s[h], e[h]
+        # reference[region_start : start] and reference[end : region_end], with fetch()'s clamping of the end
+        put(h, 0, base + rs - lo, np.minimum(sh, L) - rs, one, up)
+        put(h, 2, base + eh - lo, re_ - eh, one, up)
+        inner_len = np.minimum(eh, L) - sh
+        m_off = np.where((typ == T_INV) | tan, base + sh - lo, mid_off[:, h])
+        m_len = np.where((typ == T_INV) | tan, inner_len, mid_len[:, h])
+        m_len = np.where(typ == T_DEL, 0, m_len)
+        m_rep = np.where(tan, T.copies[rows[h]] + 1, one)
+        m_flg = np.where(typ == T_INV, up | _lib.PIECE_REVCOMP, np.where(tan | (typ == T_DUP_INT), up, 0))
+        put(h, 1, m_off, m_len, m_rep, m_flg)
+    return pieces, extra_parts
 
 
-def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None):
-    """Cluster each partition (2..10 members) by complete linkage over haplotype edit distances.  The
-    haplotype strings of all cross-haplotype pairs are assembled on the GPU from one reference window per
-    partition, their distances come from one batch per mode, the linkage cuts from one more launch."""
-    ctx = ctx or _lib.default_context()
-    jobs = []  # (partition index, i, j)
-    recipes = _HaplotypePieces(reference)
-    two = [pi for pi, p in enumerate(partitions)
-           if len(p) == 2 and p[0][0] != p[1][0] and p[0][1].type in ("DEL", "INS")]
-    settled = _pair_two_member_partitions(partitions, two, reference, edit_distance_threshold, ctx)
-    for pi, partition in enumerate(partitions):
-        if len(partition) < 2 or len(partition) > 10 or pi in settled:
-            continue
-        window = None
-        for i in range(len(partition) - 1):
-            for j in range(i + 1, len(partition)):
-                if partition[i][0] != partition[j][0]:
-                    if window is None:
-                        window = recipes.partition_window(partition)
-                    jobs.append((pi, i, j))
-                    recipes.add_pair(window, partition[i][1], partition[j][1])
-    # two-member partitions only need "<= threshold?"; larger ones get exact values so that the
-    # dendrogram above the cut (hence scipy's cluster label order) is the reference's
-    dist = {}
-    thr = [k for k, (pi, _, _) in enumerate(jobs) if len(partitions[pi]) == 2]
-    exa = [k for k, (pi, _, _) in enumerate(jobs) if len(partitions[pi]) > 2]
-    # any threshold the reference accepts: a negative one pairs nothing, one beyond 32 bits everything
-    k_max = min(max(int(edit_distance_threshold), -1), 0xFFFFFFFE)
-    if thr:
-        # (a negative threshold: only "distance > threshold" matters, and every distance is >= 0)
-        pool, pieces = recipes.arrays(thr)
-        got = ctx.haplotype_distance_batch(pool, pieces, max(k_max, 0)).tolist()
-        for k, d in zip(thr, got):
-            dist[jobs[k]] = d if d != 0xFFFFFFFF else max(k_max, 0) + 1
-    if exa:
-        pool, pieces = recipes.arrays(exa)
-        for k, d in zip(exa, ctx.haplotype_distance_batch(pool, pieces, 0xFFFFFFFF).tolist()):
-            dist[jobs[k]] = d
-    todo, condensed = [], []
-    for pi, partition in enumerate(partitions):
-        if 2 <= len(partition) <= 10 and pi not in settled:
-            todo.append(partition)
-            condensed.append([dist.get((pi, i, j), SAME_HAPLOTYPE_DISTANCE)
-                              for i in range(len(partition) - 1) for j in range(i + 1, len(partition))])
-    clustered = iter(_clusters_batch(todo, condensed, edit_distance_threshold, ctx))
-    clusters_final = []
-    for pi, partition in enumerate(partitions):
-        if len(partition) < 2:
-            clusters_final.append(partition)
-        elif pi in settled:
-            if settled[pi]:
-                clusters_final.append(partition)
-            else:
-                clusters_final.append([partition[0]])
-                clusters_final.append([partition[1]])
-        elif len(partition) > 10:
-            # very large partitions tend to be in difficult regions: dropped (SVIM_COMBINE.py:126-128)
+def pair_tables(t1, t2, reference, bam, options, ctx=None):
+    """pair_candidates on tables: the paired candidates as a CandidateTable, rows in the reference's order."""
+    ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
+    base_bam = getattr(bam, "_bam", bam)
+    contigs = list(base_bam.references)
+    T = CandidateTable.concat([t1, t2], contigs, [base_bam.get_reference_length(c) for c in contigs])
+    n1, n = len(t1), len(t1) + len(t2)
+    hap = np.ones(n, np.int64)
+    hap[n1:] = 2
+    counts = T.counts_by_type()
+    for ti, typ in enumerate(TYPE_ORDER):
+        logging.info("Pairing {0} {1}...".format(int(counts[ti]), _LOG_NAME[typ]))
+    if n == 0:
+        return T
+    # one sort/partition launch for all types; the input order per type is hap-1 list then hap-2 list (:182,...)
+    inp = np.lexsort((hap, T.type))
+    perm, part_id, n_parts = ctx.pair_partition(_keys_of_table(T)[inp], options.partition_max_distance)
+    order = inp[perm.astype(np.int64)]
+    p_size = np.bincount(part_id.astype(np.int64), minlength=n_parts).astype(np.int64)
+    p_start = np.cumsum(p_size) - p_size
+    p_type = T.type[order[p_start]].astype(np.int64)
+    threshold = options.max_edit_distance
+    out = _Clusters()
+
+    # ---- partitions of one member: one cluster (:123-124)
+    single = np.flatnonzero(p_size == 1)
+    out.add(single, np.ones(len(single)), order[p_start[single]], np.full(len(single), -1), np.ones(len(single)))
+    # ---- very large partitions tend to be in difficult regions: dropped (:126-128; breakends silently, :149)
+    if logging.getLogger().isEnabledFor(logging.DEBUG):
+        for pi in np.flatnonzero((p_size > 10) & (p_type != T_BND)).tolist():
+            rows = order[p_start[pi]:p_start[pi] + p_size[pi]]
+            kc, kp = T.key_contig()[rows], T.key_position()[rows]
             logging.debug("Ignored partition of size {0} and type {1}: {2}".format(
-                len(partition), partition[0][1].get_key()[0],
-                ",".join("{0}:{1}".format(m[1].get_key()[1], m[1].get_key()[2]) for m in partition)))
-        else:
-            clusters_final.extend(next(clustered))
-    return clusters_final
+                int(p_size[pi]), TYPE_ORDER[p_type[pi]], ",".join("{0}:{1}".format(T.contigs[c], p) for c, p in zip(kc.tolist(), kp.tolist()))))
 
-
-def pair_haplotypes_breakends(partitions, span_position_distance_threshold=0.3, ctx=None):
-    todo, condensed = [], []
-    for partition in partitions:
-        if 2 <= len(partition) <= 10:
-            rows = [(hap, c.get_source()[1], 1 if c.source_direction == "fwd" else 0, c.get_destination()[1],
-                     1 if c.dest_direction == "fwd" else 0) for hap, c in partition]
-            todo.append(partition)
-            condensed.append([span_position_distance_breakends(rows[i], rows[j])
-                              for i in range(len(rows) - 1) for j in range(i + 1, len(rows))])
-    clustered = iter(_clusters_batch(todo, condensed, span_position_distance_threshold, ctx))
-    clusters_final = []
-    for partition in partitions:
-        if len(partition) < 2:
-            clusters_final.append(partition)
-        elif len(partition) > 10:
+    # ---- partitions of 2..10 members: all pairs (i < j), one index template per size
+    src_like = (T.type == T_DEL) | (T.type == T_INV) | (T.type == T_DUP_TAN)
+    kstart = np.where(src_like, T.ss, T.ds)   # the interval compute_distance works on: source (DEL, INV, DUP_TAN),
+    kend = np.where(src_like, T.se, T.ds)     # destination START twice (INS, DUP_INT; :71,:83)
+    classes = []
+    for size in range(2, 11):
+        P = np.flatnonzero(p_size == size)
+        if not len(P):
             continue
-        else:
-            clusters_final.extend(next(clustered))
-    return clusters_final
+        M = order[p_start[P][:, None] + np.arange(size)[None, :]]
+        iu, ju = np.triu_indices(size, 1)
+        A, B = M[:, iu], M[:, ju]
+        cross = hap[A] != hap[B]
+        bnd = p_type[P] == T_BND
+        classes.append(dict(size=size, P=P, M=M, A=A, B=B, cross=cross, bnd=bnd))
+    # haplotype edit distances of the cross-haplotype pairs of the non-breakend partitions
+    job_a = [c["A"][~c["bnd"]][c["cross"][~c["bnd"]]] for c in classes]
+    job_b = [c["B"][~c["bnd"]][c["cross"][~c["bnd"]]] for c in classes]
+    job_p = [np.broadcast_to(c["P"][:, None], c["A"].shape)[~c["bnd"]][c["cross"][~c["bnd"]]] for c in classes]
+    job_two = [np.full(len(a), c["size"] == 2) for a, c in zip(job_a, classes)]
+    dist = np.zeros(0, np.float64)
+    if classes and sum(len(a) for a in job_a):
+        job_a, job_b, job_p, job_two = (np.concatenate(x) for x in (job_a, job_b, job_p, job_two))
+        # one reference window per partition with jobs: [min start - 100, max end + 100) of ALL its members (:45-46,...)
+        s_sorted, e_sorted = kstart[order], kend[order]
+        wp = np.unique(job_p)
+        first_row = order[p_start[wp]]
+        p_contig = np.full(n_parts, -1, np.int64)
+        p_contig[wp] = T.key_contig()[first_row]
+        L_names = _reference_lengths(reference, T.contigs, p_contig[wp])
+        L_part = np.zeros(n_parts, np.int64)
+        L_part[wp] = L_names[p_contig[wp]]
+        seg_lo = np.minimum.reduceat(s_sorted, p_start)[wp]
+        seg_hi = np.maximum.reduceat(e_sorted, p_start)[wp]
+        wlo = np.maximum(0, seg_lo - 100)
+        whi = np.minimum(L_part[wp], seg_hi + 100)
+        pool_w, off_w = _fetch_windows(reference, [T.contigs[c] for c in p_contig[wp].tolist()], wlo, np.maximum(whi, wlo), False)
+        if not np.array_equal(off_w[1:] - off_w[:-1], np.maximum(whi - wlo, 0)):
+            raise ValueError("reference windows shorter than the index says")
+        win_base = np.zeros(n_parts + 1, np.int64)
+        win_base[wp] = off_w[:-1]
+        win_base[-1] = off_w[-1]
+        win_lo = np.zeros(n_parts, np.int64)
+        win_lo[wp] = wlo
+        pieces, extra = _haplotype_pieces(T, kstart, kend, job_a, job_b, job_p, p_type, p_contig, win_base, win_lo, L_part, reference)
+        pool = np.concatenate([pool_w] + extra) if extra else pool_w
+        # two-member partitions only need "<= threshold?"; larger ones get exact values so that the dendrogram
+        # above the cut (hence scipy's cluster label order) is the reference's.  Any threshold the reference
+        # accepts: a negative one pairs nothing, one beyond 32 bits everything
+        k_max = max(min(max(int(threshold), -1), 0xFFFFFFFE), 0)
+        dist = np.zeros(len(job_a), np.float64)
+        thr, exa = np.flatnonzero(job_two), np.flatnonzero(~job_two)
+        if len(thr):
+            d = ctx.haplotype_distance_batch(pool, pieces[thr].reshape(-1), k_max).astype(np.float64)
+            d[d == float(0xFFFFFFFF)] = k_max + 1  # "more than the threshold" is all that is known, and all that matters
+            dist[thr] = d
+        if len(exa):
+            dist[exa] = ctx.haplotype_distance_batch(pool, pieces[exa].reshape(-1), 0xFFFFFFFF).astype(np.float64)
+    # condensed distance vectors per size class (row-major pairs (i < j), :131-133), then the clusters
+    at = 0
+    for c in classes:
+        size, P, M, A, B, cross, bnd = c["size"], c["P"], c["M"], c["A"], c["B"], c["cross"], c["bnd"]
+        cond = np.full(A.shape, float(SAME_HAPLOTYPE_DISTANCE))
+        nb = ~bnd
+        k = int(cross[nb].sum())
+        sub = cond[nb]
+        sub[cross[nb]] = dist[at:at + k]
+        cond[nb] = sub
+        at += k
+        if bool(bnd.any()):
+            # span-position distance of breakends (:105-117); integer sum / 3000 in float64, as Python's true division
+            a, b = A[bnd], B[bnd]
+            same = cross[bnd] & ((T.flag[a] & (F_SRC_REV | F_DST_REV)) == (T.flag[b] & (F_SRC_REV | F_DST_REV)))
+            d = (np.abs(T.ss[a] - T.ss[b]) + np.abs(T.ds[a] - T.ds[b])).astype(np.float64) / 3000.0
+            cond[bnd] = np.where(same, d, float(BREAKEND_MISMATCH_DISTANCE))
+        cut = np.where(bnd, 0.3, float(threshold))
+        if size == 2:
+            # complete linkage of two points: one cluster iff d <= t, else member 0 is label 1, member 1 label 2
+            together = cond[:, 0] <= cut
+            tp = P[together]
+            out.add(tp, np.ones(len(tp)), M[together, 0], M[together, 1], np.full(len(tp), 2))
+            ap = P[~together]
+            for member in (0, 1):
+                out.add(ap, np.full(len(ap), member + 1), M[~together, member], np.full(len(ap), -1), np.ones(len(ap)))
+            continue
+        labels = np.zeros(M.shape, np.int64)
+        for sel, t in ((nb, float(threshold)), (bnd, 0.3)):
+            if bool(sel.any()):
+                k = int(sel.sum())
+                labels[sel] = ctx.linkage_cut_batch(cond[sel].reshape(-1), np.full(k, size, np.uint32), t).astype(np.int64).reshape(k, size)
+        # clusters in label order, members in partition order (:136-139)
+        o = np.argsort(labels, axis=1, kind="stable")
+        lab = np.take_along_axis(labels, o, axis=1).reshape(-1)
+        rows = np.take_along_axis(M, o, axis=1).reshape(-1)
+        part = np.repeat(P, size)
+        new = np.ones(len(lab), bool)
+        new[1:] = (part[1:] != part[:-1]) | (lab[1:] != lab[:-1])
+        st = np.flatnonzero(new)
+        sz = np.diff(np.concatenate((st, [len(lab)])))
+        second = np.where(sz >= 2, rows[np.minimum(st + 1, len(rows) - 1)], -1)
+        out.add(part[st], lab[st], rows[st], second, sz)
+
+    c_part, first, second, size = out.ordered()
+    for bad in size[size > 2].tolist():
+        logging.error("Cluster size should be either 1 or 2 but is " + str(bad))
+    ok = size <= 2
+    return _rebuild_rows(T, hap, first[ok], second[ok])
 
 
-# ------------------------------------------------------------------------------ pairing
-def _rebuild(typ, cluster, bam):
-    """Candidate of a cluster: coordinates/payload of its first member, reads concatenated,
-    flags OR-ed, copy number averaged with round() (banker's rounding) — :184-363."""
-    first = cluster[0][1]
-    if len(cluster) == 1:
-        genotype = "1/0" if cluster[0][0] == 1 else "0/1"
-        second, reads = None, first.reads
-    else:
-        genotype = "1/1"
-        second = cluster[1][1]
-        reads = first.reads + second.reads
-    if typ == "DEL":
-        # the constructor would clamp coordinates that are clamped already: same object state from a copy
-        assert first.source_end >= first.source_start, \
-            "Deletion end ({0}:{1}) is smaller than its start ({0}:{2}). From read {3}".format(
-                first.source_contig, first.source_end, first.source_start, reads)
-        new = CandidateDeletion.__new__(CandidateDeletion)
-        new.__dict__.update(first.__dict__)
-        new.reads, new.genotype = reads, genotype
-        return new
-    if typ == "INV":
-        complete = first.complete if second is None else (first.complete or second.complete)
-        return CandidateInversion(first.source_contig, first.source_start, first.source_end, reads, complete, bam,
-                                  genotype)
-    if typ == "INS":
-        assert first.dest_end >= first.dest_start, \
-            "Insertion end ({0}:{1}) is smaller than its start ({0}:{2}). From read {3}".format(
-                first.dest_contig, first.dest_end, first.dest_start, reads)
-        new = CandidateInsertion.__new__(CandidateInsertion)
-        new.__dict__.update(first.__dict__)
-        new.reads, new.genotype = reads, genotype
-        return new
-    if typ == "DUP_TAN":
-        copies = first.copies if second is None else round(mean([first.copies, second.copies]))
-        fully = first.fully_covered if second is None else (first.fully_covered or second.fully_covered)
-        return CandidateDuplicationTandem(first.source_contig, first.source_start, first.source_end, copies, fully,
-                                          reads, bam, genotype)
-    if typ == "DUP_INT":
-        cutpaste = first.cutpaste if second is None else (first.cutpaste or second.cutpaste)
-        return CandidateDuplicationInterspersed(first.source_contig, first.source_start, first.source_end,
-                                                first.dest_contig, first.dest_start, first.dest_end, reads, bam,
-                                                cutpaste, genotype)
-    return CandidateBreakend(first.source_contig, first.source_start, first.source_direction, first.dest_contig,
-                             first.dest_start, first.dest_direction, reads, bam, genotype)
+def _rebuild_rows(T, hap, first, second):
+    """Candidates of the clusters (:184-363): coordinates and payload of the first member, reads of both
+    concatenated, complete / fully_covered / cutpaste OR-ed, copy number averaged with round() — banker's
+    rounding —, genotype 1/1 for pairs, 1/0 or 0/1 for singletons by haplotype; the constructors re-applied."""
+    paired = second >= 0
+    sec = np.where(paired, second, first)
+    out = T.take(first)
+    gt = {g: i for i, g in enumerate(out.genotypes)}
+    for g in GENOTYPES:
+        if g not in gt:
+            out.genotypes = list(out.genotypes) + [g]
+            gt[g] = len(out.genotypes) - 1
+    out.gt = np.where(paired, gt["1/1"], np.where(hap[first] == 1, gt["1/0"], gt["0/1"])).astype(np.uint8)
+    # reads = first.reads + second.reads
+    cnt1 = T.r_off[first + 1] - T.r_off[first]
+    cnt2 = np.where(paired, T.r_off[sec + 1] - T.r_off[sec], 0)
+    total = cnt1 + cnt2
+    r_off = np.zeros(len(first) + 1, np.int64)
+    np.cumsum(total, out=r_off[1:])
+    starts = np.stack((T.r_off[first], T.r_off[sec]), axis=1).reshape(-1)
+    lens = np.stack((cnt1, cnt2), axis=1).reshape(-1)
+    out.with_reads(r_off, T.r_flat[_ranges(starts, lens)])
+    # flags OR-ed (INV complete :224, DUP_TAN fully_covered :284, DUP_INT cutpaste :319)
+    both = paired & ((out.type == T_INV) | (out.type == T_DUP_TAN) | (out.type == T_DUP_INT))
+    out.flag = np.where(both, out.flag | (T.flag[sec] & F_BOOL), out.flag).astype(np.uint8)
+    # copies = round(mean([c1, c2])) (:290): exact halves go to the even neighbour
+    tan = paired & (out.type == T_DUP_TAN)
+    if bool(tan.any()):
+        total = T.copies[first] + T.copies[sec]
+        floor = total // 2
+        rounded = np.where(total % 2 == 0, floor, np.where(floor % 2 == 0, floor, floor + 1))
+        out.copies = np.where(tan, rounded, out.copies)
+    _apply_constructors(out)
+    return out
 
 
 _LOG_NAME = {"DEL": "deletions", "INV": "inversions", "INS": "insertions", "DUP_TAN": "tandem duplications",
@@ -458,52 +459,75 @@ _LOG_NAME = {"DEL": "deletions", "INV": "inversions", "INS": "insertions", "DUP_
 
 
 def pair_candidates(sv_candidates1, sv_candidates2, reference, bam, options):
-    ctx = _lib.default_context(getattr(options, "device", 0) or 0)
-    # one sort/partition launch for all types; the input order per type is hap-1 list then hap-2 list
-    per_type = {typ: ([], []) for typ in TYPE_ORDER}
-    for hap, cands in ((0, sv_candidates1), (1, sv_candidates2)):
-        for c in cands:
-            bucket = per_type.get(c.type)
-            if bucket is not None:
-                bucket[hap].append((hap + 1, c))
-    tagged = []
-    for typ in TYPE_ORDER:
-        tagged += per_type[typ][0]
-        tagged += per_type[typ][1]
-    partitions = form_partitions(tagged, options.partition_max_distance, ctx=ctx)
-    by_type = defaultdict(list)
-    for part in partitions:
-        by_type[part[0][1].type].append(part)
-    paired_candidates = []
-    for typ in TYPE_ORDER:
-        n = len(per_type[typ][0]) + len(per_type[typ][1])
-        logging.info("Pairing {0} {1}...".format(n, _LOG_NAME[typ]))
-        if typ == "BND":
-            clusters = pair_haplotypes_breakends(by_type[typ])
+    t1, t2 = as_table(sv_candidates1, bam), as_table(sv_candidates2, bam)
+    return CandidateList(pair_tables(t1, t2, reference, bam, options))
+
+
+def pair_haplotypes(partitions, reference, edit_distance_threshold=10, ctx=None):
+    """Cluster each partition (lists of (haplotype, candidate)) by complete linkage over haplotype edit
+    distances (:120-140): the object-level seam, answered by the columnar pairing."""
+    return _pair_partitions(partitions, reference, edit_distance_threshold, ctx)
+
+
+def pair_haplotypes_breakends(partitions, span_position_distance_threshold=0.3, ctx=None):
+    if span_position_distance_threshold != 0.3:
+        raise ValueError("the breakend cut is fixed at 0.3 (SVIM_COMBINE.py:143)")
+    return _pair_partitions(partitions, None, None, ctx)
+
+
+def _pair_partitions(partitions, reference, threshold, ctx):
+    """Clusters (lists of the input tuples) of already formed partitions, through the same arithmetic as
+    pair_tables: every partition is kept apart by giving it its own key contig."""
+    ctx = ctx or _lib.default_context()
+    clusters_final = []
+    for partition in partitions:
+        if len(partition) < 2:
+            clusters_final.append(list(partition))
+            continue
+        if len(partition) > 10:
+            if partition[0][1].type != "BND":
+                logging.debug("Ignored partition of size {0} and type {1}: {2}".format(
+                    len(partition), partition[0][1].get_key()[0],
+                    ",".join("{0}:{1}".format(m[1].get_key()[1], m[1].get_key()[2]) for m in partition)))
+            continue
+        n = len(partition)
+        if partition[0][1].type == "BND":
+            rows = [(hap, c.get_source()[1], c.source_direction, c.get_destination()[1], c.dest_direction) for hap, c in partition]
+            cond = [span_position_distance_breakends(rows[i], rows[j]) for i in range(n - 1) for j in range(i + 1, n)]
+            cut = 0.3
         else:
-            clusters = pair_haplotypes(by_type[typ], reference, options.max_edit_distance, ctx=ctx)
-        for cluster in clusters:
-            if len(cluster) in (1, 2):
-                paired_candidates.append(_rebuild(typ, cluster, bam))
-            else:
-                logging.error("Cluster size should be either 1 or 2 but is " + str(len(cluster)))
-    return paired_candidates
+            pairs = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+            cross = [(i, j) for i, j in pairs if partition[i][0] != partition[j][0]]
+            d = dict(zip(cross, edit_distances([tuple(haplotype_pair(partition[i][1], partition[j][1], reference))
+                                                for i, j in cross], ctx=ctx)))
+            cond = [d.get(p, SAME_HAPLOTYPE_DISTANCE) for p in pairs]
+            cut = threshold
+        labels = ctx.linkage_cut_batch(cond, [n], float(cut)).tolist()
+        clusters = [[] for _ in range(max(labels))]
+        for member, l in zip(partition, labels):
+            clusters[l - 1].append(member)
+        clusters_final.extend(clusters)
+    return clusters_final
 
 
 # ------------------------------------------------------------------------------ output
 def sorted_nicely(vcf_entries):
     """Natural sort of ((contig, start, end), vcf_string, sv_type) entries: chr10 after chr2."""
-    # a sample has a few dozen contig names and tens of thousands of entries: the names are ranked once under
-    # the natural key (equal keys — "chr01" and "chr1" — share a rank), the entries sort on integers
-    names = set(entry[0][0] for entry in vcf_entries)
+    rank = _natural_ranks(set(entry[0][0] for entry in vcf_entries))
+    return sorted(vcf_entries, key=lambda entry: (rank[entry[0][0]], entry[0][1], entry[0][2]))
+
+
+def _natural_ranks(names):
+    """Rank of every contig name under the reference's key (:373-375: the name split at digit runs, the runs
+    as integers); names whose keys are equal — "chr01" and "chr1" — share a rank."""
     natural = {name: [int(tok) if tok.isdigit() else tok for tok in re.split("([0-9]+)", str(name))] for name in names}
-    rank, last = {}, None
-    for name in sorted(names, key=natural.__getitem__):
+    rank, last, r = {}, None, 0
+    for name in sorted(natural, key=natural.__getitem__):
         if last is None or natural[name] != natural[last]:
             r = len(rank)
         rank[name] = r
         last = name
-    return sorted(vcf_entries, key=lambda entry: (rank[entry[0][0]], entry[0][1], entry[0][2]))
+    return rank
 
 
 def _header_lines(version, contig_names, contig_lengths, types_to_output, options):
@@ -535,67 +559,127 @@ def _header_lines(version, contig_names, contig_lengths, types_to_output, option
     yield "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + options.sample
 
 
-def collect_vcf_entries(int_duplication_candidates, inversion_candidates, tandem_duplication_candidates,
-                        deletion_candidates, insertion_candidates, breakend_candidates, types_to_output, reference,
-                        options):
-    """((contig, start, end), line, label) per record, in the reference's list order (:428-464)."""
-    seq = not options.symbolic_alleles
-    names = options.query_names
-    entries = []
+def _pool_of_strings(strings):
+    enc = [s.encode("utf-8", "surrogateescape") for s in strings]
+    off = np.zeros(len(enc) + 1, np.int64)
+    if enc:
+        np.cumsum([len(e) for e in enc], out=off[1:])
+    return b"".join(enc), off
+
+
+def vcf_body(table, types_to_output, reference, options):
+    """The record lines of write_final_vcf (:428-477) for the rows of `table` as bytes (every line ends with a
+    newline): entries in the reference's list order, formatted, naturally sorted and numbered by
+    svx_vcf_format."""
+    lib = _lib.load()
+    t = table
+    rows_of = lambda ti: np.flatnonzero(t.type == ti)
+    kinds, rows = [], []
+
+    def add(kind, r):
+        kinds.append(np.full(len(r), kind, np.uint8))
+        rows.append(r)
     if "DEL" in types_to_output:
-        for c in deletion_candidates:
-            contig, start, end = c.get_source()
-            entries.append(((contig, max(1, start), end), c.get_vcf_entry(seq, reference, names), "DEL"))
+        add(_lib.VCF_DEL, rows_of(T_DEL))
     if "INV" in types_to_output:
-        for c in inversion_candidates:
-            contig, start, end = c.get_source()
-            entries.append(((contig, start + 1, end), c.get_vcf_entry(seq, reference, names), "INV"))
+        add(_lib.VCF_INV, rows_of(T_INV))
     if "INS" in types_to_output:
-        for c in insertion_candidates:
-            contig, start, end = c.get_destination()
-            entries.append(((contig, max(1, start), end), c.get_vcf_entry(seq, reference, names), "INS"))
+        add(_lib.VCF_INS, rows_of(T_INS))
     if options.tandem_duplications_as_insertions:
         if "INS" in types_to_output:
-            for c in tandem_duplication_candidates:
-                entries.append(((c.source_contig, c.source_start + 1, c.source_end),
-                                c.get_vcf_entry_as_ins(seq, reference, names), "INS"))
+            add(_lib.VCF_DUPTAN_INS, rows_of(T_DUP_TAN))
     elif "DUP:TANDEM" in types_to_output:
-        for c in tandem_duplication_candidates:
-            entries.append(((c.source_contig, c.source_start + 1, c.source_end), c.get_vcf_entry_as_dup(names),
-                            "DUP_TANDEM"))
+        add(_lib.VCF_DUPTAN_DUP, rows_of(T_DUP_TAN))
     if options.interspersed_duplications_as_insertions:
         if "INS" in types_to_output:
-            for c in int_duplication_candidates:
-                contig, start, end = c.get_destination()
-                entries.append(((contig, max(1, start), end), c.get_vcf_entry_as_ins(seq, reference, names), "INS"))
+            add(_lib.VCF_DUPINT_INS, rows_of(T_DUP_INT))
     elif "DUP:INT" in types_to_output:
-        for c in int_duplication_candidates:
-            contig, start, end = c.get_source()
-            entries.append(((contig, start + 1, end), c.get_vcf_entry_as_dup(names), "DUP_INT"))
+        add(_lib.VCF_DUPINT_DUP, rows_of(T_DUP_INT))
     if "BND" in types_to_output:
-        for c in breakend_candidates:
-            (sc, sp), (dc, dp) = c.get_source(), c.get_destination()
-            entries.append(((sc, sp + 1, sp + 2), c.get_vcf_entry(names), "BND"))
-            entries.append(((dc, dp + 1, dp + 2), c.get_vcf_entry_reverse(names), "BND"))
-    return entries
+        b = rows_of(T_BND)  # two entries per breakend, the mate's right behind it (:463-464)
+        kinds.append(np.tile(np.array([_lib.VCF_BND, _lib.VCF_BND_REV], np.uint8), len(b)))
+        rows.append(np.repeat(b, 2))
+    kind = np.concatenate(kinds) if kinds else np.zeros(0, np.uint8)
+    row = np.concatenate(rows).astype(np.int64) if rows else np.zeros(0, np.int64)
+    ne = len(kind)
+    seq = not options.symbolic_alleles
+    bases = np.zeros(0, np.uint8)
+    b_off = b_len = b2_off = b2_len = np.zeros(ne, np.int64)
+    if seq and ne:
+        # the REF alleles the formatters fetch (SVCandidate.py:57,105,155,210,301-302), one batch, upper-cased
+        ss, se, ds = t.ss[row], t.se[row], t.ds[row]
+        on_dst = (kind == _lib.VCF_INS) | (kind == _lib.VCF_DUPINT_INS)
+        wants = (kind == _lib.VCF_DEL) | (kind == _lib.VCF_INV) | (kind == _lib.VCF_DUPTAN_INS) | on_dst
+        cid = np.where(on_dst, t.dc[row], t.sc[row])
+        lo = np.where(kind == _lib.VCF_DEL, np.maximum(0, ss - 1), np.where(on_dst, np.maximum(0, ds - 1), ss))
+        hi = np.where(on_dst, ds, se)
+        w = np.flatnonzero(wants)
+        w2 = np.flatnonzero(kind == _lib.VCF_DUPINT_INS)
+        f_cid = np.concatenate((cid[w], t.sc[row][w2]))
+        f_lo = np.concatenate((lo[w], ss[w2]))
+        f_hi = np.concatenate((hi[w], se[w2]))
+        bases, off = _fetch_windows(reference, [t.contigs[c] for c in f_cid.tolist()], f_lo, f_hi, True)
+        b_off, b_len = np.zeros(ne, np.int64), np.zeros(ne, np.int64)
+        b2_off, b2_len = np.zeros(ne, np.int64), np.zeros(ne, np.int64)
+        ln = off[1:] - off[:-1]
+        b_off[w], b_len[w] = off[:-1][:len(w)], ln[:len(w)]
+        b2_off[w2], b2_len[w2] = off[:-1][len(w):], ln[len(w):]
+    if seq:
+        reference.close()  # (:466-467)
+    if ne == 0:
+        return b""
+    natural = _natural_ranks(set(t.contigs))
+    contig_rank = np.array([natural[c] for c in t.contigs], dtype=np.int32)
+    contig_pool, contig_off = _pool_of_strings(t.contigs)
+    gt_pool, gt_off = _pool_of_strings(t.genotypes)
+    keep = []  # arrays the struct points into
+
+    def ptr(a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        keep.append(a)
+        return a.ctypes.data if a.size else None
+    names_pool = t.names.pool if options.query_names else b""
+    keep.extend([contig_pool, gt_pool, names_pool])
+    arg = _lib.VcfIn(
+        n_rows=len(t), sc=ptr(t.sc, np.int32), ss=ptr(t.ss, np.int64), se=ptr(t.se, np.int64), dc=ptr(t.dc, np.int32),
+        ds=ptr(t.ds, np.int64), de=ptr(t.de, np.int64), flag=ptr(t.flag, np.uint8), copies=ptr(t.copies, np.int64),
+        gt=ptr(t.gt, np.uint8), q_off=ptr(t.q_off, np.int64), q_len=ptr(t.q_len, np.int64),
+        r_off=ptr(t.r_off, np.int64), r_flat=ptr(t.r_flat, np.int64), seqs=ptr(t.seqs, np.uint8),
+        names=C.cast(C.c_char_p(names_pool), C.c_void_p).value, name_off=ptr(t.names.off, np.int64),
+        contigs=C.cast(C.c_char_p(contig_pool), C.c_void_p).value, contig_off=ptr(contig_off, np.int64),
+        contig_rank=ptr(contig_rank, np.int32), n_contigs=len(t.contigs),
+        genotypes=C.cast(C.c_char_p(gt_pool), C.c_void_p).value, genotype_off=ptr(gt_off, np.int64),
+        n_genotypes=len(t.genotypes), n_entries=ne, kind=ptr(kind, np.uint8), row=ptr(row, np.uint32),
+        bases=ptr(bases, np.uint8), b_off=ptr(b_off, np.int64), b_len=ptr(b_len, np.int64),
+        b2_off=ptr(b2_off, np.int64), b2_len=ptr(b2_len, np.int64), sequence_alleles=1 if seq else 0,
+        read_names=1 if options.query_names else 0)
+    text, n_bytes, n_lines = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = lib.svx_vcf_format(C.byref(arg), C.byref(text), C.byref(n_bytes), C.byref(n_lines))
+    if rc != 0:
+        raise _lib.SvxError(rc, "svx_vcf_format")
+    try:
+        return C.string_at(text, n_bytes.value)
+    finally:
+        lib.svx_vcf_free(text)
+
+
+def write_vcf_table(table, version, contig_names, contig_lengths, types_to_output, reference, options):
+    """write_final_vcf for a CandidateTable (rows of each type in the order the reference's per-type lists have)."""
+    with open(options.working_dir + "/variants.vcf", "wb") as vcf_output:
+        header = "".join(line + "\n" for line in _header_lines(version, contig_names, contig_lengths, types_to_output, options))
+        vcf_output.write(header.encode("utf-8", "surrogateescape"))
+        vcf_output.write(vcf_body(table, types_to_output, reference, options))
 
 
 def write_final_vcf(int_duplication_candidates, inversion_candidates, tandem_duplication_candidates,
                     deletion_candidates, insertion_candidates, breakend_candidates, version, contig_names,
                     contig_lengths, types_to_output, reference, options):
-    with open(options.working_dir + "/variants.vcf", "w") as vcf_output:
-        for line in _header_lines(version, contig_names, contig_lengths, types_to_output, options):
-            print(line, file=vcf_output)
-        entries = collect_vcf_entries(int_duplication_candidates, inversion_candidates,
-                                      tandem_duplication_candidates, deletion_candidates, insertion_candidates,
-                                      breakend_candidates, types_to_output, reference, options)
-        if not options.symbolic_alleles:
-            reference.close()
-        counter = defaultdict(int)
-        lines = []
-        for _, entry, svtype in sorted_nicely(entries):
-            counter[svtype] += 1
-            lines.append(entry.replace("PLACEHOLDERFORID", "svim_asm.{0}.{1}".format(svtype, counter[svtype]), 1))
-        if lines:
-            vcf_output.write("\n".join(lines))
-            vcf_output.write("\n")
+    class _Header(object):
+        references = tuple(contig_names)
+
+        def get_reference_length(self, name):
+            return contig_lengths[list(contig_names).index(name)]
+    everything = list(deletion_candidates) + list(inversion_candidates) + list(insertion_candidates) + \
+        list(tandem_duplication_candidates) + list(int_duplication_candidates) + list(breakend_candidates)
+    table = CandidateTable.from_objects(everything, _Header())
+    write_vcf_table(table, version, contig_names, contig_lengths, types_to_output, reference, options)

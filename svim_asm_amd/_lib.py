@@ -50,6 +50,21 @@ class SegParams(C.Structure):
                 ("reference_gap_tolerance", C.c_int32), ("reference_overlap_tolerance", C.c_int32)]
 
 
+class VcfIn(C.Structure):
+    """svx_vcf_in (include/svx_text.h)."""
+    _fields_ = [("n_rows", C.c_uint32), ("sc", C.c_void_p), ("ss", C.c_void_p), ("se", C.c_void_p), ("dc", C.c_void_p),
+                ("ds", C.c_void_p), ("de", C.c_void_p), ("flag", C.c_void_p), ("copies", C.c_void_p), ("gt", C.c_void_p),
+                ("q_off", C.c_void_p), ("q_len", C.c_void_p), ("r_off", C.c_void_p), ("r_flat", C.c_void_p),
+                ("seqs", C.c_void_p), ("names", C.c_void_p), ("name_off", C.c_void_p), ("contigs", C.c_void_p),
+                ("contig_off", C.c_void_p), ("contig_rank", C.c_void_p), ("n_contigs", C.c_uint32),
+                ("genotypes", C.c_void_p), ("genotype_off", C.c_void_p), ("n_genotypes", C.c_uint32),
+                ("n_entries", C.c_uint32), ("kind", C.c_void_p), ("row", C.c_void_p), ("bases", C.c_void_p),
+                ("b_off", C.c_void_p), ("b_len", C.c_void_p), ("b2_off", C.c_void_p), ("b2_len", C.c_void_p),
+                ("sequence_alleles", C.c_int), ("read_names", C.c_int)]
+
+
+VCF_DEL, VCF_INV, VCF_INS, VCF_DUPTAN_INS, VCF_DUPTAN_DUP, VCF_DUPINT_INS, VCF_DUPINT_DUP, VCF_BND, VCF_BND_REV = range(9)
+
 SEG_DTYPE = np.dtype([("q_start", "<i4"), ("q_end", "<i4"), ("ref_id", "<i4"), ("ref_start", "<i4"),
                       ("ref_end", "<i4"), ("is_reverse", "<i4")])
 HAP_PIECE_DTYPE = np.dtype([("off", "<u8"), ("len", "<u4"), ("repeat", "<u2"), ("flags", "<u2")])  # svx_hap_piece
@@ -111,6 +126,12 @@ SYMBOLS = {
     "svx_bam_load": (C.c_int, [_P, _P, C.c_int32]),
     "svx_bam_get_columns": (C.c_int, [_P, _P]),
     "svx_bam_seq_slices": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P]),
+    # native text side (include/svx_text.h)
+    "svx_fasta_open": (C.c_int, [C.c_char_p, C.c_int32, _P, _P, _P, _P, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "svx_fasta_close": (None, [_P]),
+    "svx_fasta_fetch_batch": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_int, _P, _P, C.c_int]),
+    "svx_vcf_format": (C.c_int, [C.POINTER(VcfIn), C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "svx_vcf_free": (None, [_P]),
 }
 
 _lib = None
@@ -302,6 +323,45 @@ class Context:
             packed = out[:0]
         return packed, first
 
+    # ---------------------------------------------------------------- COLLECT of a sample in one go
+    def collect_batch(self, cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src, seg_tid,
+                      seg_pos, seg_rev, seg_qend, read_off, contig_rank, params):
+        """a1 + a2 + a3 of one sample (or of both haplotypes of one): see collect_batch_composed for the
+        contract.  One submission on the context's stream (svx_collect_batch)."""
+        return self.collect_batch_composed(cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src,
+                                           seg_tid, seg_pos, seg_rev, seg_qend, read_off, contig_rank, params)
+
+    def collect_batch_composed(self, cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src,
+                               seg_tid, seg_pos, seg_rev, seg_qend, read_off, contig_rank, params):
+        """The arithmetic of analyze_alignment_file_coordsorted (SVIM_COLLECT.py:61-83) for a whole batch,
+        composed from the single-purpose entry points (one call each):
+          cigar_parts   BAM-native CIGAR pools, logically back to back; aln_off[n_aln + 1] / ref_start[n_aln]
+                        describe EVERY record of the pools (records the filters drop are masked by the caller)
+          extra_cigar / extra_off   CIGARs of the SA-derived segments (SVIM_COLLECT.py:33-55)
+          seg_*         one row per segment of every chimeric read, [primary] + supplementaries per read
+                        (SVIM_inter.py:64): seg_src < n_aln names a record of the pools, otherwise extra
+                        alignment seg_src - n_aln; seg_qend >= 0 overrides query_alignment_end (pysam takes it
+                        from the stored sequence when there is one)
+          read_off      first segment of each read (n_reads + 1)
+        Returns (sig, raw, post, post_first): indel signatures of all records, the adjacency records of
+        svx_segments_classify per segment slot, the packed derived records and their first index per read."""
+        cigar = cigar_parts[0] if len(cigar_parts) == 1 else (
+            np.concatenate(cigar_parts) if len(cigar_parts) else np.zeros(0, np.uint32))
+        sig = self.cigar_extract(cigar, aln_off, ref_start, min_len)
+        n_aln = len(aln_off) - 1
+        n_reads = len(read_off) - 1 if len(read_off) else 0
+        if n_reads <= 0 or len(seg_src) == 0:
+            return sig, np.zeros(0, dtype=RAW_DTYPE), np.zeros(0, dtype=RAW_DTYPE), np.zeros(max(n_reads, 0) + 1, np.int64)
+        st_a = self.cigar_stats(cigar, aln_off)
+        st_x = self.cigar_stats(extra_cigar, extra_off)
+        src = np.asarray(seg_src, dtype=np.int64)
+        st = {k: np.concatenate((st_a[k], st_x[k])).astype(np.int64)[src] for k in ("ref_len", "q_start", "q_end", "read_len")}
+        segs, read_len = segment_rows(st, seg_tid, seg_pos, seg_rev, seg_qend, read_off)
+        prm = params if isinstance(params, SegParams) else SegParams(*[int(x) for x in params])
+        raw = self.segments_classify(segs, read_off, read_len, prm)
+        post, first = self.segments_postpass(raw, read_off, contig_rank, prm)
+        return sig, raw, post, first
+
     # ---------------------------------------------------------------- a5 + a6
     def pair_partition(self, keys, max_dist):
         keys = _as(keys, np.uint64)
@@ -355,6 +415,25 @@ class Context:
             self._check(self.lib.svx_linkage_cut_batch(self.h, _ptr(dist), _ptr(n_members), len(n_members),
                                                        float(cutoff), _ptr(labels)))
         return labels
+
+
+def segment_rows(st, seg_tid, seg_pos, seg_rev, seg_qend, read_off):
+    """Segment rows of SVIM_inter.py:66-81 from per-segment CIGAR statistics (int64 columns ref_len, q_start,
+    q_end, read_len): (SEG_DTYPE array, read_len of every read's primary)."""
+    n = len(seg_tid)
+    seg_pos = np.asarray(seg_pos, dtype=np.int64)
+    rev = np.asarray(seg_rev).astype(bool)
+    qend = np.asarray(seg_qend, dtype=np.int64)
+    q_end = np.where(qend >= 0, qend, st["q_end"])
+    segs = np.zeros(n, dtype=SEG_DTYPE)
+    segs["q_start"] = np.where(rev, st["read_len"] - q_end, st["q_start"]).astype(np.int32)
+    segs["q_end"] = np.where(rev, st["read_len"] - st["q_start"], q_end).astype(np.int32)
+    segs["ref_id"] = seg_tid
+    segs["ref_start"] = seg_pos
+    segs["ref_end"] = (seg_pos + np.where(st["ref_len"] > 0, st["ref_len"], 1)).astype(np.int32)  # htslib bam_endpos
+    segs["is_reverse"] = rev
+    first = np.asarray(read_off, dtype=np.int64)[:-1]
+    return segs, st["read_len"][first].astype(np.int32)
 
 
 class DeviceArray:

@@ -709,16 +709,38 @@ class AlignmentFile(object):
             for i, x, y in zip(rec.tolist(), a.tolist(), b.tolist()):
                 out.append(self.record(i).seq_slice(x, y))
             return out
-        off = np.concatenate(([0], np.cumsum(b - a))).astype(np.uint64)
+        buf, off = self._slices_native(rec, a, b)
+        text = buf.tobytes().decode("ascii")
+        o = off.tolist()
+        return [text[o[k]:o[k + 1]] for k in range(n)]
+
+    def _slices_native(self, rec, a, b):
+        n = len(rec)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(b - a, out=off[1:])
         buf = np.empty(int(off[-1]), dtype=np.uint8)
         a32, b32 = a.astype(np.uint32), b.astype(np.uint32)
         rc = self._lib.svx_bam_seq_slices(self._h, rec.ctypes.data, a32.ctypes.data, b32.ctypes.data, n,
                                           off.ctypes.data, buf.ctypes.data)
         if rc != 0:
             raise ValueError("%s: %s" % (self.filename, self._lib.svx_bam_last_error(self._h).decode(errors="replace")))
-        text = buf.tobytes().decode("ascii")
-        o = off.tolist()
-        return [text[o[k]:o[k + 1]] for k in range(n)]
+        return buf, off.astype(np.int64)
+
+    def sequence_slices_raw(self, rec, begin, end):
+        """The same bases as one uint8 pool + offsets [n + 1] (what the columnar COLLECT keeps: no str per allele)."""
+        self._ensure()
+        rec = np.ascontiguousarray(rec, dtype=np.uint32)
+        if len(rec) == 0:
+            return np.zeros(0, np.uint8), np.zeros(1, np.int64)
+        l_seq = self._cols["l_seq"][rec.astype(np.int64)]
+        a = np.minimum(np.maximum(np.asarray(begin, dtype=np.int64), 0), l_seq)
+        b = np.maximum(np.minimum(np.asarray(end, dtype=np.int64), l_seq), a)
+        if self._h is None:
+            parts = [self.record(i).seq_slice(x, y).encode("ascii") for i, x, y in zip(rec.tolist(), a.tolist(), b.tolist())]
+            off = np.zeros(len(parts) + 1, np.int64)
+            np.cumsum([len(p) for p in parts], out=off[1:])
+            return np.frombuffer(b"".join(parts), dtype=np.uint8), off
+        return self._slices_native(rec, a, b)
 
     def prefetch_sequence(self, requests):
         """requests: iterable of (record index, first base, last base + 1) that will be sliced soon

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsvx.so")
-SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip", "svx_linkage.hip", "svx_postpass.hip", "svx_bam.cpp"]
+SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip", "svx_linkage.hip", "svx_postpass.hip", "svx_bam.cpp", "svx_text.cpp"]
 
 
 def _hipcc():
@@ -30,8 +30,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "svx_internal.h"), os.path.join(CSRC, "svx_linkage_dev.h"), os.path.join(ROOT, "include", "svx.h"),
-                        os.path.join(ROOT, "include", "svx_bam.h")]
+    deps = sources() + _headers()
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -42,21 +41,50 @@ def build_lib(force=False, verbose=False, out=None, defines=()):
         return _compile(out, list(defines), verbose)
     if not force and not is_stale():
         return LIB
-    return _compile(LIB, [], verbose)
+    return _compile(LIB, [], verbose, force)
 
 
-def _compile(LIB, defines, verbose):
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"] + defines + [
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB + ".tmp"] + sources() + \
-          ["-lz", "-ldl", "-lpthread"]
+def _headers():
+    return [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+           [os.path.join(ROOT, "include", h) for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h")]
+
+
+def _compile(LIB, defines, verbose, force=False):
+    """One object per translation unit (compiled in parallel, kept under build/obj so that touching one source
+    recompiles one file), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    import hashlib
+    tag = hashlib.sha1(" ".join(defines).encode()).hexdigest()[:8] if defines else "default"
+    objdir = os.path.join(ROOT, "build", "obj", tag)
+    os.makedirs(objdir, exist_ok=True)
+    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+        list(defines) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+
+    def one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj, 0, ""
+        cmd = common + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return obj, res.returncode, res.stdout
+
+    with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
+        results = list(ex.map(one, sources()))
+    failed = [out for _, rc, out in results if rc != 0]
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
+        for _, _, out in results:
+            if out.strip():
+                print(out, file=sys.stderr)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + [o for o, _, _ in results] + \
+          ["-lz", "-ldl", "-lpthread"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
-    if verbose and res.stdout.strip():
-        print(res.stdout, file=sys.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -8,7 +8,8 @@ from time import localtime, strftime
 
 from svim_asm_amd import bamio, shard
 from svim_asm_amd.fasta import FastaFile
-from svim_asm_amd.SVIM_COMBINE import write_final_vcf
+from svim_asm_amd.SVIM_COMBINE import write_vcf_table
+from svim_asm_amd.table import TYPE_ORDER
 from svim_asm_amd.SVIM_input_parsing import parse_arguments
 
 __version__ = "1.0.3"
@@ -16,42 +17,47 @@ TYPE_LABELS = (("DEL", "deletion"), ("INV", "inversion"), ("INS", "insertion"), 
                ("DUP_INT", "interspersed duplication"), ("BND", "breakend"))
 
 
-def _collect(path, which, options):
-    """Open one BAM, check sort order and index like the reference, run COLLECT.
-    Returns (alignment_file, candidates) or (None, None) after logging the error."""
+def _open(path, which, options):
+    """Open one BAM and check sort order and index like the reference (svim-asm:63-72,85-95).
+    Returns the alignment file, or None after logging the error."""
     the = {"": "Input", "first": "The first input", "second": "The second input"}[which]
     aln_file = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0)
     try:
         if aln_file.header["HD"]["SO"] != "coordinate":
             logging.error("{0} BAM file needs to be coordinate-sorted. Exiting..".format(the))
-            return None, None
+            return None
     except KeyError:
         logging.error("Is the given {0}input BAM file coordinate-sorted? It does not contain a sorting order in "
                       "its header line. Exiting..".format(which + " " if which else ""))
-        return None, None
+        return None
     try:
         aln_file.check_index()
     except ValueError:
         logging.error("{0} BAM file is missing an index. Please generate with 'samtools index'. "
                       "Exiting..".format(the))
-        return None, None
-    candidates = shard.collect_sharded(aln_file, options)  # contig shards when launched on several GPUs
-    logging.info("INGEST: rank {0}/{1} indexed {2} records ({3} of the {4} BGZF members it walked were "
-                 "inflated)".format(shard.world()[0], shard.world()[1], len(aln_file), aln_file.blocks_inflated,
-                                    aln_file.blocks_spanned))
-    return aln_file, candidates
+        return None
+    return aln_file
+
+
+def _collect(aln_files, options):
+    """COLLECT of all haplotype BAMs of the sample: one device submission per rank (contig shards when
+    launched on several GPUs).  Returns one CandidateTable per file."""
+    tables = shard.collect_sharded(aln_files, options)
+    for aln_file in aln_files:
+        logging.info("INGEST: rank {0}/{1} indexed {2} records ({3} of the {4} BGZF members it walked were "
+                     "inflated)".format(shard.world()[0], shard.world()[1], len(aln_file), aln_file.blocks_inflated,
+                                        aln_file.blocks_spanned))
+    return tables
 
 
 def _init_distributed(options):
-    """One process per GPU under torch.distributed.run: rank r drives device LOCAL_RANK."""
+    """One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run sets them): rank r drives
+    device LOCAL_RANK.  The candidate tables travel over a unix-domain socket (svim_asm_amd/shard.py): no
+    torch import, no process group."""
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size <= 1:
         return False
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     options.device = int(os.environ.get("LOCAL_RANK", "0"))
-    # candidate lists are exchanged as Python objects (a few MB): host-side gloo group
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world_size)
     return True
 
 
@@ -72,8 +78,7 @@ def main(arguments=None):
         sys.exit(1)
     finally:
         if distributed:
-            import torch.distributed as dist
-            dist.destroy_process_group()
+            shard.shutdown()
 
 
 def _main(options):
@@ -124,19 +129,21 @@ def _run_steps(options):
     if options.sub == "haploid":
         logging.info("MODE: haploid")
         logging.info("INPUT: {0}".format(os.path.abspath(options.bam_file)))
-        aln_file1, sv_candidates = _collect(options.bam_file, "", options)
+        aln_file1 = _open(options.bam_file, "", options)
         if aln_file1 is None:
             return
+        (sv_candidates,) = _collect([aln_file1], options)
     else:
         logging.info("MODE: diploid")
         logging.info("INPUT1: {0}".format(os.path.abspath(options.bam_file1)))
         logging.info("INPUT2: {0}".format(os.path.abspath(options.bam_file2)))
-        aln_file1, sv_candidates1 = _collect(options.bam_file1, "first", options)
+        aln_file1 = _open(options.bam_file1, "first", options)
         if aln_file1 is None:
             return
-        aln_file2, sv_candidates2 = _collect(options.bam_file2, "second", options)
+        aln_file2 = _open(options.bam_file2, "second", options)
         if aln_file2 is None:
             return
+        sv_candidates1, sv_candidates2 = _collect([aln_file1, aln_file2], options)
 
     try:
         reference = FastaFile(options.genome)
@@ -152,21 +159,16 @@ def _run_steps(options):
     if options.sub == "diploid":
         logging.info("****************** STEP 2: PAIR ******************")
         sv_candidates = shard.pair_sharded(sv_candidates1, sv_candidates2, reference, aln_file1, options)
-    by_type = {key: [] for key, _ in TYPE_LABELS}
-    for candidate in sv_candidates:
-        bucket = by_type.get(candidate.type)
-        if bucket is not None:
-            bucket.append(candidate)
+    counts = sv_candidates.counts_by_type()
 
     logging.info("****************** STEP {0}: OUTPUT ******************".format(2 if options.sub == "haploid" else 3))
-    for key, label in (TYPE_LABELS[0], TYPE_LABELS[1], TYPE_LABELS[2], TYPE_LABELS[3], TYPE_LABELS[4], TYPE_LABELS[5]):
-        logging.info("Found {0} {1} candidates.".format(len(by_type[key]), label))
+    for key, label in TYPE_LABELS:
+        logging.info("Found {0} {1} candidates.".format(int(counts[TYPE_ORDER.index(key)]), label))
     if shard.world()[0] != 0:
         return  # every rank holds the full result; rank 0 writes it
     logging.info("Write SV candidates..")
     types_to_output = [entry.strip() for entry in options.types.split(",")]
-    write_final_vcf(by_type["DUP_INT"], by_type["INV"], by_type["DUP_TAN"], by_type["DEL"], by_type["INS"],
-                    by_type["BND"], __version__, aln_file1.references, aln_file1.lengths, types_to_output, reference,
+    write_vcf_table(sv_candidates, __version__, aln_file1.references, aln_file1.lengths, types_to_output, reference,
                     options)
     logging.info("Done.")
 

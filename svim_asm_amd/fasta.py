@@ -32,6 +32,45 @@ class FastaFile(object):
             self._map = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ) if os.path.getsize(path) else None
         except (OSError, ValueError):
             self._map = None
+        self._native = None  # svx_fasta handle (libsvx.so), opened by the first batch fetch
+
+    def _handle(self):
+        if self._native is None:
+            import ctypes as C
+            from svim_asm_amd import _lib
+            lib = _lib.load()
+            rows = [self._idx[name] for name in self.references]
+            cols = [np.array([r[k] for r in rows], dtype=dt) for k, dt in ((0, np.int64), (1, np.int64), (2, np.int32), (3, np.int32))]
+            h, err = C.c_void_p(), C.create_string_buffer(256)
+            rc = lib.svx_fasta_open(os.fsencode(self.filename), len(rows), cols[0].ctypes.data, cols[1].ctypes.data,
+                                    cols[2].ctypes.data, cols[3].ctypes.data, C.byref(h), err, len(err))
+            if rc != 0:
+                raise IOError(err.value.decode(errors="replace"))
+            self._native = (lib, h)
+            self._ref_index = {}
+            for i, name in enumerate(self.references):
+                self._ref_index.setdefault(name, i)
+        return self._native
+
+    def fetch_batch(self, contigs, start, end, upper=True):
+        """fetch(contigs[i], start[i], end[i]) for all i in one native call (threads, no str objects):
+        (uint8 pool, int64 offsets [n + 1]); `upper` applies str.upper() to every slice."""
+        lib, h = self._handle()
+        n = len(contigs)
+        ref = np.fromiter((self._ref_index[c] for c in contigs), dtype=np.int32, count=n)
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        end = np.ascontiguousarray(end, dtype=np.int64)
+        if n and (bool((start < 0).any()) or bool((end < start).any())):
+            raise ValueError("fetch coordinates out of range")
+        length = np.asarray(self.lengths, dtype=np.int64)[ref] if n else np.zeros(0, np.int64)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.maximum(np.minimum(end, length) - start, 0), out=off[1:])
+        out = np.empty(int(off[-1]), dtype=np.uint8)
+        rc = lib.svx_fasta_fetch_batch(h, ref.ctypes.data, start.ctypes.data, end.ctypes.data, n, 1 if upper else 0,
+                                       off.ctypes.data, out.ctypes.data, 0)
+        if rc != 0:
+            raise ValueError("reference windows shorter than the index says (%s)" % self.filename)
+        return out, off.astype(np.int64)
 
     def get_reference_length(self, name):
         return self._idx[name][0]
@@ -63,6 +102,10 @@ class FastaFile(object):
         return raw
 
     def close(self):
+        if getattr(self, "_native", None) is not None:
+            lib, h = self._native
+            lib.svx_fasta_close(h)
+            self._native = None
         if getattr(self, "_map", None) is not None:
             self._map.close()
             self._map = None

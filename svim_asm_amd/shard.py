@@ -2,25 +2,34 @@
 
 COLLECT: every alignment (and every chimeric read: its SA-derived segments are reconstructed
 from the primary's tag, SVIM_COLLECT.py:76) lives wholly in the contig of its record, so contigs
-are independent units.  They are distributed over the ranks by LPT bin packing on their CIGAR
-op counts; each rank runs the ordinary batched COLLECT on its contigs with its own GPU and the
-per-contig candidate lists are exchanged with one all_gather_object (host concat — a few MB;
-no RCCL data-path collective is justified) and re-assembled in header-contig order, which is
-the reference's output order (SVIM_COLLECT.py:64).
+are independent units.  They are distributed over the ranks by LPT bin packing on the compressed
+bytes the `.bai` attributes to them; each rank walks and inflates only its own contigs of BOTH
+haplotype BAMs, runs the ordinary batched COLLECT (one device submission) on its own GPU, and the
+candidate TABLES (numpy columns, a few MB) are exchanged once and re-assembled in header-contig
+order, which is the reference's output order (SVIM_COLLECT.py:64).
 PAIR: partitions never span key contigs (SVIM_COMBINE.py:24-25), so after the exchange each
 rank pairs the key contigs it owns and the results are merged type by type in contig-name
 (Python str) order — the order the reference's sort produces.
-One process per GPU, launched with torch.distributed.run; world size 1 needs no process group.
+
+The path has no device-side exchange step (no RCCL collective is justified for a few MB of host
+columns).  One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run sets them.
+The exchange itself needs no torch: rank 0 listens on a unix-domain socket named after the job
+(MASTER_PORT), the others connect, one pickled message each way per all-gather.  When the caller
+has initialised a torch.distributed process group (the CPU tests do, with gloo), that group's
+all_gather_object is used instead.
 """
 import os
 import sys
+import time
 
 import numpy as np
 
+from svim_asm_amd.table import CandidateTable
 
-def _dist():
-    # importing torch costs seconds: only look for a process group when one can exist
-    if "torch.distributed" not in sys.modules and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+
+# ------------------------------------------------------------------------------ the group
+def _torch_group():
+    if "torch.distributed" not in sys.modules:
         return None
     try:
         import torch.distributed as dist
@@ -32,10 +41,103 @@ def _dist():
 
 
 def world():
-    d = _dist()
-    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+    d = _torch_group()
+    if d is not None:
+        return d.get_rank(), d.get_world_size()
+    size = int(os.environ.get("WORLD_SIZE", "1"))
+    return (int(os.environ.get("RANK", "0")), size) if size > 1 else (0, 1)
 
 
+class _SocketGroup(object):
+    """all_gather of picklable objects over a unix-domain socket: rank 0 collects and redistributes."""
+
+    def __init__(self, rank, size, timeout=120.0):
+        from multiprocessing.connection import Client, Listener
+        self.rank, self.size = rank, size
+        job = os.environ.get("SVX_RENDEZVOUS") or "svx-%s-%s-%d" % (
+            os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.getuid())
+        address = "\0" + job  # abstract namespace: nothing to unlink, gone with the processes
+        key = job.encode()
+        if rank == 0:
+            self.listener = Listener(address, family="AF_UNIX", authkey=key)
+            self.peers = [None] * size
+            self.listener._listener._socket.settimeout(timeout)
+            for _ in range(size - 1):
+                conn = self.listener.accept()
+                self.peers[conn.recv()] = conn
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    self.conn = Client(address, family="AF_UNIX", authkey=key)
+                    break
+                except (ConnectionRefusedError, FileNotFoundError):
+                    if time.time() > deadline:
+                        raise RuntimeError("rank %d: rank 0 did not open the exchange socket within %.0f s" % (rank, timeout))
+                    time.sleep(0.005)
+            self.conn.send(rank)
+
+    def all_gather(self, obj):
+        if self.rank == 0:
+            everything = [obj] + [None] * (self.size - 1)
+            for r in range(1, self.size):
+                everything[r] = self.peers[r].recv()
+            for r in range(1, self.size):
+                self.peers[r].send(everything)
+            return everything
+        self.conn.send(obj)
+        return self.conn.recv()
+
+    def close(self):
+        if self.rank == 0:
+            for c in self.peers[1:]:
+                if c is not None:
+                    c.close()
+            self.listener.close()
+        else:
+            self.conn.close()
+
+
+_group = None
+
+
+def _all_gather(obj):
+    global _group
+    d = _torch_group()
+    if d is not None:
+        gathered = [None] * d.get_world_size()
+        d.all_gather_object(gathered, obj)
+        return gathered
+    if _group is None:
+        rank, size = world()
+        _group = _SocketGroup(rank, size)
+    return _group.all_gather(obj)
+
+
+def shutdown():
+    global _group
+    if _group is not None:
+        _group.close()
+        _group = None
+
+
+def _gather_or_raise(compute):
+    """all-gather of compute()'s result.  A rank whose compute() raises still takes part in the exchange
+    (with an error marker), so the others do not wait for it until a timeout; every rank then raises."""
+    rank = world()[0]
+    try:
+        mine = ("ok", compute())
+    except Exception as e:  # noqa: BLE001 — forwarded to every rank below
+        import traceback
+        mine = ("error", "rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+    gathered = _all_gather(mine)
+    errors = [payload for status, payload in gathered if status == "error"]
+    if errors:
+        raise RuntimeError("sharded step failed on %d of %d ranks:\n%s" % (len(errors), len(gathered), "\n".join(errors)))
+    return [payload for _, payload in gathered]
+
+
+# ------------------------------------------------------------------------------ the plan
 def lpt_assign(weights, n_bins):
     """Longest-processing-time bin packing.  Returns bin index per item; deterministic
     (ties broken by item index) so every rank computes the same plan without communication."""
@@ -86,71 +188,68 @@ class ContigView(object):
         return getattr(self._bam, name)
 
 
-def _gather_or_raise(compute):
-    """all_gather_object of compute()'s result.  A rank whose compute() raises still takes part in
-    the exchange (with an error marker), so the others do not wait for it until the process-group
-    timeout; every rank then raises."""
-    d = _dist()
-    try:
-        mine = ("ok", compute())
-    except Exception as e:  # noqa: BLE001 — forwarded to every rank below
-        import traceback
-        mine = ("error", "rank %d: %s\n%s" % (d.get_rank(), e, traceback.format_exc()))
-    gathered = [None] * d.get_world_size()
-    d.all_gather_object(gathered, mine)
-    errors = [payload for status, payload in gathered if status == "error"]
-    if errors:
-        raise RuntimeError("sharded step failed on %d of %d ranks:\n%s" % (len(errors), len(gathered), "\n".join(errors)))
-    return [payload for _, payload in gathered]
-
-
-def collect_sharded(bam, options, collect_fn=None):
-    """Distributed analyze_alignment_file_coordsorted: same return value on every rank."""
+# ------------------------------------------------------------------------------ COLLECT / PAIR
+def collect_sharded(bams, options, collect_fn=None):
+    """Distributed COLLECT of the haplotype BAMs of one sample: the CandidateTable of every bam, the same
+    on every rank."""
     if collect_fn is None:
-        from svim_asm_amd.SVIM_COLLECT import analyze_alignment_file_coordsorted as collect_fn
+        from svim_asm_amd.SVIM_COLLECT import collect_tables as collect_fn
+    bams = list(bams)
     rank, size = world()
     if size == 1:
-        return collect_fn(bam, options)
-    owner = lpt_assign(contig_weights(bam), size)
+        return collect_fn(bams, options)
+    weights = sum(np.asarray(contig_weights(b), dtype=np.int64) for b in bams)
+    owner = lpt_assign(weights, size)
     mine = [i for i, r in enumerate(owner) if r == rank]
 
     def local():
-        load = getattr(bam, "load", None)
-        if load is not None:  # walk / inflate only the BGZF ranges of the contigs this rank owns
-            load([bam.references[i] for i in mine])
-        # one COLLECT call per owned contig keeps the per-contig lists separable
-        return [(i, collect_fn(ContigView(bam, [i]), options)) for i in mine]
+        views = []
+        for b in bams:
+            load = getattr(b, "load", None)
+            if load is not None:  # walk / inflate only the BGZF ranges of the contigs this rank owns
+                load([b.references[i] for i in mine])
+            views.append(ContigView(b, mine))
+        tables = collect_fn(views, options)
+        for t in tables:
+            if getattr(t, "rec_tid", None) is None:
+                raise RuntimeError("COLLECT tables of a sharded run need the record contig of every row")
+        return tables
 
-    merged = {}
-    for part in _gather_or_raise(local):
-        for i, cands in part:
-            merged[i] = cands
+    parts = _gather_or_raise(local)
     out = []
-    for i in range(len(bam.references)):
-        out.extend(merged.get(i, []))
+    for k, bam in enumerate(bams):
+        merged = CandidateTable.concat([p[k] for p in parts], list(bam.references),
+                                       [bam.get_reference_length(c) for c in bam.references])
+        rec_tid = np.concatenate([p[k].rec_tid for p in parts])
+        # every rank's rows are in header order for its own contigs, and the contigs are disjoint
+        o = np.argsort(rec_tid, kind="stable")
+        merged = merged.take(o)
+        merged.rec_tid = rec_tid[o]
+        out.append(merged)
     return out
 
 
-def pair_sharded(sv_candidates1, sv_candidates2, reference, bam, options, pair_fn=None, type_order=None):
-    """Distributed pair_candidates: same return value on every rank."""
+def pair_sharded(table1, table2, reference, bam, options, pair_fn=None):
+    """Distributed pair_candidates on tables: the same CandidateTable on every rank."""
     if pair_fn is None:
-        from svim_asm_amd.SVIM_COMBINE import pair_candidates as pair_fn
-    if type_order is None:
-        type_order = ("DEL", "INV", "INS", "DUP_TAN", "DUP_INT", "BND")
+        from svim_asm_amd.SVIM_COMBINE import pair_tables as pair_fn
     rank, size = world()
     if size == 1:
-        return pair_fn(sv_candidates1, sv_candidates2, reference, bam, options)
-    key_contig = lambda c: c.get_key()[1]
-    contigs = sorted(set(key_contig(c) for c in sv_candidates1) | set(key_contig(c) for c in sv_candidates2))
-    counts = {n: 0 for n in contigs}
-    for c in list(sv_candidates1) + list(sv_candidates2):
-        counts[key_contig(c)] += 1
-    owner = dict(zip(contigs, lpt_assign([counts[n] for n in contigs], size)))
-    mine1 = [c for c in sv_candidates1 if owner[key_contig(c)] == rank]
-    mine2 = [c for c in sv_candidates2 if owner[key_contig(c)] == rank]
-    gathered = _gather_or_raise(lambda: pair_fn(mine1, mine2, reference, bam, options))
-    everything = [c for part in gathered for c in part]
-    out = []
-    for typ in type_order:  # reference order: type by type, sorted (contig name, position) inside
-        out.extend(sorted((c for c in everything if c.type == typ), key=key_contig))
-    return out
+        return pair_fn(table1, table2, reference, bam, options)
+    from svim_asm_amd.SVIM_COMBINE import _str_rank
+    # key contigs by NAME (the two tables may number contigs differently)
+    names1 = np.array(table1.contigs, dtype=object)[table1.key_contig()] if len(table1) else np.zeros(0, object)
+    names2 = np.array(table2.contigs, dtype=object)[table2.key_contig()] if len(table2) else np.zeros(0, object)
+    counts = {}
+    for name in names1.tolist() + names2.tolist():
+        counts[name] = counts.get(name, 0) + 1
+    contigs = sorted(counts)
+    owner = dict(zip(contigs, lpt_assign([counts[c] for c in contigs], size)))
+    mine1 = np.flatnonzero(np.fromiter((owner[c] == rank for c in names1.tolist()), dtype=bool, count=len(names1)))
+    mine2 = np.flatnonzero(np.fromiter((owner[c] == rank for c in names2.tolist()), dtype=bool, count=len(names2)))
+    gathered = _gather_or_raise(lambda: pair_fn(table1.take(mine1), table2.take(mine2), reference, bam, options))
+    base = getattr(bam, "_bam", bam)
+    everything = CandidateTable.concat(gathered, list(base.references), [base.get_reference_length(c) for c in base.references])
+    # reference order: type by type, (contig name, position) inside — every rank's part is sorted already
+    o = np.lexsort((_str_rank(everything.contigs)[everything.key_contig()], everything.type))
+    return everything.take(o)

@@ -298,6 +298,38 @@ def write_bam(path, contigs, records, level=1):
     bamio.write_bam(path, names, lengths, blobs, level=level)
 
 
+def payload_digest(path, chunk_members=4096):
+    """SHA-256 of the UNCOMPRESSED content of a BGZF file (the inflated members in file order): the identity
+    of a generated BAM independent of the deflate implementation that wrote it (zlib builds differ in the
+    compressed bytes they produce for the same input, never in what those bytes inflate to)."""
+    import hashlib
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    spans = bamio._bgzf_block_spans(raw)
+    view = memoryview(raw)
+    h = hashlib.sha256()
+
+    def inflate(span):
+        st, ln, isz = span[:3]
+        return zlib.decompress(view[st:st + ln], -15) if isz else b""
+    with ThreadPoolExecutor(min(8, __import__("os").cpu_count() or 1)) as ex:
+        for lo in range(0, len(spans), chunk_members):
+            for part in ex.map(inflate, spans[lo:lo + chunk_members]):
+                h.update(part)
+    return h.hexdigest()
+
+
+def file_digest(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for block in iter(lambda: fh.read(1 << 24), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
 def write_dataset(outdir, seed=1, contigs=CONFIG1_CONTIGS, diploid=True, n_shared=25, n_private=6,
                   median_aln=30000, mean_m=2000, dense_cluster=True, with_splits=True):
     """FASTA + one or two haplotype BAMs under `outdir`; returns their paths."""

@@ -1,0 +1,363 @@
+"""Columnar SV candidates.
+
+The reference keeps one Python object per candidate (SVCandidate.py:1-443) from COLLECT through PAIR to
+the VCF writer; at human scale that is ~10^5 objects and most of the wall-clock.  Here the same state lives
+in numpy columns — one row per candidate, the attributes the reference's constructors set AFTER their
+clamping / normalisation — and the reference's objects are materialised only when somebody asks for them
+(`CandidateList` behaves like the list the reference returns).
+
+Row layout (all types share the columns; unused ones are 0 / -1):
+  type    u8   index into TYPE_ORDER = the processing order of pair_candidates (SVIM_COMBINE.py:182-366)
+  sc ss se     source contig id / start / end      (DEL, INV, DUP_TAN, DUP_INT; BND: sc, ss)
+  dc ds de     destination contig id / start / end (INS, DUP_INT; BND: dc, ds)
+  flag    u8   bit 0: complete (INV) / fully_covered (DUP_TAN) / cutpaste (DUP_INT);
+               bit 1: source_direction == 'rev', bit 2: dest_direction == 'rev' (BND)
+  copies  i64  DUP_TAN
+  gt      u8   index into `genotypes`
+  r_off        CSR offsets into r_flat: the `reads` list = names[r_flat[r_off[i] : r_off[i + 1]]]
+  q_off q_len  the inserted sequence (INS) = seqs[q_off : q_off + q_len]
+Stores shared by the rows: `contigs` / `contig_len` (the BAM header the candidates were clamped against),
+`names` (NamePool), `seqs` (uint8 pool), `genotypes`.
+"""
+from collections.abc import Sequence
+
+import numpy as np
+
+from svim_asm_amd.SVCandidate import (CandidateBreakend, CandidateDeletion, CandidateDuplicationInterspersed,
+                                      CandidateDuplicationTandem, CandidateInsertion, CandidateInversion)
+
+TYPE_ORDER = ("DEL", "INV", "INS", "DUP_TAN", "DUP_INT", "BND")
+T_DEL, T_INV, T_INS, T_DUP_TAN, T_DUP_INT, T_BND = range(6)
+TYPE_INDEX = {t: i for i, t in enumerate(TYPE_ORDER)}
+_CLASSES = (CandidateDeletion, CandidateInversion, CandidateInsertion, CandidateDuplicationTandem,
+            CandidateDuplicationInterspersed, CandidateBreakend)
+F_BOOL, F_SRC_REV, F_DST_REV = 1, 2, 4
+GENOTYPES = ("1/1", "1/0", "0/1")
+_DIR = ("fwd", "rev")
+
+_COLUMNS = (("type", np.uint8), ("sc", np.int32), ("ss", np.int64), ("se", np.int64), ("dc", np.int32),
+            ("ds", np.int64), ("de", np.int64), ("flag", np.uint8), ("copies", np.int64), ("gt", np.uint8),
+            ("q_off", np.int64), ("q_len", np.int64))
+
+
+class NamePool(object):
+    """Read names as one byte pool + offsets (the native BAM reader's layout); str on demand."""
+
+    def __init__(self, pool=b"", off=None):
+        self.pool = pool if isinstance(pool, (bytes, bytearray)) else bytes(pool)
+        self.off = np.zeros(1, np.int64) if off is None else np.ascontiguousarray(off, dtype=np.int64)
+
+    @classmethod
+    def from_strings(cls, strings):
+        enc = [s.encode("utf-8", "surrogateescape") for s in strings]
+        off = np.zeros(len(enc) + 1, np.int64)
+        if enc:
+            np.cumsum([len(e) for e in enc], out=off[1:])
+        return cls(b"".join(enc), off)
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def get(self, i):
+        return self.pool[self.off[i]:self.off[i + 1]].decode("utf-8", "surrogateescape")
+
+    def strings(self, idx):
+        o, p = self.off, self.pool
+        return [p[o[i]:o[i + 1]].decode("utf-8", "surrogateescape") for i in idx]
+
+    @staticmethod
+    def concat(pools):
+        """One pool holding the names of `pools` back to back; returns (pool, index shift per input)."""
+        shifts, offs, at, n = [], [np.zeros(1, np.int64)], 0, 0
+        for p in pools:
+            shifts.append(n)
+            offs.append(p.off[1:] + at)
+            at += int(p.off[-1])
+            n += len(p)
+        return NamePool(b"".join(bytes(p.pool[:int(p.off[-1])]) for p in pools), np.concatenate(offs)), shifts
+
+
+class CandidateTable(object):
+    def __init__(self, contigs, contig_len, n=0, names=None, seqs=None, genotypes=GENOTYPES):
+        self.contigs = list(contigs)
+        self.contig_len = np.asarray(contig_len, dtype=np.int64)
+        self.names = names if names is not None else NamePool()
+        self.seqs = seqs if seqs is not None else np.zeros(0, np.uint8)
+        self.genotypes = list(genotypes)
+        for k, dt in _COLUMNS:
+            setattr(self, k, np.zeros(n, dtype=dt))
+        self.sc[:] = -1
+        self.dc[:] = -1
+        self.r_off = np.zeros(n + 1, np.int64)
+        self.r_flat = np.zeros(0, np.int64)
+
+    def __len__(self):
+        return len(self.type)
+
+    # ------------------------------------------------------------------ row algebra
+    def _like(self, n):
+        return CandidateTable(self.contigs, self.contig_len, n, self.names, self.seqs, self.genotypes)
+
+    def take(self, idx):
+        """Rows `idx` (any order, repeats allowed); the stores are shared, not copied."""
+        idx = np.asarray(idx, dtype=np.int64)
+        out = self._like(0)
+        for k, _ in _COLUMNS:
+            setattr(out, k, getattr(self, k)[idx])
+        cnt = (self.r_off[1:] - self.r_off[:-1])[idx]
+        out.r_off = np.zeros(len(idx) + 1, np.int64)
+        np.cumsum(cnt, out=out.r_off[1:])
+        out.r_flat = self.r_flat[_ranges(self.r_off[:-1][idx], cnt)]
+        return out
+
+    def with_reads(self, r_off, r_flat):
+        self.r_off, self.r_flat = np.ascontiguousarray(r_off, np.int64), np.ascontiguousarray(r_flat, np.int64)
+        return self
+
+    @staticmethod
+    def concat(tables, contigs=None, contig_len=None):
+        """Rows of `tables` back to back.  Contig ids are re-expressed in `contigs` (default: the first
+        table's header; names it lacks are appended with length -1 = unknown); name and sequence pools are
+        concatenated."""
+        tables = list(tables)
+        if contigs is None:
+            contigs, contig_len = list(tables[0].contigs), tables[0].contig_len.tolist()
+        else:
+            contigs, contig_len = list(contigs), list(np.asarray(contig_len).tolist())
+        index = {}
+        for i, name in enumerate(contigs):
+            index.setdefault(name, i)
+        names, shifts = NamePool.concat([t.names for t in tables])
+        genotypes = list(GENOTYPES)
+        out = CandidateTable(contigs, contig_len, 0, names, None, genotypes)
+        cols = {k: [] for k, _ in _COLUMNS}
+        r_cnt, r_flat, seq_parts, seq_at = [], [], [], 0
+        for t, shift in zip(tables, shifts):
+            if t.contigs == contigs[:len(t.contigs)] and len(t.contigs) <= len(contigs):
+                remap = None
+            else:
+                remap = np.empty(len(t.contigs) + 1, np.int32)
+                for i, name in enumerate(t.contigs):
+                    if name not in index:
+                        index[name] = len(contigs)
+                        contigs.append(name)
+                        contig_len.append(-1)
+                    remap[i] = index[name]
+                remap[-1] = -1  # id -1 (unused column) stays -1
+            gmap = None
+            if list(t.genotypes) != genotypes[:len(t.genotypes)]:
+                gmap = np.empty(len(t.genotypes), np.uint8)
+                for i, g in enumerate(t.genotypes):
+                    if g not in genotypes:
+                        genotypes.append(g)
+                    gmap[i] = genotypes.index(g)
+            for k, _ in _COLUMNS:
+                v = getattr(t, k)
+                if k in ("sc", "dc") and remap is not None:
+                    v = remap[v]
+                elif k == "gt" and gmap is not None:
+                    v = gmap[v]
+                elif k == "q_off":
+                    v = v + seq_at
+                cols[k].append(v)
+            r_cnt.append(t.r_off[1:] - t.r_off[:-1])
+            r_flat.append(t.r_flat + shift)
+            seq_parts.append(np.asarray(t.seqs, dtype=np.uint8))
+            seq_at += len(t.seqs)
+        for k, dt in _COLUMNS:
+            setattr(out, k, np.concatenate(cols[k]).astype(dt, copy=False))
+        out.contigs, out.contig_len = contigs, np.asarray(contig_len, dtype=np.int64)
+        out.r_off = np.zeros(len(out.type) + 1, np.int64)
+        np.cumsum(np.concatenate(r_cnt), out=out.r_off[1:])
+        out.r_flat = np.concatenate(r_flat)
+        out.seqs = np.concatenate(seq_parts) if seq_parts else np.zeros(0, np.uint8)
+        out.genotypes = genotypes
+        return out
+
+    # ------------------------------------------------------------------ keys (SVCandidate.py get_key)
+    def key_contig(self):
+        """Contig id of Candidate.get_key(): destination for INS / DUP_INT, source otherwise."""
+        return np.where((self.type == T_INS) | (self.type == T_DUP_INT), self.dc, self.sc)
+
+    def key_position(self):
+        """Position of get_key(): interval midpoint (DEL, INV, DUP_TAN), destination start (INS, DUP_INT),
+        source start (BND) — SVCandidate.py:17-19,147-148,292-293,386-387."""
+        mid = (self.ss + self.se) // 2
+        return np.where((self.type == T_INS) | (self.type == T_DUP_INT), self.ds,
+                        np.where(self.type == T_BND, self.ss, mid))
+
+    def counts_by_type(self):
+        return np.bincount(self.type, minlength=len(TYPE_ORDER))
+
+    # ------------------------------------------------------------------ objects
+    def objects(self):
+        """The reference's Candidate objects of all rows, with exactly the attributes its constructors set."""
+        n = len(self)
+        if n == 0:
+            return []
+        cn = self.contigs
+        typ, sc, ss, se = self.type.tolist(), self.sc.tolist(), self.ss.tolist(), self.se.tolist()
+        dc, ds, de = self.dc.tolist(), self.ds.tolist(), self.de.tolist()
+        flag, copies = self.flag.tolist(), self.copies.tolist()
+        gts = [self.genotypes[g] for g in self.gt.tolist()]
+        q_off, q_len = self.q_off.tolist(), self.q_len.tolist()
+        r_off = self.r_off.tolist()
+        uniq, inv = np.unique(self.r_flat, return_inverse=True)
+        strs = self.names.strings(uniq.tolist())
+        flat = [strs[i] for i in inv.tolist()]
+        seqs = None
+        out = []
+        for i in range(n):
+            t = typ[i]
+            reads = flat[r_off[i]:r_off[i + 1]]
+            c = _CLASSES[t].__new__(_CLASSES[t])
+            if t == T_DEL:
+                c.__dict__ = {"source_contig": cn[sc[i]], "source_start": ss[i], "source_end": se[i], "reads": reads,
+                              "genotype": gts[i]}
+            elif t == T_INS:
+                if seqs is None:
+                    seqs = bytes(self.seqs)
+                c.__dict__ = {"dest_contig": cn[dc[i]], "dest_start": ds[i], "dest_end": de[i], "reads": reads,
+                              "sequence": seqs[q_off[i]:q_off[i] + q_len[i]].decode("latin-1"), "genotype": gts[i]}
+            elif t == T_INV:
+                c.__dict__ = {"source_contig": cn[sc[i]], "source_start": ss[i], "source_end": se[i], "reads": reads,
+                              "complete": bool(flag[i] & F_BOOL), "genotype": gts[i]}
+            elif t == T_DUP_TAN:
+                c.__dict__ = {"source_contig": cn[sc[i]], "source_start": ss[i], "source_end": se[i],
+                              "copies": copies[i], "reads": reads, "fully_covered": bool(flag[i] & F_BOOL),
+                              "genotype": gts[i]}
+            elif t == T_DUP_INT:
+                c.__dict__ = {"source_contig": cn[sc[i]], "source_start": ss[i], "source_end": se[i],
+                              "dest_contig": cn[dc[i]], "dest_start": ds[i], "dest_end": de[i],
+                              "cutpaste": bool(flag[i] & F_BOOL), "reads": reads, "genotype": gts[i]}
+            else:
+                c.__dict__ = {"source_contig": cn[sc[i]], "source_direction": _DIR[(flag[i] >> 1) & 1],
+                              "source_start": ss[i], "dest_contig": cn[dc[i]],
+                              "dest_direction": _DIR[(flag[i] >> 2) & 1], "dest_start": ds[i], "reads": reads,
+                              "genotype": gts[i]}
+            out.append(c)
+        return out
+
+    @staticmethod
+    def from_objects(candidates, bam):
+        """Rows for Candidate objects (any object with the reference's attribute surface).  The objects'
+        state is taken as it is (their constructors clamped already); contig ids refer to bam.references,
+        names the header lacks get ids behind it with length -1."""
+        cands = list(candidates)
+        contigs = list(bam.references)
+        lengths = [bam.get_reference_length(c) for c in contigs]
+        index = {}
+        for i, name in enumerate(contigs):
+            index.setdefault(name, i)
+
+        def cid(name):
+            i = index.get(name)
+            if i is None:
+                i = index[name] = len(contigs)
+                contigs.append(name)
+                lengths.append(-1)
+            return i
+        n = len(cands)
+        t = CandidateTable(contigs, lengths, n)
+        genotypes = list(GENOTYPES)
+        name_index, name_list, r_flat, r_cnt = {}, [], [], []
+        seq_parts, seq_at = [], 0
+        for i, c in enumerate(cands):
+            ti = TYPE_INDEX.get(c.type)
+            if ti is None:
+                raise ValueError("unknown candidate type %r" % (c.type,))
+            t.type[i] = ti
+            if ti in (T_DEL, T_INV, T_DUP_TAN, T_DUP_INT):
+                t.sc[i], t.ss[i], t.se[i] = cid(c.source_contig), c.source_start, c.source_end
+            if ti in (T_INS, T_DUP_INT):
+                t.dc[i], t.ds[i], t.de[i] = cid(c.dest_contig), c.dest_start, c.dest_end
+            if ti == T_INV:
+                t.flag[i] = F_BOOL if c.complete else 0
+            elif ti == T_DUP_TAN:
+                t.flag[i] = F_BOOL if c.fully_covered else 0
+                t.copies[i] = c.copies
+            elif ti == T_DUP_INT:
+                t.flag[i] = F_BOOL if c.cutpaste else 0
+            elif ti == T_BND:
+                t.sc[i], t.ss[i] = cid(c.source_contig), c.source_start
+                t.dc[i], t.ds[i] = cid(c.dest_contig), c.dest_start
+                t.flag[i] = (F_SRC_REV if c.source_direction == "rev" else 0) | (F_DST_REV if c.dest_direction == "rev" else 0)
+            elif ti == T_INS:
+                s = c.sequence.encode("latin-1")
+                t.q_off[i], t.q_len[i] = seq_at, len(s)
+                seq_parts.append(s)
+                seq_at += len(s)
+            g = c.genotype
+            if g not in genotypes:
+                genotypes.append(g)
+            t.gt[i] = genotypes.index(g)
+            for r in c.reads:
+                k = name_index.get(r)
+                if k is None:
+                    k = name_index[r] = len(name_list)
+                    name_list.append(r)
+                r_flat.append(k)
+            r_cnt.append(len(c.reads))
+        t.contigs, t.contig_len = contigs, np.asarray(lengths, dtype=np.int64)
+        t.genotypes = genotypes
+        t.names = NamePool.from_strings(name_list)
+        t.seqs = np.frombuffer(b"".join(seq_parts), dtype=np.uint8) if seq_parts else np.zeros(0, np.uint8)
+        t.r_off = np.zeros(n + 1, np.int64)
+        if n:
+            np.cumsum(r_cnt, out=t.r_off[1:])
+        t.r_flat = np.asarray(r_flat, dtype=np.int64)
+        return t
+
+
+def _ranges(starts, counts):
+    """Concatenation of arange(starts[i], starts[i] + counts[i]) for all i."""
+    counts = np.asarray(counts, dtype=np.int64)
+    total = int(counts.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    ends = np.cumsum(counts)
+    base = np.repeat(np.asarray(starts, dtype=np.int64) - (ends - counts), counts)
+    return base + np.arange(total, dtype=np.int64)
+
+
+class CandidateList(Sequence):
+    """What the reference's analyze_alignment_file_coordsorted / pair_candidates return — a list of Candidate
+    objects — backed by a CandidateTable: the objects are built the first time one is looked at."""
+
+    def __init__(self, table):
+        self.table = table
+        self._objs = None
+
+    def _materialise(self):
+        if self._objs is None:
+            self._objs = self.table.objects()
+        return self._objs
+
+    def __len__(self):
+        return len(self.table)
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return "CandidateList(%d candidates)" % len(self)
+
+
+def as_table(candidates, bam):
+    if isinstance(candidates, CandidateList):
+        return candidates.table
+    if isinstance(candidates, CandidateTable):
+        return candidates
+    return CandidateTable.from_objects(candidates, bam)

@@ -353,6 +353,10 @@ class OracleBackedContext(object):
     def pair_partition(self, keys, max_dist):
         return _orc().pair_partition(keys, max_dist)
 
+    def collect_batch(self, *args, **kw):
+        # the product's own composition of the single-purpose calls, each answered by the oracle above / below
+        return _svxlib().Context.collect_batch_composed(self, *args, **kw)
+
     def edit_distance_batch(self, seq, a_off, a_len, b_off, b_len, k_max=0xFFFFFFFF):
         seq = np.ascontiguousarray(seq, np.uint8)
         out = []

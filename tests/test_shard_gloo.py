@@ -29,51 +29,51 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport):
+    """One rank: the PRODUCT's sharded COLLECT + PAIR (native BAM reader, columnar host logic, table exchange)
+    with the device answered by the oracle — there is no GPU here.  transport "gloo": the exchange runs over a
+    torch.distributed process group; "socket": over the product's own unix-domain socket group, the way the
+    svim-asm CLI runs under torch.distributed.run (RANK / WORLD_SIZE in the environment, no torch)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist = None
+    if transport == "gloo":
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     try:
-        from oracle import orc, run_oracle, svim_oracle
-        from svim_asm_amd import SVCandidate, bamio, fasta, shard
+        from svim_asm_amd import _lib, bamio, fasta, shard
         from tests import helpers
+        ctx = helpers.OracleBackedContext()
+        _lib.default_context = lambda device=0: ctx
         o = helpers.options()
         ref = fasta.FastaFile(os.path.join(GOLD, "ref.fa"))
-
-        def collect_fn(bam_view, options):
-            # oracle-backed stand-in for the GPU COLLECT, restricted to the view's contigs
-            recs, names, lengths = run_oracle.read_records(bam_view.filename)
-            keep = {names.index(n) for n in bam_view.references}
-            tuples = svim_oracle.collect([r for r in recs if r["tid"] in keep], names, lengths, options)
-            return [helpers.build_candidate(t, bam_view, SVCandidate) for t in tuples]
-
-        def pair_fn(c1, c2, reference, bam, options):
-            names, lengths = list(bam.references), list(bam.lengths)
-            t = svim_oracle.pair_candidates([helpers.candidate_tuple(c) for c in c1],
-                                            [helpers.candidate_tuple(c) for c in c2], reference.fetch, names, lengths,
-                                            dict(zip(reference.references, reference.lengths)), options,
-                                            edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
-            return [helpers.build_candidate(x, bam, SVCandidate) for x in t]
-
         b1 = bamio.AlignmentFile(os.path.join(GOLD, "hap1.bam"))
         b2 = bamio.AlignmentFile(os.path.join(GOLD, "hap2.bam"))
-        c1 = shard.collect_sharded(b1, o, collect_fn)
-        c2 = shard.collect_sharded(b2, o, collect_fn)
-        paired = shard.pair_sharded(c1, c2, ref, b1, o, pair_fn)
-        q.put((rank, [helpers.candidate_tuple(c) for c in c1], [helpers.candidate_tuple(c) for c in paired]))
+        t1, t2 = shard.collect_sharded([b1, b2], o)
+        paired = shard.pair_sharded(t1, t2, ref, b1, o)
+        assert "torch" not in sys.modules or transport == "gloo", "the socket transport must not import torch"
+        q.put((rank, [helpers.candidate_tuple(c) for c in t1.objects()], [helpers.candidate_tuple(c) for c in t2.objects()],
+               [helpers.candidate_tuple(c) for c in paired.objects()], len(b1), len(b2)))
     finally:
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.destroy_process_group()
+        else:
+            from svim_asm_amd import shard
+            shard.shutdown()
 
 
-def test_sharded_collect_and_pair_equal_single_process():
+@pytest.mark.parametrize("transport", ["gloo", "socket"])
+def test_sharded_collect_and_pair_equal_single_process(transport):
     import torch.multiprocessing as mp
     from oracle import orc, run_oracle, svim_oracle
+    from svim_asm_amd import bamio
     from tests import helpers
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]
@@ -87,6 +87,9 @@ def test_sharded_collect_and_pair_equal_single_process():
     fa = ps.FastaFile(os.path.join(GOLD, "ref.fa"))
     exp_pair = svim_oracle.pair_candidates(exp1, exp2, fa.fetch, names, lengths, dict(zip(fa.references, fa.lengths)), o,
                                            edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
-    for rank, c1, paired in results:
-        assert c1 == exp1, "rank %d collect order differs" % rank
+    total = len(bamio.AlignmentFile(os.path.join(GOLD, "hap1.bam")))
+    for rank, c1, c2, paired, n1, n2 in results:
+        assert c1 == exp1, "rank %d collect order differs (hap 1)" % rank
+        assert c2 == exp2, "rank %d collect order differs (hap 2)" % rank
         assert paired == exp_pair, "rank %d pair order differs" % rank
+        assert 0 < n1 < total, "rank %d indexed %d of %d records: contig-restricted ingest" % (rank, n1, total)
