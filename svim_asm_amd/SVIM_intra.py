@@ -67,43 +67,6 @@ def candidates_from_signatures(alignment, bam, query_name, ref_chr, ref_pos, rea
     return out
 
 
-def candidates_from_signature_arrays(alignments, bam, sig, ref_pos, ins_sequences=None):
-    """All signature rows of a BAM at once → Candidate objects, row order (SVIM_intra.py:38-43 for every
-    alignment).  The constructors' work — `assert end >= start`, start = max(0, start), end = min(contig
-    length, end) (SVCandidate.py:40-46,130-136) — is done on the arrays; the objects get exactly the
-    attributes the constructors set."""
-    n = len(sig["aln"])
-    if n == 0:
-        return []
-    names = [bam.getrname(a.reference_id) for a in alignments]
-    qnames = [a.query_name for a in alignments]
-    lengths = np.array([bam.get_reference_length(c) for c in names], dtype=np.int64)
-    aln = sig["aln"].astype(np.int64)
-    start = np.asarray(ref_pos, dtype=np.int64)
-    end = start + sig["len"].astype(np.int64)
-    s_cl = np.maximum(start, 0).tolist()
-    e_cl = np.minimum(end, lengths[aln]).tolist()
-    types = sig["type"].tolist()
-    aln_l = aln.tolist()
-    read_pos, lens = sig["read_pos"].tolist(), sig["len"].tolist()
-    out = []
-    new_del, new_ins = CandidateDeletion.__new__, CandidateInsertion.__new__
-    for i in range(n):
-        k = aln_l[i]
-        if types[i] == _lib.SIG_DEL:
-            c = new_del(CandidateDeletion)
-            c.__dict__ = {"source_contig": names[k], "source_start": s_cl[i], "source_end": e_cl[i],
-                          "reads": [qnames[k]], "genotype": "1/1"}
-        else:
-            seq = ins_sequences[i] if ins_sequences is not None else \
-                _sequence_slice(alignments[k], read_pos[i], read_pos[i] + lens[i])
-            c = new_ins(CandidateInsertion)
-            c.__dict__ = {"dest_contig": names[k], "dest_start": s_cl[i], "dest_end": e_cl[i],
-                          "reads": [qnames[k]], "sequence": seq, "genotype": "1/1"}
-        out.append(c)
-    return out
-
-
 def analyze_alignment_indel(alignment, bam, query_name, options):
     ref_chr = bam.getrname(alignment.reference_id)
     words = cigar_words_of(alignment)

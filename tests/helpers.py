@@ -306,6 +306,20 @@ def run_cli_ranks(argv, world_size, timeout=600):
     return out
 
 
+def assert_inputs_are_the_golden_ones(meta, files):
+    """The regenerated BAM / FASTA inputs must be the ones the REAL reference was run on when the golden VCF
+    was made: compared through digests of their UNCOMPRESSED content (synth_bam.payload_digest — independent of
+    the zlib build that compressed them).  A difference is a failure, never a skip: a golden that silently
+    drops out of the suite checks nothing."""
+    import os
+    from svim_asm_amd import synth_bam
+    for f in files:
+        name = os.path.basename(f)
+        got = synth_bam.payload_digest(f) if name.endswith(".bam") else synth_bam.file_digest(f)
+        assert got == meta["payload_sha256"][name], \
+            "%s: regenerated content differs from the input of the golden run (generator drift): %s" % (name, got)
+
+
 # ---- reference-generated function vectors (tests/golden/pipeline_vectors.json.gz) --------------
 def _tuplify(x):
     return tuple(_tuplify(v) for v in x) if isinstance(x, list) else x

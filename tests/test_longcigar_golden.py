@@ -3,7 +3,7 @@ samtools/htslib store them (placeholder `<l_seq>S<ref_len>N` + `CG:B,I`, SAM spe
 written by the REAL reference (tests/golden/longcigar_diploid.vcf.gz, made by
 `oracle/make_golden.py longcigar`; the reference saw the records through the stub pysam, which
 restores the CIGAR like htslib's bam_tag2cigar) must be reproduced by the CPU oracle and by the
-product CLI on the GPU.  Inputs are regenerated from fixed seeds and checked by SHA-256."""
+product CLI on the GPU.  Inputs are regenerated from fixed seeds and checked by the digest of their uncompressed content (a difference fails)."""
 import gzip
 import hashlib
 import json
@@ -25,9 +25,8 @@ def dataset(tmp_path_factory):
     fasta, bams = synth_bam.write_dataset(d, seed=prm["seed"], contigs=tuple((n, l) for n, l in prm["contigs"]),
                                           n_shared=prm["n_shared"], n_private=prm["n_private"],
                                           median_aln=prm["median_aln"], mean_m=prm["mean_m"])
-    for f in [fasta] + bams:
-        if hashlib.sha256(open(f, "rb").read()).hexdigest() != META["sha256"][os.path.basename(f)]:
-            pytest.skip("regenerated inputs differ from the ones the golden VCF was made from (generator/zlib drift)")
+    from tests import helpers
+    helpers.assert_inputs_are_the_golden_ones(META, [fasta] + bams)
     return fasta, bams
 
 

@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""End-to-end BAM → VCF wall-clock of the product CLI next to the CPU oracle pipeline, on a
-synthetic diploid sample written as real BAM + FASTA files (scaled).
+"""End-to-end BAM → VCF wall-clock of the product (in-process phases, the command line as a fresh process,
+and the contig-sharded command line as R rank processes) on a synthetic diploid sample written as real
+BAM + FASTA files (config 5 with --mean-m 400).
 
-    python tools/e2e_bench.py --scale 0.1 [--keep DIR]
+    python tools/e2e_bench.py --scale 1.0 [--keep DIR] [--ranks 1,2,4]
 
---scale 1.0 = GRCh38 contig lengths (3.1 Gbp); 0.1 (default) = every contig at 1/10 length.
-Prints one JSON object: generation time, product phases (BAM open/inflate, COLLECT, PAIR, VCF)
-and total, oracle (CPython restatement of the reference, C edit distance) total, and whether
-the two VCFs are identical.  The oracle is used here as the reference-equivalent CPU path and
-checker only.
+--scale 1.0 = GRCh38 contig lengths (3.1 Gbp, the configuration BASELINE's BAM→VCF wall-clock is quoted
+on); 0.25 = the 772 Mbp sample of tests/golden/large_inputs.json.  At those two scales the generated
+inputs are the ones the REAL reference was run on in the build container (oracle/make_golden.py full /
+large): their identity is checked through digests of their UNCOMPRESSED content and the product's VCF is
+compared with the digest of the reference's VCF.  The CPU oracle pipeline (CPython restatement of the
+reference, C edit distance) is the checker at other scales (and with --with-oracle), timed beside it.
+Prints one JSON object.
 """
 import argparse
+import hashlib
 import json
 import logging
 import os
 import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -23,104 +28,192 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-
-def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, skip_oracle=False, dataset=None, threads=0, repeat=1,
-            device=0):
-    """Generate (or reuse) the dataset, run the product pipeline `repeat` times with phase clocks, then
-    the oracle pipeline once; returns the result dict."""
-    from svim_asm_amd import synth, synth_bam
+def dataset_args(scale, sv_per_mbp=8.0, mean_m=2000, seed=3):
+    from svim_asm_amd import synth
     contigs = tuple((n, max(60000, int(l * scale))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
-    out = keep or tempfile.mkdtemp(prefix="svx_e2e_")
-    res = {"scale": scale, "genome_bp": int(sum(c[1] for c in contigs)), "dir": out}
+    n_shared = max(4, int(sv_per_mbp * max(c[1] for c in contigs) / 1e6))
+    return dict(seed=seed, contigs=contigs, diploid=True, n_shared=n_shared, n_private=max(2, n_shared // 5),
+                median_aln=300000, mean_m=mean_m)
 
+
+def reference_meta(scale, sv_per_mbp, mean_m):
+    """Committed description of the real reference's run on exactly these generator arguments, if any."""
+    for name in ("full_inputs.json", "large_inputs.json", "config5_inputs.json"):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if not os.path.exists(path):
+            continue
+        meta = json.load(open(path))
+        prm = meta["params"]
+        if abs(scale - prm["scale"]) < 1e-12 and sv_per_mbp == prm["sv_per_mbp"] and mean_m == prm["mean_m"] and \
+                "payload_sha256" in meta:
+            return name, meta
+    return None, None
+
+
+def masked(path):
+    return "".join(l for l in open(path) if not l.startswith("##fileDate="))
+
+
+def run_ranks(argv, world_size, n_devices=1, timeout=900):
+    """`svim-asm <argv>` as `world_size` fresh rank processes, the environment torch.distributed.run would give
+    them (rank r on device r mod n_devices).  Returns (wall seconds from first start to last exit,
+    [(returncode, output)] by rank).  The children make their own first GPU call; this process only waits."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    t0 = time.perf_counter()
+    for rank in range(world_size):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), WORLD_SIZE=str(world_size), LOCAL_RANK=str(rank % max(1, n_devices)),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world_size == 1:
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bin", "svim-asm")] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    out = []
+    for p in procs:
+        try:
+            text, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            text, _ = p.communicate()
+            text += "\n[timeout]"
+        out.append((p.returncode, text))
+    return time.perf_counter() - t0, out
+
+
+def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None, threads=0, repeat=1, device=0,
+            ranks=(1, 2, 4), n_devices=1, mean_m=2000, in_process=True):
+    """Generate (or reuse) the dataset, run the product pipeline `repeat` times in this process with phase
+    clocks (in_process=False: the caller must not touch the GPU — only the child processes run), then the
+    command line as fresh processes (1 rank and the sharded runs), then the checker."""
+    from svim_asm_amd import synth_bam
+    out = keep or tempfile.mkdtemp(prefix="svx_e2e_")
+    res = {"scale": scale, "mean_m": mean_m}
     t0 = time.perf_counter()
     if dataset:
         out = dataset
         fasta, bams = os.path.join(out, "ref.fa"), [os.path.join(out, "hap1.bam"), os.path.join(out, "hap2.bam")]
     else:
-        n_shared = max(4, int(sv_per_mbp * max(c[1] for c in contigs) / 1e6))
-        fasta, bams = synth_bam.write_dataset(out, seed=3, contigs=contigs, diploid=True, n_shared=n_shared,
-                                              n_private=max(2, n_shared // 5), median_aln=300000, mean_m=2000)
+        fasta, bams = synth_bam.write_dataset(out, **dataset_args(scale, sv_per_mbp, mean_m))
     res["generate_s"] = time.perf_counter() - t0
+    res["genome_bp"] = int(sum(max(60000, int(l * scale)) for l in __import__("svim_asm_amd.synth", fromlist=["x"]).GRCH38_LENGTHS))
     res["bam_bytes"] = [os.path.getsize(b) for b in bams]
 
-    # ---- product: timed phases through the same functions the CLI calls
-    from svim_asm_amd import bamio, cli, shard
-    from svim_asm_amd.fasta import FastaFile
-    from svim_asm_amd.SVIM_COMBINE import write_final_vcf
-    from svim_asm_amd.SVIM_input_parsing import parse_arguments
-    wd = os.path.join(out, "wd_product")
-    opts = parse_arguments("1.0.3", ["diploid", wd, bams[0], bams[1], fasta])
-    opts.device = device
-    os.makedirs(wd, exist_ok=True)
+    # ---- are these the inputs the REAL reference was run on?  (digests of the uncompressed content)
+    meta_name, meta = reference_meta(scale, sv_per_mbp, mean_m)
+    same_inputs = None
+    if meta is not None:
+        t0 = time.perf_counter()
+        same_inputs = all(synth_bam.payload_digest(b) == meta["payload_sha256"][os.path.basename(b)] for b in bams) and \
+            synth_bam.file_digest(fasta) == meta["payload_sha256"][os.path.basename(fasta)]
+        res["inputs_match_real_reference_run"] = same_inputs
+        res["real_reference_fixture"] = "tests/golden/" + meta_name
+        res["real_reference_wall_s_build_container"] = meta.get("reference_wall_s_build_container")
+        res["input_digest_s"] = time.perf_counter() - t0
+
+    def check(vcf_text):
+        if not same_inputs:
+            return None
+        return hashlib.sha256(vcf_text.encode()).hexdigest() == meta["vcf_sha256"] and len(vcf_text.encode()) == meta["vcf_bytes"]
+
     level = logging.getLogger().level
     logging.getLogger().setLevel(logging.WARNING)
-    from svim_asm_amd import _lib
-    _lib.default_context(device)  # context creation / first-touch outside the timed region
-    runs = []
-    import gc
-    for _ in range(max(1, repeat)):
-        r = {}
-        # as cli._run does for the whole command: the run allocates some hundred thousand long-lived objects and
-        # drops none before it ends — generational collections in between only rescan them
-        gc.collect()
-        gc.disable()
-        t_all = time.perf_counter()
-        t = time.perf_counter()
-        f1 = bamio.AlignmentFile(bams[0], threads=threads, device=device).load()
-        f2 = bamio.AlignmentFile(bams[1], threads=threads, device=device).load()
-        r["open_index_s"] = time.perf_counter() - t
-        t = time.perf_counter(); c1 = shard.collect_sharded(f1, opts); c2 = shard.collect_sharded(f2, opts); r["collect_s"] = time.perf_counter() - t
-        ref = FastaFile(fasta)
-        t = time.perf_counter(); paired = shard.pair_sharded(c1, c2, ref, f1, opts); r["pair_s"] = time.perf_counter() - t
-        by = {k: [c for c in paired if c.type == k] for k, _ in cli.TYPE_LABELS}
-        t = time.perf_counter()
-        write_final_vcf(by["DUP_INT"], by["INV"], by["DUP_TAN"], by["DEL"], by["INS"], by["BND"], "1.0.3", f1.references,
-                        f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
-        r["vcf_s"] = time.perf_counter() - t
-        r["product_total_s"] = time.perf_counter() - t_all
-        gc.enable()
-        runs.append(r)
-    res.update(runs[0])
-    if len(runs) > 1:
-        res["best_run"] = min(runs, key=lambda x: x["product_total_s"])
-        res["all_runs_total_s"] = [r["product_total_s"] for r in runs]
-    res["index_state"] = f1.index_state()
-    res["bgzf_members_inflated"] = [f1.blocks_inflated, f2.blocks_inflated]
-    res["bgzf_members_walked"] = [f1.blocks_spanned, f2.blocks_spanned]
-    res["ingest_threads"] = threads or min(64, os.cpu_count() or 1)
-    res["candidates"] = [len(c1), len(c2), len(paired)]
-    res["cigar_ops"] = [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]
-    got = "".join(l for l in open(os.path.join(wd, "variants.vcf")) if not l.startswith("##fileDate="))
-    res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
-    # at the scale of tests/golden/large_inputs.json the inputs are the ones the REAL reference was run on in the
-    # build container (same generator arguments): compare with the digest of its VCF
-    try:
-        import hashlib
-        meta = json.load(open(os.path.join(ROOT, "tests", "golden", "large_inputs.json")))
-        prm = meta["params"]
-        if not dataset and abs(scale - prm["scale"]) < 1e-12 and sv_per_mbp == prm["sv_per_mbp"]:
-            same_inputs = all(hashlib.sha256(open(b, "rb").read()).hexdigest() == meta["sha256"][os.path.basename(b)] for b in bams)
-            res["inputs_match_real_reference_run"] = same_inputs
-            if same_inputs:
-                res["vcf_matches_real_reference_digest"] = hashlib.sha256(got.encode()).hexdigest() == meta["vcf_sha256"]
-    except Exception as e:  # noqa: BLE001 — informative only
-        res["real_reference_digest_error"] = repr(e)
+    got = None
+    if in_process:
+        # ---- product: timed phases through the same functions the CLI calls
+        from svim_asm_amd import _lib, bamio, shard
+        from svim_asm_amd.fasta import FastaFile
+        from svim_asm_amd.SVIM_COMBINE import write_vcf_table
+        from svim_asm_amd.SVIM_input_parsing import parse_arguments
+        wd = os.path.join(out, "wd_product")
+        opts = parse_arguments("1.0.3", ["diploid", wd, bams[0], bams[1], fasta])
+        opts.device = device
+        os.makedirs(wd, exist_ok=True)
+        _lib.default_context(device)  # context creation / first touch outside the timed region
+        runs = []
+        import gc
+        for _ in range(max(1, repeat)):
+            r = {}
+            gc.collect()
+            gc.disable()  # as cli._run does for the whole command
+            t_all = time.perf_counter()
+            t = time.perf_counter()
+            f1 = bamio.AlignmentFile(bams[0], threads=threads, device=device).load()
+            f2 = bamio.AlignmentFile(bams[1], threads=threads, device=device).load()
+            r["open_index_s"] = time.perf_counter() - t
+            t = time.perf_counter()
+            t1, t2 = shard.collect_sharded([f1, f2], opts)
+            r["collect_s"] = time.perf_counter() - t
+            ref = FastaFile(fasta)
+            t = time.perf_counter()
+            paired = shard.pair_sharded(t1, t2, ref, f1, opts)
+            r["pair_s"] = time.perf_counter() - t
+            t = time.perf_counter()
+            write_vcf_table(paired, "1.0.3", f1.references, f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
+            r["vcf_s"] = time.perf_counter() - t
+            r["product_total_s"] = time.perf_counter() - t_all
+            gc.enable()
+            runs.append(r)
+        res.update(runs[0])
+        if len(runs) > 1:
+            res["best_run"] = min(runs, key=lambda x: x["product_total_s"])
+            res["all_runs_total_s"] = [r["product_total_s"] for r in runs]
+        res["index_state"] = f1.index_state()
+        res["bgzf_members_inflated"] = [f1.blocks_inflated, f2.blocks_inflated]
+        res["bgzf_members_walked"] = [f1.blocks_spanned, f2.blocks_spanned]
+        res["ingest_threads"] = threads or min(64, os.cpu_count() or 1)
+        res["candidates"] = [len(t1), len(t2), len(paired)]
+        res["cigar_ops"] = [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]
+        got = masked(os.path.join(wd, "variants.vcf"))
+        res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
+        res["vcf_matches_real_reference_digest"] = check(got)
 
-    # ---- the command line itself, as a fresh process: interpreter start, imports, HIP initialisation and
-    # log writing included — what `time svim-asm diploid ...` shows
-    import subprocess
-    wd_cli = os.path.join(out, "wd_cli")
-    t = time.perf_counter()
-    rc = subprocess.call([sys.executable, os.path.join(ROOT, "bin", "svim-asm"), "diploid", wd_cli, bams[0], bams[1], fasta],
-                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    res["cli_wall_s"] = time.perf_counter() - t
-    res["cli_rc"] = rc
-    if rc == 0:
-        cli_vcf = "".join(l for l in open(os.path.join(wd_cli, "variants.vcf")) if not l.startswith("##fileDate="))
-        res["cli_vcf_identical_to_in_process"] = (cli_vcf == got)
+    # ---- the command line itself, as fresh processes: interpreter start, imports, HIP initialisation and log
+    # writing included — what `time svim-asm diploid ...` shows; R > 1: contig-sharded ranks (BASELINE config 4)
+    sharded = []
+    for R in ranks:
+        wd_r = os.path.join(out, "wd_cli_r%d" % R)
+        walls = []
+        for _ in range(2):  # wall_s: the better of two runs (the first one of a rank count also pays the page-cache warm-up)
+            shutil.rmtree(wd_r, ignore_errors=True)
+            wall, results = run_ranks(["diploid", wd_r, bams[0], bams[1], fasta], R, n_devices)
+            walls.append(wall)
+            if any(rc != 0 for rc, _ in results):
+                break
+        wall = min(walls)
+        leg = {"ranks": R, "devices": min(R, max(1, n_devices)), "wall_s": wall, "all_wall_s": walls, "rc": [rc for rc, _ in results]}
+        if all(rc == 0 for rc, _ in results):
+            text = masked(os.path.join(wd_r, "variants.vcf"))
+            if got is None:
+                got = text
+                res["vcf_records"] = sum(1 for l in got.split("\n") if l and not l.startswith("#"))
+            leg["vcf_identical_to_single_process"] = (text == got)
+            leg["vcf_matches_real_reference_digest"] = check(text)
+            walked = []
+            for r in range(R):
+                logs = [f for f in os.listdir(wd_r) if f.endswith(".log") and (".rank%d." % r in f or (r == 0 and ".rank" not in f))]
+                n = 0
+                for f in logs:
+                    for line in open(os.path.join(wd_r, f)):
+                        if "INGEST: rank" in line:
+                            n += int(line.split(" of the ")[1].split(" BGZF")[0])
+                walked.append(n)
+            leg["bgzf_members_walked_per_rank"] = walked
+        else:
+            leg["output_tail"] = [t[-600:] for _, t in results]
+        sharded.append(leg)
+    res["cli_ranks"] = sharded
+    if sharded and sharded[0]["ranks"] == 1:
+        res["cli_wall_s"] = sharded[0]["wall_s"]
 
-    if not skip_oracle:
+    if with_oracle is None:
+        with_oracle = not same_inputs
+    if with_oracle and got is not None:
         from oracle import orc, run_oracle
         t = time.perf_counter()
         exp = run_oracle.vcf_from_files(bams, fasta, run_oracle.default_options(),
@@ -130,7 +223,8 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, skip_oracle=False, dataset=Non
     logging.getLogger().setLevel(level)
     if not keep and not dataset:
         shutil.rmtree(out)
-        res.pop("dir")
+    else:
+        res["dir"] = out
     return res
 
 
@@ -139,13 +233,18 @@ def main():
     ap.add_argument("--scale", type=float, default=0.1)
     ap.add_argument("--keep", default=None)
     ap.add_argument("--sv-per-mbp", type=float, default=8.0)
-    ap.add_argument("--skip-oracle", action="store_true")
+    ap.add_argument("--mean-m", type=int, default=2000, help="mean M-run length of the CIGARs (400: BASELINE config 5)")
+    ap.add_argument("--with-oracle", action="store_true", help="run the CPU oracle pipeline even when the real reference's digest is available")
     ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
     ap.add_argument("--threads", type=int, default=0, help="ingest threads (0: one per hardware thread, at most 64)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the product pipeline, report the best run too")
+    ap.add_argument("--ranks", default="1,2,4", help="rank counts of the command-line runs")
+    ap.add_argument("--devices", type=int, default=1, help="HIP devices the ranks are spread over")
+    ap.add_argument("--no-in-process", action="store_true", help="only the command-line runs (this process never touches the GPU)")
     args = ap.parse_args()
-    print(json.dumps(run_e2e(args.scale, args.keep, args.sv_per_mbp, args.skip_oracle, args.dataset, args.threads,
-                             args.repeat)))
+    print(json.dumps(run_e2e(args.scale, args.keep, args.sv_per_mbp, True if args.with_oracle else None, args.dataset,
+                             args.threads, args.repeat, ranks=tuple(int(x) for x in args.ranks.split(",") if x),
+                             n_devices=args.devices, mean_m=args.mean_m, in_process=not args.no_in_process)))
 
 
 if __name__ == "__main__":

@@ -19,10 +19,10 @@ def main():
     from tools import e2e_bench
     import tempfile
     d = tempfile.mkdtemp(prefix="svx_prof_")
-    e2e_bench.run_e2e(scale=args.scale, keep=d, skip_oracle=True)  # generates + warms up
+    e2e_bench.run_e2e(scale=args.scale, keep=d, with_oracle=False, ranks=())  # generates + warms up
     pr = cProfile.Profile()
     pr.enable()
-    r = e2e_bench.run_e2e(scale=args.scale, dataset=d, skip_oracle=True)
+    r = e2e_bench.run_e2e(scale=args.scale, dataset=d, with_oracle=False, ranks=())
     pr.disable()
     print({k: r[k] for k in ("open_index_s", "collect_s", "pair_s", "vcf_s", "product_total_s")})
     pstats.Stats(pr).sort_stats("tottime").print_stats(args.top)

@@ -28,8 +28,11 @@ if __name__ == "__main__":
     pr = cProfile.Profile()
     t = time.time(); f1 = bamio.AlignmentFile(bams[0]).load(); f2 = bamio.AlignmentFile(bams[1]).load(); print("open+index", time.time() - t, f1.index_state(), f1.blocks_inflated, f1.blocks_spanned)
     pr.enable()
-    t = time.time(); c1 = shard.collect_sharded(f1, opts); c2 = shard.collect_sharded(f2, opts); print("collect", time.time() - t)
+    t = time.time(); c1, c2 = shard.collect_sharded([f1, f2], opts); print("collect", time.time() - t)
     ref = FastaFile(fasta)
     t = time.time(); paired = shard.pair_sharded(c1, c2, ref, f1, opts); print("pair", time.time() - t)
+    from svim_asm_amd.SVIM_COMBINE import write_vcf_table
+    os.makedirs(opts.working_dir, exist_ok=True)
+    t = time.time(); write_vcf_table(paired, "1.0.3", f1.references, f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts); print("vcf", time.time() - t)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
