@@ -273,6 +273,46 @@ def make_full(keep=None):
         shutil.rmtree(d)
 
 
+CONFIG5 = dict(seed=5, scale=0.05, sv_per_mbp=400.0, median_aln=300000, mean_m=400, min_gap=200)
+
+
+def config5_dataset_args():
+    """BASELINE config 5 as a diploid end-to-end case: 10x the small-indel density (mean M run 400 bp) and SV
+    events dense enough (50x config 3's rate, at least 200 bp apart) that neighbouring events chain inside the
+    pairing step's 1000 bp: > 131072 candidates (the pair sort takes its radix plan), tens of thousands of
+    partitions with 3..10 members (the complete-linkage path) and hundreds with more than 10 (dropped,
+    SVIM_COMBINE.py:126-128).  24 contigs at 1/20 of GRCh38 (154 Mbp)."""
+    kw = full_dataset_args(CONFIG5)
+    kw["min_gap"] = CONFIG5["min_gap"]
+    return kw
+
+
+def make_config5(keep=None):
+    """`svim-asm diploid` of the REAL reference on the config-5 sample; committed like `full`: VCF digest, counts,
+    first / last records, digests of the inputs' uncompressed content."""
+    import time
+    from svim_asm_amd import synth_bam
+    keep = keep or os.environ.get("SVX_KEEP_CONFIG5")
+    d = keep or tempfile.mkdtemp(prefix="svx_config5_")
+    fasta, bams = synth_bam.write_dataset(d, **config5_dataset_args())
+    wd = os.path.join(d, "wd_reference")
+    t0 = time.time()
+    run_reference_cli(["diploid", wd, bams[0], bams[1], fasta])
+    t_ref = time.time() - t0
+    vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
+    log = "".join(open(os.path.join(wd, f)).read() for f in os.listdir(wd) if f.endswith(".log"))
+    meta = {"params": CONFIG5,
+            "payload_sha256": dict([(os.path.basename(f), synth_bam.payload_digest(f)) for f in bams] +
+                                   [(os.path.basename(fasta), synth_bam.file_digest(fasta))]),
+            "reference_wall_s_build_container": round(t_ref, 1),
+            "reference_log_pairing_lines": [l.split("]  ", 1)[-1] for l in log.split("\n") if "Pairing " in l]}
+    meta.update(_vcf_summary(vcf))
+    with open(os.path.join(GOLD, "config5_inputs.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    if not keep:
+        shutil.rmtree(d)
+
+
 def refresh_payload_digests():
     """Add `payload_sha256` (uncompressed-content digests) to medium / large / longcigar metadata: the inputs are
     regenerated here, checked byte for byte against the compressed-file digests taken when the reference ran on
@@ -493,7 +533,7 @@ def main():
     if len(sys.argv) > 1:   # regenerate selected fixtures only: functions / config1 / medium / longcigar
         for what in sys.argv[1:]:
             {"functions": make_function_vectors, "config1": make_config1, "medium": make_medium,
-             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors, "large": make_large, "full": make_full,
+             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors, "large": make_large, "full": make_full, "config5": make_config5,
              "digests": refresh_payload_digests}[what]()
         return
     make_longcigar()

@@ -457,6 +457,13 @@ def _table_of(s, options):
         s.seq_job[0].start()
     # ---- the constructors, on the columns
     _apply_constructors(t, n_ref)
+    s.table = t
+    return t
+
+
+def _join_sequences(s):
+    """Wait for the sample's sequence decoding (started by _table_of) and attach the pool to its table."""
+    t = s.table
     if s.seq_job is not None:
         job, box = s.seq_job
         job.join()
@@ -464,8 +471,8 @@ def _table_of(s, options):
             raise box["error"]
         pool, off = box["out"]
         t.seqs = np.asarray(pool, dtype=np.uint8)
-        t.q_off[rows] = off[:-1]
-        t.q_len[rows] = off[1:] - off[:-1]
+        t.q_off[s.seq_rows] = off[:-1]
+        t.q_len[s.seq_rows] = off[1:] - off[:-1]
     return t
 
 
@@ -537,15 +544,57 @@ def _same_header(bams):
     return True
 
 
+def _load_together(bams):
+    """Index the records of all native bams at the same time (each walk runs on the reader's own threads and
+    releases the GIL); a contig view loads the contigs it names."""
+    jobs = []
+    for bam in bams:
+        base = getattr(bam, "_bam", bam)
+        if not (isinstance(base, AlignmentFile) and base._h is not None):
+            continue
+        if base._loaded is None:
+            want = None if base is bam else list(bam.references)
+            jobs.append((base, want))
+    if len(jobs) < 2:
+        return
+    errors = []
+
+    def run(base, want):
+        try:
+            base.load(want)
+        except BaseException as e:  # noqa: BLE001 — re-raised below
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=j, daemon=True) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+
+
+LAST_TIMING = {}  # seconds per stage of the latest collect_tables call (tools/, bench legs)
+
+
 def collect_tables(bams, options, ctx=None):
     """CandidateTable of every bam in `bams` (the two haplotypes of a diploid sample): one device submission
     for all of them when their reference dictionaries agree."""
+    import time
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
+    t0 = time.perf_counter()
+    _load_together(bams)
     samples = [_prepare(bam, options) for bam in bams]
+    t1 = time.perf_counter()
     groups = [samples] if _same_header(bams) else [[s] for s in samples]
     for group in groups:
         _submit(group, options, ctx)
-    return [_table_of(s, options) for s in samples]
+    t2 = time.perf_counter()
+    for s in samples:   # starts every sample's sequence decoding (the readers' threads) before waiting for any
+        _table_of(s, options)
+    t3 = time.perf_counter()
+    tables = [_join_sequences(s) for s in samples]
+    LAST_TIMING.update(prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=time.perf_counter() - t3)
+    return tables
 
 
 def analyze_alignment_file_coordsorted(bam, options):

@@ -61,12 +61,29 @@ def _init_distributed(options):
     return True
 
 
+def _warm_device(device):
+    """Start HIP initialisation and the creation of the device context (150-350 ms in a fresh process) on a
+    thread of its own: the BAM headers, indices and record walks of STEP 1 do not need the device and run
+    meanwhile (ctypes releases the GIL for the call).  Errors are not lost: the first real use of the context
+    creates it again and raises."""
+    import threading
+    from svim_asm_amd import _lib
+
+    def create():
+        try:
+            _lib.default_context(device)
+        except Exception:  # noqa: BLE001 — reported by the caller that needs the context
+            pass
+    threading.Thread(target=create, daemon=True).start()
+
+
 def main(arguments=None):
     options = parse_arguments(program_version=__version__, arguments=arguments)
     if not options.sub:
         print("Please choose one of the two modes ('haploid' or 'diploid'). See --help for more information.")
         return
     distributed = _init_distributed(options)
+    _warm_device(getattr(options, "device", 0) or 0)
     try:
         return _main(options)
     except Exception as e:
@@ -86,8 +103,7 @@ def _main(options):
     log_format = logging.Formatter("%(asctime)s [%(levelname)-7.7s]  %(message)s")
     root = logging.getLogger()
     root.setLevel(logging.DEBUG if options.verbose else logging.INFO)
-    if not os.path.exists(options.working_dir):
-        os.makedirs(options.working_dir)
+    os.makedirs(options.working_dir, exist_ok=True)  # (several ranks create it at the same moment)
     rank, world_size = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     # one log file per rank (rank 0 keeps the reference's name); only rank 0 talks on the console
     suffix = "" if world_size <= 1 or rank == 0 else ".rank{0}".format(rank)

@@ -106,6 +106,34 @@ struct Inflater {
         if (rc != Z_STREAM_END || zs.avail_out != 0) return false;
         return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), out, (uInt)out_len) == crc;
     }
+    // Streaming use (zlib): begin() a member, then extend() the inflated prefix as far as somebody needs it.
+    // A slice of a contig-sized SEQ field sits somewhere inside a 64 KiB member: inflating only up to its last
+    // byte halves the work on average.  The CRC covers whole members, so it is checked when (and only when)
+    // the prefix reaches the member's end.
+    bool can_stream() const { return libdeflate() == nullptr; }
+    bool begin(const uint8_t* in, size_t in_len) {
+        ++n_blocks;
+        if (!z_ready) {
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            z_ready = true;
+        } else if (inflateReset(&zs) != Z_OK) {
+            return false;
+        }
+        zs.next_in = const_cast<Bytef*>(in);
+        zs.avail_in = (uInt)in_len;
+        return true;
+    }
+    bool extend(uint8_t* out, size_t have, size_t want, size_t member_len, uint32_t crc) {
+        zs.next_out = out + have;
+        zs.avail_out = (uInt)(want - have);
+        const int rc = inflate(&zs, want == member_len ? Z_FINISH : Z_SYNC_FLUSH);
+        if (zs.avail_out != 0 || (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR)) return false;
+        if (want == member_len) {
+            if (rc != Z_STREAM_END) return false;
+            return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), out, (uInt)member_len) == crc;
+        }
+        return true;
+    }
 };
 
 // ------------------------------------------------------------------ BGZF members
@@ -162,6 +190,8 @@ struct Cursor {
     bool eof = false;
     bool bad = false;
     uint64_t buf_coff = ~0ull;  // member currently held in `buf`
+    uint32_t buf_valid = 0;     // bytes of it inflated so far (prefix mode; the whole member otherwise)
+    bool prefix_mode = false;   // inflate members only as far as the bytes asked for (svx_bam_seq_slices)
     uint64_t n_hopped = 0;      // members passed (inflated or not)
     std::vector<uint8_t> buf;
 
@@ -185,22 +215,38 @@ struct Cursor {
         return settle();
     }
     VPos tell() const { VPos p; p.coff = coff; p.uoff = uoff; return p; }
-    bool ensure() {
-        if (buf_coff == coff) return true;
+    bool ensure(uint32_t upto) {  // bytes [0, upto) of the current member are in `buf`
         if (buf.empty()) buf.resize(65536);
+        // prefix mode: zlib's streaming inflate up to the last byte asked for — unless most of the member is wanted
+        // anyway and libdeflate (no streaming interface, but ~1.5x faster per byte on SEQ data) can take all of it
+        if (prefix_mode && (buf_coff == coff || inf->can_stream() || (uint64_t)upto * 5 <= (uint64_t)blk.isize * 3)) {
+            if (buf_coff != coff) {
+                buf_coff = ~0ull;
+                if (!inf->begin(f->map + coff + blk.payload_off, blk.payload_len)) { bad = true; return false; }
+                buf_coff = coff;
+                buf_valid = 0;
+            }
+            if (buf_valid < upto) {
+                if (!inf->extend(buf.data(), buf_valid, upto, blk.isize, blk.crc)) { bad = true; buf_coff = ~0ull; return false; }
+                buf_valid = upto;
+            }
+            return true;
+        }
+        if (buf_coff == coff) return true;
         if (!inf->run(f->map + coff + blk.payload_off, blk.payload_len, buf.data(), blk.isize, blk.crc)) {
             bad = true;
             return false;
         }
         buf_coff = coff;
+        buf_valid = blk.isize;
         return true;
     }
     bool read(void* dst, size_t n) {
         uint8_t* d = static_cast<uint8_t*>(dst);
         while (n) {
             if (eof || bad) { bad = true; return false; }
-            if (!ensure()) return false;
             const size_t take = std::min<size_t>(n, blk.isize - uoff);
+            if (!ensure(uoff + (uint32_t)take)) return false;
             memcpy(d, buf.data() + uoff, take);
             d += take;
             n -= take;
@@ -896,6 +942,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
     auto work = [&](uint32_t lo, uint32_t hi) {
         Inflater inf;
         Cursor c(&b->file, &inf);
+        c.prefix_mode = true;
         std::vector<uint8_t> packed;
         uint32_t cur_rec = ~0u;
         uint64_t cur_byte = 0;  // bytes of the record's SEQ field already passed by the cursor

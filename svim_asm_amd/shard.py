@@ -203,13 +203,8 @@ def collect_sharded(bams, options, collect_fn=None):
     mine = [i for i, r in enumerate(owner) if r == rank]
 
     def local():
-        views = []
-        for b in bams:
-            load = getattr(b, "load", None)
-            if load is not None:  # walk / inflate only the BGZF ranges of the contigs this rank owns
-                load([b.references[i] for i in mine])
-            views.append(ContigView(b, mine))
-        tables = collect_fn(views, options)
+        # a view makes COLLECT walk / inflate only the BGZF ranges of the contigs this rank owns
+        tables = collect_fn([ContigView(b, mine) for b in bams], options)
         for t in tables:
             if getattr(t, "rec_tid", None) is None:
                 raise RuntimeError("COLLECT tables of a sharded run need the record contig of every row")

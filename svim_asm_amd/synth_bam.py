@@ -43,11 +43,12 @@ class Event(object):
         self.pos, self.kind, self.length, self.seq = pos, kind, length, seq
 
 
-def make_events(rng, contig_len, n, min_len=40, max_len=2000):
-    """n non-overlapping SV-sized insertion/deletion events on one contig."""
+def make_events(rng, contig_len, n, min_len=40, max_len=2000, min_gap=1500):
+    """n non-overlapping SV-sized insertion/deletion events on one contig, at least `min_gap` bp apart (below the
+    pairing step's partition distance of 1000 neighbouring events chain into crowded partitions: config 5)."""
     out, pos = [], 2000
     for _ in range(n):
-        pos += int(rng.integers(1500, max(1501, (contig_len - 4000) // max(n, 1))))
+        pos += int(rng.integers(min_gap, max(min_gap + 1, (contig_len - 4000) // max(n, 1))))
         if pos + max_len + 3000 >= contig_len:
             break
         length = int(np.exp(rng.uniform(np.log(min_len), np.log(max_len))))
@@ -331,7 +332,7 @@ def file_digest(path):
 
 
 def write_dataset(outdir, seed=1, contigs=CONFIG1_CONTIGS, diploid=True, n_shared=25, n_private=6,
-                  median_aln=30000, mean_m=2000, dense_cluster=True, with_splits=True):
+                  median_aln=30000, mean_m=2000, dense_cluster=True, with_splits=True, min_gap=1500):
     """FASTA + one or two haplotype BAMs under `outdir`; returns their paths."""
     import os
     os.makedirs(outdir, exist_ok=True)
@@ -339,7 +340,7 @@ def write_dataset(outdir, seed=1, contigs=CONFIG1_CONTIGS, diploid=True, n_share
     fasta = os.path.join(outdir, "ref.fa")
     write_fasta(fasta, [c[0] for c in contigs], [genome[c[0]] for c in contigs])
     rng = np.random.default_rng(seed + 1000)
-    shared = {name: make_events(rng, length, n_shared) for name, length in contigs}
+    shared = {name: make_events(rng, length, n_shared, min_gap=min_gap) for name, length in contigs}
     # a knot of six small deletions within 1 kb near the end of the first contig, identical in
     # both haplotypes: 12 candidates in one partition, which the pairing step drops (> 10)
     knot = []

@@ -28,15 +28,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def dataset_args(scale, sv_per_mbp=8.0, mean_m=2000, seed=3):
+def dataset_args(scale, sv_per_mbp=8.0, mean_m=2000, seed=3, min_gap=1500):
     from svim_asm_amd import synth
     contigs = tuple((n, max(60000, int(l * scale))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
     n_shared = max(4, int(sv_per_mbp * max(c[1] for c in contigs) / 1e6))
     return dict(seed=seed, contigs=contigs, diploid=True, n_shared=n_shared, n_private=max(2, n_shared // 5),
-                median_aln=300000, mean_m=mean_m)
+                median_aln=300000, mean_m=mean_m, min_gap=min_gap)
 
 
-def reference_meta(scale, sv_per_mbp, mean_m):
+CONFIG5 = dict(scale=0.05, sv_per_mbp=400.0, mean_m=400, seed=5, min_gap=200)  # oracle/make_golden.py CONFIG5
+
+
+def reference_meta(scale, sv_per_mbp, mean_m, seed=3, min_gap=1500):
     """Committed description of the real reference's run on exactly these generator arguments, if any."""
     for name in ("full_inputs.json", "large_inputs.json", "config5_inputs.json"):
         path = os.path.join(ROOT, "tests", "golden", name)
@@ -45,7 +48,7 @@ def reference_meta(scale, sv_per_mbp, mean_m):
         meta = json.load(open(path))
         prm = meta["params"]
         if abs(scale - prm["scale"]) < 1e-12 and sv_per_mbp == prm["sv_per_mbp"] and mean_m == prm["mean_m"] and \
-                "payload_sha256" in meta:
+                seed == prm["seed"] and min_gap == prm.get("min_gap", 1500) and "payload_sha256" in meta:
             return name, meta
     return None, None
 
@@ -87,7 +90,7 @@ def run_ranks(argv, world_size, n_devices=1, timeout=900):
 
 
 def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None, threads=0, repeat=1, device=0,
-            ranks=(1, 2, 4), n_devices=1, mean_m=2000, in_process=True):
+            ranks=(1, 2, 4), n_devices=1, mean_m=2000, in_process=True, seed=3, min_gap=1500):
     """Generate (or reuse) the dataset, run the product pipeline `repeat` times in this process with phase
     clocks (in_process=False: the caller must not touch the GPU — only the child processes run), then the
     command line as fresh processes (1 rank and the sharded runs), then the checker."""
@@ -99,13 +102,13 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
         out = dataset
         fasta, bams = os.path.join(out, "ref.fa"), [os.path.join(out, "hap1.bam"), os.path.join(out, "hap2.bam")]
     else:
-        fasta, bams = synth_bam.write_dataset(out, **dataset_args(scale, sv_per_mbp, mean_m))
+        fasta, bams = synth_bam.write_dataset(out, **dataset_args(scale, sv_per_mbp, mean_m, seed, min_gap))
     res["generate_s"] = time.perf_counter() - t0
     res["genome_bp"] = int(sum(max(60000, int(l * scale)) for l in __import__("svim_asm_amd.synth", fromlist=["x"]).GRCH38_LENGTHS))
     res["bam_bytes"] = [os.path.getsize(b) for b in bams]
 
     # ---- are these the inputs the REAL reference was run on?  (digests of the uncompressed content)
-    meta_name, meta = reference_meta(scale, sv_per_mbp, mean_m)
+    meta_name, meta = reference_meta(scale, sv_per_mbp, mean_m, seed, min_gap)
     same_inputs = None
     if meta is not None:
         t0 = time.perf_counter()
@@ -149,6 +152,8 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             t = time.perf_counter()
             t1, t2 = shard.collect_sharded([f1, f2], opts)
             r["collect_s"] = time.perf_counter() - t
+            from svim_asm_amd import SVIM_COLLECT
+            r["collect_stages_s"] = dict(SVIM_COLLECT.LAST_TIMING)
             ref = FastaFile(fasta)
             t = time.perf_counter()
             paired = shard.pair_sharded(t1, t2, ref, f1, opts)
@@ -234,6 +239,8 @@ def main():
     ap.add_argument("--keep", default=None)
     ap.add_argument("--sv-per-mbp", type=float, default=8.0)
     ap.add_argument("--mean-m", type=int, default=2000, help="mean M-run length of the CIGARs (400: BASELINE config 5)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5 as a diploid sample: the generator arguments of "
+                    "oracle/make_golden.py config5 (10x small-indel density, crowded partitions, > 131072 candidates)")
     ap.add_argument("--with-oracle", action="store_true", help="run the CPU oracle pipeline even when the real reference's digest is available")
     ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
     ap.add_argument("--threads", type=int, default=0, help="ingest threads (0: one per hardware thread, at most 64)")
@@ -242,9 +249,13 @@ def main():
     ap.add_argument("--devices", type=int, default=1, help="HIP devices the ranks are spread over")
     ap.add_argument("--no-in-process", action="store_true", help="only the command-line runs (this process never touches the GPU)")
     args = ap.parse_args()
+    seed, min_gap = 3, 1500
+    if args.config5:
+        args.scale, args.sv_per_mbp, args.mean_m, seed, min_gap = (CONFIG5[k] for k in ("scale", "sv_per_mbp", "mean_m", "seed", "min_gap"))
     print(json.dumps(run_e2e(args.scale, args.keep, args.sv_per_mbp, True if args.with_oracle else None, args.dataset,
                              args.threads, args.repeat, ranks=tuple(int(x) for x in args.ranks.split(",") if x),
-                             n_devices=args.devices, mean_m=args.mean_m, in_process=not args.no_in_process)))
+                             n_devices=args.devices, mean_m=args.mean_m, in_process=not args.no_in_process, seed=seed,
+                             min_gap=min_gap)))
 
 
 if __name__ == "__main__":
