@@ -290,6 +290,88 @@ int svx_segments_postpass(svx_ctx* ctx, const svx_raw* raw, const uint32_t* read
                           const int32_t* contig_rank, uint32_t n_contigs, const svx_seg_params* params,
                           svx_post* out, const uint64_t* out_off, uint32_t* out_cnt);
 
+/* Asynchronous form on device pointers.  The HOST copies `read_off` / `out_off` size the per-read scratch and
+ * are validated exactly like above (nothing of them is read after the call returns); d_read_off / d_out_off are
+ * the same arrays in HBM.  Enqueues on the context's stream, does not synchronise. */
+int svx_segments_postpass_dev(svx_ctx* ctx, const svx_raw* d_raw, const uint32_t* read_off, const uint32_t* d_read_off,
+                              uint32_t n_reads, const int32_t* d_contig_rank, uint32_t n_contigs,
+                              const svx_seg_params* params, svx_post* d_out, const uint64_t* out_off,
+                              const uint64_t* d_out_off, uint32_t* d_out_cnt);
+
+/*
+ * Segment rows of chimeric reads straight from CIGARs in HBM: the dictionaries analyze_read_segments builds per
+ * alignment (SVIM_inter.py:66-81) — q_start / q_end from query_alignment_start / _end (flipped with
+ * infer_read_length() for reverse records), reference_end = reference_start + Σ{M,D,N,=,X} (1 when that is 0,
+ * htslib bam_endpos).  Segment j is alignment d_seg_src[j] of (d_cigar, d_aln_off); d_seg_qend[j] >= 0 overrides
+ * query_alignment_end (pysam takes it from the stored sequence when the record has one: l_seq minus the trailing
+ * soft clips), -1 derives it from the CIGAR.  d_read_len[r] = infer_read_length() of read r's first segment
+ * (its primary, SVIM_inter.py:120).  One wave per segment; asynchronous.
+ */
+int svx_segments_rows_dev(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, const uint32_t* d_seg_src,
+                          const int32_t* d_seg_tid, const int32_t* d_seg_pos, const uint8_t* d_seg_rev,
+                          const int32_t* d_seg_qend, uint32_t n_segs, const uint32_t* d_read_off, uint32_t n_reads,
+                          svx_seg* d_segs, int32_t* d_read_len);
+
+/* ------------------------------------------------------- COLLECT, whole ---- */
+/*
+ * The device work of analyze_alignment_file_coordsorted (SVIM_COLLECT.py:61-83) for every record of a sample —
+ * or of both haplotype BAMs of a diploid sample — as ONE submission: svx_cigar_extract_dev over all records
+ * (a1 + a2), svx_segments_rows_dev + svx_segments_classify_dev + svx_segments_postpass_dev over the chimeric reads
+ * (a3), enqueued on the context's stream behind the uploads; two read-backs (the counts, then exactly the results).
+ *
+ *   cigar_parts / part_ops   n_parts host arrays of BAM-native CIGAR words, logically back to back (the pools of
+ *                 svx_bam_get_columns: page-locked, uploaded where they lie — no concatenation on the host)
+ *   aln_off       n_aln + 1 offsets into that concatenation, EVERY record of the pools (records the caller's
+ *                 filters drop are walked too — their signatures are masked by the caller; cheaper than compacting
+ *                 the pools); ref_start[n_aln]; min_len = options.min_sv_size
+ *   extra_cigar / extra_off   CIGARs of the n_extra SA-derived segments (SVIM_COLLECT.py:33-55)
+ *   seg_*[n_segs] one row per segment of every chimeric read, [primary] + supplementaries per read
+ *                 (SVIM_inter.py:64): seg_src < n_aln names a record of the pools, otherwise extra alignment
+ *                 seg_src - n_aln; seg_tid / seg_pos / seg_rev its reference id, start and strand; seg_qend as in
+ *                 svx_segments_rows_dev
+ *   read_off      n_reads + 1 offsets into the segment rows
+ *   contig_rank, params   as for svx_segments_postpass
+ * Output (host arrays):
+ *   sig, sig_cap, n_sig    as svx_cigar_extract (SVX_E_CAPACITY with n_sig set when sig_cap is too small)
+ *   raw[n_segs]            as svx_segments_classify
+ *   post, post_off, post_cnt   as svx_segments_postpass (post_off: n_reads + 1 region offsets, chosen by the caller)
+ */
+typedef struct svx_collect_in {
+    const uint32_t* const* cigar_parts;
+    const uint64_t* part_ops;
+    uint32_t n_parts;
+    const uint64_t* aln_off;
+    const int32_t* ref_start;
+    uint32_t n_aln;
+    uint32_t min_len;
+    const uint32_t* extra_cigar;
+    const uint64_t* extra_off;
+    uint32_t n_extra;
+    const uint32_t* seg_src;
+    const int32_t* seg_tid;
+    const int32_t* seg_pos;
+    const uint8_t* seg_rev;
+    const int32_t* seg_qend;
+    uint32_t n_segs;
+    const uint32_t* read_off;
+    uint32_t n_reads;
+    const int32_t* contig_rank;
+    uint32_t n_contigs;
+    svx_seg_params params;
+} svx_collect_in;
+
+typedef struct svx_collect_out {
+    svx_sig_soa sig;
+    uint64_t sig_cap;
+    uint64_t n_sig;
+    svx_raw* raw;
+    svx_post* post;
+    const uint64_t* post_off;
+    uint32_t* post_cnt;
+} svx_collect_out;
+
+int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_collect_out* out);
+
 /* ------------------------------------------------------------ a5 + a6 ------ */
 /*
  * Pair sort + partition: form_partitions (SVIM_COMBINE.py:15-32).
@@ -365,6 +447,11 @@ typedef struct svx_hap_piece {
 
 int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
                                  const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist);
+/* The same with the byte pool already in HBM (d_pool: e.g. one upload of the reference windows serving the
+ * thresholded and the exact batch of a PAIR step).  pieces and dist stay host arrays and the call synchronises:
+ * the stages of the distance computation are planned from read-backs (which pairs the wavefront pass resolved). */
+int svx_haplotype_distance_batch_dev(svx_ctx* ctx, const uint8_t* d_pool, uint64_t pool_bytes,
+                                     const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist);
 
 /*
  * Batched complete linkage + flat cut: for every partition p (n_members[p] candidates, condensed
@@ -380,6 +467,10 @@ int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t poo
  */
 int svx_linkage_cut_batch(svx_ctx* ctx, const double* dist, const uint32_t* n_members, uint32_t n_parts,
                           double cutoff, uint32_t* labels);
+/* Asynchronous form: distances, member counts and labels in HBM; the HOST copy of n_members only sizes the scratch
+ * of partitions too large for LDS (not read after the call returns).  No synchronisation. */
+int svx_linkage_cut_batch_dev(svx_ctx* ctx, const double* d_dist, const uint32_t* n_members,
+                              const uint32_t* d_n_members, uint32_t n_parts, double cutoff, uint32_t* d_labels);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,8 @@ import threading
 
 import numpy as np
 
+from svim_asm_amd import _warm
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVX_LIB") or os.path.join(HERE, "libsvx.so")  # SVX_LIB: A/B builds
 
@@ -65,6 +67,22 @@ class VcfIn(C.Structure):
 
 VCF_DEL, VCF_INV, VCF_INS, VCF_DUPTAN_INS, VCF_DUPTAN_DUP, VCF_DUPINT_INS, VCF_DUPINT_DUP, VCF_BND, VCF_BND_REV = range(9)
 
+class CollectIn(C.Structure):
+    """svx_collect_in (include/svx.h)."""
+    _fields_ = [("cigar_parts", C.POINTER(C.c_void_p)), ("part_ops", C.c_void_p), ("n_parts", C.c_uint32),
+                ("aln_off", C.c_void_p), ("ref_start", C.c_void_p), ("n_aln", C.c_uint32), ("min_len", C.c_uint32),
+                ("extra_cigar", C.c_void_p), ("extra_off", C.c_void_p), ("n_extra", C.c_uint32),
+                ("seg_src", C.c_void_p), ("seg_tid", C.c_void_p), ("seg_pos", C.c_void_p), ("seg_rev", C.c_void_p),
+                ("seg_qend", C.c_void_p), ("n_segs", C.c_uint32), ("read_off", C.c_void_p), ("n_reads", C.c_uint32),
+                ("contig_rank", C.c_void_p), ("n_contigs", C.c_uint32), ("params", SegParams)]
+
+
+class CollectOut(C.Structure):
+    """svx_collect_out (include/svx.h)."""
+    _fields_ = [("sig", SigSoa), ("sig_cap", C.c_uint64), ("n_sig", C.c_uint64), ("raw", C.c_void_p),
+                ("post", C.c_void_p), ("post_off", C.c_void_p), ("post_cnt", C.c_void_p)]
+
+
 SEG_DTYPE = np.dtype([("q_start", "<i4"), ("q_end", "<i4"), ("ref_id", "<i4"), ("ref_start", "<i4"),
                       ("ref_end", "<i4"), ("is_reverse", "<i4")])
 HAP_PIECE_DTYPE = np.dtype([("off", "<u8"), ("len", "<u4"), ("repeat", "<u2"), ("flags", "<u2")])  # svx_hap_piece
@@ -107,6 +125,11 @@ SYMBOLS = {
                                             C.POINTER(SegParams), _P]),
     "svx_segments_postpass_bound": (C.c_uint64, [C.c_uint32]),
     "svx_segments_postpass": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(SegParams), _P, _P, _P]),
+    "svx_segments_postpass_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(SegParams), _P, _P, _P, _P]),
+    "svx_segments_rows_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]),
+    "svx_collect_batch": (C.c_int, [_P, C.POINTER(CollectIn), C.POINTER(CollectOut)]),
+    "svx_linkage_cut_batch_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_double, _P]),
+    "svx_haplotype_distance_batch_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P]),
     "svx_pair_partition": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32)]),
     "svx_pair_partition_dev": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "svx_pair_partition_dev_bits": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, _P]),
@@ -170,7 +193,10 @@ class Context:
     def __init__(self, device=0, stream=None):
         self.lib = load()
         h = _P()
-        if stream is None:
+        warm = _warm.take(device) if stream is None else None
+        if warm is not None:
+            h, rc = warm, SVX_OK  # created while the process was still importing (svim_asm_amd/_warm.py)
+        elif stream is None:
             rc = self.lib.svx_ctx_create(int(device), C.byref(h))
         else:
             rc = self.lib.svx_ctx_create_on_stream(int(device), _P(stream), C.byref(h))
@@ -328,8 +354,59 @@ class Context:
                       seg_pos, seg_rev, seg_qend, read_off, contig_rank, params):
         """a1 + a2 + a3 of one sample (or of both haplotypes of one): see collect_batch_composed for the
         contract.  One submission on the context's stream (svx_collect_batch)."""
-        return self.collect_batch_composed(cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src,
-                                           seg_tid, seg_pos, seg_rev, seg_qend, read_off, contig_rank, params)
+        parts = [np.ascontiguousarray(p, dtype=np.uint32) for p in cigar_parts]
+        aln_off = _as(aln_off, np.uint64)
+        ref_start = _as(ref_start, np.int32)
+        n_aln = len(aln_off) - 1 if len(aln_off) else 0
+        extra_cigar, extra_off = _as(extra_cigar, np.uint32), _as(extra_off, np.uint64)
+        n_extra = len(extra_off) - 1 if len(extra_off) else 0
+        seg_src, seg_tid, seg_pos = _as(seg_src, np.uint32), _as(seg_tid, np.int32), _as(seg_pos, np.int32)
+        seg_rev, seg_qend = _as(seg_rev, np.uint8), _as(seg_qend, np.int32)
+        read_off = _as(read_off, np.uint32)
+        contig_rank = _as(contig_rank, np.int32)
+        n_segs = len(seg_src)
+        n_reads = len(read_off) - 1 if len(read_off) and n_segs else 0
+        prm = params if isinstance(params, SegParams) else SegParams(*[int(x) for x in params])
+        n_ops = int(aln_off[-1]) if n_aln else 0
+        part_ops = np.array([len(p) for p in parts], dtype=np.uint64)
+        part_ptrs = (C.c_void_p * max(1, len(parts)))(*[p.ctypes.data if p.size else None for p in parts])
+        slots = np.diff(read_off[:n_reads + 1].astype(np.int64)) if n_reads else np.zeros(0, np.int64)
+        post_off = np.zeros(n_reads + 1, np.uint64)
+        if n_reads:
+            np.cumsum(slots * (slots + 3) // 2, out=post_off[1:])
+        raw = np.zeros(n_segs, dtype=RAW_DTYPE)
+        post = np.zeros(int(post_off[-1]), dtype=RAW_DTYPE)  # svx_post has svx_raw's layout
+        cnt = np.zeros(n_reads, np.uint32)
+        cap = max(1024, n_ops // 16)
+        arg = CollectIn(cigar_parts=part_ptrs, part_ops=_ptr(part_ops), n_parts=len(parts), aln_off=_ptr(aln_off),
+                        ref_start=_ptr(ref_start), n_aln=n_aln, min_len=int(min_len), extra_cigar=_ptr(extra_cigar),
+                        extra_off=_ptr(extra_off) if n_extra else None, n_extra=n_extra, seg_src=_ptr(seg_src),
+                        seg_tid=_ptr(seg_tid), seg_pos=_ptr(seg_pos), seg_rev=_ptr(seg_rev), seg_qend=_ptr(seg_qend),
+                        n_segs=n_segs if n_reads else 0, read_off=_ptr(read_off), n_reads=n_reads,
+                        contig_rank=_ptr(contig_rank), n_contigs=len(contig_rank), params=prm)
+        while True:
+            sig = {"aln": np.empty(cap, np.uint32), "ref_pos": np.empty(cap, np.uint32), "read_pos": np.empty(cap, np.uint32),
+                   "len": np.empty(cap, np.uint32), "type": np.empty(cap, np.uint8)}
+            res = CollectOut(sig=SigSoa(*[_ptr(sig[k]) for k in ("aln", "ref_pos", "read_pos", "len", "type")]),
+                             sig_cap=cap, n_sig=0, raw=_ptr(raw), post=_ptr(post), post_off=_ptr(post_off),
+                             post_cnt=_ptr(cnt))
+            rc = self.lib.svx_collect_batch(self.h, C.byref(arg), C.byref(res))
+            if rc == SVX_E_CAPACITY and int(res.n_sig) > cap:
+                cap = int(res.n_sig)
+                continue
+            self._check(rc)
+            break
+        k = int(res.n_sig)
+        sig = {key: v[:k] for key, v in sig.items()}
+        first = np.zeros(n_reads + 1, np.int64)
+        if n_reads:
+            np.cumsum(cnt.astype(np.int64), out=first[1:])
+        if int(first[-1]):
+            take = np.repeat(post_off[:-1].astype(np.int64) - first[:-1], cnt) + np.arange(int(first[-1]))
+            packed = post[take]
+        else:
+            packed = post[:0]
+        return sig, raw, packed, first
 
     def collect_batch_composed(self, cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src,
                                seg_tid, seg_pos, seg_rev, seg_qend, read_off, contig_rank, params):

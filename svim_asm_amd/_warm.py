@@ -1,0 +1,60 @@
+"""Earliest possible start of the HIP runtime in a fresh `svim-asm` process.
+
+Creating the first context (hipInit, device enumeration, stream) takes 150-350 ms and nothing of STEP 1
+needs the device before the BAM headers, indices and records have been walked — so bin/svim-asm starts it
+on a thread BEFORE numpy and the package are imported (this module needs ctypes only), and
+`_lib.Context` adopts the context the thread made.  One process per GPU: under a launcher (LOCAL_RANK set)
+the process is restricted to its own device first, which also keeps the runtime from initialising the other
+seven."""
+import ctypes
+import os
+import threading
+
+_state = {"thread": None, "device": None, "handle": None, "lib": None}
+
+
+def restrict_to_local_rank():
+    """Multi-GPU launch: show this process only the device of its LOCAL_RANK (which then is device 0).  Returns
+    the device index to use from now on, or None outside a multi-rank launch.  A caller that has restricted the
+    visible devices itself is left alone (LOCAL_RANK then indexes what it left visible)."""
+    if "restricted" in _state:
+        return _state["restricted"]
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or os.environ.get("LOCAL_RANK") is None:
+        return None
+    local = os.environ["LOCAL_RANK"]
+    if "HIP_VISIBLE_DEVICES" in os.environ or "ROCR_VISIBLE_DEVICES" in os.environ:
+        _state["restricted"] = int(local)
+    else:
+        os.environ["HIP_VISIBLE_DEVICES"] = local
+        _state["restricted"] = 0
+    return _state["restricted"]
+
+
+def start(device, lib_path):
+    """Begin creating the context of `device` in the background (no-op when already started)."""
+    if _state["thread"] is not None or not os.path.exists(lib_path):
+        return
+
+    def create():
+        try:
+            lib = ctypes.CDLL(lib_path)
+            lib.svx_ctx_create.restype = ctypes.c_int
+            lib.svx_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+            h = ctypes.c_void_p()
+            if lib.svx_ctx_create(int(device), ctypes.byref(h)) == 0:
+                _state["handle"], _state["lib"] = h, lib
+        except Exception:  # noqa: BLE001 — the regular path reports what is wrong
+            pass
+    _state["device"] = int(device)
+    _state["thread"] = threading.Thread(target=create, daemon=True)
+    _state["thread"].start()
+
+
+def take(device):
+    """The context handle made for `device` by start(), once (None if there is none)."""
+    th = _state["thread"]
+    if th is None or _state["device"] != int(device):
+        return None
+    th.join()
+    h, _state["handle"] = _state["handle"], None
+    return h

@@ -57,7 +57,10 @@ def _init_distributed(options):
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size <= 1:
         return False
-    options.device = int(os.environ.get("LOCAL_RANK", "0"))
+    from svim_asm_amd import _warm
+    options.device = _warm.restrict_to_local_rank()
+    if options.device is None:
+        options.device = int(os.environ.get("LOCAL_RANK", "0"))
     return True
 
 

@@ -982,45 +982,107 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+struct AlnStats {
+    uint32_t lead, ref, qal, rl, hard;
+};
+
+// Statistics of the alignment whose ops are cigar[b .. e), computed by one wave (every lane returns the same):
+// lead = Σ leading S (skipping H), ref = Σ{M,D,N,=,X}, qal = Σ{M,I,=,X}, rl = Σ{M,I,S,=,X,H}, hard = Σ H.
+__device__ __forceinline__ AlnStats wave_alignment_stats(const uint32_t* cigar, uint64_t b, uint64_t e, int lane) {
+    AlnStats r;
+    // leading soft clips: S ops before the first op that is neither S nor H
+    // (pysam getQueryStart)
+    uint32_t lead = 0;
+    {
+        uint64_t i = b;
+        bool done = false;
+        while (!done && i < e) {
+            uint64_t j = i + lane;
+            uint32_t w = (j < e) ? cigar[j] : 0u;  // op 0 (M) terminates the prefix
+            uint32_t op = w & 15u;
+            bool clip = (j < e) && (op == 4u || op == 5u);
+            uint64_t nb = __ballot(!clip);
+            int first = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
+            uint32_t s = (lane < first && op == 4u && j < e) ? (w >> 4) : 0u;
+            lead += wave_sum(s);
+            done = first < 64;
+            i += 64;
+        }
+    }
+    uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
+    for (uint64_t i = b + lane; i < e; i += 64) {
+        const uint32_t w = cigar[i], op = w & 15u, len = w >> 4;
+        if ((0x18Du >> op) & 1u) ref += len;   // M D N = X  (htslib bam_endpos)
+        if ((0x183u >> op) & 1u) qal += len;   // M I = X
+        if ((0x1B3u >> op) & 1u) rl += len;    // M I S H = X (infer_read_length)
+        if (op == 5u) hard += len;
+    }
+    r.lead = lead;
+    r.ref = wave_sum(ref); r.qal = wave_sum(qal); r.rl = wave_sum(rl); r.hard = wave_sum(hard);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_cigar_stats(StatsArgs p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t a = blockIdx.x * 4 + wave; a < p.n_aln; a += gridDim.x * 4) {
-        const uint64_t b = p.aln_off[a], e = p.aln_off[a + 1];
-        // leading soft clips: S ops before the first op that is neither S nor H
-        // (pysam getQueryStart)
-        uint32_t lead = 0;
-        {
-            uint64_t i = b;
-            bool done = false;
-            while (!done && i < e) {
-                uint64_t j = i + lane;
-                uint32_t w = (j < e) ? p.cigar[j] : 0u;  // op 0 (M) terminates the prefix
-                uint32_t op = w & 15u;
-                bool clip = (j < e) && (op == 4u || op == 5u);
-                uint64_t nb = __ballot(!clip);
-                int first = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
-                uint32_t s = (lane < first && op == 4u && j < e) ? (w >> 4) : 0u;
-                lead += wave_sum(s);
-                done = first < 64;
-                i += 64;
-            }
-        }
-        uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
-        for (uint64_t i = b + lane; i < e; i += 64) {
-            const uint32_t w = p.cigar[i], op = w & 15u, len = w >> 4;
-            if ((0x18Du >> op) & 1u) ref += len;   // M D N = X  (htslib bam_endpos)
-            if ((0x183u >> op) & 1u) qal += len;   // M I = X
-            if ((0x1B3u >> op) & 1u) rl += len;    // M I S H = X (infer_read_length)
-            if (op == 5u) hard += len;
-        }
-        ref = wave_sum(ref); qal = wave_sum(qal); rl = wave_sum(rl); hard = wave_sum(hard);
+        const AlnStats st = wave_alignment_stats(p.cigar, p.aln_off[a], p.aln_off[a + 1], lane);
         if (lane == 0) {
-            if (p.out.ref_len) p.out.ref_len[a] = ref;
-            if (p.out.q_start) p.out.q_start[a] = lead;
-            if (p.out.q_end) p.out.q_end[a] = lead + qal;
-            if (p.out.read_len) p.out.read_len[a] = rl;
-            if (p.out.n_hard) p.out.n_hard[a] = hard;
+            if (p.out.ref_len) p.out.ref_len[a] = st.ref;
+            if (p.out.q_start) p.out.q_start[a] = st.lead;
+            if (p.out.q_end) p.out.q_end[a] = st.lead + st.qal;
+            if (p.out.read_len) p.out.read_len[a] = st.rl;
+            if (p.out.n_hard) p.out.n_hard[a] = st.hard;
         }
+    }
+}
+
+// ---- segment rows of the chimeric reads (SVIM_inter.py:66-81): one wave per segment ----
+struct SegRowArgs {
+    const uint32_t* cigar;
+    const uint64_t* aln_off;
+    const uint32_t* seg_src;   // alignment (index into aln_off) each segment is
+    const int32_t* seg_tid;
+    const int32_t* seg_pos;
+    const uint8_t* seg_rev;
+    const int32_t* seg_qend;   // >= 0: query_alignment_end taken from the stored sequence (pysam), else from the CIGAR
+    uint32_t n_segs;
+    const uint32_t* read_off;  // n_reads + 1
+    uint32_t n_reads;
+    svx_seg* segs;
+    int32_t* read_len;         // per read: infer_read_length() of its first segment (the primary)
+};
+
+__global__ __launch_bounds__(256) void k_segment_rows(SegRowArgs p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t j = blockIdx.x * 4 + wave; j < p.n_segs; j += gridDim.x * 4) {
+        const uint32_t a = p.seg_src[j];
+        const AlnStats st = wave_alignment_stats(p.cigar, p.aln_off[a], p.aln_off[a + 1], lane);
+        if (lane == 0) {
+            const int32_t q_start = (int32_t)st.lead;
+            const int32_t over = p.seg_qend[j];
+            const int32_t q_end = over >= 0 ? over : (int32_t)(st.lead + st.qal);
+            const int32_t rl = (int32_t)st.rl;
+            const bool rev = p.seg_rev[j] != 0;
+            svx_seg s;
+            s.q_start = rev ? rl - q_end : q_start;      // :68-73 (query coordinates flipped for reverse records)
+            s.q_end = rev ? rl - q_start : q_end;
+            s.ref_id = p.seg_tid[j];
+            s.ref_start = p.seg_pos[j];
+            s.ref_end = p.seg_pos[j] + (int32_t)(st.ref ? st.ref : 1u);  // htslib bam_endpos
+            s.is_reverse = rev ? 1 : 0;
+            p.segs[j] = s;
+        }
+    }
+    // read_len[r] = read length of read r's primary = its first segment; recomputed by the wave that owns it
+    for (uint32_t r = blockIdx.x * 4 + wave; r < p.n_reads; r += gridDim.x * 4) {
+        const uint32_t j = p.read_off[r];
+        if (j >= p.n_segs || p.read_off[r + 1] == j) {
+            if (lane == 0) p.read_len[r] = 0;
+            continue;
+        }
+        const uint32_t a = p.seg_src[j];
+        const AlnStats st = wave_alignment_stats(p.cigar, p.aln_off[a], p.aln_off[a + 1], lane);
+        if (lane == 0) p.read_len[r] = (int32_t)st.rl;
     }
 }
 
@@ -1282,6 +1344,26 @@ extern "C" int svx_cigar_stats(svx_ctx* ctx, const uint32_t* cigar, const uint64
     if (out.read_len) SVX_HIP(ctx, hipMemcpyAsync(out.read_len, d.read_len, b, hipMemcpyDeviceToHost, ctx->stream));
     if (out.n_hard) SVX_HIP(ctx, hipMemcpyAsync(out.n_hard, d.n_hard, b, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SVX_OK;
+}
+
+extern "C" int svx_segments_rows_dev(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off,
+                                     const uint32_t* d_seg_src, const int32_t* d_seg_tid, const int32_t* d_seg_pos,
+                                     const uint8_t* d_seg_rev, const int32_t* d_seg_qend, uint32_t n_segs,
+                                     const uint32_t* d_read_off, uint32_t n_reads, svx_seg* d_segs, int32_t* d_read_len) {
+    if (!ctx) return SVX_E_INVALID;
+    if (n_segs == 0 && n_reads == 0) return SVX_OK;
+    if (!d_aln_off || !d_seg_src || !d_seg_tid || !d_seg_pos || !d_seg_rev || !d_seg_qend || !d_read_off || !d_segs ||
+        !d_read_len)
+        return SVX_E_INVALID;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SegRowArgs a{d_cigar, d_aln_off, d_seg_src, d_seg_tid, d_seg_pos, d_seg_rev, d_seg_qend, n_segs, d_read_off, n_reads,
+                 d_segs, d_read_len};
+    const uint32_t work = n_segs > n_reads ? n_segs : n_reads;
+    uint32_t blocks = (work + 3) / 4;
+    const uint32_t cap = (uint32_t)ctx->n_cu * 8u;
+    hipLaunchKernelGGL(k_segment_rows, dim3(blocks < cap ? blocks : cap), dim3(256), 0, ctx->stream, a);
+    SVX_HIP(ctx, hipGetLastError());
     return SVX_OK;
 }
 

@@ -49,6 +49,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     for (int i = 0; i < 4; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_dom) (void)hipEventDestroy(ctx->ev_dom);

@@ -630,12 +630,12 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
     return ed_run(ctx, d_seq, a_off, a_len, b_off, b_len, n_pairs, k_max, dist, plan);
 }
 
-extern "C" int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
-                                            const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max,
-                                            uint32_t* dist) {
+// pool: host bytes staged to HBM by this call, or (d_pool_resident != nullptr) already there
+static int hap_distance_impl(svx_ctx* ctx, const uint8_t* pool, const uint8_t* d_pool_resident, bool resident, uint64_t pool_bytes,
+                             const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist) {
     if (!ctx) return SVX_E_INVALID;
     if (n_pairs == 0) return SVX_OK;
-    if (!pieces || !dist || (pool_bytes && !pool)) return SVX_E_INVALID;
+    if (!pieces || !dist || (pool_bytes && !(resident ? d_pool_resident : pool))) return SVX_E_INVALID;
     const uint32_t n_strings = 2 * n_pairs;
     std::vector<uint64_t> str_off(n_strings), a_off(n_pairs), b_off(n_pairs);
     std::vector<uint32_t> a_len(n_pairs), b_len(n_pairs);
@@ -664,19 +664,35 @@ extern "C" int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, u
     int rc = ed_validate_and_plan(ctx, total, a_off.data(), a_len.data(), b_off.data(), b_len.data(), n_pairs, &plan);
     if (rc != SVX_OK) return rc;
     SVX_HIP(ctx, hipSetDevice(ctx->device));
-    rc = svx_stage_reserve(ctx, svx_take_bytes(pool_bytes ? pool_bytes : 1, 1) + svx_take_bytes((size_t)n_strings * 3, sizeof(svx_hap_piece)) +
+    rc = svx_stage_reserve(ctx, (resident ? 0 : svx_take_bytes(pool_bytes ? pool_bytes : 1, 1)) + svx_take_bytes((size_t)n_strings * 3, sizeof(svx_hap_piece)) +
                                     svx_take_bytes(n_strings, 8) + svx_take_bytes(total ? total : 1, 1) + ed_stage_need(n_pairs, plan));
     if (rc != SVX_OK) return rc;
     HapArgs h;
-    uint8_t* d_pool = svx_stage_take<uint8_t>(ctx, pool_bytes ? pool_bytes : 1);
+    const uint8_t* d_pool = d_pool_resident;
+    if (!resident) {
+        uint8_t* staged = svx_stage_take<uint8_t>(ctx, pool_bytes ? pool_bytes : 1);
+        if (pool_bytes) SVX_HIP(ctx, hipMemcpyAsync(staged, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_pool = staged;
+    }
     svx_hap_piece* d_pc = svx_stage_take<svx_hap_piece>(ctx, (size_t)n_strings * 3);
     uint64_t* d_soff = svx_stage_take<uint64_t>(ctx, n_strings);
     uint8_t* d_str = svx_stage_take<uint8_t>(ctx, total ? total : 1);
-    if (pool_bytes) SVX_HIP(ctx, hipMemcpyAsync(d_pool, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_pc, pieces, (size_t)n_strings * 3 * sizeof(svx_hap_piece), hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_soff, str_off.data(), (size_t)n_strings * 8, hipMemcpyHostToDevice, ctx->stream));
     h.pool = d_pool; h.pieces = d_pc; h.str_off = d_soff; h.out = d_str; h.n_strings = n_strings;
     hipLaunchKernelGGL(k_hap_build, dim3(n_strings), dim3(256), 0, ctx->stream, h);
     SVX_HIP(ctx, hipGetLastError());
     return ed_run(ctx, d_str, a_off.data(), a_len.data(), b_off.data(), b_len.data(), n_pairs, k_max, dist, plan);
+}
+
+extern "C" int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
+                                            const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max,
+                                            uint32_t* dist) {
+    return hap_distance_impl(ctx, pool, nullptr, false, pool_bytes, pieces, n_pairs, k_max, dist);
+}
+
+extern "C" int svx_haplotype_distance_batch_dev(svx_ctx* ctx, const uint8_t* d_pool, uint64_t pool_bytes,
+                                                const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max,
+                                                uint32_t* dist) {
+    return hap_distance_impl(ctx, nullptr, d_pool, true, pool_bytes, pieces, n_pairs, k_max, dist);
 }

@@ -20,6 +20,9 @@ struct svx_ctx {
     char* stage = nullptr;
     size_t stage_bytes = 0;
     size_t stage_used = 0;
+    // page-locked host block of svx_collect_batch (control block up, packed results down)
+    char* hpin = nullptr;
+    size_t hpin_bytes = 0;
     // timing
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -51,7 +51,64 @@ __global__ __launch_bounds__(kThreads) void k_linkage_cut(LinkArgs a) {
     svx_linkage_cut_one(n, a.dist + a.dist_off[p], a.cutoff, a.labels + a.label_off[p], mem);
 }
 
+// offsets of partition p in the distance / label / scratch arrays, from the member counts: one workgroup, each
+// thread a contiguous chunk (the asynchronous entry point reads no host memory after it returns)
+__global__ __launch_bounds__(256) void k_linkage_offsets(const uint32_t* n_members, uint32_t n_parts, uint64_t* dist_off,
+                                                         uint64_t* label_off, uint64_t* scratch_off) {
+    __shared__ uint64_t s_d[256], s_l[256], s_s[256];
+    const uint32_t chunk = (n_parts + 255) / 256;
+    const uint32_t lo = threadIdx.x * chunk, hi = min(n_parts, lo + chunk);
+    uint64_t d = 0, l = 0, sc = 0;
+    for (uint32_t p = lo; p < hi; ++p) {
+        const uint64_t n = n_members[p];
+        d += n * (n ? n - 1 : 0) / 2;
+        l += n;
+        if (n > kLdsN) sc += (svx_link_bytes((uint32_t)n) + 15) / 16 * 16;
+    }
+    s_d[threadIdx.x] = d; s_l[threadIdx.x] = l; s_s[threadIdx.x] = sc;
+    __syncthreads();
+    d = l = sc = 0;
+    for (uint32_t t = 0; t < threadIdx.x; ++t) { d += s_d[t]; l += s_l[t]; sc += s_s[t]; }
+    for (uint32_t p = lo; p < hi; ++p) {
+        const uint64_t n = n_members[p];
+        dist_off[p] = d; label_off[p] = l; scratch_off[p] = sc;
+        d += n * (n ? n - 1 : 0) / 2;
+        l += n;
+        if (n > kLdsN) sc += (svx_link_bytes((uint32_t)n) + 15) / 16 * 16;
+    }
+}
+
 }  // namespace
+
+extern "C" int svx_linkage_cut_batch_dev(svx_ctx* ctx, const double* d_dist, const uint32_t* n_members,
+                                         const uint32_t* d_n_members, uint32_t n_parts, double cutoff, uint32_t* d_labels) {
+    if (!ctx) return SVX_E_INVALID;
+    if (n_parts == 0) return SVX_OK;
+    if (!n_members || !d_n_members || !d_labels) return SVX_E_INVALID;
+    uint64_t n_dist = 0, n_lab = 0, n_scratch = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const uint64_t n = n_members[p];
+        n_dist += n * (n ? n - 1 : 0) / 2;
+        n_lab += n;
+        if (n > kLdsN) n_scratch += svx_align_up(svx_link_bytes((uint32_t)n), 16);
+    }
+    if (n_dist && !d_dist) return SVX_E_INVALID;
+    if (n_lab == 0) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = svx_ws_reserve(ctx, 3 * svx_take_bytes(n_parts, 8) + svx_take_bytes(n_scratch ? n_scratch : 1, 1));
+    if (rc != SVX_OK) return rc;
+    LinkArgs a;
+    uint64_t* d_doff = svx_ws_take<uint64_t>(ctx, n_parts);
+    uint64_t* d_loff = svx_ws_take<uint64_t>(ctx, n_parts);
+    uint64_t* d_soff = svx_ws_take<uint64_t>(ctx, n_parts);
+    char* d_scratch = svx_ws_take<char>(ctx, n_scratch ? n_scratch : 1);
+    hipLaunchKernelGGL(k_linkage_offsets, dim3(1), dim3(256), 0, ctx->stream, d_n_members, n_parts, d_doff, d_loff, d_soff);
+    a.dist = d_dist; a.dist_off = d_doff; a.n_members = d_n_members; a.label_off = d_loff; a.scratch_off = d_soff;
+    a.scratch = d_scratch; a.n_parts = n_parts; a.cutoff = cutoff; a.labels = d_labels;
+    hipLaunchKernelGGL(k_linkage_cut, dim3((n_parts + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream, a);
+    SVX_HIP(ctx, hipGetLastError());
+    return SVX_OK;
+}
 
 extern "C" int svx_linkage_cut_batch(svx_ctx* ctx, const double* dist, const uint32_t* n_members, uint32_t n_parts,
                                      double cutoff, uint32_t* labels) {

@@ -193,11 +193,80 @@ __global__ __launch_bounds__(kThreads) void k_segments_post(PostArgs p) {
     p.out_cnt[r] = n_out;
 }
 
+// scratch_off[r] = Σ_{r' < r} align16(post_scratch_bytes(slots of r')): one workgroup, each thread a contiguous chunk
+__global__ __launch_bounds__(256) void k_post_scratch_offsets(const uint32_t* read_off, uint32_t n_reads, uint64_t* scratch_off) {
+    __shared__ uint64_t s_part[256];
+    const uint32_t chunk = (n_reads + 255) / 256;
+    const uint32_t lo = threadIdx.x * chunk, hi = min(n_reads, lo + chunk);
+    uint64_t sum = 0;
+    for (uint32_t r = lo; r < hi; ++r) sum += (post_scratch_bytes(read_off[r + 1] - read_off[r]) + 15) / 16 * 16;
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    uint64_t base = 0;
+    for (uint32_t t = 0; t < threadIdx.x; ++t) base += s_part[t];
+    for (uint32_t r = lo; r < hi; ++r) {
+        scratch_off[r] = base;
+        base += (post_scratch_bytes(read_off[r + 1] - read_off[r]) + 15) / 16 * 16;
+    }
+}
+
 uint64_t post_bound(uint32_t s) { return (uint64_t)s * ((uint64_t)s + 3) / 2; }
 
 }  // namespace
 
 extern "C" uint64_t svx_segments_postpass_bound(uint32_t n_slots) { return post_bound(n_slots); }
+
+// shared front end: validates the host copy of read_off / out_off and lays out the per-read scratch slices
+static int post_plan(svx_ctx* ctx, const uint32_t* read_off, uint32_t n_reads, const uint64_t* out_off,
+                     std::vector<uint64_t>* scratch_off, uint64_t* n_scratch) {
+    if (read_off[0] != 0) return SVX_E_INVALID;
+    scratch_off->resize(n_reads);
+    *n_scratch = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        if (read_off[r + 1] < read_off[r] || out_off[r + 1] < out_off[r]) {
+            SVX_SET_ERR(ctx, "read_off / out_off must be non-decreasing (index %u)", r);
+            return SVX_E_INVALID;
+        }
+        const uint32_t s = read_off[r + 1] - read_off[r];
+        if (out_off[r + 1] - out_off[r] < post_bound(s)) {
+            SVX_SET_ERR(ctx, "read %u: %llu output slots for %u segment slots, svx_segments_postpass_bound() = %llu", r,
+                        (unsigned long long)(out_off[r + 1] - out_off[r]), s, (unsigned long long)post_bound(s));
+            return SVX_E_CAPACITY;
+        }
+        (*scratch_off)[r] = *n_scratch;
+        *n_scratch += svx_align_up(post_scratch_bytes(s), 16);
+    }
+    return SVX_OK;
+}
+
+extern "C" int svx_segments_postpass_dev(svx_ctx* ctx, const svx_raw* d_raw, const uint32_t* read_off,
+                                         const uint32_t* d_read_off, uint32_t n_reads, const int32_t* d_contig_rank,
+                                         uint32_t n_contigs, const svx_seg_params* params, svx_post* d_out,
+                                         const uint64_t* out_off, const uint64_t* d_out_off, uint32_t* d_out_cnt) {
+    if (!ctx || !params) return SVX_E_INVALID;
+    if (n_reads == 0) return SVX_OK;
+    if (!read_off || !d_read_off || !out_off || !d_out_off || !d_out_cnt || (n_contigs && !d_contig_rank)) return SVX_E_INVALID;
+    std::vector<uint64_t> scratch_off;
+    uint64_t n_scratch = 0;
+    int rc = post_plan(ctx, read_off, n_reads, out_off, &scratch_off, &n_scratch);
+    if (rc != SVX_OK) return rc;
+    if (read_off[n_reads] && (!d_raw || !d_out)) return SVX_E_INVALID;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    rc = svx_ws_reserve(ctx, svx_take_bytes((size_t)n_reads + 1, 8) + svx_take_bytes(n_scratch ? n_scratch : 1, 1));
+    if (rc != SVX_OK) return rc;
+    uint64_t* d_soff = svx_ws_take<uint64_t>(ctx, (size_t)n_reads + 1);
+    char* d_scratch = svx_ws_take<char>(ctx, n_scratch ? n_scratch : 1);
+    // the scratch slices are laid out on the device from d_read_off (nothing of this call's host memory is read
+    // after it returns: the call is asynchronous)
+    hipLaunchKernelGGL(k_post_scratch_offsets, dim3(1), dim3(256), 0, ctx->stream, d_read_off, n_reads, d_soff);
+    PostArgs a;
+    a.raw = d_raw; a.read_off = d_read_off; a.n_reads = n_reads; a.contig_rank = d_contig_rank; a.n_contigs = n_contigs;
+    a.min_sv = params->min_sv_size; a.max_sv = params->max_sv_size;
+    a.out = d_out; a.out_off = d_out_off; a.out_cnt = d_out_cnt; a.scratch = d_scratch; a.scratch_off = d_soff;
+    hipLaunchKernelGGL(k_segments_post, dim3((n_reads + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream, a);
+    SVX_HIP(ctx, hipGetLastError());
+    return SVX_OK;
+}
 
 extern "C" int svx_segments_postpass(svx_ctx* ctx, const svx_raw* raw, const uint32_t* read_off, uint32_t n_reads,
                                      const int32_t* contig_rank, uint32_t n_contigs, const svx_seg_params* params,

@@ -1,0 +1,193 @@
+"""svx_collect_batch — COLLECT of a whole sample as one submission — and the asynchronous *_dev entry points it is
+made of (svx_segments_rows_dev, svx_segments_postpass_dev) plus svx_linkage_cut_batch_dev and
+svx_haplotype_distance_batch_dev, through the C-ABI.  Checked against the composition of the single-purpose
+host-pointer entry points (each of which has its own oracle test) and against the oracle directly.
+
+Reference seams: analyze_alignment_file_coordsorted (SVIM_COLLECT.py:61-83), analyze_read_segments
+(SVIM_inter.py:62-340), fcluster(linkage(...)) (SVIM_COMBINE.py:134-135), compute_distance (:35-102)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from svim_asm_amd import _lib
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+PARAMS = (40, 100000, 50, 50, 50, 50)
+
+
+def random_batch(rng, n_aln, n_parts=2, n_reads=40, max_supp=4, long_read=False):
+    """Records with random CIGARs split over `n_parts` pools, and chimeric reads whose segments name pool records
+    (primaries) and extra alignments (SA-derived)."""
+    tuples = [helpers.random_cigar(rng, int(rng.integers(1, 60)), hard=bool(rng.random() < 0.15)) for _ in range(n_aln)]
+    words = [np.array([(l << 4) | o for o, l in t], dtype=np.uint32) for t in tuples]
+    cut = sorted(rng.integers(0, n_aln + 1, size=n_parts - 1).tolist())
+    bounds = [0] + cut + [n_aln]
+    parts = [np.concatenate(words[a:b]) if b > a else np.zeros(0, np.uint32) for a, b in zip(bounds, bounds[1:])]
+    aln_off = np.concatenate(([0], np.cumsum([len(w) for w in words]))).astype(np.uint64)
+    ref_start = rng.integers(0, 1 << 28, size=n_aln).astype(np.int32)
+    extra, seg_src, seg_tid, seg_pos, seg_rev, seg_qend, counts = [], [], [], [], [], [], []
+    for r in range(n_reads):
+        k = int(rng.integers(1, max_supp + 1)) if not (long_read and r == 0) else 23  # > 8 segments: the serial path
+        prim = int(rng.integers(0, n_aln))
+        seg_src.append(prim); seg_tid.append(int(rng.integers(0, 4))); seg_pos.append(int(ref_start[prim]))
+        seg_rev.append(int(rng.random() < 0.3))
+        seg_qend.append(int(rng.integers(0, 5000)) if rng.random() < 0.5 else -1)
+        for _ in range(k):
+            t = helpers.random_cigar(rng, int(rng.integers(1, 12)))
+            seg_src.append(n_aln + len(extra))
+            extra.append(np.array([(l << 4) | o for o, l in t], dtype=np.uint32))
+            seg_tid.append(int(rng.integers(0, 4))); seg_pos.append(int(rng.integers(0, 1 << 27)))
+            seg_rev.append(int(rng.random() < 0.3)); seg_qend.append(-1)
+        counts.append(1 + k)
+    extra_off = np.concatenate(([0], np.cumsum([len(w) for w in extra]))).astype(np.uint64) if extra else np.zeros(1, np.uint64)
+    extra_cigar = np.concatenate(extra) if extra else np.zeros(0, np.uint32)
+    read_off = np.concatenate(([0], np.cumsum(counts))).astype(np.uint32)
+    rank = np.array([2, 0, 3, 1], dtype=np.int32)
+    return dict(parts=parts, aln_off=aln_off, ref_start=ref_start, extra_cigar=extra_cigar, extra_off=extra_off,
+                seg_src=np.array(seg_src, np.uint32), seg_tid=np.array(seg_tid, np.int32), seg_pos=np.array(seg_pos, np.int32),
+                seg_rev=np.array(seg_rev, np.uint8), seg_qend=np.array(seg_qend, np.int32), read_off=read_off, rank=rank)
+
+
+def call(fn, b, min_len=40, params=PARAMS):
+    return fn(b["parts"], b["aln_off"], b["ref_start"], min_len, b["extra_cigar"], b["extra_off"], b["seg_src"],
+              b["seg_tid"], b["seg_pos"], b["seg_rev"], b["seg_qend"], b["read_off"], b["rank"], params)
+
+
+def same(a, b):
+    (sa, ra, pa, fa), (sb, rb, pb, fb) = a, b
+    assert sorted(sa) == sorted(sb)
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(ra, rb) and np.array_equal(pa, pb) and np.array_equal(fa, fb)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_one_submission_equals_the_single_purpose_calls(svx_ctx, seed):
+    rng = np.random.default_rng(100 + seed)
+    b = random_batch(rng, n_aln=int(rng.choice([1, 7, 300, 3000])), n_parts=int(rng.choice([1, 2, 3])),
+                     n_reads=int(rng.choice([0, 1, 60, 500])), long_read=seed % 2 == 1)
+    for min_len, params in ((40, PARAMS), (1, (1, 100000, 500, 500, 500, 500)), (30, (50, 3000, 0, 0, 0, 0))):
+        got = call(svx_ctx.collect_batch, b, min_len, params)
+        exp = call(svx_ctx.collect_batch_composed, b, min_len, params)
+        same(got, exp)
+        # and the oracle directly for the signatures (the composed calls have their own oracle tests)
+        cigar = np.concatenate(b["parts"]) if len(b["parts"]) > 1 else b["parts"][0]
+        o = orc.cigar_extract(cigar, b["aln_off"], b["ref_start"], min_len)
+        for k in o:
+            assert np.array_equal(got[0][k], o[k]), k
+
+
+def test_streaming_path_and_capacity_retry(svx_ctx):
+    """A batch above the small-batch limit (five-launch streaming path inside the submission) and a tiny first
+    capacity guess (dense signatures: the binding retries with the exact count)."""
+    rng = np.random.default_rng(7)
+    b = random_batch(rng, n_aln=4000, n_parts=2, n_reads=100)
+    svx_ctx.set_small_batch_ops(0)
+    try:
+        same(call(svx_ctx.collect_batch, b, 1), call(svx_ctx.collect_batch_composed, b, 1))
+    finally:
+        svx_ctx.set_small_batch_ops(1 << 21)
+
+
+def test_empty_and_degenerate_batches(svx_ctx):
+    z32, z64 = np.zeros(0, np.uint32), np.zeros(1, np.uint64)
+    sig, raw, post, first = svx_ctx.collect_batch([z32], z64, np.zeros(0, np.int32), 40, z32, z64, z32, np.zeros(0, np.int32),
+                                                  np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros(0, np.int32),
+                                                  np.zeros(1, np.uint32), np.zeros(0, np.int32), PARAMS)
+    assert len(sig["aln"]) == 0 and len(raw) == 0 and len(post) == 0 and first.tolist() == [0]
+    # alignments without ops, no chimeric reads
+    off = np.array([0, 0, 3, 3], dtype=np.uint64)
+    words = np.array([(100 << 4) | 0, (50 << 4) | 2, (10 << 4) | 0], dtype=np.uint32)
+    sig, raw, post, first = svx_ctx.collect_batch([words], off, np.array([5, 7, 9], np.int32), 40, z32, z64, z32,
+                                                  np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint8),
+                                                  np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.int32), PARAMS)
+    assert sig["aln"].tolist() == [1] and sig["ref_pos"].tolist() == [107] and sig["len"].tolist() == [50]
+
+
+def test_bad_arguments_are_refused(svx_ctx):
+    rng = np.random.default_rng(3)
+    b = random_batch(rng, n_aln=20, n_parts=1, n_reads=3)
+    bad = dict(b)
+    bad["seg_src"] = b["seg_src"].copy()
+    bad["seg_src"][0] = 10_000  # names no alignment
+    with pytest.raises(_lib.SvxError):
+        call(svx_ctx.collect_batch, bad)
+    bad = dict(b)
+    bad["aln_off"] = b["aln_off"].copy()
+    bad["aln_off"][-1] += 1  # does not end at the pools' op count
+    with pytest.raises(_lib.SvxError):
+        call(svx_ctx.collect_batch, bad)
+    same(call(svx_ctx.collect_batch, b), call(svx_ctx.collect_batch_composed, b))  # the context is still usable
+
+
+def test_linkage_dev_matches_host_entry(svx_ctx):
+    rng = np.random.default_rng(11)
+    sizes = rng.integers(1, 13, size=400).astype(np.uint32)
+    sizes[5] = 150  # beyond the LDS slice: HBM scratch
+    dist = np.concatenate([np.round(rng.random(int(n) * (int(n) - 1) // 2) * 6) / 2 for n in sizes])
+    exp = svx_ctx.linkage_cut_batch(dist, sizes, 1.5)
+    d_dist, d_n = svx_ctx.dev_array(dist), svx_ctx.dev_array(sizes)
+    d_lab = svx_ctx.dev_array(nbytes=4 * int(sizes.sum()))
+    svx_ctx._check(svx_ctx.lib.svx_linkage_cut_batch_dev(svx_ctx.h, d_dist.ptr, sizes.ctypes.data, d_n.ptr, len(sizes),
+                                                         1.5, d_lab.ptr))
+    assert np.array_equal(d_lab.download(np.uint32), exp)
+
+
+def test_haplotype_distance_dev_matches_host_entry(svx_ctx):
+    rng = np.random.default_rng(12)
+    pool = np.frombuffer(b"ACGTacgtN", np.uint8)[rng.integers(0, 9, size=40000)]
+    n = 300
+    pieces = np.zeros(n * 6, dtype=_lib.HAP_PIECE_DTYPE)
+    pieces["off"] = rng.integers(0, 30000, size=n * 6)
+    pieces["len"] = rng.integers(0, 600, size=n * 6)
+    pieces["repeat"] = rng.integers(0, 3, size=n * 6)
+    pieces["flags"] = rng.integers(0, 4, size=n * 6)
+    for k_max in (0xFFFFFFFF, 50):
+        exp = svx_ctx.haplotype_distance_batch(pool, pieces, k_max)
+        d_pool = svx_ctx.dev_array(pool)
+        got = np.zeros(n, np.uint32)
+        svx_ctx._check(svx_ctx.lib.svx_haplotype_distance_batch_dev(svx_ctx.h, d_pool.ptr, len(pool), pieces.ctypes.data, n,
+                                                                    k_max, got.ctypes.data))
+        assert np.array_equal(got, exp)
+
+
+def test_postpass_dev_and_rows_dev_raw_calls(svx_ctx):
+    """The asynchronous entry points called by hand on svx_dev_malloc'ed buffers, one stream, one synchronisation."""
+    rng = np.random.default_rng(13)
+    b = random_batch(rng, n_aln=200, n_parts=1, n_reads=80, long_read=True)
+    cigar = np.concatenate((b["parts"][0], b["extra_cigar"]))
+    n_aln = len(b["aln_off"]) - 1
+    off = np.concatenate((b["aln_off"], int(b["aln_off"][-1]) + b["extra_off"][1:])).astype(np.uint64)
+    n_segs, n_reads = len(b["seg_src"]), len(b["read_off"]) - 1
+    ctx = svx_ctx
+    d = {k: ctx.dev_array(v) for k, v in dict(cigar=cigar, off=off, src=b["seg_src"], tid=b["seg_tid"], pos=b["seg_pos"],
+                                               rev=b["seg_rev"], qend=b["seg_qend"], roff=b["read_off"], rank=b["rank"]).items()}
+    d_segs, d_rl = ctx.dev_array(nbytes=24 * n_segs), ctx.dev_array(nbytes=4 * n_reads)
+    d_raw = ctx.dev_array(nbytes=32 * n_segs)
+    slots = np.diff(b["read_off"].astype(np.int64))
+    post_off = np.concatenate(([0], np.cumsum(slots * (slots + 3) // 2))).astype(np.uint64)
+    d_poff, d_post, d_cnt = ctx.dev_array(post_off), ctx.dev_array(nbytes=32 * int(post_off[-1])), ctx.dev_array(nbytes=4 * n_reads)
+    prm = _lib.SegParams(*PARAMS)
+    ctx._check(ctx.lib.svx_segments_rows_dev(ctx.h, d["cigar"].ptr, d["off"].ptr, d["src"].ptr, d["tid"].ptr, d["pos"].ptr,
+                                             d["rev"].ptr, d["qend"].ptr, n_segs, d["roff"].ptr, n_reads, d_segs.ptr, d_rl.ptr))
+    ctx._check(ctx.lib.svx_segments_classify_dev(ctx.h, d_segs.ptr, n_segs, d["roff"].ptr, n_reads, d_rl.ptr, C.byref(prm), d_raw.ptr))
+    ctx._check(ctx.lib.svx_segments_postpass_dev(ctx.h, d_raw.ptr, b["read_off"].ctypes.data, d["roff"].ptr, n_reads, d["rank"].ptr,
+                                                 len(b["rank"]), C.byref(prm), d_post.ptr, post_off.ctypes.data, d_poff.ptr, d_cnt.ptr))
+    ctx.sync()
+    # expectations from the host-side composition
+    st_a = ctx.cigar_stats(cigar, off)
+    st = {k: st_a[k].astype(np.int64)[b["seg_src"].astype(np.int64)] for k in ("ref_len", "q_start", "q_end", "read_len")}
+    segs, read_len = _lib.segment_rows(st, b["seg_tid"], b["seg_pos"], b["seg_rev"], b["seg_qend"], b["read_off"])
+    assert np.array_equal(d_segs.download(np.int32).reshape(-1, 6), segs.view(np.int32).reshape(-1, 6))
+    assert np.array_equal(d_rl.download(np.int32), read_len)
+    raw = ctx.segments_classify(segs, b["read_off"], read_len, PARAMS)
+    assert np.array_equal(d_raw.download(np.int32).reshape(-1, 8), raw.view(np.int32).reshape(-1, 8))
+    post, first = ctx.segments_postpass(raw, b["read_off"], b["rank"], PARAMS)
+    cnt = d_cnt.download(np.uint32)
+    assert np.array_equal(np.concatenate(([0], np.cumsum(cnt))), first)
+    got = d_post.download(np.int32).reshape(-1, 8)
+    take = np.repeat(post_off[:-1].astype(np.int64) - first[:-1], cnt) + np.arange(int(first[-1]))
+    assert np.array_equal(got[take], post.view(np.int32).reshape(-1, 8))
