@@ -304,6 +304,9 @@ def roofline_pair(local_rank):
 # VALU instructions per systolic step of k_edit_myers<16> (hot path of the inner loop in the gfx950 ISA,
 # `hipcc -S`; 64-bit logic counts as two): a step updates 64 lanes x 64 rows of the DP matrix
 EDIT_VALU_PER_STEP = 75
+# the recurrence alone (Myers 1999 / Hyyro 2003, one 64-row block and one column): 18 operations on 64-bit words,
+# two 32-bit VALU each — the floor any bit-vector formulation on this ISA pays per 64 x 64 lane-cells
+EDIT_ALGO_VALU_PER_STEP = 36
 
 
 def _edit_cells(la, lb, k):
@@ -382,11 +385,21 @@ def roofline_editdist(local_rank, n_cu):
                       "achieved": cells / (tot_ms * 1e-3) / 1e9, "two_stage_plan_ms": plan_ms,
                       "two_stage_pairs_per_s": n_pairs / (plan_ms * 1e-3)})
     peak = n_cu * 4 * 2.4e9 / (EDIT_VALU_PER_STEP * 4) * 4096 / 1e9
+    peak_algo = n_cu * 4 * 2.4e9 / (EDIT_ALGO_VALU_PER_STEP * 4) * 4096 / 1e9
     for c in cases:
-        c["frac"] = c["achieved"] / peak
+        c["frac"] = c["achieved"] / peak_algo          # against the recurrence itself: the honest distance
+        c["frac_of_formulation_ceiling"] = c["achieved"] / peak
     ctx.close()
-    return {"bound": "valu", "kernel": "k_edit_myers<16>", "unit": "G cell updates/s", "peak": peak,
-            "peak_basis": "%d CUs x 4 SIMDs x 2.4 GHz / (%d VALU x 4 clk per 64x64-cell step)" % (n_cu, EDIT_VALU_PER_STEP),
+    return {"bound": "valu", "kernel": "k_edit_myers<16>", "unit": "G cell updates/s", "peak": peak_algo,
+            "peak_basis": "algorithm-level: %d CUs x 4 SIMDs x 2.4 GHz / (%d VALU x 4 clk per 64x64-cell step); %d = the "
+                          "Myers/Hyyro block recurrence alone, 18 64-bit word operations per block and column "
+                          "(Eq|Mv; &Pv, +Pv, ^Pv, |X; Pv&D0; Pv|D0, ~, Mv|; two carry extractions; two shifts with their "
+                          "carry-ins; D0|Hp, ~, Hn|; Hp&D0; the score update) = 36 32-bit VALU — no symbol fetch, no "
+                          "hand-off between blocks, no band bookkeeping" % (n_cu, EDIT_ALGO_VALU_PER_STEP, EDIT_ALGO_VALU_PER_STEP),
+            "formulation_peak": peak,
+            "formulation_peak_basis": "%d VALU per step as this kernel is written (gfx950 ISA of the inner loop): the recurrence "
+                                      "plus the systolic hand-off (DPP wave_shr of the horizontal delta and the text symbol), "
+                                      "the match-vector fetch from LDS and the band / strip bookkeeping" % EDIT_VALU_PER_STEP,
             "cases": cases, "exact_vs_oracle_on_sample": True,
             "note": "ms / cells / achieved: the bit-vector kernel alone (svx_ctx_set_edit_wavefront_cap(0)); "
                     "two_stage_plan_ms: the default plan, whose wavefront pass (k_edit_wfa, O(n + d^2)) resolves nearly "

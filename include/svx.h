@@ -74,10 +74,17 @@ int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
  * radix path (P + 2 launches).  Default and upper limit 131072; 0 disables the one-launch path.  Results
  * are identical on both.  The launch holds at most min(64, CUs / 4) workgroups, all resident: up to four
  * contexts may run it on one device at the same time.  Should its workgroups (or those of the radix path's
- * partition sweep) ever wait for each other longer than 20 s, they give up: the call — for the asynchronous
- * entry points the next svx_ctx_sync — returns SVX_E_HIP, the outputs of that call are invalid, the context
- * stays usable. */
+ * partition sweep) ever wait for each other longer than 20 s, they give up: svx_pair_partition re-runs the call on
+ * the wait-free plan (below) and succeeds; for the asynchronous entry points the next svx_ctx_sync returns
+ * SVX_E_HIP, the outputs of that call are invalid, the context stays usable. */
 int svx_ctx_set_pair_single_launch_max(svx_ctx* ctx, uint32_t max_candidates);
+/* The plan that never waits between workgroups inside a launch: radix passes (P + 1 launches) and the partition
+ * sweep as two launches.  Slower than the plans above and independent of who else is resident on the device.
+ * svx_pair_partition (host pointers, synchronous) falls back to it by itself when a wait of the faster plans
+ * runs out — the call then succeeds, svx_ctx_pair_retries counts such calls —; callers of the asynchronous *_dev
+ * entry points, which cannot be re-run behind their back, may select it up front.  Results are identical. */
+int svx_ctx_set_pair_wait_free(svx_ctx* ctx, int enabled);
+int svx_ctx_pair_retries(const svx_ctx* ctx);
 
 /* Device buffers for callers that have no other owner of HBM (a ctypes binding without torch, the
  * tests): plain hipMalloc / hipFree / hipMemcpyAsync on the context's device and stream.

@@ -103,6 +103,8 @@ SYMBOLS = {
     "svx_ctx_set_small_batch_ops": (C.c_int, [_P, C.c_uint64]),
     "svx_ctx_set_pair_single_launch_max": (C.c_int, [_P, C.c_uint32]),
     "svx_ctx_set_edit_wavefront_cap": (C.c_int, [_P, C.c_uint32]),
+    "svx_ctx_set_pair_wait_free": (C.c_int, [_P, C.c_int]),
+    "svx_ctx_pair_retries": (C.c_int, [_P]),
     "svx_dev_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "svx_dev_free": (C.c_int, [_P, _P]),
     "svx_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -231,6 +233,14 @@ class Context:
     def set_pair_single_launch_max(self, max_candidates):
         """Largest batch (candidates) of the one-launch pair sort; 0 forces the radix path."""
         self._check(self.lib.svx_ctx_set_pair_single_launch_max(self.h, int(max_candidates)))
+
+    def set_pair_wait_free(self, on=True):
+        """Sort on the plan without waits between workgroups inside a launch (radix passes + two-launch sweep)."""
+        self._check(self.lib.svx_ctx_set_pair_wait_free(self.h, 1 if on else 0))
+
+    def pair_retries(self):
+        """Host-pointer pair_partition calls re-run on the wait-free plan after a wait of the fast plans ran out."""
+        return int(self.lib.svx_ctx_pair_retries(self.h))
 
     def set_edit_wavefront_cap(self, max_edits):
         """Edits the wavefront pass of the edit distance resolves (0: bit-vector kernel only)."""

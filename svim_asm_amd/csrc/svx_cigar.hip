@@ -1166,11 +1166,17 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t blocks_cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
+#ifdef SVX_EXP_STREAM_SEARCH  // experiment (profiles/README.md): the small path's wave search instead of the table kernel
+    rc = svx_timing_mark(ctx, 1);
+    if (rc != SVX_OK) return rc;
+    hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_SEARCH>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
+#else
     hipLaunchKernelGGL(k_tile_alo, dim3((n_aln + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
                        a.tile_alo);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
     hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
+#endif
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)

@@ -36,6 +36,8 @@ struct svx_ctx {
     bool barrier_pending = false;      // a kernel with a grid barrier went out since the last svx_barrier_check
     bool pair_lds_set = false;         // k_pair_single's dynamic-LDS limit raised on this context's device
     uint32_t pair_launches = 0;        // launches of k_pair_single so far: which set of arrival counters is next
+    bool pair_wait_free = false;       // svx_ctx_set_pair_wait_free: sort on the plan without waits inside a launch
+    uint32_t pair_retries = 0;         // host-pointer calls that were re-run on that plan after a wait ran out
     uint32_t pair_single_max = 131072;  // svx_ctx_set_pair_single_launch_max: largest batch of the one-launch pair sort
     uint64_t small_batch_ops = 1ull << 21;  // svx_ctx_set_small_batch_ops: largest batch of the single-launch CIGAR path
     char err[512] = {0};

@@ -333,12 +333,28 @@ __device__ __forceinline__ uint32_t chunk_flags(const PartArgs& p, uint32_t base
 // workgroups, each first counts its flags, publishes the count and meets the others at one arrival
 // counter (every workgroup is resident: the grid never exceeds half a workgroup per CU); its carry-in
 // is the sum of the earlier workgroups' counts.  A range of one chunk keeps its flags in registers.
+// MODE 0: one launch, the workgroups meet at the arrival counter.  MODE 1 / MODE 2: the same sweep as two
+// launches without any waiting between workgroups — 1 publishes the flag counts, 2 picks them up after the launch
+// boundary: the plan svx_pair_partition falls back to when a wait of the one-launch forms runs out.
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_partition(PartArgs p, uint32_t span) {
     __shared__ uint32_t s_w[16];
     const uint32_t lo = blockIdx.x * span, hi = min(p.n, lo + span);
-    const bool one_chunk = hi - lo <= kPartChunk;
+    const bool one_chunk = MODE == 0 && hi - lo <= kPartChunk;
     uint32_t carry = 0, kept = 0;
-    if (gridDim.x > 1) {
+    if (MODE == 1) {
+        uint32_t cnt = 0;
+        for (uint32_t base = lo; base < hi; base += kPartChunk) cnt += __popc(chunk_flags(p, base, hi));
+        uint32_t tot;
+        (void)block_scan_1024(cnt, s_w, &tot);
+        if (threadIdx.x == 0) p.block_tot[blockIdx.x] = tot;
+        return;
+    }
+    if (MODE == 2) {
+        const uint32_t v = threadIdx.x < blockIdx.x ? p.block_tot[threadIdx.x] : 0u;
+        (void)block_scan_1024(v, s_w, &carry);
+    }
+    if (MODE == 0 && gridDim.x > 1) {
         uint32_t cnt = 0;
         for (uint32_t base = lo; base < hi; base += kPartChunk) {
             kept = chunk_flags(p, base, hi);
@@ -954,7 +970,7 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
         b.f.n = 1;
         b.f.shift[0] = 0; b.f.off[0] = 0; b.f.mask[0] = 1;
     }
-    if (n <= ctx->pair_single_max) return pair_single_launch(ctx, d_keys, n, max_dist, b.f, live, d_perm, d_part_id, d_n_parts);
+    if (n <= ctx->pair_single_max && !ctx->pair_wait_free) return pair_single_launch(ctx, d_keys, n, max_dist, b.f, live, d_perm, d_part_id, d_n_parts);
     b.passes = (live + kMaxDigitBits - 1) / kMaxDigitBits;
     b.digit_bits = (live + b.passes - 1) / b.passes;
     b.n = n;
@@ -1003,9 +1019,15 @@ int pair_partition_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n, uint32
     pa.block_tot = block_tot;
     pa.counter = reinterpret_cast<uint32_t*>(ctx->ws) + 64;  // workspace header: zero between calls
     const uint32_t span = ((n + part_grid - 1) / part_grid + 1023) / 1024 * 1024;
-    hipLaunchKernelGGL(k_partition, dim3((n + span - 1) / span), dim3(1024), 0, ctx->stream, pa, span);
-    SVX_HIP(ctx, hipGetLastError());
-    ctx->barrier_pending = true;
+    if (ctx->pair_wait_free) {
+        hipLaunchKernelGGL(k_partition<1>, dim3((n + span - 1) / span), dim3(1024), 0, ctx->stream, pa, span);
+        hipLaunchKernelGGL(k_partition<2>, dim3((n + span - 1) / span), dim3(1024), 0, ctx->stream, pa, span);
+        SVX_HIP(ctx, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_partition<0>, dim3((n + span - 1) / span), dim3(1024), 0, ctx->stream, pa, span);
+        SVX_HIP(ctx, hipGetLastError());
+        ctx->barrier_pending = true;
+    }
     return svx_timing_end(ctx);
 }
 
@@ -1077,5 +1099,28 @@ extern "C" int svx_pair_partition(svx_ctx* ctx, const uint64_t* keys, uint32_t n
     SVX_HIP(ctx, hipMemcpyAsync(part_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(n_parts, d_np, 4, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return svx_barrier_check(ctx);
+    rc = svx_barrier_check(ctx);
+    if (rc != SVX_E_HIP || ctx->pair_wait_free) return rc;
+    // A wait between the workgroups of that launch ran out (its other workgroups were not resident in time: too
+    // many tenants on the device).  The keys are still staged: run the call again on the plan that never waits
+    // inside a launch — radix passes and the partition sweep as two launches — instead of failing it.
+    ctx->pair_wait_free = true;
+    rc = pair_partition_bits(ctx, d_k, n, max_dist, bits, d_p, d_id, d_np);
+    ctx->pair_wait_free = false;
+    if (rc != SVX_OK) return rc;
+    SVX_HIP(ctx, hipMemcpyAsync(perm, d_p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(part_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipMemcpyAsync(n_parts, d_np, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->err[0] = 0;
+    ++ctx->pair_retries;
+    return SVX_OK;
 }
+
+extern "C" int svx_ctx_set_pair_wait_free(svx_ctx* ctx, int enabled) {
+    if (!ctx) return SVX_E_INVALID;
+    ctx->pair_wait_free = enabled != 0;
+    return SVX_OK;
+}
+
+extern "C" int svx_ctx_pair_retries(const svx_ctx* ctx) { return ctx ? (int)ctx->pair_retries : 0; }

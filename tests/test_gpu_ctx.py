@@ -113,17 +113,21 @@ ctx = _lib.Context(0)
 rng = np.random.default_rng(4)
 big = (rng.integers(0, 100, 70_000).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 28, 70_000).astype(np.uint64)
 small = big[:700]
+b_perm, b_part, b_n = orc.pair_partition(big, 1000)
+retries = 0
 for limit in (131072, 0):                       # one-launch plan (59 workgroups), radix plan (k_partition: 18)
     ctx.set_pair_single_launch_max(limit)
-    for rep in range(2):                        # the context recovers: the second failure looks like the first
-        try:
-            ctx.pair_partition(big, 1000)
-            raise SystemExit("no error from a launch whose waits cannot succeed")
-        except _lib.SvxError as e:
-            assert "ran out" in str(e), str(e)
-        perm, part, n_parts = ctx.pair_partition(small, 1000)   # one workgroup: nobody to wait for
+    for rep in range(2):
+        # every wait of this build runs out at once: the host-pointer call notices, re-runs itself on the plan
+        # without waits inside a launch and SUCCEEDS with the reference's answer
+        perm, part, n_parts = ctx.pair_partition(big, 1000)
+        assert n_parts == b_n and np.array_equal(perm, b_perm) and np.array_equal(part, b_part)
+        retries += 1
+        assert ctx.pair_retries() == retries
+        perm, part, n_parts = ctx.pair_partition(small, 1000)   # one workgroup: nobody to wait for, no retry
         e_perm, e_part, e_n = orc.pair_partition(small, 1000)
         assert n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
+        assert ctx.pair_retries() == retries
 # the asynchronous entry reports at the next synchronisation
 d_k, d_p, d_id = ctx.dev_array(big), ctx.dev_array(nbytes=4 * len(big)), ctx.dev_array(nbytes=4 * len(big))
 d_np = ctx.dev_array(np.zeros(1, np.uint32))
@@ -136,15 +140,22 @@ try:
 except _lib.SvxError as e:
     assert "ran out" in str(e), str(e)
 ctx.sync()
+# ... and an asynchronous caller that cannot be re-run behind its back selects the wait-free plan itself
+ctx.set_pair_wait_free(True)
+ctx._check(ctx.lib.svx_pair_partition_dev_bits(ctx.h, d_k.ptr, len(big), 1000, int(np.bitwise_or.reduce(big)), d_p.ptr,
+                                               d_id.ptr, d_np.ptr))
+ctx.sync()
+assert np.array_equal(d_p.download(np.uint32), b_perm) and np.array_equal(d_id.download(np.uint32), b_part)
+assert int(d_np.download(np.uint32)[0]) == b_n
 print("barrier child ok")
 '''
 
 
 def test_a_wait_between_workgroups_that_runs_out_is_an_error_not_a_hang(tmp_path):
     """The kernels that wait for their other workgroups inside a launch (k_pair_single, k_partition) bound the
-    wait; a build whose bound is zero turns every such wait into the failure: the call (or the next
-    svx_ctx_sync after an asynchronous one) returns SVX_E_HIP with a text, nothing hangs, the context works
-    on."""
+    wait; a build whose bound is zero turns every such wait into the failure: svx_pair_partition re-runs the call
+    on the wait-free plan and succeeds with the oracle's output; the next svx_ctx_sync after an asynchronous call
+    returns SVX_E_HIP with a text; nothing hangs, the context works on."""
     import os
     import subprocess
     import sys

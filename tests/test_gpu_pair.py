@@ -10,14 +10,18 @@ from oracle import orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["single_launch", "radix"])
+@pytest.fixture(autouse=True, params=["single_launch", "radix", "wait_free"])
 def pair_path(request, svx_ctx):
-    """Every test of this module runs on both sort paths: batches up to 131072 candidates in one launch
-    (k_pair_single: windows of buckets sorted in LDS) and the radix path (P + 2 launches) that larger
-    batches take — forced here with svx_ctx_set_pair_single_launch_max(0)."""
+    """Every test of this module runs on all three sort plans: batches up to 131072 candidates in one launch
+    (k_pair_single: windows of buckets sorted in LDS), the radix plan (P + 2 launches) that larger batches take —
+    forced here with svx_ctx_set_pair_single_launch_max(0) —, and the plan without any wait between workgroups
+    inside a launch (radix passes + the partition sweep as two launches) that a call falls back to when a wait of
+    the other two runs out — forced with svx_ctx_set_pair_wait_free(1)."""
     svx_ctx.set_pair_single_launch_max(0 if request.param == "radix" else 131072)
+    svx_ctx.set_pair_wait_free(request.param == "wait_free")
     yield request.param
     svx_ctx.set_pair_single_launch_max(131072)
+    svx_ctx.set_pair_wait_free(False)
 
 
 def make_keys(rng, n, n_groups, pos_max, dup_frac=0.3):
