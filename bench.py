@@ -716,6 +716,10 @@ def main():
         dist.destroy_process_group()
         if rank != 0:
             return
+        # this process goes on alone: it is no longer a rank of anything (the BAM -> VCF legs look at the launcher's
+        # variables to decide whether they are a contig-sharded run)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK"):
+            os.environ.pop(k, None)
     if rank == 0:
         if not args.no_extras:
             del d_cig, d_op, out_sets  # the cohort is not needed any more
