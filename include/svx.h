@@ -379,6 +379,54 @@ typedef struct svx_collect_out {
 
 int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_collect_out* out);
 
+/*
+ * The kernels of svx_collect_batch on inputs that are already in HBM, asynchronously: what that call enqueues
+ * between its uploads and its read-backs.  a1 + a2 (svx_cigar_extract_dev) run on the context's stream, the
+ * split-segment chain a3 (svx_segments_rows_dev, svx_segments_classify_dev, svx_segments_postpass_dev) on a second
+ * stream of the context between a fork and a join event, so that the two branches overlap; everything enqueued on
+ * the context's stream afterwards is ordered behind both.
+ *   d_cigar      the pools' words and, from word n_ops on, the CIGARs of the n_extra SA-derived segments
+ *   d_aln_off    n_aln + n_extra + 1 offsets into it (PRECONDITIONS as for svx_cigar_extract_dev)
+ *   read_off, post_off   HOST copies (sizes of the per-read scratch and output regions; validated by
+ *                svx_collect_batch, here a precondition), d_read_off / d_post_off the same in HBM
+ *   d_segs, d_read_len   n_segs rows / n_reads lengths of scratch the chain writes and reads
+ * Outputs as svx_collect_batch, in HBM: d_sig (exactly min(count, sig_cap) signatures), d_n_sig (one uint64),
+ * d_raw[n_segs], d_post / d_post_cnt.
+ */
+typedef struct svx_collect_dev {
+    const uint32_t* d_cigar;
+    uint64_t n_ops;
+    const uint64_t* d_aln_off;
+    uint32_t n_aln;
+    uint32_t n_extra;
+    const int32_t* d_ref_start;
+    uint32_t min_len;
+    const uint32_t* d_seg_src;
+    const int32_t* d_seg_tid;
+    const int32_t* d_seg_pos;
+    const uint8_t* d_seg_rev;
+    const int32_t* d_seg_qend;
+    uint32_t n_segs;
+    const uint32_t* read_off;
+    const uint32_t* d_read_off;
+    uint32_t n_reads;
+    const int32_t* d_contig_rank;
+    uint32_t n_contigs;
+    svx_seg_params params;
+    svx_sig_soa d_sig;
+    uint64_t sig_cap;
+    uint64_t* d_n_sig;
+    svx_seg* d_segs;
+    int32_t* d_read_len;
+    svx_raw* d_raw;
+    svx_post* d_post;
+    const uint64_t* post_off;
+    const uint64_t* d_post_off;
+    uint32_t* d_post_cnt;
+} svx_collect_dev;
+
+int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d);
+
 /* ------------------------------------------------------------ a5 + a6 ------ */
 /*
  * Pair sort + partition: form_partitions (SVIM_COMBINE.py:15-32).

@@ -77,6 +77,18 @@ class CollectIn(C.Structure):
                 ("contig_rank", C.c_void_p), ("n_contigs", C.c_uint32), ("params", SegParams)]
 
 
+class CollectDev(C.Structure):
+    """svx_collect_dev (include/svx.h)."""
+    _fields_ = [("d_cigar", C.c_void_p), ("n_ops", C.c_uint64), ("d_aln_off", C.c_void_p), ("n_aln", C.c_uint32),
+                ("n_extra", C.c_uint32), ("d_ref_start", C.c_void_p), ("min_len", C.c_uint32), ("d_seg_src", C.c_void_p),
+                ("d_seg_tid", C.c_void_p), ("d_seg_pos", C.c_void_p), ("d_seg_rev", C.c_void_p), ("d_seg_qend", C.c_void_p),
+                ("n_segs", C.c_uint32), ("read_off", C.c_void_p), ("d_read_off", C.c_void_p), ("n_reads", C.c_uint32),
+                ("d_contig_rank", C.c_void_p), ("n_contigs", C.c_uint32), ("params", SegParams), ("d_sig", SigSoa),
+                ("sig_cap", C.c_uint64), ("d_n_sig", C.c_void_p), ("d_segs", C.c_void_p), ("d_read_len", C.c_void_p),
+                ("d_raw", C.c_void_p), ("d_post", C.c_void_p), ("post_off", C.c_void_p), ("d_post_off", C.c_void_p),
+                ("d_post_cnt", C.c_void_p)]
+
+
 class CollectOut(C.Structure):
     """svx_collect_out (include/svx.h)."""
     _fields_ = [("sig", SigSoa), ("sig_cap", C.c_uint64), ("n_sig", C.c_uint64), ("raw", C.c_void_p),
@@ -130,6 +142,7 @@ SYMBOLS = {
     "svx_segments_postpass_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(SegParams), _P, _P, _P, _P]),
     "svx_segments_rows_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]),
     "svx_collect_batch": (C.c_int, [_P, C.POINTER(CollectIn), C.POINTER(CollectOut)]),
+    "svx_collect_batch_dev": (C.c_int, [_P, C.POINTER(CollectDev)]),
     "svx_linkage_cut_batch_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_double, _P]),
     "svx_haplotype_distance_batch_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P]),
     "svx_pair_partition": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32)]),

@@ -1113,11 +1113,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const bool small = n_ops <= (uint64_t)kSmallMaxTiles * kSmallTileOps && n_ops <= ctx->small_batch_ops;
     const uint32_t n_tiles = small ? (uint32_t)((n_ops + kSmallTileOps - 1) / kSmallTileOps)
                                    : (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
-    size_t need = svx_take_bytes(n_tiles, sizeof(uint4)) +
-                  svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
-                  5 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
-                  2 * svx_take_bytes((n_tiles + kScanBlock - 1) / kScanBlock, sizeof(uint4));
-    int rc = svx_ws_reserve(ctx, need);
+    int rc = svx_ws_reserve(ctx, svx_cigar_extract_ws_need(ctx, n_ops));
     if (rc != SVX_OK) return rc;
 
     CigarArgs a;
@@ -1351,6 +1347,15 @@ extern "C" int svx_cigar_stats(svx_ctx* ctx, const uint32_t* cigar, const uint64
     if (out.n_hard) SVX_HIP(ctx, hipMemcpyAsync(out.n_hard, d.n_hard, b, hipMemcpyDeviceToHost, ctx->stream));
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SVX_OK;
+}
+
+size_t svx_cigar_extract_ws_need(const svx_ctx* ctx, uint64_t n_ops) {
+    const bool small = n_ops <= (uint64_t)kSmallMaxTiles * kSmallTileOps && n_ops <= ctx->small_batch_ops;
+    const uint32_t n_tiles = small ? (uint32_t)((n_ops + kSmallTileOps - 1) / kSmallTileOps)
+                                   : (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
+    return svx_take_bytes(n_tiles, sizeof(uint4)) + svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
+           5 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
+           2 * svx_take_bytes((n_tiles + kScanBlock - 1) / kScanBlock, sizeof(uint4));
 }
 
 extern "C" int svx_segments_rows_dev(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off,

@@ -7,10 +7,11 @@
 //   H2D  every CIGAR pool as it lies in the reader's page-locked memory (no host-side concatenation), the CIGARs
 //        of the SA-derived segments behind them, ONE packed control block (offsets, reference starts, segment
 //        table, read offsets, contig ranks);
-//   k_cigar_tiles + k_cigar_finish_small (or the five-launch streaming path)   a1 + a2, all records
-//   k_segment_rows      CIGAR statistics + segment rows of the chimeric reads   (SVIM_inter.py:66-81)
-//   k_segments          the adjacent-pair decision tree                         (:91-258)
-//   k_post_scratch_offsets + k_segments_post   the three post-passes            (:260-338)
+//   stream 1: k_cigar_tiles + k_cigar_finish_small (or the five-launch streaming path)   a1 + a2, all records
+//   stream 2, between a fork and a join event (svx_collect_batch_dev):
+//     k_segment_rows    CIGAR statistics + segment rows of the chimeric reads   (SVIM_inter.py:66-81)
+//     k_segments        the adjacent-pair decision tree                         (:91-258)
+//     k_segments_post   the three post-passes                                   (:260-338)
 //   D2H  one packed block of counts (signature count, derived records per read), first synchronisation;
 //   D2H  one packed block with exactly the signatures, raw records and derived-record regions, second one.
 #include <algorithm>
@@ -43,6 +44,64 @@ int host_stage_reserve(svx_ctx* ctx, size_t bytes) {
 }
 
 }  // namespace
+
+// The kernels of COLLECT on resident inputs.  a1 + a2 and the split-segment chain a3 do not depend on each other:
+// the chain goes out on the context's second stream between a fork and a join event, so the two overlap (a sample's
+// COLLECT is five short launches; serialised they cost twice what the longer of the two branches does).  All scratch
+// comes from ONE workspace reservation (ws_hold): kernels of both streams are in flight together.
+extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
+    if (!ctx || !d) return SVX_E_INVALID;
+    if (d->n_aln == 0) {
+        if (d->d_n_sig) SVX_HIP(ctx, hipMemsetAsync(d->d_n_sig, 0, 8, ctx->stream));
+        return d->n_segs ? SVX_E_INVALID : SVX_OK;
+    }
+    if (!d->d_aln_off || !d->d_n_sig || (d->n_ops && !d->d_cigar)) return SVX_E_INVALID;
+    const bool chain = d->n_reads != 0;
+    if (chain && (!d->read_off || !d->d_read_off || !d->post_off || !d->d_post_off || !d->d_post_cnt || !d->d_segs ||
+                  !d->d_read_len || !d->d_raw || !d->d_seg_src))
+        return SVX_E_INVALID;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    size_t need = svx_cigar_extract_ws_need(ctx, d->n_ops) + 4096;
+    if (chain) need += svx_take_bytes(d->n_segs, sizeof(svx_seg)) + svx_postpass_ws_need(d->read_off, d->n_reads) + 4096;
+    int rc = svx_ws_reserve(ctx, need);
+    if (rc != SVX_OK) return rc;
+    if (chain && !ctx->stream2) {
+        SVX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    ctx->ws_hold = true;
+    hipStream_t main_stream = ctx->stream;
+    if (chain) {
+        // fork: the chain's inputs were produced on the main stream (uploads, earlier kernels)
+        rc = hipEventRecord(ctx->ev_fork, main_stream) == hipSuccess &&
+             hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0) == hipSuccess ? SVX_OK : SVX_E_HIP;
+        if (rc == SVX_OK) {
+            ctx->stream = ctx->stream2;
+            rc = svx_segments_rows_dev(ctx, d->d_cigar, d->d_aln_off, d->d_seg_src, d->d_seg_tid, d->d_seg_pos, d->d_seg_rev,
+                                       d->d_seg_qend, d->n_segs, d->d_read_off, d->n_reads, d->d_segs, d->d_read_len);
+            if (rc == SVX_OK)
+                rc = svx_segments_classify_dev(ctx, d->d_segs, d->n_segs, d->d_read_off, d->n_reads, d->d_read_len, &d->params, d->d_raw);
+            if (rc == SVX_OK)
+                rc = svx_segments_postpass_dev(ctx, d->d_raw, d->read_off, d->d_read_off, d->n_reads, d->d_contig_rank, d->n_contigs,
+                                               &d->params, d->d_post, d->post_off, d->d_post_off, d->d_post_cnt);
+            ctx->stream = main_stream;
+        }
+    }
+    if (rc == SVX_OK)
+        rc = svx_cigar_extract_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len, d->d_sig,
+                                   d->sig_cap, d->d_n_sig);
+    ctx->ws_hold = false;
+    if (chain) {  // join (also after an error: nothing may stay unordered behind the caller's next call)
+        const bool ok = hipEventRecord(ctx->ev_join, ctx->stream2) == hipSuccess &&
+                        hipStreamWaitEvent(main_stream, ctx->ev_join, 0) == hipSuccess;
+        if (!ok && rc == SVX_OK) {
+            SVX_SET_ERR(ctx, "joining the streams of svx_collect_batch_dev failed");
+            rc = SVX_E_HIP;
+        }
+    }
+    return rc;
+}
 
 extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_collect_out* out) {
     if (!ctx || !in || !out) return SVX_E_INVALID;
@@ -168,34 +227,25 @@ extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_col
     if (n_xops) SVX_HIP(ctx, hipMemcpyAsync(d_cigar + n_ops, in->extra_cigar, (size_t)n_xops * 4, hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_cb, h, cb_bytes, hipMemcpyHostToDevice, ctx->stream));
 
-    // ---- kernels
-    svx_sig_soa d_sig;
-    d_sig.aln = reinterpret_cast<uint32_t*>(d_rb + r_aln);
-    d_sig.ref_pos = reinterpret_cast<uint32_t*>(d_rb + r_ref);
-    d_sig.read_pos = reinterpret_cast<uint32_t*>(d_rb + r_read);
-    d_sig.len = reinterpret_cast<uint32_t*>(d_rb + r_len);
-    d_sig.type = reinterpret_cast<uint8_t*>(d_rb + r_type);
-    const uint64_t* d_off = reinterpret_cast<const uint64_t*>(d_cb + o_off);
-    rc = svx_cigar_extract_dev(ctx, d_cigar, n_ops, d_off, n_aln, reinterpret_cast<const int32_t*>(d_cb + o_rs), in->min_len,
-                               d_sig, cap, reinterpret_cast<uint64_t*>(d_rb + r_n));
+    // ---- kernels (two overlapping branches, svx_collect_batch_dev)
+    svx_collect_dev dv;
+    memset(&dv, 0, sizeof(dv));
+    dv.d_cigar = d_cigar; dv.n_ops = n_ops;
+    dv.d_aln_off = reinterpret_cast<const uint64_t*>(d_cb + o_off); dv.n_aln = n_aln; dv.n_extra = n_extra;
+    dv.d_ref_start = reinterpret_cast<const int32_t*>(d_cb + o_rs); dv.min_len = in->min_len;
+    dv.d_seg_src = reinterpret_cast<const uint32_t*>(d_cb + o_src); dv.d_seg_tid = reinterpret_cast<const int32_t*>(d_cb + o_tid);
+    dv.d_seg_pos = reinterpret_cast<const int32_t*>(d_cb + o_pos); dv.d_seg_rev = reinterpret_cast<const uint8_t*>(d_cb + o_rev);
+    dv.d_seg_qend = reinterpret_cast<const int32_t*>(d_cb + o_qe); dv.n_segs = n_segs;
+    dv.read_off = in->read_off; dv.d_read_off = reinterpret_cast<const uint32_t*>(d_cb + o_roff); dv.n_reads = n_reads;
+    dv.d_contig_rank = reinterpret_cast<const int32_t*>(d_cb + o_rank); dv.n_contigs = in->n_contigs; dv.params = in->params;
+    dv.d_sig.aln = reinterpret_cast<uint32_t*>(d_rb + r_aln); dv.d_sig.ref_pos = reinterpret_cast<uint32_t*>(d_rb + r_ref);
+    dv.d_sig.read_pos = reinterpret_cast<uint32_t*>(d_rb + r_read); dv.d_sig.len = reinterpret_cast<uint32_t*>(d_rb + r_len);
+    dv.d_sig.type = reinterpret_cast<uint8_t*>(d_rb + r_type); dv.sig_cap = cap; dv.d_n_sig = reinterpret_cast<uint64_t*>(d_rb + r_n);
+    dv.d_segs = d_segs; dv.d_read_len = d_read_len; dv.d_raw = reinterpret_cast<svx_raw*>(d_rb + r_raw);
+    dv.d_post = reinterpret_cast<svx_post*>(d_rb + r_post); dv.post_off = out->post_off;
+    dv.d_post_off = reinterpret_cast<const uint64_t*>(d_cb + o_poff); dv.d_post_cnt = reinterpret_cast<uint32_t*>(d_rb + r_cnt);
+    rc = svx_collect_batch_dev(ctx, &dv);
     if (rc != SVX_OK) return rc;
-    const uint32_t* d_roff = reinterpret_cast<const uint32_t*>(d_cb + o_roff);
-    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(d_rb + r_cnt);
-    svx_raw* d_raw = reinterpret_cast<svx_raw*>(d_rb + r_raw);
-    svx_post* d_post = reinterpret_cast<svx_post*>(d_rb + r_post);
-    if (n_reads) {
-        rc = svx_segments_rows_dev(ctx, d_cigar, d_off, reinterpret_cast<const uint32_t*>(d_cb + o_src),
-                                   reinterpret_cast<const int32_t*>(d_cb + o_tid), reinterpret_cast<const int32_t*>(d_cb + o_pos),
-                                   reinterpret_cast<const uint8_t*>(d_cb + o_rev), reinterpret_cast<const int32_t*>(d_cb + o_qe),
-                                   n_segs, d_roff, n_reads, d_segs, d_read_len);
-        if (rc != SVX_OK) return rc;
-        rc = svx_segments_classify_dev(ctx, d_segs, n_segs, d_roff, n_reads, d_read_len, &in->params, d_raw);
-        if (rc != SVX_OK) return rc;
-        rc = svx_segments_postpass_dev(ctx, d_raw, in->read_off, d_roff, n_reads, reinterpret_cast<const int32_t*>(d_cb + o_rank),
-                                       in->n_contigs, &in->params, d_post, out->post_off,
-                                       reinterpret_cast<const uint64_t*>(d_cb + o_poff), d_cnt);
-        if (rc != SVX_OK) return rc;
-    }
 
     // ---- read-back 1: the counts
     SVX_HIP(ctx, hipMemcpyAsync(h, d_rb, head_bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -16,6 +16,10 @@ struct svx_ctx {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     size_t ws_used = 0;
+    bool ws_hold = false;  // svx_collect_batch_dev: its inner calls bump-allocate from ONE reservation (kernels of two
+                           // streams are in flight together: their scratch must not overlap)
+    hipStream_t stream2 = nullptr;  // second stream of svx_collect_batch_dev (the split-segment chain) and its events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // second, independent region for host-pointer entry points (staged inputs/outputs)
     char* stage = nullptr;
     size_t stage_bytes = 0;
@@ -68,6 +72,9 @@ int svx_ws_reserve(svx_ctx* ctx, size_t total);
 #define SVX_WS_BARRIER_NOTE_WORD 80
 int svx_barrier_check(svx_ctx* ctx);
 int svx_stage_reserve(svx_ctx* ctx, size_t total);
+// workspace bytes svx_cigar_extract*_dev / svx_segments_postpass_dev reserve for a batch (svx_collect_batch_dev sums them)
+size_t svx_cigar_extract_ws_need(const svx_ctx* ctx, uint64_t n_ops);
+size_t svx_postpass_ws_need(const uint32_t* read_off, uint32_t n_reads);
 
 template <typename T>
 static inline T* svx_ws_take(svx_ctx* ctx, size_t count) {

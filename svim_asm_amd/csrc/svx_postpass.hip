@@ -24,6 +24,7 @@
 #include "svx_internal.h"
 #include "svx_linkage_dev.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -42,6 +43,7 @@ struct PostArgs {
     uint32_t* out_cnt;
     char* scratch;
     const uint64_t* scratch_off;
+    uint64_t scratch_stride;  // != 0: every read's slice has this size (slice r at r * stride; no offset table)
 };
 
 // scratch of a read with s slots: 5 int arrays (rank, ref, start, end, side) + labels + the condensed
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void k_segments_post(PostArgs p) {
     // ---- 3. inversions
     {
         const uint32_t s = e - b;
-        char* mem = p.scratch + p.scratch_off[r];
+        char* mem = p.scratch + (p.scratch_stride ? (uint64_t)r * p.scratch_stride : p.scratch_off[r]);
         int32_t* rk = reinterpret_cast<int32_t*>(mem);
         int32_t* rf = rk + s;
         int32_t* st = rf + s;
@@ -216,6 +218,22 @@ uint64_t post_bound(uint32_t s) { return (uint64_t)s * ((uint64_t)s + 3) / 2; }
 
 extern "C" uint64_t svx_segments_postpass_bound(uint32_t n_slots) { return post_bound(n_slots); }
 
+// one slice size for every read, if that wastes little: the largest read's slice, at most 64 MiB in total
+static uint64_t post_uniform_stride(const uint32_t* read_off, uint32_t n_reads) {
+    uint32_t s_max = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) s_max = std::max(s_max, read_off[r + 1] - read_off[r]);
+    const uint64_t stride = svx_align_up(post_scratch_bytes(s_max), 16);
+    return stride * n_reads <= (64ull << 20) ? stride : 0;
+}
+
+size_t svx_postpass_ws_need(const uint32_t* read_off, uint32_t n_reads) {
+    const uint64_t stride = post_uniform_stride(read_off, n_reads);
+    if (stride) return svx_take_bytes((size_t)n_reads * stride, 1);
+    uint64_t n_scratch = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) n_scratch += svx_align_up(post_scratch_bytes(read_off[r + 1] - read_off[r]), 16);
+    return svx_take_bytes((size_t)n_reads + 1, 8) + svx_take_bytes(n_scratch ? n_scratch : 1, 1);
+}
+
 // shared front end: validates the host copy of read_off / out_off and lays out the per-read scratch slices
 static int post_plan(svx_ctx* ctx, const uint32_t* read_off, uint32_t n_reads, const uint64_t* out_off,
                      std::vector<uint64_t>* scratch_off, uint64_t* n_scratch) {
@@ -252,14 +270,23 @@ extern "C" int svx_segments_postpass_dev(svx_ctx* ctx, const svx_raw* d_raw, con
     if (rc != SVX_OK) return rc;
     if (read_off[n_reads] && (!d_raw || !d_out)) return SVX_E_INVALID;
     SVX_HIP(ctx, hipSetDevice(ctx->device));
-    rc = svx_ws_reserve(ctx, svx_take_bytes((size_t)n_reads + 1, 8) + svx_take_bytes(n_scratch ? n_scratch : 1, 1));
+    rc = svx_ws_reserve(ctx, svx_postpass_ws_need(read_off, n_reads));
     if (rc != SVX_OK) return rc;
-    uint64_t* d_soff = svx_ws_take<uint64_t>(ctx, (size_t)n_reads + 1);
-    char* d_scratch = svx_ws_take<char>(ctx, n_scratch ? n_scratch : 1);
-    // the scratch slices are laid out on the device from d_read_off (nothing of this call's host memory is read
-    // after it returns: the call is asynchronous)
-    hipLaunchKernelGGL(k_post_scratch_offsets, dim3(1), dim3(256), 0, ctx->stream, d_read_off, n_reads, d_soff);
+    // scratch slices: one size for all reads when that is cheap (reads have a handful of segments: no offset table,
+    // one launch less); otherwise laid out on the device from d_read_off.  Nothing of this call's host memory is
+    // read after it returns: the call is asynchronous
+    const uint64_t stride = post_uniform_stride(read_off, n_reads);
+    uint64_t* d_soff = nullptr;
+    char* d_scratch;
+    if (stride) {
+        d_scratch = svx_ws_take<char>(ctx, (size_t)n_reads * stride);
+    } else {
+        d_soff = svx_ws_take<uint64_t>(ctx, (size_t)n_reads + 1);
+        d_scratch = svx_ws_take<char>(ctx, n_scratch ? n_scratch : 1);
+        hipLaunchKernelGGL(k_post_scratch_offsets, dim3(1), dim3(256), 0, ctx->stream, d_read_off, n_reads, d_soff);
+    }
     PostArgs a;
+    a.scratch_stride = stride;
     a.raw = d_raw; a.read_off = d_read_off; a.n_reads = n_reads; a.contig_rank = d_contig_rank; a.n_contigs = n_contigs;
     a.min_sv = params->min_sv_size; a.max_sv = params->max_sv_size;
     a.out = d_out; a.out_off = d_out_off; a.out_cnt = d_out_cnt; a.scratch = d_scratch; a.scratch_off = d_soff;
@@ -318,6 +345,7 @@ extern "C" int svx_segments_postpass(svx_ctx* ctx, const svx_raw* raw, const uin
     a.raw = d_raw; a.read_off = d_off; a.n_reads = n_reads; a.contig_rank = d_rank; a.n_contigs = n_contigs;
     a.min_sv = params->min_sv_size; a.max_sv = params->max_sv_size;
     a.out = d_out; a.out_off = d_ooff; a.out_cnt = d_cnt; a.scratch = d_scratch; a.scratch_off = d_soff;
+    a.scratch_stride = 0;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
     rc = svx_timing_mark(ctx, 1);

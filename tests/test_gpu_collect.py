@@ -191,3 +191,44 @@ def test_postpass_dev_and_rows_dev_raw_calls(svx_ctx):
     got = d_post.download(np.int32).reshape(-1, 8)
     take = np.repeat(post_off[:-1].astype(np.int64) - first[:-1], cnt) + np.arange(int(first[-1]))
     assert np.array_equal(got[take], post.view(np.int32).reshape(-1, 8))
+
+
+def test_collect_batch_dev_on_resident_buffers(svx_ctx):
+    """svx_collect_batch_dev by hand: everything resident, asynchronous, one synchronisation; repeated calls reuse
+    the context's second stream and its events."""
+    rng = np.random.default_rng(21)
+    b = random_batch(rng, n_aln=500, n_parts=1, n_reads=120, long_read=True)
+    exp_sig, exp_raw, exp_post, exp_first = call(svx_ctx.collect_batch_composed, b)
+    ctx = svx_ctx
+    n_aln, n_ops = len(b["aln_off"]) - 1, int(b["aln_off"][-1])
+    cigar = np.concatenate((b["parts"][0], b["extra_cigar"]))
+    off = np.concatenate((b["aln_off"], n_ops + b["extra_off"][1:])).astype(np.uint64)
+    n_segs, n_reads = len(b["seg_src"]), len(b["read_off"]) - 1
+    slots = np.diff(b["read_off"].astype(np.int64))
+    post_off = np.concatenate(([0], np.cumsum(slots * (slots + 3) // 2))).astype(np.uint64)
+    d = {k: ctx.dev_array(v) for k, v in dict(cigar=cigar, off=off, rs=b["ref_start"], src=b["seg_src"], tid=b["seg_tid"],
+                                               pos=b["seg_pos"], rev=b["seg_rev"], qend=b["seg_qend"], roff=b["read_off"],
+                                               rank=b["rank"], poff=post_off).items()}
+    cap = len(exp_sig["aln"]) + 5
+    o = [ctx.dev_array(nbytes=4 * cap) for _ in range(4)] + [ctx.dev_array(nbytes=cap), ctx.dev_array(np.zeros(1, np.uint64))]
+    d_segs, d_rl = ctx.dev_array(nbytes=24 * n_segs), ctx.dev_array(nbytes=4 * n_reads)
+    d_raw, d_post, d_cnt = ctx.dev_array(nbytes=32 * n_segs), ctx.dev_array(nbytes=32 * int(post_off[-1])), ctx.dev_array(nbytes=4 * n_reads)
+    dv = _lib.CollectDev(d_cigar=d["cigar"].ptr, n_ops=n_ops, d_aln_off=d["off"].ptr, n_aln=n_aln, n_extra=len(b["extra_off"]) - 1,
+                         d_ref_start=d["rs"].ptr, min_len=40, d_seg_src=d["src"].ptr, d_seg_tid=d["tid"].ptr, d_seg_pos=d["pos"].ptr,
+                         d_seg_rev=d["rev"].ptr, d_seg_qend=d["qend"].ptr, n_segs=n_segs, read_off=b["read_off"].ctypes.data,
+                         d_read_off=d["roff"].ptr, n_reads=n_reads, d_contig_rank=d["rank"].ptr, n_contigs=len(b["rank"]),
+                         params=_lib.SegParams(*PARAMS), d_sig=_lib.SigSoa(*[x.ptr for x in o[:5]]), sig_cap=cap, d_n_sig=o[5].ptr,
+                         d_segs=d_segs.ptr, d_read_len=d_rl.ptr, d_raw=d_raw.ptr, d_post=d_post.ptr, post_off=post_off.ctypes.data,
+                         d_post_off=d["poff"].ptr, d_post_cnt=d_cnt.ptr)
+    for _ in range(3):
+        ctx._check(ctx.lib.svx_collect_batch_dev(ctx.h, C.byref(dv)))
+    ctx.sync()
+    n = int(o[5].download(np.uint64)[0])
+    assert n == len(exp_sig["aln"])
+    for x, key in zip(o[:5], ("aln", "ref_pos", "read_pos", "len", "type")):
+        assert np.array_equal(x.download(np.uint32 if key != "type" else np.uint8, n), exp_sig[key]), key
+    assert np.array_equal(d_raw.download(np.int32).reshape(-1, 8), exp_raw.view(np.int32).reshape(-1, 8))
+    cnt = d_cnt.download(np.uint32)
+    assert np.array_equal(np.concatenate(([0], np.cumsum(cnt))), exp_first)
+    take = np.repeat(post_off[:-1].astype(np.int64) - exp_first[:-1], cnt) + np.arange(int(exp_first[-1]))
+    assert np.array_equal(d_post.download(np.int32).reshape(-1, 8)[take], exp_post.view(np.int32).reshape(-1, 8))
