@@ -148,10 +148,9 @@ def _event_ms(ctx, fn, reps):
 
 def latency_case(args, local_rank, torch):
     """The product CLI's operating point: ONE config-2 sample per submission, through the call path COLLECT uses:
-    svx_collect_batch_dev (a1+a2 = svx_cigar_extract_dev on one stream, a3 = svx_segments_rows_dev ->
-    svx_segments_classify_dev -> svx_segments_postpass_dev on the context's second stream, overlapping) with the inputs
-    resident in HBM — wall-clock per step —, and the host call svx_collect_batch itself (uploads from page-locked
-    memory, the same kernels, two read-backs) beside it."""
+    svx_collect_batch_dev (a1+a2 = svx_cigar_extract_dev, a3 = svx_segments_rows_dev -> svx_segments_classify_dev ->
+    svx_segments_postpass_dev, one stream) with the inputs resident in HBM — wall-clock per step —, and the host call
+    svx_collect_batch itself (uploads from page-locked memory, the same kernels, two read-backs) beside it."""
     from svim_asm_amd import _lib, synth
     import ctypes as C
     b = synth.synth_cigar_batch(seed=1000 + args.config * 100, mean_m=4000 if args.config == 2 else 400)
@@ -243,9 +242,9 @@ def latency_case(args, local_rank, torch):
     ctx.close()
     return {"workload": "BASELINE config %d, ONE sample per submission (%d ops, %d alignments, %d signatures, %d chimeric reads / "
                         "%d segments): what `svim-asm haploid` submits per BAM" % (args.config, n_ops, n_aln, n_sig, n_reads, n_segs),
-            "step": "svx_collect_batch_dev, inputs resident in HBM: svx_cigar_extract_dev on the context's stream, "
-                    "svx_segments_rows_dev + svx_segments_classify_dev + svx_segments_postpass_dev on its second stream between "
-                    "a fork and a join event — what svx_collect_batch enqueues between its uploads and its read-backs",
+            "step": "svx_collect_batch_dev, inputs resident in HBM: svx_cigar_extract_dev + svx_segments_rows_dev + "
+                    "svx_segments_classify_dev + svx_segments_postpass_dev on the context's stream (five launches) — what "
+                    "svx_collect_batch enqueues between its uploads and its read-backs",
             "ms_per_step": dt * 1e3, "value": n_ops / dt, "unit": "CIGAR ops/s",
             "algorithmic_bytes": algo, "a3_bytes": 24 * n_segs + 32 * n_segs, "achieved": algo / dt / 1e9,
             "frac": algo / dt / 1e9 / HBM_PEAK_GBS,

@@ -381,10 +381,8 @@ int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_collect_out* o
 
 /*
  * The kernels of svx_collect_batch on inputs that are already in HBM, asynchronously: what that call enqueues
- * between its uploads and its read-backs.  a1 + a2 (svx_cigar_extract_dev) run on the context's stream, the
- * split-segment chain a3 (svx_segments_rows_dev, svx_segments_classify_dev, svx_segments_postpass_dev) on a second
- * stream of the context between a fork and a join event, so that the two branches overlap; everything enqueued on
- * the context's stream afterwards is ordered behind both.
+ * between its uploads and its read-backs — svx_cigar_extract_dev (a1 + a2), then svx_segments_rows_dev,
+ * svx_segments_classify_dev and svx_segments_postpass_dev (a3) — on the context's stream, no synchronisation.
  *   d_cigar      the pools' words and, from word n_ops on, the CIGARs of the n_extra SA-derived segments
  *   d_aln_off    n_aln + n_extra + 1 offsets into it (PRECONDITIONS as for svx_cigar_extract_dev)
  *   read_off, post_off   HOST copies (sizes of the per-read scratch and output regions; validated by

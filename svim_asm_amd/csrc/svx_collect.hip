@@ -7,11 +7,10 @@
 //   H2D  every CIGAR pool as it lies in the reader's page-locked memory (no host-side concatenation), the CIGARs
 //        of the SA-derived segments behind them, ONE packed control block (offsets, reference starts, segment
 //        table, read offsets, contig ranks);
-//   stream 1: k_cigar_tiles + k_cigar_finish_small (or the five-launch streaming path)   a1 + a2, all records
-//   stream 2, between a fork and a join event (svx_collect_batch_dev):
-//     k_segment_rows    CIGAR statistics + segment rows of the chimeric reads   (SVIM_inter.py:66-81)
-//     k_segments        the adjacent-pair decision tree                         (:91-258)
-//     k_segments_post   the three post-passes                                   (:260-338)
+//   k_cigar_tiles + k_cigar_finish_small (or the five-launch streaming path)   a1 + a2, all records
+//   k_segment_rows      CIGAR statistics + segment rows of the chimeric reads   (SVIM_inter.py:66-81)
+//   k_segments          the adjacent-pair decision tree                         (:91-258)
+//   k_segments_post     the three post-passes                                   (:260-338)
 //   D2H  one packed block of counts (signature count, derived records per read), first synchronisation;
 //   D2H  one packed block with exactly the signatures, raw records and derived-record regions, second one.
 #include <algorithm>
@@ -45,10 +44,10 @@ int host_stage_reserve(svx_ctx* ctx, size_t bytes) {
 
 }  // namespace
 
-// The kernels of COLLECT on resident inputs.  a1 + a2 and the split-segment chain a3 do not depend on each other:
-// the chain goes out on the context's second stream between a fork and a join event, so the two overlap (a sample's
-// COLLECT is five short launches; serialised they cost twice what the longer of the two branches does).  All scratch
-// comes from ONE workspace reservation (ws_hold): kernels of both streams are in flight together.
+// The kernels of COLLECT on resident inputs, in stream order: a1 + a2, then the split-segment chain a3.
+// (The two do not depend on each other; putting the chain on a second stream between a fork and a join event was
+// measured and dropped: the cross-stream dependencies cost more than the overlap of five short launches gains —
+// 45.6 vs 29.4 us per config-2 sample, profiles/README.md.)
 extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
     if (!ctx || !d) return SVX_E_INVALID;
     if (d->n_aln == 0) {
@@ -60,47 +59,16 @@ extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
     if (chain && (!d->read_off || !d->d_read_off || !d->post_off || !d->d_post_off || !d->d_post_cnt || !d->d_segs ||
                   !d->d_read_len || !d->d_raw || !d->d_seg_src))
         return SVX_E_INVALID;
-    SVX_HIP(ctx, hipSetDevice(ctx->device));
-    size_t need = svx_cigar_extract_ws_need(ctx, d->n_ops) + 4096;
-    if (chain) need += svx_take_bytes(d->n_segs, sizeof(svx_seg)) + svx_postpass_ws_need(d->read_off, d->n_reads) + 4096;
-    int rc = svx_ws_reserve(ctx, need);
-    if (rc != SVX_OK) return rc;
-    if (chain && !ctx->stream2) {
-        SVX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    ctx->ws_hold = true;
-    hipStream_t main_stream = ctx->stream;
-    if (chain) {
-        // fork: the chain's inputs were produced on the main stream (uploads, earlier kernels)
-        rc = hipEventRecord(ctx->ev_fork, main_stream) == hipSuccess &&
-             hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0) == hipSuccess ? SVX_OK : SVX_E_HIP;
-        if (rc == SVX_OK) {
-            ctx->stream = ctx->stream2;
-            rc = svx_segments_rows_dev(ctx, d->d_cigar, d->d_aln_off, d->d_seg_src, d->d_seg_tid, d->d_seg_pos, d->d_seg_rev,
-                                       d->d_seg_qend, d->n_segs, d->d_read_off, d->n_reads, d->d_segs, d->d_read_len);
-            if (rc == SVX_OK)
-                rc = svx_segments_classify_dev(ctx, d->d_segs, d->n_segs, d->d_read_off, d->n_reads, d->d_read_len, &d->params, d->d_raw);
-            if (rc == SVX_OK)
-                rc = svx_segments_postpass_dev(ctx, d->d_raw, d->read_off, d->d_read_off, d->n_reads, d->d_contig_rank, d->n_contigs,
-                                               &d->params, d->d_post, d->post_off, d->d_post_off, d->d_post_cnt);
-            ctx->stream = main_stream;
-        }
-    }
-    if (rc == SVX_OK)
-        rc = svx_cigar_extract_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len, d->d_sig,
+    int rc = svx_cigar_extract_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len, d->d_sig,
                                    d->sig_cap, d->d_n_sig);
-    ctx->ws_hold = false;
-    if (chain) {  // join (also after an error: nothing may stay unordered behind the caller's next call)
-        const bool ok = hipEventRecord(ctx->ev_join, ctx->stream2) == hipSuccess &&
-                        hipStreamWaitEvent(main_stream, ctx->ev_join, 0) == hipSuccess;
-        if (!ok && rc == SVX_OK) {
-            SVX_SET_ERR(ctx, "joining the streams of svx_collect_batch_dev failed");
-            rc = SVX_E_HIP;
-        }
-    }
-    return rc;
+    if (rc != SVX_OK || !chain) return rc;
+    rc = svx_segments_rows_dev(ctx, d->d_cigar, d->d_aln_off, d->d_seg_src, d->d_seg_tid, d->d_seg_pos, d->d_seg_rev,
+                               d->d_seg_qend, d->n_segs, d->d_read_off, d->n_reads, d->d_segs, d->d_read_len);
+    if (rc != SVX_OK) return rc;
+    rc = svx_segments_classify_dev(ctx, d->d_segs, d->n_segs, d->d_read_off, d->n_reads, d->d_read_len, &d->params, d->d_raw);
+    if (rc != SVX_OK) return rc;
+    return svx_segments_postpass_dev(ctx, d->d_raw, d->read_off, d->d_read_off, d->n_reads, d->d_contig_rank, d->n_contigs,
+                                     &d->params, d->d_post, d->post_off, d->d_post_off, d->d_post_cnt);
 }
 
 extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_collect_out* out) {
@@ -227,7 +195,7 @@ extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_col
     if (n_xops) SVX_HIP(ctx, hipMemcpyAsync(d_cigar + n_ops, in->extra_cigar, (size_t)n_xops * 4, hipMemcpyHostToDevice, ctx->stream));
     SVX_HIP(ctx, hipMemcpyAsync(d_cb, h, cb_bytes, hipMemcpyHostToDevice, ctx->stream));
 
-    // ---- kernels (two overlapping branches, svx_collect_batch_dev)
+    // ---- kernels (svx_collect_batch_dev)
     svx_collect_dev dv;
     memset(&dv, 0, sizeof(dv));
     dv.d_cigar = d_cigar; dv.n_ops = n_ops;

@@ -50,9 +50,6 @@ extern "C" void svx_ctx_destroy(svx_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (int i = 0; i < 4; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_dom) (void)hipEventDestroy(ctx->ev_dom);
@@ -113,13 +110,6 @@ int svx_ws_reserve(svx_ctx* ctx, size_t total) {
         SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         int rc = svx_barrier_check(ctx);
         if (rc != SVX_OK) return rc;
-    }
-    if (ctx->ws_hold) {  // inside svx_collect_batch_dev: continue after what the calls before took
-        if (svx_align_up(ctx->ws_used, 256) + total > ctx->ws_bytes) {
-            SVX_SET_ERR(ctx, "internal: the combined workspace reservation is too small");
-            return SVX_E_NOMEM;
-        }
-        return SVX_OK;
     }
     // the first 4 KiB of the workspace are a header of self-cleaning counters (zeroed at
     // allocation, left at zero by the kernels that use them); per-call scratch starts after it

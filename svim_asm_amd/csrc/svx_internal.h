@@ -16,10 +16,6 @@ struct svx_ctx {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     size_t ws_used = 0;
-    bool ws_hold = false;  // svx_collect_batch_dev: its inner calls bump-allocate from ONE reservation (kernels of two
-                           // streams are in flight together: their scratch must not overlap)
-    hipStream_t stream2 = nullptr;  // second stream of svx_collect_batch_dev (the split-segment chain) and its events
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // second, independent region for host-pointer entry points (staged inputs/outputs)
     char* stage = nullptr;
     size_t stage_bytes = 0;

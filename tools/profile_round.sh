@@ -7,8 +7,8 @@
 #   kernel_stats_extras.csv        same for the latency / pair / edit-distance legs (tools/kbench.py)
 #   pmc/ (with "pmc" as $2)        counter passes, separate runs
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/${1:-r02}; mkdir -p $out
-timeout 900 python3 bench.py > $out/bench.json 2> $out/bench.err
+out=gpurun_out/${1:-r03}; mkdir -p $out
+timeout 1500 python3 bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/rocprof.err
 find $out/stats -name "s_kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_extras -o s -- python3 tools/kbench.py latency pair editdist > $out/kbench_under_rocprof.json 2>> $out/rocprof.err
