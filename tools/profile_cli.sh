@@ -3,7 +3,7 @@
 #   $1 = output directory under gpurun_out/ (default r03_cli); copies wanted go to profiles/.
 #   hip_api_stats.csv   rocprofv3 --hip-trace --stats: how many hipMemcpy* / hipStreamSynchronize the command issues
 #   kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
-cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp SVX_ORDERLY_EXIT=1; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${1:-r03_cli}; mkdir -p $out
 d=/tmp/svx_cli_dataset
 python3 tools/e2e_bench.py --scale ${2:-1.0} --keep $d --ranks 1 --repeat 2 > $out/e2e.json 2> $out/e2e.err
