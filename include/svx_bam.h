@@ -97,7 +97,10 @@ int svx_bam_get_columns(const svx_bam* bam, svx_bam_columns* out);
 /* Decode bases [begin[i], end[i]) of record rec[i] (index into the loaded columns) to ASCII
  * (=ACMGRSVTWYHKDBN, BAM orientation) at out + out_off[i]; n slices, walked by the handle's
  * threads.  Ranges are clipped to [0, l_seq]; out_off[i+1] - out_off[i] must hold the
- * clipped length.  Slices sorted by (rec, begin) reuse inflated blocks. */
+ * clipped length.  Slices sorted by (rec, begin) reuse inflated blocks.  A slice is 0.3 % of the 64 KiB member it
+ * sits in: members are inflated only up to the last byte a slice needs (half the work on average); the CRC32 of a
+ * member is checked when it ends up inflated completely, and always with SVX_BAM_VERIFY=1 in the environment
+ * (every touched member inflated in full, as htslib does).  svx_bam_load always inflates and checks whole members. */
 int svx_bam_seq_slices(svx_bam* bam, const uint32_t* rec, const uint32_t* begin, const uint32_t* end,
                        uint32_t n, const uint64_t* out_off, uint8_t* out);
 

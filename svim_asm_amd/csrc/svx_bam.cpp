@@ -937,12 +937,15 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
     for (uint32_t i = 0; i < n; ++i)
         if (rec[i] >= b->n_records) return fail(b, SVX_E_INVALID, "svx_bam_seq_slices: record index out of range");
     static const char kLut[17] = "=ACMGRSVTWYHKDBN";
+    // SVX_BAM_VERIFY=1: inflate every member a slice touches completely and check its CRC32 (htslib's behaviour)
+    // instead of stopping at the last byte needed (members inflated only in part cannot be checked)
+    static const bool verify_all = [] { const char* v = getenv("SVX_BAM_VERIFY"); return v && v[0] == '1'; }();
     std::atomic<bool> failed(false);
     std::atomic<uint64_t> inflated(0);
     auto work = [&](uint32_t lo, uint32_t hi) {
         Inflater inf;
         Cursor c(&b->file, &inf);
-        c.prefix_mode = true;
+        c.prefix_mode = !verify_all;
         std::vector<uint8_t> packed;
         uint32_t cur_rec = ~0u;
         uint64_t cur_byte = 0;  // bytes of the record's SEQ field already passed by the cursor

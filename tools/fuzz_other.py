@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential tests of the other C-ABI kernels against the C oracle:
 svx_segments_classify, svx_segments_postpass, svx_pair_partition, svx_edit_distance_batch,
-svx_haplotype_distance_batch, svx_linkage_cut_batch, svx_cigar_stats.
+svx_haplotype_distance_batch, svx_linkage_cut_batch, svx_cigar_stats, svx_collect_batch (the pair sort on all three plans).
 
     python tools/fuzz_other.py [--seconds 120] [--seed 1]
 """
@@ -49,13 +49,16 @@ def fuzz_pair(ctx, rng):
     if rng.random() < 0.2 and n:
         keys |= np.uint64(int(rng.integers(0, 1 << 20))) << np.uint64(44)  # high group bits in use
     md = int(rng.choice([0, 1, 1000, 1 << 20, (1 << 32) - 1]))
-    single = bool(rng.random() < 0.8)
-    ctx.set_pair_single_launch_max(131072 if single else 0)
+    plan = str(rng.choice(["one launch", "one launch", "one launch", "radix", "wait-free"]))
+    single = plan == "one launch"
+    ctx.set_pair_single_launch_max(0 if plan == "radix" else 131072)
+    ctx.set_pair_wait_free(plan == "wait-free")
     perm, part, n_parts = ctx.pair_partition(keys, md)
     ctx.set_pair_single_launch_max(131072)
+    ctx.set_pair_wait_free(False)
     e_perm, e_part, e_n = orc.pair_partition(keys, md)
     ok = n_parts == e_n and np.array_equal(perm, e_perm) and np.array_equal(part, e_part)
-    return ok, "pair n %d groups %d pos_max %d max_dist %d shape %s one-launch %s" % (n, groups, pos_max, md, shape, single)
+    return ok, "pair n %d groups %d pos_max %d max_dist %d shape %s plan %s" % (n, groups, pos_max, md, shape, plan)
 
 
 def fuzz_edit(ctx, rng):
@@ -207,6 +210,31 @@ def fuzz_haplotypes(ctx, rng):
     return ok, "haplotypes pairs %d kmax %d" % (n_pairs, kmax)
 
 
+def fuzz_collect(ctx, rng):
+    """svx_collect_batch (one submission) against the composition of the single-purpose entry points."""
+    import test_gpu_collect as tcol
+    b = tcol.random_batch(rng, n_aln=int(rng.choice([1, 2, 50, 800, 6000])), n_parts=int(rng.choice([1, 2, 3, 5])),
+                          n_reads=int(rng.choice([0, 1, 7, 300, 2000])), max_supp=int(rng.choice([1, 3, 7, 12])),
+                          long_read=bool(rng.random() < 0.3))
+    min_len = int(rng.choice([1, 30, 40, 500]))
+    prm = (int(rng.choice([1, 40, 50, 1000])), int(rng.choice([20, 1000, 100000, 1 << 30])),
+           int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])))
+    streaming = bool(rng.random() < 0.25)
+    ctx.set_small_batch_ops(0 if streaming else 1 << 21)
+    try:
+        got = tcol.call(ctx.collect_batch, b, min_len, prm)
+        exp = tcol.call(ctx.collect_batch_composed, b, min_len, prm)
+    finally:
+        ctx.set_small_batch_ops(1 << 21)
+    try:
+        tcol.same(got, exp)
+        ok = True
+    except AssertionError:
+        ok = False
+    return ok, "collect n_aln %d parts %d reads %d min_len %d prm %s streaming %s" % (
+        len(b["aln_off"]) - 1, len(b["parts"]), len(b["read_off"]) - 1, min_len, prm, streaming)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -214,7 +242,7 @@ def main():
     ap.add_argument("--only", default="", help="one of the fuzz_* functions, e.g. pair")
     a = ap.parse_args()
     ctx = _lib.default_context(0)
-    fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats, fuzz_linkage, fuzz_postpass, fuzz_haplotypes]
+    fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats, fuzz_linkage, fuzz_postpass, fuzz_haplotypes, fuzz_collect]
     if a.only:
         fns = [f for f in fns if f.__name__ == "fuzz_" + a.only]
     counts = {f.__name__: 0 for f in fns}

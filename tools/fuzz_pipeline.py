@@ -66,7 +66,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=180.0)
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--oracle-device", action="store_true",
+                    help="no GPU here: answer every kernel call with the CPU oracle (tests/helpers.OracleBackedContext) — "
+                         "the campaign then exercises the product's HOST logic (columns, constructors, pairing arithmetic)")
     a = ap.parse_args()
+    if a.oracle_device:
+        from svim_asm_amd import _lib
+        ctx = helpers.OracleBackedContext()
+        _lib.default_context = lambda device=0: ctx
     t0, seed, n = time.time(), a.seed, [0, 0]
     while time.time() - t0 < a.seconds:
         ok, what = (collect_case if seed % 2 == 0 else pair_case)(seed)
