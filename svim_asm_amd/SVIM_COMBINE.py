@@ -274,9 +274,21 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
     return pieces, extra_parts
 
 
+LAST_TIMING = {}  # seconds per stage of the latest pair_tables / vcf_body call (tools/, bench legs)
+
+
+def _clock(stage, t0):
+    now = time.perf_counter()
+    LAST_TIMING[stage] = LAST_TIMING.get(stage, 0.0) + now - t0
+    return now
+
+
 def pair_tables(t1, t2, reference, bam, options, ctx=None):
     """pair_candidates on tables: the paired candidates as a CandidateTable, rows in the reference's order."""
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
+    for k in [k for k in LAST_TIMING if k.startswith("pair_")]:
+        del LAST_TIMING[k]
+    tc = time.perf_counter()
     base_bam = getattr(bam, "_bam", bam)
     contigs = list(base_bam.references)
     T = CandidateTable.concat([t1, t2], contigs, [base_bam.get_reference_length(c) for c in contigs])
@@ -288,9 +300,11 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
         logging.info("Pairing {0} {1}...".format(int(counts[ti]), _LOG_NAME[typ]))
     if n == 0:
         return T
+    tc = _clock("pair_concat_s", tc)
     # one sort/partition launch for all types; the input order per type is hap-1 list then hap-2 list (:182,...)
     inp = np.lexsort((hap, T.type))
     perm, part_id, n_parts = ctx.pair_partition(_keys_of_table(T)[inp], options.partition_max_distance)
+    tc = _clock("pair_sort_s", tc)
     order = inp[perm.astype(np.int64)]
     p_size = np.bincount(part_id.astype(np.int64), minlength=n_parts).astype(np.int64)
     p_start = np.cumsum(p_size) - p_size
@@ -330,6 +344,7 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
     job_p = [np.broadcast_to(c["P"][:, None], c["A"].shape)[~c["bnd"]][c["cross"][~c["bnd"]]] for c in classes]
     job_two = [np.full(len(a), c["size"] == 2) for a, c in zip(job_a, classes)]
     dist = np.zeros(0, np.float64)
+    tc = _clock("pair_enumerate_s", tc)
     if classes and sum(len(a) for a in job_a):
         job_a, job_b, job_p, job_two = (np.concatenate(x) for x in (job_a, job_b, job_p, job_two))
         # one reference window per partition with jobs: [min start - 100, max end + 100) of ALL its members (:45-46,...)
@@ -345,7 +360,9 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
         seg_hi = np.maximum.reduceat(e_sorted, p_start)[wp]
         wlo = np.maximum(0, seg_lo - 100)
         whi = np.minimum(L_part[wp], seg_hi + 100)
+        tc = _clock("pair_windows_plan_s", tc)
         pool_w, off_w = _fetch_windows(reference, [T.contigs[c] for c in p_contig[wp].tolist()], wlo, np.maximum(whi, wlo), False)
+        tc = _clock("pair_windows_fetch_s", tc)
         if not np.array_equal(off_w[1:] - off_w[:-1], np.maximum(whi - wlo, 0)):
             raise ValueError("reference windows shorter than the index says")
         win_base = np.zeros(n_parts + 1, np.int64)
@@ -355,6 +372,7 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
         win_lo[wp] = wlo
         pieces, extra = _haplotype_pieces(T, kstart, kend, job_a, job_b, job_p, p_type, p_contig, win_base, win_lo, L_part, reference)
         pool = np.concatenate([pool_w] + extra) if extra else pool_w
+        tc = _clock("pair_recipes_s", tc)
         # two-member partitions only need "<= threshold?"; larger ones get exact values so that the dendrogram
         # above the cut (hence scipy's cluster label order) is the reference's.  Any threshold the reference
         # accepts: a negative one pairs nothing, one beyond 32 bits everything
@@ -367,6 +385,7 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
             dist[thr] = d
         if len(exa):
             dist[exa] = ctx.haplotype_distance_batch(pool, pieces[exa].reshape(-1), 0xFFFFFFFF).astype(np.float64)
+        tc = _clock("pair_distances_s", tc)
     # condensed distance vectors per size class (row-major pairs (i < j), :131-133), then the clusters
     at = 0
     for c in classes:
@@ -411,11 +430,14 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
         second = np.where(sz >= 2, rows[np.minimum(st + 1, len(rows) - 1)], -1)
         out.add(part[st], lab[st], rows[st], second, sz)
 
+    tc = _clock("pair_clusters_s", tc)
     c_part, first, second, size = out.ordered()
     for bad in size[size > 2].tolist():
         logging.error("Cluster size should be either 1 or 2 but is " + str(bad))
     ok = size <= 2
-    return _rebuild_rows(T, hap, first[ok], second[ok])
+    res = _rebuild_rows(T, hap, first[ok], second[ok])
+    _clock("pair_rebuild_s", tc)
+    return res
 
 
 def _rebuild_rows(T, hap, first, second):
@@ -567,12 +589,15 @@ def _pool_of_strings(strings):
     return b"".join(enc), off
 
 
-def vcf_body(table, types_to_output, reference, options):
+def vcf_body(table, types_to_output, reference, options, sink=None):
     """The record lines of write_final_vcf (:428-477) for the rows of `table` as bytes (every line ends with a
     newline): entries in the reference's list order, formatted, naturally sorted and numbered by
-    svx_vcf_format."""
+    svx_vcf_format.  With `sink` (a binary file object) the lines are written to it instead of being returned."""
     lib = _lib.load()
     t = table
+    for k in [k for k in LAST_TIMING if k.startswith("vcf_")]:
+        del LAST_TIMING[k]
+    tc = time.perf_counter()
     rows_of = lambda ti: np.flatnonzero(t.type == ti)
     kinds, rows = [], []
 
@@ -618,7 +643,9 @@ def vcf_body(table, types_to_output, reference, options):
         f_cid = np.concatenate((cid[w], t.sc[row][w2]))
         f_lo = np.concatenate((lo[w], ss[w2]))
         f_hi = np.concatenate((hi[w], se[w2]))
+        tc = _clock("vcf_entries_s", tc)
         bases, off = _fetch_windows(reference, [t.contigs[c] for c in f_cid.tolist()], f_lo, f_hi, True)
+        tc = _clock("vcf_fetch_s", tc)
         b_off, b_len = np.zeros(ne, np.int64), np.zeros(ne, np.int64)
         b2_off, b2_len = np.zeros(ne, np.int64), np.zeros(ne, np.int64)
         ln = off[1:] - off[:-1]
@@ -627,7 +654,7 @@ def vcf_body(table, types_to_output, reference, options):
     if seq:
         reference.close()  # (:466-467)
     if ne == 0:
-        return b""
+        return b"" if sink is None else None
     natural = _natural_ranks(set(t.contigs))
     contig_rank = np.array([natural[c] for c in t.contigs], dtype=np.int32)
     contig_pool, contig_off = _pool_of_strings(t.contigs)
@@ -654,13 +681,19 @@ def vcf_body(table, types_to_output, reference, options):
         b2_off=ptr(b2_off, np.int64), b2_len=ptr(b2_len, np.int64), sequence_alleles=1 if seq else 0,
         read_names=1 if options.query_names else 0)
     text, n_bytes, n_lines = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    tc = _clock("vcf_prepare_s", tc)
     rc = lib.svx_vcf_format(C.byref(arg), C.byref(text), C.byref(n_bytes), C.byref(n_lines))
     if rc != 0:
         raise _lib.SvxError(rc, "svx_vcf_format")
+    tc = _clock("vcf_format_s", tc)
     try:
+        if sink is not None:  # straight from the library's buffer into the file: no bytes object in between
+            sink.write(memoryview((C.c_char * n_bytes.value).from_address(text.value)) if n_bytes.value else b"")
+            return None
         return C.string_at(text, n_bytes.value)
     finally:
         lib.svx_vcf_free(text)
+        _clock("vcf_write_s", tc)
 
 
 def write_vcf_table(table, version, contig_names, contig_lengths, types_to_output, reference, options):
@@ -668,7 +701,7 @@ def write_vcf_table(table, version, contig_names, contig_lengths, types_to_outpu
     with open(options.working_dir + "/variants.vcf", "wb") as vcf_output:
         header = "".join(line + "\n" for line in _header_lines(version, contig_names, contig_lengths, types_to_output, options))
         vcf_output.write(header.encode("utf-8", "surrogateescape"))
-        vcf_output.write(vcf_body(table, types_to_output, reference, options))
+        vcf_body(table, types_to_output, reference, options, sink=vcf_output)
 
 
 def write_final_vcf(int_duplication_candidates, inversion_candidates, tandem_duplication_candidates,

@@ -235,15 +235,16 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
             if (x.start != y.start) return x.start < y.start;
             return x.end < y.end;
         });
-        // ---- lines in sorted order, IDs numbered per label (:470-475)
-        Out o;
-        size_t guess = (size_t)ne * 96;
-        if (in->sequence_alleles) {
-            for (uint32_t e = 0; e < ne; ++e) guess += (size_t)in->b_len[e] * 2;
+        // ---- IDs numbered per label in sorted order (:470-475): serial, one counter per label
+        std::vector<int64_t> id_no(ne);
+        {
+            int64_t counter[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t q = 0; q < ne; ++q) id_no[q] = ++counter[KIND_LABEL[in->kind[ent[q].idx]]];
         }
-        o.s.reserve(guess);
-        int64_t counter[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t q = 0; q < ne; ++q) {
+        // ---- lines in sorted order: contiguous chunks of entries formatted by a few threads, then joined
+        std::atomic<int> status(SVX_OK);
+        auto format_range = [&](uint32_t q_lo, uint32_t q_hi, Out& o) -> int {
+        for (uint32_t q = q_lo; q < q_hi; ++q) {
             const uint32_t e = ent[q].idx;
             const uint32_t r = in->row[e];
             const uint8_t k = in->kind[e];
@@ -261,7 +262,7 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
             const int lab = KIND_LABEL[k];
             o.lit(LABELS[lab]);
             o.ch('.');
-            o.num(++counter[lab]);
+            o.num(id_no[q]);
             o.ch('\t');
             // REF ALT
             const int64_t ss = in->ss[r], se = in->se[r], ds = in->ds[r], de = in->de[r];
@@ -380,11 +381,53 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
             }
             o.ch('\n');
         }
-        char* buf = (char*)malloc(o.s.size() ? o.s.size() : 1);
+        return SVX_OK;
+        };
+        unsigned n_thr = std::min<unsigned>(8u, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+        if (ne < 4096) n_thr = 1;
+        std::vector<Out> parts(n_thr);
+        auto run = [&](unsigned t) {
+            const uint32_t q_lo = (uint32_t)((uint64_t)ne * t / n_thr), q_hi = (uint32_t)((uint64_t)ne * (t + 1) / n_thr);
+            size_t guess = (size_t)(q_hi - q_lo) * 96;
+            if (in->sequence_alleles)
+                for (uint32_t q = q_lo; q < q_hi; ++q) guess += (size_t)in->b_len[ent[q].idx] * 2;
+            try {
+                parts[t].s.reserve(guess);
+                const int rc = format_range(q_lo, q_hi, parts[t]);
+                if (rc != SVX_OK) status.store(rc);
+            } catch (const std::bad_alloc&) {
+                status.store(SVX_E_NOMEM);
+            } catch (...) {
+                status.store(SVX_E_INVALID);
+            }
+        };
+        if (n_thr == 1) {
+            run(0);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(run, t);
+            for (std::thread& t : th) t.join();
+        }
+        if (status.load() != SVX_OK) return status.load();
+        size_t total = 0;
+        for (const Out& part : parts) total += part.s.size();
+        char* buf = (char*)malloc(total ? total : 1);
         if (!buf) return SVX_E_NOMEM;
-        memcpy(buf, o.s.data(), o.s.size());
+        {
+            std::vector<size_t> at(n_thr);
+            size_t pos = 0;
+            for (unsigned t = 0; t < n_thr; ++t) { at[t] = pos; pos += parts[t].s.size(); }
+            auto copy = [&](unsigned t) { if (parts[t].s.size()) memcpy(buf + at[t], parts[t].s.data(), parts[t].s.size()); };
+            if (n_thr == 1) {
+                copy(0);
+            } else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(copy, t);
+                for (std::thread& t : th) t.join();
+            }
+        }
         *text = buf;
-        *n_bytes = o.s.size();
+        *n_bytes = total;
         if (n_lines) *n_lines = ne;
         return SVX_OK;
     } catch (const std::bad_alloc&) {

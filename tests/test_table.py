@@ -116,11 +116,12 @@ def test_constructor_assertion_and_unknown_contig_are_raised():
         _apply_constructors(t)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(5))
 def test_native_vcf_lines_equal_the_object_formatters(seed):
     rng = np.random.default_rng(200 + seed)
     seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=l)) for n, l in zip(NAMES, LENGTHS)}
-    bam, tuples, objs = _random_objects(rng, 200, seqs)
+    # (seed 4: more than 4096 entries — the formatter then works on chunks in several threads)
+    bam, tuples, objs = _random_objects(rng, 200 if seed < 4 else 6000, seqs)
     for o in objs[::5]:
         o.reads = o.reads + ["extra"]
         o.genotype = ["1/0", "0/1"][int(rng.integers(0, 2))]

@@ -158,9 +158,12 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             t = time.perf_counter()
             paired = shard.pair_sharded(t1, t2, ref, f1, opts)
             r["pair_s"] = time.perf_counter() - t
+            from svim_asm_amd import SVIM_COMBINE
+            r["pair_stages_s"] = {k: v for k, v in SVIM_COMBINE.LAST_TIMING.items() if k.startswith("pair_")}
             t = time.perf_counter()
             write_vcf_table(paired, "1.0.3", f1.references, f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
             r["vcf_s"] = time.perf_counter() - t
+            r["vcf_stages_s"] = {k: v for k, v in SVIM_COMBINE.LAST_TIMING.items() if k.startswith("vcf_")}
             r["product_total_s"] = time.perf_counter() - t_all
             gc.enable()
             runs.append(r)
