@@ -581,8 +581,9 @@ def collect_tables(bams, options, ctx=None):
     for all of them when their reference dictionaries agree."""
     import time
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
-    t0 = time.perf_counter()
+    tl = time.perf_counter()
     _load_together(bams)
+    t0 = time.perf_counter()
     samples = [_prepare(bam, options) for bam in bams]
     t1 = time.perf_counter()
     groups = [samples] if _same_header(bams) else [[s] for s in samples]
@@ -593,7 +594,7 @@ def collect_tables(bams, options, ctx=None):
         _table_of(s, options)
     t3 = time.perf_counter()
     tables = [_join_sequences(s) for s in samples]
-    LAST_TIMING.update(prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=time.perf_counter() - t3)
+    LAST_TIMING.update(load_s=t0 - tl, prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=time.perf_counter() - t3)
     return tables
 
 

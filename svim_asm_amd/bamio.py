@@ -444,6 +444,15 @@ def _restore_long_cigar(words, l_seq, tid, pos, aux):
     return None
 
 
+def ingest_threads(n_files=1):
+    """Threads one reader gets when `n_files` BAMs are walked / decoded at the same time (both haplotypes of a
+    diploid sample): a quarter of the hardware threads in total, at most 64 and at least 8 per file.  The inflate
+    work scales to 16-32 threads per file on the GPU hosts (shared nodes: more threads than free cores only
+    oversubscribe — tools/slice_probe.py, profiles/README.md)."""
+    hw = os.cpu_count() or 1
+    return int(max(1, min(64, max(8, hw // (4 * max(1, n_files))), hw)))
+
+
 class _BamColumns(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("l_seq", C.c_void_p),
                 ("ref_len", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p), ("cigar_off", C.c_void_p),

@@ -21,7 +21,8 @@ def _open(path, which, options):
     """Open one BAM and check sort order and index like the reference (svim-asm:63-72,85-95).
     Returns the alignment file, or None after logging the error."""
     the = {"": "Input", "first": "The first input", "second": "The second input"}[which]
-    aln_file = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0)
+    aln_file = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
+                                   threads=bamio.ingest_threads(2 if options.sub == "diploid" else 1))
     try:
         if aln_file.header["HD"]["SO"] != "coordinate":
             logging.error("{0} BAM file needs to be coordinate-sorted. Exiting..".format(the))

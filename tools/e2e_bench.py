@@ -146,8 +146,10 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             gc.disable()  # as cli._run does for the whole command
             t_all = time.perf_counter()
             t = time.perf_counter()
-            f1 = bamio.AlignmentFile(bams[0], threads=threads, device=device).load()
-            f2 = bamio.AlignmentFile(bams[1], threads=threads, device=device).load()
+            # as cli._open does: headers and indices here; the record walks of both files run side by side inside COLLECT
+            f1 = bamio.AlignmentFile(bams[0], threads=threads or bamio.ingest_threads(2), device=device)
+            f2 = bamio.AlignmentFile(bams[1], threads=threads or bamio.ingest_threads(2), device=device)
+            f1.check_index(), f2.check_index()
             r["open_index_s"] = time.perf_counter() - t
             t = time.perf_counter()
             t1, t2 = shard.collect_sharded([f1, f2], opts)
@@ -174,7 +176,7 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
         res["index_state"] = f1.index_state()
         res["bgzf_members_inflated"] = [f1.blocks_inflated, f2.blocks_inflated]
         res["bgzf_members_walked"] = [f1.blocks_spanned, f2.blocks_spanned]
-        res["ingest_threads"] = threads or min(64, os.cpu_count() or 1)
+        res["ingest_threads"] = threads or bamio.ingest_threads(2)
         res["candidates"] = [len(t1), len(t2), len(paired)]
         res["cigar_ops"] = [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]
         got = masked(os.path.join(wd, "variants.vcf"))
