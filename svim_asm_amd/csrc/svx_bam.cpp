@@ -629,13 +629,29 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out, char
             bool good = true, any = false;
             VPos lowest;
             lowest.coff = ~0ull;
-            for (const RefIndex& R : b->refs) {
-                for (uint64_t v : R.points) {
-                    Blk blk;
-                    const uint64_t co = v >> 16;
-                    const int rc = parse_block(b->file.map, b->file.fsize, co, &blk);
-                    if (rc < 0 || (rc == 1 && (v & 0xFFFF)) || (rc == 0 && (v & 0xFFFF) > blk.isize)) good = false;
+            {   // every index point against the member header it names: ~10^5 page touches, spread over the threads
+                std::vector<uint64_t> pts;
+                for (const RefIndex& R : b->refs) pts.insert(pts.end(), R.points.begin(), R.points.end());
+                std::atomic<bool> bad(false);
+                auto check = [&](size_t lo, size_t hi) {
+                    for (size_t i = lo; i < hi && !bad.load(std::memory_order_relaxed); ++i) {
+                        Blk blk;
+                        const uint64_t v = pts[i], co = v >> 16;
+                        const int rc = parse_block(b->file.map, b->file.fsize, co, &blk);
+                        if (rc < 0 || (rc == 1 && (v & 0xFFFF)) || (rc == 0 && (v & 0xFFFF) > blk.isize)) bad.store(true);
+                    }
+                };
+                const size_t nt = pts.size() < 4096 ? 1 : (size_t)std::max(1, std::min(b->n_threads, 16));
+                if (nt == 1) {
+                    check(0, pts.size());
+                } else {
+                    std::vector<std::thread> th;
+                    for (size_t t = 0; t < nt; ++t) th.emplace_back(check, pts.size() * t / nt, pts.size() * (t + 1) / nt);
+                    for (std::thread& t : th) t.join();
                 }
+                good = !bad.load();
+            }
+            for (const RefIndex& R : b->refs) {
                 if (!R.points.empty()) {
                     any = true;
                     Cursor k(&b->file, &inf);

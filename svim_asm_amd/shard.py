@@ -61,9 +61,16 @@ class _SocketGroup(object):
         if rank == 0:
             self.listener = Listener(address, family="AF_UNIX", authkey=key)
             self.peers = [None] * size
-            self.listener._listener._socket.settimeout(timeout)
+            try:  # a rank that never shows up must not block rank 0 for ever
+                self.listener._listener._socket.settimeout(timeout)
+            except AttributeError:
+                pass
             for _ in range(size - 1):
-                conn = self.listener.accept()
+                try:
+                    conn = self.listener.accept()
+                except OSError as e:  # socket.timeout
+                    raise RuntimeError("rank 0: only %d of %d ranks reached the exchange within %.0f s (%s)"
+                                       % (1 + sum(p is not None for p in self.peers), size, timeout, e))
                 self.peers[conn.recv()] = conn
         else:
             deadline = time.time() + timeout
