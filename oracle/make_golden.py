@@ -177,6 +177,43 @@ def make_medium():
     shutil.rmtree(d)
 
 
+MEDIUM_OPTION_RUNS = {
+    # the same 62 Mbp inputs through the option paths that change what the VCF writer and the pairing step do
+    "medium_names_dupins": ["--query_names", "--tandem_duplications_as_insertions", "--interspersed_duplications_as_insertions",
+                            "--min_sv_size", "30", "--max_edit_distance", "50", "--sample", "M2"],
+    "medium_symbolic_strict": ["--symbolic_alleles", "--max_edit_distance", "0", "--partition_max_distance", "100",
+                               "--types", "DEL,INS,BND,DUP:TANDEM", "--min_mapq", "0"],
+}
+
+
+def make_medium_options():
+    """More goldens on the medium sample: the real reference with non-default options (read names in INFO,
+    duplications written as insertions, symbolic alleles, strict pairing, a subset of types)."""
+    import gzip
+    from svim_asm_amd import synth_bam
+    d = tempfile.mkdtemp(prefix="svx_medium_opt_")
+    fasta, bams = synth_bam.write_dataset(d, seed=MEDIUM["seed"], contigs=medium_contigs(), n_shared=MEDIUM["n_shared"],
+                                          n_private=MEDIUM["n_private"], median_aln=MEDIUM["median_aln"],
+                                          mean_m=MEDIUM["mean_m"])
+    meta = json.load(open(os.path.join(GOLD, "medium_inputs.json")))
+    for f in [fasta] + bams:
+        got = synth_bam.payload_digest(f) if f.endswith(".bam") else synth_bam.file_digest(f)
+        if got != meta["payload_sha256"][os.path.basename(f)]:
+            raise SystemExit("regenerated medium inputs differ from the committed digests")
+    runs = {}
+    for name, extra in MEDIUM_OPTION_RUNS.items():
+        wd = os.path.join(d, "wd_" + name)
+        run_reference_cli(["diploid", wd, bams[0], bams[1], fasta] + extra)
+        vcf = masked_vcf(os.path.join(wd, "variants.vcf"))
+        with gzip.GzipFile(os.path.join(GOLD, name + ".vcf.gz"), "wb", compresslevel=9, mtime=0) as fh:
+            fh.write(vcf.encode())
+        runs[name] = {"options": extra, "records": sum(1 for l in vcf.split("\n") if l and l[0] != "#")}
+    meta["option_runs"] = runs
+    with open(os.path.join(GOLD, "medium_inputs.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    shutil.rmtree(d)
+
+
 LARGE = dict(seed=3, scale=0.25, sv_per_mbp=8.0, median_aln=300000, mean_m=2000)
 
 
@@ -533,7 +570,7 @@ def main():
     if len(sys.argv) > 1:   # regenerate selected fixtures only: functions / config1 / medium / longcigar
         for what in sys.argv[1:]:
             {"functions": make_function_vectors, "config1": make_config1, "medium": make_medium,
-             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors, "large": make_large, "full": make_full, "config5": make_config5,
+             "longcigar": make_longcigar, "pipeline": make_pipeline_vectors, "large": make_large, "full": make_full, "config5": make_config5, "medium_options": make_medium_options,
              "digests": refresh_payload_digests}[what]()
         return
     make_longcigar()

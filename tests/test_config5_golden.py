@@ -74,3 +74,15 @@ def test_config5_has_crowded_and_dropped_partitions(svx_ctx, config5_dataset):
     assert len(keys) > 131072
     assert int(((sizes >= 3) & (sizes <= 10)).sum()) > 10000
     assert int((sizes > 10).sum()) > 50
+
+
+@pytest.mark.spawns_gpu_children
+def test_three_rank_cli_reproduces_reference_vcf_config5(config5_dataset, tmp_path):
+    """BASELINE config 4 on the config-5 sample: three contig-sharded ranks (fresh processes, product kernels, one
+    device), 184 k candidates exchanged as tables, PAIR sharded by key contig over crowded partitions."""
+    from tests import helpers
+    fasta, bams = config5_dataset
+    res = helpers.run_cli_ranks(["diploid", str(tmp_path), bams[0], bams[1], fasta], 3)
+    for rank, (rc, text) in enumerate(res):
+        assert rc == 0, "rank %d failed:\n%s" % (rank, text)
+    _check(tmp_path / "variants.vcf")

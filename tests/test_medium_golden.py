@@ -74,3 +74,46 @@ def test_two_rank_cli_reproduces_reference_vcf_medium(medium_dataset, tmp_path):
     total = whole.blocks_spanned
     for rank in (0, 1):
         assert 0.35 * total < spanned[rank][0] < 0.65 * total, (rank, spanned, total)
+
+
+# ---- the same sample through non-default options (oracle/make_golden.py medium_options): read names in INFO,
+# duplications written as insertions, symbolic alleles, strict pairing, a subset of the types
+OPTION_RUNS = sorted(META.get("option_runs", {}))
+
+
+def _expected(name):
+    return gzip.open(os.path.join(GOLD, name + ".vcf.gz"), "rb").read().decode()
+
+
+@pytest.mark.parametrize("name", OPTION_RUNS)
+def test_oracle_reproduces_reference_vcf_medium_options(medium_dataset, name):
+    from oracle import orc, run_oracle
+    from tests.test_oracle_pins import _parse_run
+    fasta, bams = medium_dataset
+    _, kw = _parse_run(META["option_runs"][name]["options"])
+    got = run_oracle.vcf_from_files(bams, fasta, run_oracle.default_options(**kw),
+                                    edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+    assert got == _expected(name)
+    assert sum(1 for l in got.split("\n") if l and l[0] != "#") == META["option_runs"][name]["records"]
+
+
+@pytest.mark.parametrize("name", OPTION_RUNS)
+def test_host_path_reproduces_reference_vcf_medium_options(medium_dataset, tmp_path, monkeypatch, name):
+    """The product's host path (native reader, columns, native VCF body) with the device answered by the oracle."""
+    from svim_asm_amd import cli
+    from tests import helpers
+    helpers.oracle_backed_device(monkeypatch)
+    fasta, bams = medium_dataset
+    cli.main(["diploid", str(tmp_path), bams[0], bams[1], fasta] + META["option_runs"][name]["options"])
+    got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == _expected(name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", OPTION_RUNS)
+def test_cli_reproduces_reference_vcf_medium_options(svx_ctx, medium_dataset, tmp_path, name):
+    from svim_asm_amd import cli
+    fasta, bams = medium_dataset
+    cli.main(["diploid", str(tmp_path), bams[0], bams[1], fasta] + META["option_runs"][name]["options"])
+    got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == _expected(name)
