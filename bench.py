@@ -51,6 +51,9 @@ def parse():
                     help="BAM->VCF wall-clock legs (e2e, e2e_sharded): fraction of the GRCh38 contig lengths of the "
                          "synthetic diploid sample written as real BAM+FASTA files (1.0 = 3.1 Gbp, the configuration the "
                          "metric is quoted on: ~1 min of generation on the GPU box); 0 skips the legs")
+    ap.add_argument("--a3-after-dominant", type=int, default=0,
+                    help="1: the a3 launch of a step waits (svx_ctx_wait_dominant) for the step's streaming kernel and "
+                         "overlaps the scan / finish tail; 0: it starts at once, beside the streaming kernel")
     ap.add_argument("--pipeline", action="store_true",
                     help="alternate two contexts between consecutive steps (independent batches overlap; "
                          "per-kernel durations then overlap too, so the default keeps one context)")
@@ -564,7 +567,11 @@ def main():
         c.cigar_extract_dev(d_cig.data_ptr(), n_ops, d_off.data_ptr(), n_aln, d_rs.data_ptr(),
                             args.min_sv_size, tuple(t.data_ptr() for t in o[:5]), cap, o[5].data_ptr(),
                             d_op=None if d_op is None else d_op.data_ptr())
-        # a3: split-segment decision tree for the chimeric reads of the batch
+        # a3: split-segment decision tree for the chimeric reads of the batch — independent of a1/a2, on its own
+        # stream, placed behind this step's streaming kernel: it then runs beside the latency-bound scan / finish
+        # tail instead of competing with the HBM-bound kernel for bandwidth
+        if args.a3_after_dominant:
+            ctx2.wait_dominant(c)
         ctx2._check(ctx2.lib.svx_segments_classify_dev(ctx2.h, d_segs.data_ptr(), n_segs, d_read_off.data_ptr(),
                                                        n_reads, d_read_len.data_ptr(), C.byref(seg_prm),
                                                        d_raw.data_ptr()))
