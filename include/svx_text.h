@@ -75,10 +75,12 @@ typedef struct svx_vcf_in {
     const int64_t* q_len;
     const int64_t* r_off;     /* n_rows + 1: reads of row i = read names r_flat[r_off[i] .. r_off[i+1]) */
     const int64_t* r_flat;
-    /* ---- stores */
+    /* ---- stores (the sizes bound every offset above and below: a slice that leaves its pool is SVX_E_INVALID) */
     const uint8_t* seqs;
+    uint64_t seqs_bytes;
     const char* names;        /* read-name pool (only read when read_names != 0) */
-    const int64_t* name_off;
+    const int64_t* name_off;  /* n_names + 1 */
+    uint64_t n_names;
     const char* contigs;      /* contig-name pool */
     const int64_t* contig_off; /* n_contigs + 1 */
     const int32_t* contig_rank; /* rank of every contig name under sorted_nicely's natural key (equal keys share one) */
@@ -94,6 +96,7 @@ typedef struct svx_vcf_in {
      * bases[b_off[e] .. b_off[e] + b_len[e]) = the REF allele the entry's formatter fetches; for
      * SVX_VCF_DUPINT_INS a second slice bases[b2_off[e] ...) = the source interval appended to ALT */
     const uint8_t* bases;
+    uint64_t bases_bytes;
     const int64_t* b_off;
     const int64_t* b_len;
     const int64_t* b2_off;

@@ -671,13 +671,13 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
         n_rows=len(t), sc=ptr(t.sc, np.int32), ss=ptr(t.ss, np.int64), se=ptr(t.se, np.int64), dc=ptr(t.dc, np.int32),
         ds=ptr(t.ds, np.int64), de=ptr(t.de, np.int64), flag=ptr(t.flag, np.uint8), copies=ptr(t.copies, np.int64),
         gt=ptr(t.gt, np.uint8), q_off=ptr(t.q_off, np.int64), q_len=ptr(t.q_len, np.int64),
-        r_off=ptr(t.r_off, np.int64), r_flat=ptr(t.r_flat, np.int64), seqs=ptr(t.seqs, np.uint8),
-        names=C.cast(C.c_char_p(names_pool), C.c_void_p).value, name_off=ptr(t.names.off, np.int64),
+        r_off=ptr(t.r_off, np.int64), r_flat=ptr(t.r_flat, np.int64), seqs=ptr(t.seqs, np.uint8), seqs_bytes=len(t.seqs),
+        names=C.cast(C.c_char_p(names_pool), C.c_void_p).value, name_off=ptr(t.names.off, np.int64), n_names=len(t.names),
         contigs=C.cast(C.c_char_p(contig_pool), C.c_void_p).value, contig_off=ptr(contig_off, np.int64),
         contig_rank=ptr(contig_rank, np.int32), n_contigs=len(t.contigs),
         genotypes=C.cast(C.c_char_p(gt_pool), C.c_void_p).value, genotype_off=ptr(gt_off, np.int64),
         n_genotypes=len(t.genotypes), n_entries=ne, kind=ptr(kind, np.uint8), row=ptr(row, np.uint32),
-        bases=ptr(bases, np.uint8), b_off=ptr(b_off, np.int64), b_len=ptr(b_len, np.int64),
+        bases=ptr(bases, np.uint8), bases_bytes=len(bases), b_off=ptr(b_off, np.int64), b_len=ptr(b_len, np.int64),
         b2_off=ptr(b2_off, np.int64), b2_len=ptr(b2_len, np.int64), sequence_alleles=1 if seq else 0,
         read_names=1 if options.query_names else 0)
     text, n_bytes, n_lines = C.c_void_p(), C.c_uint64(), C.c_uint64()

@@ -57,11 +57,12 @@ class VcfIn(C.Structure):
     _fields_ = [("n_rows", C.c_uint32), ("sc", C.c_void_p), ("ss", C.c_void_p), ("se", C.c_void_p), ("dc", C.c_void_p),
                 ("ds", C.c_void_p), ("de", C.c_void_p), ("flag", C.c_void_p), ("copies", C.c_void_p), ("gt", C.c_void_p),
                 ("q_off", C.c_void_p), ("q_len", C.c_void_p), ("r_off", C.c_void_p), ("r_flat", C.c_void_p),
-                ("seqs", C.c_void_p), ("names", C.c_void_p), ("name_off", C.c_void_p), ("contigs", C.c_void_p),
+                ("seqs", C.c_void_p), ("seqs_bytes", C.c_uint64), ("names", C.c_void_p), ("name_off", C.c_void_p),
+                ("n_names", C.c_uint64), ("contigs", C.c_void_p),
                 ("contig_off", C.c_void_p), ("contig_rank", C.c_void_p), ("n_contigs", C.c_uint32),
                 ("genotypes", C.c_void_p), ("genotype_off", C.c_void_p), ("n_genotypes", C.c_uint32),
                 ("n_entries", C.c_uint32), ("kind", C.c_void_p), ("row", C.c_void_p), ("bases", C.c_void_p),
-                ("b_off", C.c_void_p), ("b_len", C.c_void_p), ("b2_off", C.c_void_p), ("b2_len", C.c_void_p),
+                ("bases_bytes", C.c_uint64), ("b_off", C.c_void_p), ("b_len", C.c_void_p), ("b2_off", C.c_void_p), ("b2_len", C.c_void_p),
                 ("sequence_alleles", C.c_int), ("read_names", C.c_int)]
 
 

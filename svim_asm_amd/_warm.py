@@ -53,8 +53,14 @@ def start(device, lib_path):
 def take(device):
     """The context handle made for `device` by start(), once (None if there is none)."""
     th = _state["thread"]
-    if th is None or _state["device"] != int(device):
+    if th is None:
         return None
     th.join()
     h, _state["handle"] = _state["handle"], None
+    if h is not None and _state["device"] != int(device):
+        # made for another device than the one that is wanted after all: give it back
+        _state["lib"].svx_ctx_destroy.argtypes = [ctypes.c_void_p]
+        _state["lib"].svx_ctx_destroy.restype = None
+        _state["lib"].svx_ctx_destroy(h)
+        return None
     return h

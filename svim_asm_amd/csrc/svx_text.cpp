@@ -208,7 +208,9 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
         return SVX_E_INVALID;
     if (ne && in->read_names && (!in->r_off || (!in->r_flat && in->r_off[in->n_rows]) || !in->names || !in->name_off))
         return SVX_E_INVALID;
-    if (ne && in->sequence_alleles && (!in->b_off || !in->b_len)) return SVX_E_INVALID;
+    if (ne && in->sequence_alleles && (!in->b_off || !in->b_len || !in->q_len || (in->bases_bytes && !in->bases) ||
+                                       (in->seqs_bytes && !in->seqs)))
+        return SVX_E_INVALID;
     try {
         // ---- sort keys: ((contig, start, end)) per entry, SVIM_COMBINE.py:431-464; natural contig order :369-376
         std::vector<Entry> ent(ne);
@@ -228,6 +230,21 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
             }
             if (contig < 0 || (uint32_t)contig >= in->n_contigs) return SVX_E_INVALID;
             if (in->gt[r] >= in->n_genotypes) return SVX_E_INVALID;
+            // every slice the formatter will read stays inside its pool
+            if (in->sequence_alleles) {
+                if (in->b_off[e] < 0 || in->b_len[e] < 0 || (uint64_t)in->b_off[e] + (uint64_t)in->b_len[e] > in->bases_bytes) return SVX_E_INVALID;
+                if (k == SVX_VCF_DUPINT_INS && in->b2_off && in->b2_len &&
+                    (in->b2_off[e] < 0 || in->b2_len[e] < 0 || (uint64_t)in->b2_off[e] + (uint64_t)in->b2_len[e] > in->bases_bytes))
+                    return SVX_E_INVALID;
+                if (k == SVX_VCF_INS && in->q_len[r] > 0 &&
+                    (!in->q_off || in->q_off[r] < 0 || (uint64_t)in->q_off[r] + (uint64_t)in->q_len[r] > in->seqs_bytes))
+                    return SVX_E_INVALID;
+            }
+            if (in->read_names) {
+                if (in->r_off[r] < 0 || in->r_off[r + 1] < in->r_off[r]) return SVX_E_INVALID;
+                for (int64_t j = in->r_off[r]; j < in->r_off[r + 1]; ++j)
+                    if (in->r_flat[j] < 0 || (uint64_t)in->r_flat[j] >= in->n_names) return SVX_E_INVALID;
+            }
             ent[e] = Entry{in->contig_rank[contig], a, b, e};
         }
         std::stable_sort(ent.begin(), ent.end(), [](const Entry& x, const Entry& y) {
