@@ -102,3 +102,28 @@ def test_cli_reproduces_reference_vcf_config1(tmp_path, name):
     cli.main(argv)
     got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
     assert got == open(os.path.join(GOLD, "config1", name + ".vcf")).read()
+
+
+def test_two_haplotypes_with_differently_ordered_headers():
+    """The two BAMs of a diploid run need not list their contigs in the same order: COLLECT then submits them
+    separately (contig ids mean different things) and PAIR re-expresses the second table's contig ids by NAME in the
+    first BAM's header — candidates, pairing and order as the oracle computes them from names."""
+    rng = np.random.default_rng(42)
+    perm = [2, 0, 3, 1]
+    names2, lengths2 = [NAMES[i] for i in perm], [LENGTHS[i] for i in perm]
+    recs1 = helpers.random_records(rng, NAMES, LENGTHS, 50) + helpers.engineered_split_records(rng, NAMES, LENGTHS, 60)
+    recs1.sort(key=lambda r: (r["tid"], r["pos"]))
+    recs2 = helpers.random_records(rng, names2, lengths2, 50) + helpers.engineered_split_records(rng, names2, lengths2, 60)
+    recs2.sort(key=lambda r: (r["tid"], r["pos"]))
+    o = helpers.options()
+    bam1, bam2 = helpers.FakeBam(NAMES, LENGTHS, recs1), helpers.FakeBam(names2, lengths2, recs2)
+    t1, t2 = SVIM_COLLECT.collect_tables([bam1, bam2], o)
+    exp1, exp2 = svim_oracle.collect(recs1, NAMES, LENGTHS, o), svim_oracle.collect(recs2, names2, lengths2, o)
+    assert [helpers.candidate_tuple(c) for c in t1.objects()] == exp1
+    assert [helpers.candidate_tuple(c) for c in t2.objects()] == exp2
+    seqs = {n: "".join(rng.choice(list("ACGT"), size=l)) for n, l in zip(NAMES, LENGTHS)}
+    ref = helpers.FakeFasta(seqs)
+    got = [helpers.candidate_tuple(c) for c in SVIM_COMBINE.pair_tables(t1, t2, ref, bam1, o).objects()]
+    exp = svim_oracle.pair_candidates(exp1, exp2, ref.fetch, NAMES, LENGTHS, dict(zip(NAMES, LENGTHS)), o,
+                                      edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
+    assert got == exp
