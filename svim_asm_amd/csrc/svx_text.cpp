@@ -240,6 +240,9 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
                     (!in->q_off || in->q_off[r] < 0 || (uint64_t)in->q_off[r] + (uint64_t)in->q_len[r] > in->seqs_bytes))
                     return SVX_E_INVALID;
             }
+            if (in->sequence_alleles && k == SVX_VCF_DUPTAN_INS && in->copies[r] > 0 &&
+                (uint64_t)in->b_len[e] * ((uint64_t)in->copies[r] + 1) > (1ull << 31))
+                return SVX_E_TOO_LARGE;  // ALT = REF x (copies + 1) (:209-214): a line of more than 2 GiB is a damaged input
             if (in->read_names) {
                 if (in->r_off[r] < 0 || in->r_off[r + 1] < in->r_off[r]) return SVX_E_INVALID;
                 for (int64_t j = in->r_off[r]; j < in->r_off[r + 1]; ++j)
