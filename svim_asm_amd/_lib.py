@@ -489,16 +489,27 @@ class Context:
                                                          int(k_max) & 0xFFFFFFFF, _ptr(dist)))
         return dist
 
+    def resident(self, host_bytes):
+        """`host_bytes` (uint8 array) uploaded once into HBM: pass the result as `pool` to several
+        haplotype_distance_batch calls (svx_haplotype_distance_batch_dev) instead of staging it per call."""
+        return DeviceArray(self, host=_as(host_bytes, np.uint8))
+
     def haplotype_distance_batch(self, pool, pieces, k_max=0xFFFFFFFF):
-        """Edit distances of haplotype pairs assembled on the device from pieces of `pool` (bytes):
-        `pieces` is a HAP_PIECE_DTYPE array with 6 entries per pair (3 of haplotype a, 3 of b)."""
-        pool = _as(pool, np.uint8)
+        """Edit distances of haplotype pairs assembled on the device from pieces of `pool` (bytes: a uint8 array,
+        or the DeviceArray `resident()` returned): `pieces` is a HAP_PIECE_DTYPE array with 6 entries per pair
+        (3 of haplotype a, 3 of b)."""
         pieces = np.ascontiguousarray(pieces, dtype=HAP_PIECE_DTYPE)
         if len(pieces) % 6:
             raise SvxError(SVX_E_INVALID, "6 pieces per pair")
         n = len(pieces) // 6
         dist = np.zeros(n, np.uint32)
-        if n:
+        if not n:
+            return dist
+        if isinstance(pool, DeviceArray):
+            self._check(self.lib.svx_haplotype_distance_batch_dev(self.h, pool.ptr, pool.nbytes, _ptr(pieces), n,
+                                                                  int(k_max) & 0xFFFFFFFF, _ptr(dist)))
+        else:
+            pool = _as(pool, np.uint8)
             self._check(self.lib.svx_haplotype_distance_batch(self.h, _ptr(pool), len(pool), _ptr(pieces), n,
                                                               int(k_max) & 0xFFFFFFFF, _ptr(dist)))
         return dist

@@ -392,6 +392,9 @@ class OracleBackedContext(object):
             first.append(len(recs))
         return np.array(recs, dtype=_svxlib().RAW_DTYPE) if recs else np.zeros(0, dtype=_svxlib().RAW_DTYPE), np.array(first, np.int64)
 
+    def resident(self, host_bytes):
+        return host_bytes  # (no device here: the "resident" pool is the array itself)
+
     def haplotype_distance_batch(self, pool, pieces, k_max=0xFFFFFFFF):
         comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
 
