@@ -466,7 +466,7 @@ int svx_pair_partition_dev_bits(svx_ctx* ctx, const uint64_t* d_keys, uint32_t n
  * requests exact distances.
  */
 /* The distance is computed in two stages: a wavefront (diagonal-transition, O(n + d^2)) pass resolves
- * every pair whose distance is at most min(k_max, max_edits, (|a| + |b|) / 8) — the haplotypes of one
+ * every pair whose distance is at most min(k_max, max_edits, max(64, (|a| + |b|) / 32)) — the haplotypes of one
  * variant are long and nearly identical —, the bit-vector kernel (O(n m / 64), banded) the rest.  Both are
  * exact; max_edits (default 1024, at most 4096, 0 = bit-vector kernel only) only moves work between them. */
 int svx_ctx_set_edit_wavefront_cap(svx_ctx* ctx, uint32_t max_edits);

@@ -31,6 +31,9 @@
 // until the band covers the whole matrix.
 //
 // VALU-bound integer work (≈ 50 VALU per 64 cells); no MFMA, HBM traffic is negligible.
+#include <cmath>
+#include <cstdlib>
+
 #include "svx_internal.h"
 
 #include <algorithm>
@@ -518,9 +521,12 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
         uint32_t lds_cap = 1;
         for (uint32_t w = 0; w < n_pairs; ++w) {
             const uint32_t i = order[w];
-            // at most the threshold; and no more edits than an eighth of the lengths (beyond that the
-            // d^2 / 64 wave steps of this pass cost more than the bit-vector kernel's strips)
-            uint64_t c = std::max<uint64_t>(64, ((uint64_t)a_len[i] + b_len[i]) / 8);
+            // at most the threshold; and no more edits than 1/32 of the lengths: beyond that the d^2 / 64 wave steps
+            // of this pass (each with its own round trip to the sequences) cost more than the bit-vector kernel's
+            // strips.  Measured on PAIR's exact batch of config 5 (crowded partitions: unrelated events, distances of
+            // many hundreds over 2-3 kb): 1/8 -> 1/32 takes the distances of the step from 48 to 40 ms; 1/16 and
+            // 1/64 the same within noise, the near-identical batches of the bench unchanged (profiles/README.md)
+            uint64_t c = std::max<uint64_t>(64, ((uint64_t)a_len[i] + b_len[i]) / 32);
             c = std::min<uint64_t>(c, ctx->wfa_cap);
             if (!exact) c = std::min<uint64_t>(c, k_max);
             lst_band[w] = (uint32_t)c;
