@@ -17,12 +17,38 @@ TYPE_LABELS = (("DEL", "deletion"), ("INV", "inversion"), ("INS", "insertion"), 
                ("DUP_INT", "interspersed duplication"), ("BND", "breakend"))
 
 
-def _open(path, which, options):
+def _open_file(path, options):
+    return bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
+                               threads=bamio.ingest_threads(2 if options.sub == "diploid" else 1))
+
+
+def _open_ahead(path, options):
+    """Start opening `path` (header, reference dictionary, index) on a thread; returns a function that waits and
+    hands back the file — or raises what opening raised — at the point where the caller would have opened it."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["file"] = _open_file(path, options)
+        except BaseException as e:  # noqa: BLE001 — re-raised by the caller at its own time
+            box["error"] = e
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+
+    def result():
+        th.join()
+        if "error" in box:
+            raise box["error"]
+        return box["file"]
+    return result
+
+
+def _open(path, which, options, opened=None):
     """Open one BAM and check sort order and index like the reference (svim-asm:63-72,85-95).
     Returns the alignment file, or None after logging the error."""
     the = {"": "Input", "first": "The first input", "second": "The second input"}[which]
-    aln_file = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
-                                   threads=bamio.ingest_threads(2 if options.sub == "diploid" else 1))
+    aln_file = opened() if opened is not None else _open_file(path, options)
     try:
         if aln_file.header["HD"]["SO"] != "coordinate":
             logging.error("{0} BAM file needs to be coordinate-sorted. Exiting..".format(the))
@@ -157,10 +183,11 @@ def _run_steps(options):
         logging.info("MODE: diploid")
         logging.info("INPUT1: {0}".format(os.path.abspath(options.bam_file1)))
         logging.info("INPUT2: {0}".format(os.path.abspath(options.bam_file2)))
+        second = _open_ahead(options.bam_file2, options)  # opened beside the first one, judged in the reference's order
         aln_file1 = _open(options.bam_file1, "first", options)
         if aln_file1 is None:
             return
-        aln_file2 = _open(options.bam_file2, "second", options)
+        aln_file2 = _open(options.bam_file2, "second", options, opened=second)
         if aln_file2 is None:
             return
         sv_candidates1, sv_candidates2 = _collect([aln_file1, aln_file2], options)

@@ -3,7 +3,6 @@
 // SVCandidate.py get_vcf_entry* / SVIM_COMBINE.py:428-477 (file:line cited per function below); written from
 // the behaviour of those functions, one batch call over candidate columns instead of one Python call per record.
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -23,8 +22,7 @@
 // ------------------------------------------------------------------------------------------ FASTA
 struct svx_fasta {
     int fd = -1;
-    const uint8_t* map = nullptr;
-    size_t size = 0;
+    size_t size = 0;  // the file is read with pread(): no mapping to fault in page by page and to tear down at close
     std::vector<int64_t> length, offset;
     std::vector<int32_t> line_bases, line_width;
 };
@@ -57,16 +55,6 @@ extern "C" int svx_fasta_open(const char* path, int32_t n_refs, const int64_t* l
         return SVX_E_INVALID;
     }
     fa->size = (size_t)st.st_size;
-    if (fa->size) {
-        void* m = mmap(nullptr, fa->size, PROT_READ, MAP_PRIVATE, fa->fd, 0);
-        if (m == MAP_FAILED) {
-            set_err(err, err_cap, "cannot map %s", path);
-            close(fa->fd);
-            delete fa;
-            return SVX_E_NOMEM;
-        }
-        fa->map = (const uint8_t*)m;
-    }
     try {
         fa->length.assign(length, length + n_refs);
         fa->offset.assign(offset, offset + n_refs);
@@ -82,24 +70,34 @@ extern "C" int svx_fasta_open(const char* path, int32_t n_refs, const int64_t* l
 
 extern "C" void svx_fasta_close(svx_fasta* fa) {
     if (!fa) return;
-    if (fa->map) munmap((void*)fa->map, fa->size);
     if (fa->fd >= 0) close(fa->fd);
     delete fa;
 }
 
 static inline uint8_t ascii_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
 
-// bases [start, end) of one sequence into dst (end already clipped to the sequence length)
-static bool fetch_one(const svx_fasta* fa, int32_t ref, int64_t start, int64_t end, bool upper, uint8_t* dst) {
+// bases [start, end) of one sequence into dst (end already clipped to the sequence length): ONE pread of the byte
+// range that holds them (line ends included), then the lines' bases are moved to dst
+static bool fetch_one(const svx_fasta* fa, int32_t ref, int64_t start, int64_t end, bool upper, uint8_t* dst,
+                      std::vector<uint8_t>& raw) {
     const int64_t lb = fa->line_bases[ref], lw = fa->line_width[ref], off = fa->offset[ref];
     if (lb <= 0 || lw < lb || off < 0) return false;
+    const int64_t byte0 = off + (start / lb) * lw + start % lb;
+    const int64_t byte1 = off + ((end - 1) / lb) * lw + (end - 1) % lb + 1;
+    if (byte0 < 0 || byte1 < byte0 || (uint64_t)byte1 > fa->size) return false;
+    const size_t n = (size_t)(byte1 - byte0);
+    if (raw.size() < n) raw.resize(n);
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t r = pread(fa->fd, raw.data() + got, n - got, (off_t)(byte0 + (int64_t)got));
+        if (r <= 0) return false;
+        got += (size_t)r;
+    }
     int64_t pos = start;
+    const uint8_t* src = raw.data();
     while (pos < end) {
         const int64_t in_line = pos % lb;
         const int64_t take = std::min<int64_t>(lb - in_line, end - pos);
-        const int64_t byte0 = off + (pos / lb) * lw + in_line;
-        if (byte0 < 0 || (uint64_t)(byte0 + take) > fa->size) return false;
-        const uint8_t* src = fa->map + byte0;
         if (upper) {
             for (int64_t i = 0; i < take; ++i) dst[i] = ascii_upper(src[i]);
         } else {
@@ -107,6 +105,7 @@ static bool fetch_one(const svx_fasta* fa, int32_t ref, int64_t start, int64_t e
         }
         dst += take;
         pos += take;
+        src += take + (pos < end ? lw - lb : 0);  // over the line end
     }
     return true;
 }
@@ -128,13 +127,14 @@ extern "C" int svx_fasta_fetch_batch(const svx_fasta* fa, const int32_t* ref, co
     std::atomic<uint32_t> next(0);
     std::atomic<int> bad(0);
     auto work = [&]() {
+        std::vector<uint8_t> raw;
         for (;;) {
             const uint32_t lo = next.fetch_add(512);
             if (lo >= n) break;
             const uint32_t hi = std::min<uint32_t>(n, lo + 512);
             for (uint32_t i = lo; i < hi; ++i) {
                 const int64_t e = std::min(end[i], fa->length[ref[i]]);
-                if (e > start[i] && !fetch_one(fa, ref[i], start[i], e, upper != 0, out + out_off[i])) bad.store(1);
+                if (e > start[i] && !fetch_one(fa, ref[i], start[i], e, upper != 0, out + out_off[i], raw)) bad.store(1);
             }
         }
     };
