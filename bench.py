@@ -432,7 +432,8 @@ def e2e_leg(scale, local_rank, n_devices=1):
                                                 r["cigar_ops"][0], r["cigar_ops"][1]),
             "wall_s": best["product_total_s"], "all_runs_wall_s": r.get("all_runs_total_s"),
             "phases_s": {k: best[k] for k in ("open_index_s", "collect_s", "pair_s", "vcf_s")},
-            "collect_stages_s": best.get("collect_stages_s"),  # load_s: the record walks of both BAMs; sequences_wait_s: inflate for the inserted alleles
+            "collect_stages_s": best.get("collect_stages_s"),  # load_s: the record walks of both BAMs; sequences_wait_s: what PAIR still
+            # waited for the inflate of the inserted alleles, which starts in COLLECT and runs beside PAIR's set-up
             "command_line_wall_s": r.get("cli_wall_s"),  # `svim-asm diploid` as a fresh process: interpreter + HIP start-up included
             "inputs_match_real_reference_run": r.get("inputs_match_real_reference_run"),
             "vcf_matches_real_reference_digest": r.get("vcf_matches_real_reference_digest"),

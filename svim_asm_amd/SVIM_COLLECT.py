@@ -21,13 +21,14 @@ materialised from the table when somebody looks.
 import logging
 import re
 import threading
+import time
 
 import numpy as np
 
 from svim_asm_amd import _lib
 from svim_asm_amd import SVIM_inter, SVIM_intra
 from svim_asm_amd.bamio import AlignedRecord, AlignmentFile
-from svim_asm_amd.table import (CandidateList, CandidateTable, F_BOOL, F_DST_REV, F_SRC_REV, NamePool, T_BND, T_DEL,
+from svim_asm_amd.table import (CandidateList, CandidateTable, F_BOOL, F_DST_REV, F_SRC_REV, NamePool, PendingBytes, T_BND, T_DEL,
                                 T_DUP_INT, T_DUP_TAN, T_INS, T_INV, _ranges)
 
 _CIGAR_RE = re.compile(r"(\d+)([MIDNSHP=XB])")
@@ -446,6 +447,7 @@ def _table_of(s, options):
         l_seq = r.l_seq[seq_rec[rows]]
         lo = np.minimum(np.maximum(seq_lo[rows], 0), l_seq)
         hi = np.maximum(np.minimum(seq_hi[rows], l_seq), lo)
+        s.seq_lo, s.seq_hi = lo, hi
         box = {}
 
         def decode():
@@ -461,18 +463,29 @@ def _table_of(s, options):
     return t
 
 
-def _join_sequences(s):
-    """Wait for the sample's sequence decoding (started by _table_of) and attach the pool to its table."""
+def _pending_sequences(s):
+    """The table's sequence pool while the sample's decoding (started by _table_of) is still running: offsets and
+    lengths are known from the requests, the bytes are waited for when somebody reads `table.seqs`."""
     t = s.table
     if s.seq_job is not None:
         job, box = s.seq_job
-        job.join()
-        if "error" in box:
-            raise box["error"]
-        pool, off = box["out"]
-        t.seqs = np.asarray(pool, dtype=np.uint8)
+        cnt = s.seq_hi - s.seq_lo
+        off = np.zeros(len(cnt) + 1, np.int64)
+        np.cumsum(cnt, out=off[1:])
         t.q_off[s.seq_rows] = off[:-1]
-        t.q_len[s.seq_rows] = off[1:] - off[:-1]
+        t.q_len[s.seq_rows] = cnt
+
+        def resolve():
+            t0 = time.perf_counter()
+            job.join()
+            LAST_TIMING["sequences_wait_s"] = LAST_TIMING.get("sequences_wait_s", 0.0) + time.perf_counter() - t0
+            if "error" in box:
+                raise box["error"]
+            pool, got_off = box["out"]
+            if not np.array_equal(got_off, off):
+                raise ValueError("the reader returned other slice lengths than were asked for")
+            return pool
+        t.seqs = PendingBytes(int(off[-1]), resolve)
     return t
 
 
@@ -579,7 +592,6 @@ LAST_TIMING = {}  # seconds per stage of the latest collect_tables call (tools/,
 def collect_tables(bams, options, ctx=None):
     """CandidateTable of every bam in `bams` (the two haplotypes of a diploid sample): one device submission
     for all of them when their reference dictionaries agree."""
-    import time
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
     tl = time.perf_counter()
     _load_together(bams)
@@ -593,9 +605,8 @@ def collect_tables(bams, options, ctx=None):
     for s in samples:   # starts every sample's sequence decoding (the readers' threads) before waiting for any
         _table_of(s, options)
     t3 = time.perf_counter()
-    tables = [_join_sequences(s) for s in samples]
-    LAST_TIMING.update(load_s=t0 - tl, prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=time.perf_counter() - t3)
-    return tables
+    LAST_TIMING.update(load_s=t0 - tl, prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=0.0)
+    return [_pending_sequences(s) for s in samples]  # (sequences_wait_s grows where the bytes are first needed)
 
 
 def analyze_alignment_file_coordsorted(bam, options):

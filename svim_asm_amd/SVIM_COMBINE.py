@@ -247,9 +247,10 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
             mid_len[dint, h] = n_src[where]
         extra_at += len(pool)
     ins = typ == T_INS
-    if bool(ins.any()):
-        # INS: the inserted sequence as it is — the reference does not fold its case (:74-75)
-        extra_parts.append(np.asarray(T.seqs, dtype=np.uint8))
+    want_seqs = bool(ins.any())
+    if want_seqs:
+        # INS: the inserted sequence as it is — the reference does not fold its case (:74-75).  Only the OFFSETS are
+        # needed here; the bytes (possibly still being decoded) are appended to the pool at the very end
         for h in (0, 1):
             mid_off[:, h] = np.where(ins, extra_at + T.q_off[rows[h]], mid_off[:, h])
             mid_len[:, h] = np.where(ins, T.q_len[rows[h]], mid_len[:, h])
@@ -271,6 +272,8 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
         m_rep = np.where(tan, T.copies[rows[h]] + 1, one)
         m_flg = np.where(typ == T_INV, up | _lib.PIECE_REVCOMP, np.where(tan | (typ == T_DUP_INT), up, 0))
         put(h, 1, m_off, m_len, m_rep, m_flg)
+    if want_seqs:
+        extra_parts.append(np.asarray(T.seqs, dtype=np.uint8))
     return pieces, extra_parts
 
 
@@ -676,7 +679,7 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
         n_rows=len(t), sc=ptr(t.sc, np.int32), ss=ptr(t.ss, np.int64), se=ptr(t.se, np.int64), dc=ptr(t.dc, np.int32),
         ds=ptr(t.ds, np.int64), de=ptr(t.de, np.int64), flag=ptr(t.flag, np.uint8), copies=ptr(t.copies, np.int64),
         gt=ptr(t.gt, np.uint8), q_off=ptr(t.q_off, np.int64), q_len=ptr(t.q_len, np.int64),
-        r_off=ptr(t.r_off, np.int64), r_flat=ptr(t.r_flat, np.int64), seqs=ptr(t.seqs, np.uint8), seqs_bytes=len(t.seqs),
+        r_off=ptr(t.r_off, np.int64), r_flat=ptr(t.r_flat, np.int64), seqs=ptr(t.seqs, np.uint8), seqs_bytes=t.seqs_nbytes,
         names=C.cast(C.c_char_p(names_pool), C.c_void_p).value, name_off=ptr(t.names.off, np.int64), n_names=len(t.names),
         contigs=C.cast(C.c_char_p(contig_pool), C.c_void_p).value, contig_off=ptr(contig_off, np.int64),
         contig_rank=ptr(contig_rank, np.int32), n_contigs=len(t.contigs),

@@ -77,12 +77,28 @@ class NamePool(object):
         return NamePool(b"".join(bytes(p.pool[:int(p.off[-1])]) for p in pools), np.concatenate(offs)), shifts
 
 
+class PendingBytes(object):
+    """A byte pool that is still being produced (the reader's threads are inflating the BGZF members that hold the
+    inserted sequences): its size is known, its content is waited for when somebody reads it — so that everything
+    that only needs the OFFSETS (keys, sort, partition windows, recipes) runs beside the decoding."""
+
+    def __init__(self, nbytes, resolve):
+        self.nbytes = int(nbytes)
+        self._resolve = resolve
+
+    def resolve(self):
+        out = np.asarray(self._resolve(), dtype=np.uint8)
+        if len(out) != self.nbytes:
+            raise ValueError("sequence pool of %d bytes, %d announced" % (len(out), self.nbytes))
+        return out
+
+
 class CandidateTable(object):
     def __init__(self, contigs, contig_len, n=0, names=None, seqs=None, genotypes=GENOTYPES):
         self.contigs = list(contigs)
         self.contig_len = np.asarray(contig_len, dtype=np.int64)
         self.names = names if names is not None else NamePool()
-        self.seqs = seqs if seqs is not None else np.zeros(0, np.uint8)
+        self._seqs = seqs if seqs is not None else np.zeros(0, np.uint8)
         self.genotypes = list(genotypes)
         for k, dt in _COLUMNS:
             setattr(self, k, np.zeros(n, dtype=dt))
@@ -94,9 +110,35 @@ class CandidateTable(object):
     def __len__(self):
         return len(self.type)
 
+    # the inserted-sequence pool: an array, or pending (waited for on first use)
+    @property
+    def seqs(self):
+        if isinstance(self._seqs, PendingBytes):
+            self._seqs = self._seqs.resolve()
+        return self._seqs
+
+    @seqs.setter
+    def seqs(self, value):
+        self._seqs = value
+
+    @property
+    def seqs_nbytes(self):
+        return self._seqs.nbytes if isinstance(self._seqs, PendingBytes) else len(self._seqs)
+
+    def __getstate__(self):  # (a table that travels to another rank carries its bytes)
+        state = dict(self.__dict__)
+        state["_seqs"] = self.seqs
+        return state
+
     # ------------------------------------------------------------------ row algebra
     def _like(self, n):
-        return CandidateTable(self.contigs, self.contig_len, n, self.names, self.seqs, self.genotypes)
+        out = CandidateTable(self.contigs, self.contig_len, n, self.names, None, self.genotypes)
+        if isinstance(self._seqs, PendingBytes):
+            # shared, still pending: whoever needs the bytes first resolves them for both
+            out._seqs = PendingBytes(self._seqs.nbytes, lambda: self.seqs)
+        else:
+            out._seqs = self._seqs
+        return out
 
     def take(self, idx):
         """Rows `idx` (any order, repeats allowed); the stores are shared, not copied."""
@@ -162,15 +204,18 @@ class CandidateTable(object):
                 cols[k].append(v)
             r_cnt.append(t.r_off[1:] - t.r_off[:-1])
             r_flat.append(t.r_flat + shift)
-            seq_parts.append(np.asarray(t.seqs, dtype=np.uint8))
-            seq_at += len(t.seqs)
+            seq_parts.append(t)
+            seq_at += t.seqs_nbytes
         for k, dt in _COLUMNS:
             setattr(out, k, np.concatenate(cols[k]).astype(dt, copy=False))
         out.contigs, out.contig_len = contigs, np.asarray(contig_len, dtype=np.int64)
         out.r_off = np.zeros(len(out.type) + 1, np.int64)
         np.cumsum(np.concatenate(r_cnt), out=out.r_off[1:])
         out.r_flat = np.concatenate(r_flat)
-        out.seqs = np.concatenate(seq_parts) if seq_parts else np.zeros(0, np.uint8)
+        if any(isinstance(t._seqs, PendingBytes) for t in seq_parts):
+            out._seqs = PendingBytes(seq_at, lambda: np.concatenate([np.asarray(t.seqs, dtype=np.uint8) for t in seq_parts]))
+        else:
+            out._seqs = np.concatenate([np.asarray(t.seqs, dtype=np.uint8) for t in seq_parts]) if seq_parts else np.zeros(0, np.uint8)
         out.genotypes = genotypes
         return out
 

@@ -155,7 +155,6 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             t1, t2 = shard.collect_sharded([f1, f2], opts)
             r["collect_s"] = time.perf_counter() - t
             from svim_asm_amd import SVIM_COLLECT
-            r["collect_stages_s"] = dict(SVIM_COLLECT.LAST_TIMING)
             ref = FastaFile(fasta)
             t = time.perf_counter()
             paired = shard.pair_sharded(t1, t2, ref, f1, opts)
@@ -166,6 +165,8 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             write_vcf_table(paired, "1.0.3", f1.references, f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
             r["vcf_s"] = time.perf_counter() - t
             r["vcf_stages_s"] = {k: v for k, v in SVIM_COMBINE.LAST_TIMING.items() if k.startswith("vcf_")}
+            # (sequences_wait_s: where the inserted-sequence bytes were first needed — inside PAIR — not inside COLLECT)
+            r["collect_stages_s"] = dict(SVIM_COLLECT.LAST_TIMING)
             r["product_total_s"] = time.perf_counter() - t_all
             gc.enable()
             runs.append(r)
