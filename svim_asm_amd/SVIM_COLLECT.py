@@ -19,6 +19,7 @@ records in a Python `while True / next()` loop and builds one Candidate object p
 materialised from the table when somebody looks.
 """
 import logging
+import os
 import re
 import threading
 import time
@@ -606,7 +607,15 @@ def collect_tables(bams, options, ctx=None):
         _table_of(s, options)
     t3 = time.perf_counter()
     LAST_TIMING.update(load_s=t0 - tl, prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=0.0)
-    return [_pending_sequences(s) for s in samples]  # (sequences_wait_s grows where the bytes are first needed)
+    tables = [_pending_sequences(s) for s in samples]
+    # The pool could stay pending until PAIR builds its byte pool (SVX_LAZY_SEQS=1: the decoding then runs beside
+    # PAIR's keys, sort, windows and recipes).  Measured, interleaved on one box, four pairs of five runs: medians
+    # 0.389-0.397 s pending vs 0.371-0.397 s waiting here — the host threads of the two sides compete for the same
+    # cores, the overlap buys nothing (profiles/README.md) — so the default waits here.
+    if not os.environ.get("SVX_LAZY_SEQS"):
+        for t in tables:
+            t.seqs
+    return tables
 
 
 def analyze_alignment_file_coordsorted(bam, options):
