@@ -104,6 +104,17 @@ int svx_bam_get_columns(const svx_bam* bam, svx_bam_columns* out);
 int svx_bam_seq_slices(svx_bam* bam, const uint32_t* rec, const uint32_t* begin, const uint32_t* end,
                        uint32_t n, const uint64_t* out_off, uint8_t* out);
 
+/*
+ * The DEFLATE decoder behind all of the above (svim_asm_amd/csrc/svx_inflate.h), callable on its own: raw RFC 1951
+ * stream in[in_len] → out[cap].  The decoder is first run up to each of the n_stops output positions in turn (the way
+ * svx_bam_seq_slices extends the inflated prefix of a member; a run may overshoot its stop by up to one match), then
+ * to the end of the stream.  *n_out = bytes produced.  SVX_E_INVALID: malformed stream, a stream that yields more
+ * than cap bytes, or one that ends before a stop.  Replaces zlib's inflate() under htslib's bgzf_read
+ * (pysam, SVIM_COLLECT.py:68); zlib is the oracle of tests/test_inflate.py.
+ */
+int svx_inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, const uint64_t* stops,
+                    uint32_t n_stops, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

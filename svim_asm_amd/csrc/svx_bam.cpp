@@ -26,11 +26,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "svx.h"
+#include "svx_inflate.h"
 
 namespace {
 
@@ -68,51 +70,42 @@ const LibDeflate* libdeflate() {
     return lib.handle ? &lib : nullptr;
 }
 
+// Which decoder inflates the members: the build's own (svx_inflate.h; default), or — SVX_BAM_ZLIB=1 — zlib, kept as
+// the differential oracle of the former.  libdeflate, when the runtime has it, only lends its CRC32 (carry-less
+// multiply: 64 KiB in a few µs where zlib's table walk takes 40).
+bool use_zlib() {
+    static const bool z = [] { const char* v = getenv("SVX_BAM_ZLIB"); return v && v[0] == '1'; }();
+    return z;
+}
+uint32_t member_crc(const uint8_t* p, size_t n) {
+    const LibDeflate* L = libdeflate();
+    if (L) return L->crc32(0, p, n);
+    return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), p, (uInt)n);
+}
+
 struct Inflater {
-    void* ld = nullptr;
     z_stream zs;
     bool z_ready = false;
+    std::unique_ptr<svx_inflate::Stream> own;
     uint64_t n_blocks = 0;
 
     Inflater() { memset(&zs, 0, sizeof(zs)); }
     Inflater(const Inflater&) = delete;
     Inflater& operator=(const Inflater&) = delete;
     ~Inflater() {
-        if (ld) libdeflate()->release(ld);
         if (z_ready) inflateEnd(&zs);
     }
-    // raw deflate stream `in` → exactly out_len bytes, CRC32 checked
-    bool run(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, uint32_t crc) {
-        ++n_blocks;
-        const LibDeflate* L = libdeflate();
-        if (L) {
-            if (!ld) ld = L->alloc();
-            if (!ld) return false;
-            size_t got = 0;
-            if (L->decompress(ld, in, in_len, out, out_len, &got) != 0 || got != out_len) return false;
-            return L->crc32(0, out, out_len) == crc;
-        }
-        if (!z_ready) {
-            if (inflateInit2(&zs, -15) != Z_OK) return false;
-            z_ready = true;
-        } else if (inflateReset(&zs) != Z_OK) {
-            return false;
-        }
-        zs.next_in = const_cast<Bytef*>(in);
-        zs.avail_in = (uInt)in_len;
-        zs.next_out = out;
-        zs.avail_out = (uInt)out_len;
-        const int rc = inflate(&zs, Z_FINISH);
-        if (rc != Z_STREAM_END || zs.avail_out != 0) return false;
-        return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), out, (uInt)out_len) == crc;
-    }
-    // Streaming use (zlib): begin() a member, then extend() the inflated prefix as far as somebody needs it.
+    // Streaming use: begin() a member, then extend() the inflated prefix as far as somebody needs it.
     // A slice of a contig-sized SEQ field sits somewhere inside a 64 KiB member: inflating only up to its last
     // byte halves the work on average.  The CRC covers whole members, so it is checked when (and only when)
     // the prefix reaches the member's end.
-    bool can_stream() const { return libdeflate() == nullptr; }
     bool begin(const uint8_t* in, size_t in_len) {
         ++n_blocks;
+        if (!use_zlib()) {
+            if (!own) own.reset(new svx_inflate::Stream());
+            own->begin(in, in_len);
+            return true;
+        }
         if (!z_ready) {
             if (inflateInit2(&zs, -15) != Z_OK) return false;
             z_ready = true;
@@ -123,16 +116,32 @@ struct Inflater {
         zs.avail_in = (uInt)in_len;
         return true;
     }
-    bool extend(uint8_t* out, size_t have, size_t want, size_t member_len, uint32_t crc) {
+    // `out` holds `have` bytes of the member already (zlib: exactly; own decoder: at least — it may have run past the
+    // last request by up to one match, *valid is what is there now)
+    bool extend(uint8_t* out, size_t have, size_t want, size_t member_len, uint32_t crc, uint32_t* valid) {
+        const bool whole = want == member_len;
+        if (!use_zlib()) {
+            if (!own->run(out, member_len, want, whole)) return false;
+            *valid = (uint32_t)own->produced();
+            if (whole) return own->produced() == member_len && member_crc(out, member_len) == crc;
+            return true;
+        }
+        *valid = (uint32_t)want;
+        if (want <= have && !whole) return true;
         zs.next_out = out + have;
         zs.avail_out = (uInt)(want - have);
-        const int rc = inflate(&zs, want == member_len ? Z_FINISH : Z_SYNC_FLUSH);
+        const int rc = inflate(&zs, whole ? Z_FINISH : Z_SYNC_FLUSH);
         if (zs.avail_out != 0 || (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR)) return false;
-        if (want == member_len) {
+        if (whole) {
             if (rc != Z_STREAM_END) return false;
-            return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), out, (uInt)member_len) == crc;
+            return member_crc(out, member_len) == crc;
         }
         return true;
+    }
+    // raw deflate stream `in` → exactly out_len bytes, CRC32 checked
+    bool run(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, uint32_t crc) {
+        uint32_t valid = 0;
+        return begin(in, in_len) && extend(out, 0, out_len, out_len, crc, &valid);
     }
 };
 
@@ -192,6 +201,7 @@ struct Cursor {
     uint64_t buf_coff = ~0ull;  // member currently held in `buf`
     uint32_t buf_valid = 0;     // bytes of it inflated so far (prefix mode; the whole member otherwise)
     bool prefix_mode = false;   // inflate members only as far as the bytes asked for (svx_bam_seq_slices)
+    bool whole = false;         // the member in `buf` has been inflated to its end and its CRC32 checked
     uint64_t n_hopped = 0;      // members passed (inflated or not)
     std::vector<uint8_t> buf;
 
@@ -217,28 +227,21 @@ struct Cursor {
     VPos tell() const { VPos p; p.coff = coff; p.uoff = uoff; return p; }
     bool ensure(uint32_t upto) {  // bytes [0, upto) of the current member are in `buf`
         if (buf.empty()) buf.resize(65536);
-        // prefix mode: zlib's streaming inflate up to the last byte asked for — unless most of the member is wanted
-        // anyway and libdeflate (no streaming interface, but ~1.5x faster per byte on SEQ data) can take all of it
-        if (prefix_mode && (buf_coff == coff || inf->can_stream() || (uint64_t)upto * 5 <= (uint64_t)blk.isize * 3)) {
-            if (buf_coff != coff) {
-                buf_coff = ~0ull;
-                if (!inf->begin(f->map + coff + blk.payload_off, blk.payload_len)) { bad = true; return false; }
-                buf_coff = coff;
-                buf_valid = 0;
-            }
-            if (buf_valid < upto) {
-                if (!inf->extend(buf.data(), buf_valid, upto, blk.isize, blk.crc)) { bad = true; buf_coff = ~0ull; return false; }
-                buf_valid = upto;
-            }
+        if (buf_coff != coff) {
+            buf_coff = ~0ull;
+            if (!inf->begin(f->map + coff + blk.payload_off, blk.payload_len)) { bad = true; return false; }
+            buf_valid = 0;
+            whole = false;
+        } else if (buf_valid >= upto && (prefix_mode || whole)) {
             return true;
         }
-        if (buf_coff == coff) return true;
-        if (!inf->run(f->map + coff + blk.payload_off, blk.payload_len, buf.data(), blk.isize, blk.crc)) {
-            bad = true;
-            return false;
-        }
+        // prefix mode: inflate up to the last byte asked for; otherwise the whole member, CRC32 checked
+        const uint32_t want = prefix_mode ? upto : blk.isize;
+        uint32_t valid = 0;
+        if (!inf->extend(buf.data(), buf_valid, want, blk.isize, blk.crc, &valid)) { bad = true; buf_coff = ~0ull; return false; }
         buf_coff = coff;
-        buf_valid = blk.isize;
+        buf_valid = valid;
+        whole = want == blk.isize;
         return true;
     }
     bool read(void* dst, size_t n) {
@@ -1005,4 +1008,20 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
     b->blocks_inflated += inflated.load();
     if (failed.load()) return fail(b, SVX_E_INVALID, "svx_bam_seq_slices: bad slice bounds or malformed BGZF data");
     return SVX_OK;
+}
+
+extern "C" int svx_inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, const uint64_t* stops,
+                               uint32_t n_stops, uint64_t* n_out) {
+    if ((!in && in_len) || (!out && cap) || (!stops && n_stops) || !n_out) return SVX_E_INVALID;
+    *n_out = 0;
+    std::unique_ptr<svx_inflate::Stream> st(new svx_inflate::Stream());
+    st->begin(in, in_len);
+    for (uint32_t i = 0; i < n_stops; ++i) {
+        const bool ok = st->run(out, cap, (size_t)std::min<uint64_t>(stops[i], cap), false);
+        *n_out = st->produced();
+        if (!ok) return SVX_E_INVALID;
+    }
+    const bool ok = st->run(out, cap, 0, true);
+    *n_out = st->produced();
+    return ok ? SVX_OK : SVX_E_INVALID;
 }

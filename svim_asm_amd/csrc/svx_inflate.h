@@ -1,0 +1,593 @@
+// svx_inflate.h — raw DEFLATE (RFC 1951) decoder of the BAM ingest, host C++.
+//
+// Why not zlib / libdeflate alone: the members of an assembly-to-reference BAM are SEQ bytes for the most part — two
+// 4-bit bases per byte, sixteen byte values that are about equally likely — which the writer's Huffman stage turns
+// into 4–5-bit literal codes with next to no matches.  A decoder that takes one symbol per table look-up spends
+// 65 536 look-ups on such a member (zlib ≈ 585 µs, libdeflate ≈ 377 µs per 64 KiB member on the build container);
+// here the 12-bit primary table holds up to THREE literals per entry, so the same member takes about a third of the
+// look-ups.  And the decoder stops and resumes at any output position: an inserted-sequence slice lies somewhere
+// inside a member and only the bytes up to its end are wanted (svx_bam_seq_slices), which libdeflate cannot do.
+//
+// The reference gets here through pysam → htslib → zlib (SVIM_COLLECT.py:68 `bam.fetch`, SVIM_intra.py:40
+// `alignment.query_sequence`); the format is the published one, nothing of htslib's is restated.
+// zlib stays in the build as the differential oracle of this file (tests/test_inflate.py, tests/native/) and as the
+// `SVX_BAM_ZLIB=1` path.
+//
+// Stream acceptance follows zlib's inflate: over-subscribed code sets are errors; incomplete ones too, except a set
+// with a single 1-bit code (and an empty distance set); a literal/length set without the end-of-block code is an
+// error; distances beyond the output produced so far are errors (a BGZF member has no preset dictionary).
+#ifndef SVX_INFLATE_H_
+#define SVX_INFLATE_H_
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+namespace svx_inflate {
+
+constexpr int kLitBits = 12;   // index bits of the primary literal/length table
+constexpr int kDistBits = 9;   // … of the primary distance table
+constexpr int kPreBits = 7;    // the code-length code has no longer codes
+constexpr int kLitSize = (1 << kLitBits) + 288 * 8;    // + one 3-bit sub-table per code longer than 12 bits, at most
+constexpr int kDistSize = (1 << kDistBits) + 32 * 64;  // + one 6-bit sub-table per code longer than 9 bits, at most
+
+// Table entry (32 bits).  [5:0] = ALL the stream bits the entry consumes (codes and extra bits: an x86 shift takes its
+// count modulo 64, so the entry itself is the shift count), [7:6] kind:
+//   kind 0  literal/length table: up to two literals, then perhaps a short match — [15:8], [23:16] the literal
+//           bytes, [29:28] how many, [27:24] the length (3..10: the codes without extra bits) of a match that follows
+//           them, 0 = none.  No literals + a length = a short match on its own.
+//           distance table: the all-zero entry = "no match" (see decode_fast)
+//   kind 1  a value with extra bits: [27:24] bits of the code itself, [31:28] number of extra bits (they follow the
+//           code in the stream), [23:8] base — a length (literal/length table), a distance (distance table) or a
+//           code-length symbol (no extra bits)
+//   kind 2  end of block
+//   kind 3  sub-table: [23:8] first entry, [27:24] index bits; index bits 0 = invalid code
+constexpr uint32_t kKindLit = 0u << 6, kKindVal = 1u << 6, kKindEnd = 2u << 6, kKindSub = 3u << 6, kKindMask = 3u << 6;
+constexpr uint32_t kInvalid = kKindSub;  // consumes nothing, index bits 0
+constexpr uint32_t kBitsMask = 63;
+
+struct Tables {
+    uint32_t lit[kLitSize];
+    uint32_t dist[kDistSize];
+};
+
+inline uint32_t bit_reverse(uint32_t v, int n) {  // the low n (<= 16) bits of v, mirrored
+    v = ((v & 0x5555u) << 1) | ((v >> 1) & 0x5555u);
+    v = ((v & 0x3333u) << 2) | ((v >> 2) & 0x3333u);
+    v = ((v & 0x0F0Fu) << 4) | ((v >> 4) & 0x0F0Fu);
+    v = ((v & 0x00FFu) << 8) | ((v >> 8) & 0x00FFu);
+    return v >> (16 - n);
+}
+
+// symbol payload + the bits of its code (or of the code's tail inside a sub-table) → table entry
+inline uint32_t entry_of(uint32_t payload, uint32_t code_bits) {
+    if ((payload & kKindMask) == kKindVal) return payload | (code_bits + (payload >> 28)) | (code_bits << 24);
+    return payload | code_bits;
+}
+
+// Canonical Huffman code of `n` symbols with lengths lens[] (0 = unused) → look-up table indexed by the next `tb`
+// stream bits (LSB first), sub-tables behind it for longer codes.  payload[s] = entry of symbol s without its bit
+// count.  false: over-subscribed, or incomplete in a way zlib refuses.
+inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int cap, const uint32_t* payload,
+                        bool single_code_ok) {
+    uint16_t count[16] = {0};
+    for (int s = 0; s < n; ++s) ++count[lens[s]];
+    int max = 15;
+    while (max > 0 && !count[max]) --max;
+    const int primary = 1 << tb;
+    if (max == 0) {  // no symbols at all: every look-up is an invalid code
+        for (int i = 0; i < primary; ++i) tab[i] = kInvalid;
+        return true;
+    }
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+        left <<= 1;
+        left -= count[len];
+        if (left < 0) return false;
+    }
+    if (left > 0) {
+        if (!(single_code_ok && max == 1)) return false;
+        for (int i = 0; i < primary; ++i) tab[i] = kInvalid;
+    }
+    uint16_t offs[17];
+    offs[1] = 0;
+    for (int len = 1; len <= 15; ++len) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
+    uint16_t sorted[320];
+    {
+        uint16_t at[17];
+        memcpy(at, offs, sizeof(at));
+        for (int s = 0; s < n; ++s)
+            if (lens[s]) sorted[at[lens[s]]++] = (uint16_t)s;
+    }
+    uint32_t code = 0;
+    int idx = 0;
+    const int direct = max < tb ? max : tb;
+    for (int len = 1; len <= direct; ++len) {
+        for (int k = 0; k < count[len]; ++k, ++code) {
+            const uint32_t e = entry_of(payload[sorted[idx++]], (uint32_t)len);
+            for (uint32_t i = bit_reverse(code, len); i < (uint32_t)primary; i += 1u << len) tab[i] = e;
+        }
+        code <<= 1;
+    }
+    if (max <= tb) return true;
+    // longer codes: in canonical order the codes that share their first tb bits are neighbours and grow in length,
+    // so a group's last member fixes the size of its sub-table
+    int next_free = primary;
+    int len = tb + 1;
+    int in_len = 0;  // codes of length `len` already placed
+    while (len <= max) {
+        if (in_len == count[len]) {
+            ++len;
+            code <<= 1;
+            in_len = 0;
+            continue;
+        }
+        const uint32_t prefix = code >> (len - tb);
+        // look ahead to the end of the group
+        int sb;
+        {
+            uint32_t c = code;
+            int l = len, done = in_len, last = len;
+            for (;;) {
+                if (done == count[l]) {
+                    if (l == max) break;
+                    ++l;
+                    c <<= 1;
+                    done = 0;
+                    continue;
+                }
+                if ((c >> (l - tb)) != prefix) break;
+                last = l;
+                ++c;
+                ++done;
+            }
+            sb = last - tb;
+        }
+        const int start = next_free;
+        next_free += 1 << sb;
+        if (next_free > cap) return false;
+        for (int i = start; i < next_free; ++i) tab[i] = kInvalid;
+        tab[bit_reverse(prefix, tb)] = kKindSub | ((uint32_t)start << 8) | ((uint32_t)sb << 24) | (uint32_t)tb;
+        for (;;) {  // place the group's codes
+            if (in_len == count[len]) {
+                if (len == max) { ++len; break; }
+                ++len;
+                code <<= 1;
+                in_len = 0;
+                continue;
+            }
+            if ((code >> (len - tb)) != prefix) break;
+            const int rest = len - tb;
+            const uint32_t e = entry_of(payload[sorted[idx++]], (uint32_t)rest);
+            for (uint32_t i = bit_reverse(code & ((1u << rest) - 1), rest); i < (1u << sb); i += 1u << rest)
+                tab[start + i] = e;
+            ++code;
+            ++in_len;
+        }
+    }
+    return true;
+}
+
+// Second pass over the primary literal/length table.  What the SEQ members of a BAM are made of — 4–5-bit literals
+// and matches of three to five bytes in about equal numbers, in no predictable order — costs a one-symbol-per-look-up
+// decoder a mispredicted branch per symbol.  So an entry takes along what follows its first symbol as far as the 12
+// index bits reach: up to two literals and the length code of a short match; the fast loop
+// then runs the same straight-line code for every such entry (decode_fast).
+inline void pack_entries(uint32_t* tab) {
+    uint32_t single[1 << kLitBits];
+    memcpy(single, tab, sizeof(single));
+    auto short_length = [](uint32_t e) {  // a length code without extra bits, length <= 10
+        return (e & kKindMask) == kKindVal && (e >> 28) == 0 && ((e >> 8) & 0x1FF) <= 10;
+    };
+    for (uint32_t i = 0; i < (1u << kLitBits); ++i) {
+        const uint32_t e1 = single[i];
+        uint32_t bits = e1 & kBitsMask, cnt = 0, bytes = 0, mlen = 0;
+        if (short_length(e1)) {
+            mlen = (e1 >> 8) & 0x1FF;
+        } else if (!(e1 & kKindMask)) {
+            bytes = (e1 >> 8) & 0xFF;
+            cnt = 1;
+            for (;;) {
+                const uint32_t e = single[i >> bits];
+                const uint32_t l = e & kBitsMask;
+                if (bits + l > (uint32_t)kLitBits) break;
+                if (!(e & kKindMask)) {
+                    if (cnt == 2) break;
+                    bytes |= ((e >> 8) & 0xFF) << 8;
+                    cnt = 2;
+                    bits += l;
+                    continue;
+                }
+                if (short_length(e)) {
+                    mlen = (e >> 8) & 0x1FF;
+                    bits += l;
+                }
+                break;
+            }
+        } else {
+            continue;
+        }
+        tab[i] = bits | kKindLit | (bytes << 8) | (mlen << 24) | (cnt << 28);
+    }
+}
+
+struct SymbolPayloads {
+    uint32_t lit[288];
+    uint32_t dist[32];
+    uint32_t pre[19];
+    SymbolPayloads() {
+        static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
+                                           67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t lextra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769,
+                                           1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        static const uint8_t dextra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        for (uint32_t s = 0; s < 256; ++s) lit[s] = kKindLit | (1u << 28) | (s << 8);
+        lit[256] = kKindEnd;
+        for (int s = 257; s < 286; ++s) lit[s] = kKindVal | ((uint32_t)lbase[s - 257] << 8) | ((uint32_t)lextra[s - 257] << 28);
+        lit[286] = lit[287] = kInvalid;  // in the fixed code, never valid in a stream
+        for (int s = 0; s < 30; ++s) dist[s] = kKindVal | ((uint32_t)dbase[s] << 8) | ((uint32_t)dextra[s] << 28);
+        dist[30] = dist[31] = kInvalid;
+        for (uint32_t s = 0; s < 19; ++s) pre[s] = kKindVal | (s << 8);
+    }
+};
+inline const SymbolPayloads& payloads() {
+    static const SymbolPayloads p;
+    return p;
+}
+
+inline const Tables& fixed_tables() {
+    static const Tables t = [] {
+        Tables f;
+        uint8_t lens[288];
+        for (int s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+        build_table(lens, 288, kLitBits, f.lit, kLitSize, payloads().lit, false);
+        pack_entries(f.lit);
+        for (int s = 0; s < 32; ++s) lens[s] = 5;
+        build_table(lens, 32, kDistBits, f.dist, kDistSize, payloads().dist, false);
+        return f;
+    }();
+    return t;
+}
+
+inline uint64_t load64(const uint8_t* p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;  // little-endian host (x86-64)
+}
+
+class Stream {
+  public:
+    // Start a raw DEFLATE stream.  The output buffer is handed over with every run() so that it may move between
+    // calls as long as its content is kept.
+    void begin(const uint8_t* in, size_t in_len) {
+        in_ = in;
+        in_n_ = in_len;
+        ip_ = 0;
+        bitbuf_ = 0;
+        bitcnt_ = 0;
+        op_ = 0;
+        phase_ = kHeader;
+        final_ = false;
+        cur_ = nullptr;
+    }
+    size_t produced() const { return op_; }
+    bool finished() const { return phase_ == kDone; }
+
+    // Decode until at least `stop` bytes are out (to_end: until the final block has ended).  `cap` bounds the output:
+    // a stream that yields more is an error.  May go past `stop` by up to one match; never past `cap`.
+    bool run(uint8_t* out, size_t cap, size_t stop, bool to_end) {
+        if (phase_ == kFailed) return false;
+        out_ = out;
+        cap_ = cap;
+        if (stop > cap) stop = cap;
+        for (;;) {
+            if (phase_ == kDone) {
+                if (op_ < stop) return fail();  // the stream ended before the bytes asked for
+                return true;
+            }
+            if (!to_end && op_ >= stop) return true;
+            if (phase_ == kHeader) {
+                if (!block_header()) return fail();
+                continue;
+            }
+            if (phase_ == kStored) {
+                if (stored_left_ > in_n_ - ip_ || stored_left_ > cap_ - op_) return fail();
+                memcpy(out_ + op_, in_ + ip_, stored_left_);
+                ip_ += stored_left_;
+                op_ += stored_left_;
+                phase_ = final_ ? kDone : kHeader;
+                continue;
+            }
+            const size_t target = to_end ? (size_t)-1 : stop;
+            if (!decode_fast(target)) return fail();
+            if (phase_ != kBlock) continue;
+            if (!to_end && op_ >= stop) return true;
+            if (!decode_careful(target)) return fail();
+        }
+    }
+
+  private:
+    enum Phase { kHeader, kBlock, kStored, kDone, kFailed };
+
+    bool fail() {
+        phase_ = kFailed;
+        return false;
+    }
+    void fill() {
+        while (bitcnt_ < 56 && ip_ < in_n_) {  // never beyond 63 bits: the fast loop shifts by the count
+            bitbuf_ |= (uint64_t)in_[ip_++] << bitcnt_;
+            bitcnt_ += 8;
+        }
+    }
+    bool take(uint32_t n, uint32_t* v) {  // n <= 16
+        if (bitcnt_ < n) {
+            fill();
+            if (bitcnt_ < n) return false;
+        }
+        *v = (uint32_t)(bitbuf_ & ((1u << n) - 1));
+        bitbuf_ >>= n;
+        bitcnt_ -= n;
+        return true;
+    }
+
+    bool block_header() {
+        uint32_t v;
+        if (!take(3, &v)) return false;
+        final_ = v & 1;
+        const uint32_t type = v >> 1;
+        if (type == 0) {
+            // back to a byte boundary: whole bytes still in the bit buffer go back to the input
+            const uint32_t drop = bitcnt_ & 7;
+            bitbuf_ >>= drop;
+            bitcnt_ -= drop;
+            ip_ -= bitcnt_ >> 3;
+            bitbuf_ = 0;
+            bitcnt_ = 0;
+            if (in_n_ - ip_ < 4) return false;
+            const uint32_t len = in_[ip_] | ((uint32_t)in_[ip_ + 1] << 8);
+            const uint32_t nlen = in_[ip_ + 2] | ((uint32_t)in_[ip_ + 3] << 8);
+            if ((len ^ nlen) != 0xFFFFu) return false;
+            ip_ += 4;
+            stored_left_ = len;
+            phase_ = kStored;
+            return true;
+        }
+        if (type == 1) {
+            cur_ = &fixed_tables();
+            phase_ = kBlock;
+            return true;
+        }
+        if (type != 2) return false;
+        uint32_t hlit, hdist, hclen;
+        if (!take(5, &hlit) || !take(5, &hdist) || !take(4, &hclen)) return false;
+        const int nlit = (int)hlit + 257, ndist = (int)hdist + 1, ncl = (int)hclen + 4;
+        if (nlit > 286 || ndist > 30) return false;
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        uint8_t cl[19] = {0};
+        for (int i = 0; i < ncl; ++i) {
+            if (!take(3, &v)) return false;
+            cl[order[i]] = (uint8_t)v;
+        }
+        uint32_t pre[1 << kPreBits];
+        if (!build_table(cl, 19, kPreBits, pre, 1 << kPreBits, payloads().pre, false)) return false;
+        uint8_t lens[288 + 32];
+        const int total = nlit + ndist;
+        int i = 0;
+        while (i < total) {
+            fill();
+            const uint32_t e = pre[bitbuf_ & ((1u << kPreBits) - 1)];
+            const uint32_t nb = e & kBitsMask;
+            if ((e & kKindMask) != kKindVal || nb > bitcnt_) return false;
+            bitbuf_ >>= nb;
+            bitcnt_ -= nb;
+            const uint32_t sym = (e >> 8) & 0xFF;
+            if (sym < 16) {
+                lens[i++] = (uint8_t)sym;
+                continue;
+            }
+            uint32_t rep, val = 0;
+            if (sym == 16) {
+                if (i == 0 || !take(2, &rep)) return false;
+                rep += 3;
+                val = lens[i - 1];
+            } else if (sym == 17) {
+                if (!take(3, &rep)) return false;
+                rep += 3;
+            } else {
+                if (!take(7, &rep)) return false;
+                rep += 11;
+            }
+            if (i + (int)rep > total) return false;
+            memset(lens + i, (int)val, rep);
+            i += (int)rep;
+        }
+        if (lens[256] == 0) return false;  // no end-of-block code
+        uint8_t padded[288];
+        memcpy(padded, lens, nlit);
+        memset(padded + nlit, 0, 288 - nlit);
+        if (!build_table(padded, 288, kLitBits, own_.lit, kLitSize, payloads().lit, true)) return false;
+        pack_entries(own_.lit);
+        uint8_t dl[32] = {0};
+        memcpy(dl, lens + nlit, ndist);
+        if (!build_table(dl, 32, kDistBits, own_.dist, kDistSize, payloads().dist, true)) return false;
+        cur_ = &own_;
+        phase_ = kBlock;
+        return true;
+    }
+
+    // The distance half of a match whose length is known; careful mode: every step checks what is left.
+    bool match_checked(uint32_t len) {
+        fill();
+        uint32_t d = cur_->dist[bitbuf_ & ((1u << kDistBits) - 1)];
+        if ((d & kKindMask) == kKindSub) {
+            const uint32_t sb = (d >> 24) & 15;
+            if (sb == 0 || (uint32_t)kDistBits > bitcnt_) return false;
+            bitbuf_ >>= kDistBits;
+            bitcnt_ -= kDistBits;
+            d = cur_->dist[((d >> 8) & 0xFFFF) + (bitbuf_ & ((1u << sb) - 1))];
+        }
+        if ((d & kKindMask) != kKindVal) return false;
+        const uint32_t all = d & kBitsMask;
+        if (all > bitcnt_) return false;
+        const size_t dist = ((d >> 8) & 0xFFFF) + (size_t)((bitbuf_ >> ((d >> 24) & 15)) & ((1u << (d >> 28)) - 1));
+        bitbuf_ >>= all;
+        bitcnt_ -= all;
+        if (dist > op_ || len > cap_ - op_) return false;
+        uint8_t* dst = out_ + op_;
+        const uint8_t* src = dst - dist;
+        if (dist == 1) memset(dst, src[0], len);
+        else for (uint32_t k = 0; k < len; ++k) dst[k] = src[k];
+        op_ += len;
+        return true;
+    }
+
+    // Fast loop: while 16 input bytes and 320 output bytes are in hand nothing inside needs a bounds check.  One
+    // literal/length entry per round.  The round is bound by the chain look-up → shift → look-up → shift through the
+    // bit buffer, so everything else is kept off that chain: an entry's low six bits are the whole shift count, the
+    // extra bits are read beside the shift, and for an entry of kind 0 — literals, a short match, or both — there is
+    // no branch at all: the distance half always runs, against a table of zero entries when no match follows
+    // (sixteen bytes are then copied onto themselves).
+    bool decode_fast(size_t stop) {
+        if (in_n_ < 16 || cap_ < 320) return true;
+        static const uint32_t no_match[1 << kDistBits] = {0};
+        const size_t in_last = in_n_ - 16, out_last = cap_ - 320;
+        const uint32_t* lit = cur_->lit;
+        const uint32_t* dtab = cur_->dist;
+        const uint8_t* in = in_;
+        uint8_t* out = out_;
+        size_t ip = ip_, op = op_;
+        uint64_t bb = bitbuf_;
+        uint32_t bc = bitcnt_;
+        bool ok = true;
+        constexpr uint32_t kMask = (1u << kLitBits) - 1, kDMask = (1u << kDistBits) - 1;
+        while (ip <= in_last && op <= out_last && op < stop) {
+            bb |= load64(in + ip) << bc;  // at least 56 bits: 12 + 3 + 5 for a length, 9 + 6 + 13 for a distance
+            ip += (63 - bc) >> 3;
+            bc |= 56;
+            uint32_t e = lit[bb & kMask];
+            uint32_t len;
+            if (__builtin_expect(!(e & kKindMask), 1)) {
+                const uint32_t w = e >> 8;
+                memcpy(out + op, &w, 4);
+                op += (e >> 28) & 3;
+                len = (e >> 24) & 15;
+                bb >>= e & kBitsMask;
+                bc -= e & kBitsMask;
+            } else {
+                if ((e & kKindMask) == kKindSub) {
+                    const uint32_t sb = (e >> 24) & 15;
+                    if (sb == 0) { ok = false; break; }
+                    bb >>= kLitBits;
+                    bc -= kLitBits;
+                    e = lit[((e >> 8) & 0xFFFF) + (bb & ((1u << sb) - 1))];
+                    if (!(e & kKindMask)) {  // sub-table entries hold one symbol
+                        out[op++] = (uint8_t)(e >> 8);
+                        bb >>= e & kBitsMask;
+                        bc -= e & kBitsMask;
+                        continue;
+                    }
+                    if ((e & kKindMask) == kKindSub) { ok = false; break; }
+                }
+                if ((e & kKindMask) == kKindEnd) {
+                    bb >>= e & kBitsMask;
+                    bc -= e & kBitsMask;
+                    phase_ = final_ ? kDone : kHeader;
+                    break;
+                }
+                len = ((e >> 8) & 0x1FF) + (uint32_t)((bb >> ((e >> 24) & 15)) & ((1u << (e >> 28)) - 1));
+                bb >>= e & kBitsMask;
+                bc -= e & kBitsMask;
+            }
+            const uint32_t* dsel = len ? dtab : no_match;
+            uint32_t d = dsel[bb & kDMask];
+            if (__builtin_expect((d & kKindMask) == kKindSub, 0)) {
+                const uint32_t sb = (d >> 24) & 15;
+                if (sb == 0) { ok = false; break; }
+                bb >>= kDistBits;
+                bc -= kDistBits;
+                d = dtab[((d >> 8) & 0xFFFF) + (bb & ((1u << sb) - 1))];
+                if ((d & kKindMask) != kKindVal) { ok = false; break; }
+            }
+            const size_t dist = ((d >> 8) & 0xFFFF) + (size_t)((bb >> ((d >> 24) & 15)) & ((1u << (d >> 28)) - 1));
+            bb >>= d & kBitsMask;
+            bc -= d & kBitsMask;
+            if (__builtin_expect(dist > op, 0)) { ok = false; break; }
+            uint8_t* dst = out + op;
+            const uint8_t* src = dst - dist;
+            if (__builtin_expect(dist >= 8 || dist == 0, 1)) {
+                memcpy(dst, src, 8);
+                memcpy(dst + 8, src + 8, 8);
+                for (uint32_t k = 16; k < len; k += 8) memcpy(dst + k, src + k, 8);
+            } else if (dist == 1) {
+                memset(dst, src[0], len);
+            } else {
+                for (uint32_t k = 0; k < len; ++k) dst[k] = src[k];
+            }
+            op += len;
+        }
+        // the refill leaves stream bytes above bit `bc`: give them back so that the buffer is exact again
+        bb &= (1ull << bc) - 1;
+        ip_ = ip;
+        op_ = op;
+        bitbuf_ = bb;
+        bitcnt_ = bc;
+        return ok;
+    }
+
+    // The first and last few bytes of a stream: one entry at a time, every read and write checked.
+    bool decode_careful(size_t stop) {
+        const uint32_t* lit = cur_->lit;
+        constexpr uint32_t kMask = (1u << kLitBits) - 1;
+        const bool fast_possible = in_n_ >= 16 && cap_ >= 320;
+        while (op_ < stop) {
+            if (fast_possible && ip_ <= in_n_ - 16 && op_ <= cap_ - 320) return true;  // the fast loop can go on
+            fill();
+            uint32_t e = lit[bitbuf_ & kMask];
+            if ((e & kKindMask) == kKindSub) {
+                const uint32_t sb = (e >> 24) & 15;
+                if (sb == 0 || (uint32_t)kLitBits > bitcnt_) return false;
+                bitbuf_ >>= kLitBits;
+                bitcnt_ -= kLitBits;
+                e = lit[((e >> 8) & 0xFFFF) + (bitbuf_ & ((1u << sb) - 1))];
+                if ((e & kKindMask) == kKindSub) return false;
+            }
+            const uint32_t all = e & kBitsMask;
+            if (all > bitcnt_) return false;
+            uint32_t len;
+            if (!(e & kKindMask)) {
+                const uint32_t cnt = (e >> 28) & 3;
+                if (cnt > cap_ - op_) return false;
+                for (uint32_t k = 0; k < cnt; ++k) out_[op_ + k] = (uint8_t)(e >> (8 + 8 * k));
+                op_ += cnt;
+                len = (e >> 24) & 15;
+            } else if ((e & kKindMask) == kKindEnd) {
+                bitbuf_ >>= all;
+                bitcnt_ -= all;
+                phase_ = final_ ? kDone : kHeader;
+                return true;
+            } else {
+                len = ((e >> 8) & 0x1FF) + (uint32_t)((bitbuf_ >> ((e >> 24) & 15)) & ((1u << (e >> 28)) - 1));
+            }
+            bitbuf_ >>= all;
+            bitcnt_ -= all;
+            if (len && !match_checked(len)) return false;
+        }
+        return true;
+    }
+
+    const uint8_t* in_ = nullptr;
+    size_t in_n_ = 0, ip_ = 0;
+    uint64_t bitbuf_ = 0;
+    uint32_t bitcnt_ = 0;
+    uint8_t* out_ = nullptr;
+    size_t cap_ = 0, op_ = 0;
+    Phase phase_ = kFailed;
+    bool final_ = false;
+    uint32_t stored_left_ = 0;
+    const Tables* cur_ = nullptr;
+    Tables own_;
+};
+
+}  // namespace svx_inflate
+#endif  // SVX_INFLATE_H_
