@@ -15,6 +15,8 @@
  * bases; only the BGZF blocks that hold record headers, names, CIGARs and aux tags are
  * inflated (block sizes come from the BSIZE/ISIZE fields, so SEQ/QUAL blocks are hopped
  * over), plus the blocks of the base ranges later requested with svx_bam_seq_slices.
+ * Inflate = the build's own DEFLATE decoder (svx_inflate_raw below; SVX_BAM_ZLIB=1: zlib); a member's CRC32 is
+ * checked whenever the member is inflated to its end.
  * With a `.bai` next to the BAM (the reference requires one, svim-asm:67-72) every bin
  * chunk boundary and linear-index entry is a record boundary: the file is cut there and
  * the pieces are walked by `n_threads` host threads; the per-contig chunk ranges restrict

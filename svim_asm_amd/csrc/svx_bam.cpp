@@ -9,8 +9,9 @@
 //   * a `.bai` gives record boundaries (bin chunk begins/ends, linear index entries): the
 //     requested contigs' ranges are cut there into pieces of about equal compressed size and
 //     walked by a pool of threads, each with its own inflater;
-//   * inflate: libdeflate when the runtime has it (dlopen, optional), else zlib; the CRC32 of
-//     every inflated member is checked, as htslib does.
+//   * inflate: the build's own DEFLATE decoder (svx_inflate.h; SVX_BAM_ZLIB=1: zlib, its oracle); the
+//     CRC32 of every member inflated to its end is checked, as htslib does (libdeflate's CRC routine
+//     when the runtime has the library — dlopen, optional —, zlib's otherwise).
 #include "svx_bam.h"
 
 #include <dlfcn.h>
