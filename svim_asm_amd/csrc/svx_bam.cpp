@@ -22,12 +22,17 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -508,6 +513,65 @@ T* dup_array(const std::vector<T>& v) {
 
 }  // namespace
 
+// Worker threads of one handle, started once and kept: svx_bam_load and svx_bam_seq_slices are 20-60 ms calls, and
+// threads created at the start of such a call spend a good part of it where the kernel first put them — next to
+// their parent — before the balancer spreads them over the node's cores (same slices, 64 threads: 17 ms or 90 ms
+// from one call to the next with a thread per call).  Kept threads stay where the first call spread them.
+class Pool {
+  public:
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        work_.notify_all();
+        for (std::thread& t : th_) t.join();
+    }
+    // fn() on n threads at once; returns when all have returned.  One run at a time (a handle is used by one thread).
+    void run(int n, const std::function<void()>& fn) {
+        if (n <= 1) {
+            fn();
+            return;
+        }
+        std::unique_lock<std::mutex> g(m_);
+        while ((int)th_.size() < n) {
+            const int idx = (int)th_.size();
+            th_.emplace_back([this, idx] { loop(idx); });
+        }
+        job_ = &fn;
+        active_ = n;
+        pending_ = n;
+        ++generation_;
+        work_.notify_all();
+        done_.wait(g, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop(int idx) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            work_.wait(g, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            if (idx >= active_) continue;
+            const std::function<void()>* job = job_;
+            g.unlock();
+            (*job)();
+            g.lock();
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable work_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void()>* job_ = nullptr;
+    int active_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
 struct svx_bam {
     int fd = -1;
     File file;
@@ -532,6 +596,7 @@ struct svx_bam {
     std::vector<uint8_t> aux;
     uint64_t blocks_inflated = 0, blocks_spanned = 0;
     int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
+    Pool pool;
 
     void free_cigar() {
         if (!cigar) return;
@@ -649,9 +714,11 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out, char
                 if (nt == 1) {
                     check(0, pts.size());
                 } else {
-                    std::vector<std::thread> th;
-                    for (size_t t = 0; t < nt; ++t) th.emplace_back(check, pts.size() * t / nt, pts.size() * (t + 1) / nt);
-                    for (std::thread& t : th) t.join();
+                    std::atomic<size_t> turn(0);  // (these threads then serve svx_bam_load and svx_bam_seq_slices)
+                    b->pool.run((int)nt, [&] {
+                        const size_t t = turn.fetch_add(1);
+                        check(pts.size() * t / nt, pts.size() * (t + 1) / nt);
+                    });
                 }
                 good = !bad.load();
             }
@@ -851,9 +918,7 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     if (nt <= 1) {
         worker();
     } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(worker);
-        for (std::thread& t : th) t.join();
+        b->pool.run(nt, worker);
     }
     b->blocks_inflated += inflated.load();
     if (failed.load()) {
@@ -962,13 +1027,12 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
     static const bool verify_all = [] { const char* v = getenv("SVX_BAM_VERIFY"); return v && v[0] == '1'; }();
     std::atomic<bool> failed(false);
     std::atomic<uint64_t> inflated(0);
-    auto work = [&](uint32_t lo, uint32_t hi) {
-        Inflater inf;
-        Cursor c(&b->file, &inf);
-        c.prefix_mode = !verify_all;
+    struct State {
         std::vector<uint8_t> packed;
         uint32_t cur_rec = ~0u;
         uint64_t cur_byte = 0;  // bytes of the record's SEQ field already passed by the cursor
+    };
+    auto work_on = [&](Cursor& c, State& st, uint32_t lo, uint32_t hi) {
         for (uint32_t i = lo; i < hi && !failed.load(); ++i) {
             const uint32_t r = rec[i];
             const uint32_t L = (uint32_t)b->l_seq[r];
@@ -976,35 +1040,75 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             if (out_off[i + 1] - out_off[i] != (uint64_t)(e - a)) { failed.store(true); break; }
             if (e == a) continue;
             const uint64_t b0 = a >> 1, b1 = ((uint64_t)e + 1) >> 1;
-            if (r != cur_rec || b0 < cur_byte) {
+            if (r != st.cur_rec || b0 < st.cur_byte) {
                 VPos p;
                 p.coff = b->seq_coff[r];
                 p.uoff = b->seq_uoff[r];
                 if (!c.seek(p)) { failed.store(true); break; }
-                cur_rec = r;
-                cur_byte = 0;
+                st.cur_rec = r;
+                st.cur_byte = 0;
             }
-            packed.resize((size_t)(b1 - b0));
-            if (!c.skip(b0 - cur_byte) || !c.read(packed.data(), packed.size())) { failed.store(true); break; }
-            cur_byte = b1;
+            st.packed.resize((size_t)(b1 - b0));
+            if (!c.skip(b0 - st.cur_byte) || !c.read(st.packed.data(), st.packed.size())) { failed.store(true); break; }
+            st.cur_byte = b1;
             uint8_t* dst = out + out_off[i];
             for (uint32_t k = a; k < e; ++k) {
-                const uint8_t by = packed[(k >> 1) - b0];
+                const uint8_t by = st.packed[(k >> 1) - b0];
                 *dst++ = (uint8_t)kLut[(k & 1) ? (by & 15) : (by >> 4)];
             }
         }
+    };
+    auto work = [&](uint32_t lo, uint32_t hi) {
+        Inflater inf;
+        Cursor c(&b->file, &inf);
+        c.prefix_mode = !verify_all;
+        State st;
+        work_on(c, st, lo, hi);
         inflated.fetch_add(inf.n_blocks);
     };
     const uint32_t nt = (uint32_t)std::max(1, std::min<int>(b->n_threads, (int)(n / 16 + 1)));
     if (nt <= 1) {
         work(0, n);
     } else {
-        std::vector<std::thread> th;
-        for (uint32_t t = 0; t < nt; ++t) {
-            const uint32_t lo = (uint32_t)((uint64_t)n * t / nt), hi = (uint32_t)((uint64_t)n * (t + 1) / nt);
-            th.emplace_back(work, lo, hi);
-        }
-        for (std::thread& t : th) t.join();
+        // runs of 32 slices handed out on demand: the node is shared, and with one fixed share per thread the call
+        // lasts as long as the unluckiest thread (same slices, 64 threads: 17 to 88 ms from one call to the next)
+        constexpr uint32_t kRun = 32;
+        std::atomic<uint32_t> next(0);
+        const bool debug = getenv("SVX_BAM_DEBUG") != nullptr;
+        std::atomic<int64_t> cpu_sum(0), cpu_max(0), wall_max(0), start_max(0);
+        const auto t_call = std::chrono::steady_clock::now();
+        auto pull = [&]() {
+            timespec c0;
+            clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
+            const auto w0 = std::chrono::steady_clock::now();
+            Inflater inf;
+            Cursor c(&b->file, &inf);
+            c.prefix_mode = !verify_all;
+            State st;
+            for (;;) {
+                const uint32_t lo = next.fetch_add(kRun);
+                if (lo >= n || failed.load()) break;
+                work_on(c, st, lo, std::min(n, lo + kRun));
+            }
+            inflated.fetch_add(inf.n_blocks);
+            if (debug) {  // wall time far above CPU time: the thread was waiting for a core, not working
+                timespec c1;
+                clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
+                const int64_t cpu = (c1.tv_sec - c0.tv_sec) * 1000000 + (c1.tv_nsec - c0.tv_nsec) / 1000;
+                const int64_t wall = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - w0).count();
+                const int64_t late = std::chrono::duration_cast<std::chrono::microseconds>(w0 - t_call).count();
+                cpu_sum.fetch_add(cpu);
+                for (int64_t v = cpu_max.load(); cpu > v && !cpu_max.compare_exchange_weak(v, cpu);) {}
+                for (int64_t v = wall_max.load(); wall > v && !wall_max.compare_exchange_weak(v, wall);) {}
+                for (int64_t v = start_max.load(); late > v && !start_max.compare_exchange_weak(v, late);) {}
+            }
+        };
+        b->pool.run((int)nt, pull);
+        if (debug)
+            fprintf(stderr, "svx_bam_seq_slices: %u slices, %u threads: call %.1f ms; per thread: last start +%.1f ms, longest wall %.1f ms, "
+                    "longest cpu %.1f ms, cpu sum %.1f ms\n", n, nt,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),
+                    start_max.load() / 1e3, wall_max.load() / 1e3, cpu_max.load() / 1e3, cpu_sum.load() / 1e3);
     }
     b->blocks_inflated += inflated.load();
     if (failed.load()) return fail(b, SVX_E_INVALID, "svx_bam_seq_slices: bad slice bounds or malformed BGZF data");
