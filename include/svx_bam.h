@@ -16,7 +16,7 @@
  * inflated (block sizes come from the BSIZE/ISIZE fields, so SEQ/QUAL blocks are hopped
  * over), plus the blocks of the base ranges later requested with svx_bam_seq_slices.
  * Inflate = the build's own DEFLATE decoder (svx_inflate_raw below; SVX_BAM_ZLIB=1: zlib); a member's CRC32 is
- * checked whenever the member is inflated to its end.
+ * checked whenever the member is inflated to its end (svx_bam_set_verify: always).
  * With a `.bai` next to the BAM (the reference requires one, svim-asm:67-72) every bin
  * chunk boundary and linear-index entry is a record boundary: the file is cut there and
  * the pieces are walked by `n_threads` host threads; the per-contig chunk ranges restrict
@@ -63,6 +63,14 @@ int svx_bam_index_state(const svx_bam* bam);
  * weights of the contig → rank plan.  span[n_ref].  SVX_E_INVALID when index_state != 1. */
 int svx_bam_contig_spans(const svx_bam* bam, uint64_t* span);
 
+/* What is inflated of a member that is needed: by default only as far as the last byte asked for (a record walk stops
+ * right behind a record's CIGAR instead of going on into its SEQ bytes: a third of the CPU time; a sequence slice: half
+ * of it) — the CRC32 of a member is then checked only when the member happens to be inflated to its end.  on != 0:
+ * every touched member is inflated completely and its CRC32 checked, as htslib does under the reference
+ * (bgzf_read_block).  The default of a new handle is off, or on with SVX_BAM_VERIFY=1 in the environment.  Either way
+ * a malformed DEFLATE stream, a stream longer than its ISIZE or a stream that ends early is an error. */
+int svx_bam_set_verify(svx_bam* bam, int on);
+
 /* Page-lock the CIGAR pool of later svx_bam_load calls in the context of HIP device `device`
  * (the one the svx_ctx that will consume it lives on); device < 0 (default): pageable memory. */
 int svx_bam_set_pinned_device(svx_bam* bam, int device);
@@ -100,9 +108,7 @@ int svx_bam_get_columns(const svx_bam* bam, svx_bam_columns* out);
  * (=ACMGRSVTWYHKDBN, BAM orientation) at out + out_off[i]; n slices, walked by the handle's
  * threads.  Ranges are clipped to [0, l_seq]; out_off[i+1] - out_off[i] must hold the
  * clipped length.  Slices sorted by (rec, begin) reuse inflated blocks.  A slice is 0.3 % of the 64 KiB member it
- * sits in: members are inflated only up to the last byte a slice needs (half the work on average); the CRC32 of a
- * member is checked when it ends up inflated completely, and always with SVX_BAM_VERIFY=1 in the environment
- * (every touched member inflated in full, as htslib does).  svx_bam_load always inflates and checks whole members. */
+ * sits in: members are inflated only up to the last byte a slice needs unless svx_bam_set_verify is on. */
 int svx_bam_seq_slices(svx_bam* bam, const uint32_t* rec, const uint32_t* begin, const uint32_t* end,
                        uint32_t n, const uint64_t* out_off, uint8_t* out);
 

@@ -162,6 +162,7 @@ SYMBOLS = {
     "svx_bam_index_state": (C.c_int, [_P]),
     "svx_bam_contig_spans": (C.c_int, [_P, _P]),
     "svx_bam_set_pinned_device": (C.c_int, [_P, C.c_int]),
+    "svx_bam_set_verify": (C.c_int, [_P, C.c_int]),
     "svx_bam_load": (C.c_int, [_P, _P, C.c_int32]),
     "svx_bam_get_columns": (C.c_int, [_P, _P]),
     "svx_bam_seq_slices": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P]),

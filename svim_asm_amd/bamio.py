@@ -478,9 +478,11 @@ class AlignmentFile(object):
     provides and inflate only the BGZF members holding record headers, names, CIGARs and tags.
     `load(contigs)` restricts the walk to the contigs a rank owns; anything that touches the
     records loads the whole file on demand.  reader="python" selects the pure-Python walker
-    (kept as the differential reference of the native one; also via SVX_BAM_READER=python)."""
+    (kept as the differential reference of the native one; also via SVX_BAM_READER=python).
+    verify=True inflates every touched BGZF member completely and checks its CRC32 (what htslib does); the default
+    stops at the last byte needed (svx_bam_set_verify, include/svx_bam.h)."""
 
-    def __init__(self, path, mode="rb", threads=None, reader=None, device=None):
+    def __init__(self, path, mode="rb", threads=None, reader=None, device=None, verify=None):
         self.filename = path
         self._reader = reader or os.environ.get("SVX_BAM_READER", "native")
         self._loaded = None   # None: nothing; "all" or a tuple of tids
@@ -498,6 +500,8 @@ class AlignmentFile(object):
                     raise FileNotFoundError(msg)
                 raise ValueError(msg)
             self._h = h
+            if verify is not None:  # None: the library's default (SVX_BAM_VERIFY); see include/svx_bam.h
+                lib.svx_bam_set_verify(h, 1 if verify else 0)
             text, l_text, n_ref = C.c_char_p(), C.c_uint64(), C.c_int32()
             tp = C.c_void_p()
             lib.svx_bam_header(h, C.byref(tp), C.byref(l_text), C.byref(n_ref))

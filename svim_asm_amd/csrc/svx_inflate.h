@@ -1,12 +1,15 @@
 // svx_inflate.h — raw DEFLATE (RFC 1951) decoder of the BAM ingest, host C++.
 //
 // Why not zlib / libdeflate alone: the members of an assembly-to-reference BAM are SEQ bytes for the most part — two
-// 4-bit bases per byte, sixteen byte values that are about equally likely — which the writer's Huffman stage turns
-// into 4–5-bit literal codes with next to no matches.  A decoder that takes one symbol per table look-up spends
-// 65 536 look-ups on such a member (zlib ≈ 585 µs, libdeflate ≈ 377 µs per 64 KiB member on the build container);
-// here the 12-bit primary table holds up to THREE literals per entry, so the same member takes about a third of the
-// look-ups.  And the decoder stops and resumes at any output position: an inserted-sequence slice lies somewhere
-// inside a member and only the bytes up to its end are wanted (svx_bam_seq_slices), which libdeflate cannot do.
+// 4-bit bases per byte, sixteen byte values that are about equally likely.  A deflate writer turns them into 4–5-bit
+// literals and, in about equal number, matches of three or four bytes at distances anywhere in the window, in no
+// predictable order: a 64 KiB member is ≈ 15 000 matches and ≈ 16 000 literals.  A decoder that takes one symbol per
+// table look-up and branches on its kind pays a mispredicted branch on almost every one of them (zlib ≈ 200,
+// libdeflate ≈ 160 µs per member on the GPU box's EPYC 9575F; here ≈ 120).  Here an entry of the primary table holds
+// up to two literals and the length of a short match behind them — whatever fits the index bits — and the fast
+// loop runs the same straight-line code for every such entry (pack_entries, decode_fast).  And the decoder stops and
+// resumes at any output position: an inserted-sequence slice lies somewhere inside a member and only the bytes up
+// to its end are wanted (svx_bam_seq_slices), which libdeflate cannot do.
 //
 // The reference gets here through pysam → htslib → zlib (SVIM_COLLECT.py:68 `bam.fetch`, SVIM_intra.py:40
 // `alignment.query_sequence`); the format is the published one, nothing of htslib's is restated.
@@ -25,10 +28,10 @@
 
 namespace svx_inflate {
 
-constexpr int kLitBits = 12;   // index bits of the primary literal/length table
+constexpr int kLitBits = 11;   // index bits of the primary literal/length table (10 / 11 / 12 measured: 11)
 constexpr int kDistBits = 9;   // … of the primary distance table
 constexpr int kPreBits = 7;    // the code-length code has no longer codes
-constexpr int kLitSize = (1 << kLitBits) + 288 * 8;    // + one 3-bit sub-table per code longer than 12 bits, at most
+constexpr int kLitSize = (1 << kLitBits) + 288 * (1 << (15 - kLitBits));  // + one sub-table per longer code, at most
 constexpr int kDistSize = (1 << kDistBits) + 32 * 64;  // + one 6-bit sub-table per code longer than 9 bits, at most
 
 // Table entry (32 bits).  [5:0] = ALL the stream bits the entry consumes (codes and extra bits: an x86 shift takes its
@@ -170,7 +173,7 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
 
 // Second pass over the primary literal/length table.  What the SEQ members of a BAM are made of — 4–5-bit literals
 // and matches of three to five bytes in about equal numbers, in no predictable order — costs a one-symbol-per-look-up
-// decoder a mispredicted branch per symbol.  So an entry takes along what follows its first symbol as far as the 12
+// decoder a mispredicted branch per symbol.  So an entry takes along what follows its first symbol as far as the
 // index bits reach: up to two literals and the length code of a short match; the fast loop
 // then runs the same straight-line code for every such entry (decode_fast).
 inline void pack_entries(uint32_t* tab) {
@@ -462,7 +465,7 @@ class Stream {
         bool ok = true;
         constexpr uint32_t kMask = (1u << kLitBits) - 1, kDMask = (1u << kDistBits) - 1;
         while (ip <= in_last && op <= out_last && op < stop) {
-            bb |= load64(in + ip) << bc;  // at least 56 bits: 12 + 3 + 5 for a length, 9 + 6 + 13 for a distance
+            bb |= load64(in + ip) << bc;  // at least 56 bits: 15 + 5 for a length, 15 + 13 for a distance
             ip += (63 - bc) >> 3;
             bc |= 56;
             uint32_t e = lit[bb & kMask];

@@ -20,6 +20,8 @@ static int walk(const char* path, int threads, bool per_contig) {
     char err[256] = {0};
     svx_bam* b = nullptr;
     if (svx_bam_open(path, threads, &b, err, sizeof err) != 0 || !b) return 1;  // refused: fine
+    static unsigned turn = 0;
+    (void)svx_bam_set_verify(b, (int)(++turn & 1));  // whole members + CRC32 and inflate-what-is-needed in turn
     const char* text = nullptr;
     uint64_t l_text = 0;
     int32_t n_ref = 0;
