@@ -123,6 +123,15 @@ int svx_bam_seq_slices(svx_bam* bam, const uint32_t* rec, const uint32_t* begin,
 int svx_inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, const uint64_t* stops,
                     uint32_t n_stops, uint64_t* n_out);
 
+/* Two independent streams decoded side by side in one thread (the rounds of one fill the issue slots the other's
+ * dependency chain leaves empty; svx_bam_seq_slices inflates its members two at a time this way).  stop_x = the output
+ * position to reach (a run may overshoot it by up to one match), or UINT64_MAX: to the end of the stream, which must then
+ * yield at most cap_x bytes.  Per stream: *n_out_x bytes produced, *rc_x SVX_OK or SVX_E_INVALID, exactly as
+ * svx_inflate_raw on that stream alone would report.  The return value only reflects the arguments. */
+int svx_inflate_raw_pair(const uint8_t* in_a, size_t in_len_a, uint8_t* out_a, size_t cap_a, uint64_t stop_a,
+                         uint64_t* n_out_a, int* rc_a, const uint8_t* in_b, size_t in_len_b, uint8_t* out_b,
+                         size_t cap_b, uint64_t stop_b, uint64_t* n_out_b, int* rc_b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,8 @@ SYMBOLS = {
     "svx_bam_get_columns": (C.c_int, [_P, _P]),
     "svx_bam_seq_slices": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P]),
     "svx_inflate_raw": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "svx_inflate_raw_pair": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int),
+                                       _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     # native text side (include/svx_text.h)
     "svx_fasta_open": (C.c_int, [C.c_char_p, C.c_int32, _P, _P, _P, _P, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "svx_fasta_close": (None, [_P]),

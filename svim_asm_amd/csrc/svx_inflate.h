@@ -49,6 +49,9 @@ constexpr uint32_t kKindLit = 0u << 6, kKindVal = 1u << 6, kKindEnd = 2u << 6, k
 constexpr uint32_t kInvalid = kKindSub;  // consumes nothing, index bits 0
 constexpr uint32_t kBitsMask = 63;
 
+// the distance table of a round without a match (internal linkage: no GOT detour in a shared library)
+static const uint32_t kNoMatch[1 << kDistBits] = {0};
+
 struct Tables {
     uint32_t lit[kLitSize];
     uint32_t dist[kDistSize];
@@ -280,38 +283,76 @@ class Stream {
     // Decode until at least `stop` bytes are out (to_end: until the final block has ended).  `cap` bounds the output:
     // a stream that yields more is an error.  May go past `stop` by up to one match; never past `cap`.
     bool run(uint8_t* out, size_t cap, size_t stop, bool to_end) {
-        if (phase_ == kFailed) return false;
+        aim(out, cap, stop, to_end);
+        for (;;) {
+            const Ready r = prepare();
+            if (r != kReadyFast) return r == kFinished;
+            if (!decode_fast()) return fail();
+        }
+    }
+    // Two independent streams side by side.  A round of the fast loop is a chain of dependent look-ups and shifts that
+    // leaves most of a core's issue slots empty; the rounds of a second stream fill them (decode_fast_pair).  Same
+    // arguments and results as two run() calls.
+    static void run_pair(Stream& a, uint8_t* out_a, size_t cap_a, size_t stop_a, bool end_a, bool* ok_a,
+                         Stream& b, uint8_t* out_b, size_t cap_b, size_t stop_b, bool end_b, bool* ok_b) {
+        a.aim(out_a, cap_a, stop_a, end_a);
+        b.aim(out_b, cap_b, stop_b, end_b);
+        for (;;) {
+            const Ready ra = a.prepare(), rb = b.prepare();
+            if (ra == kReadyFast && rb == kReadyFast) {
+                decode_fast_pair(a, b);
+            } else if (ra == kReadyFast) {
+                if (!a.decode_fast()) a.fail();
+            } else if (rb == kReadyFast) {
+                if (!b.decode_fast()) b.fail();
+            } else {
+                *ok_a = ra == kFinished;
+                *ok_b = rb == kFinished;
+                return;
+            }
+        }
+    }
+
+  private:
+    enum Phase { kHeader, kBlock, kStored, kDone, kFailed };
+    enum Ready { kReadyFast, kFinished, kError };
+
+    void aim(uint8_t* out, size_t cap, size_t stop, bool to_end) {
         out_ = out;
         cap_ = cap;
-        if (stop > cap) stop = cap;
+        to_end_ = to_end;
+        stop_ = stop > cap ? cap : stop;
+        target_ = to_end ? (size_t)-1 : stop_;
+    }
+    bool fast_possible() const {
+        return in_n_ >= 16 && cap_ >= 320 && ip_ <= in_n_ - 16 && op_ <= cap_ - 320 && op_ < target_;
+    }
+    // Everything that is not the fast loop: block headers, stored blocks, the checked loop near the ends of the
+    // buffers.  Returns when the fast loop can run, when the aim is reached, or on an error.
+    Ready prepare() {
+        if (phase_ == kFailed) return kError;
         for (;;) {
             if (phase_ == kDone) {
-                if (op_ < stop) return fail();  // the stream ended before the bytes asked for
-                return true;
+                if (op_ < stop_) { fail(); return kError; }  // the stream ended before the bytes asked for
+                return kFinished;
             }
-            if (!to_end && op_ >= stop) return true;
+            if (!to_end_ && op_ >= stop_) return kFinished;
             if (phase_ == kHeader) {
-                if (!block_header()) return fail();
+                if (!block_header()) { fail(); return kError; }
                 continue;
             }
             if (phase_ == kStored) {
-                if (stored_left_ > in_n_ - ip_ || stored_left_ > cap_ - op_) return fail();
+                if (stored_left_ > in_n_ - ip_ || stored_left_ > cap_ - op_) { fail(); return kError; }
                 memcpy(out_ + op_, in_ + ip_, stored_left_);
                 ip_ += stored_left_;
                 op_ += stored_left_;
                 phase_ = final_ ? kDone : kHeader;
                 continue;
             }
-            const size_t target = to_end ? (size_t)-1 : stop;
-            if (!decode_fast(target)) return fail();
-            if (phase_ != kBlock) continue;
-            if (!to_end && op_ >= stop) return true;
-            if (!decode_careful(target)) return fail();
+            if (fast_possible()) return kReadyFast;
+            if (!decode_careful(target_)) { fail(); return kError; }
         }
     }
-
-  private:
-    enum Phase { kHeader, kBlock, kStored, kDone, kFailed };
 
     bool fail() {
         phase_ = kFailed;
@@ -451,100 +492,134 @@ class Stream {
     // extra bits are read beside the shift, and for an entry of kind 0 — literals, a short match, or both — there is
     // no branch at all: the distance half always runs, against a table of zero entries when no match follows
     // (sixteen bytes are then copied onto themselves).
-    bool decode_fast(size_t stop) {
-        if (in_n_ < 16 || cap_ < 320) return true;
-        static const uint32_t no_match[1 << kDistBits] = {0};
-        const size_t in_last = in_n_ - 16, out_last = cap_ - 320;
-        const uint32_t* lit = cur_->lit;
-        const uint32_t* dtab = cur_->dist;
-        const uint8_t* in = in_;
-        uint8_t* out = out_;
-        size_t ip = ip_, op = op_;
-        uint64_t bb = bitbuf_;
-        uint32_t bc = bitcnt_;
-        bool ok = true;
+    struct Lane {
+        const uint8_t* in;
+        uint8_t* out;
+        const uint32_t* lit;
+        const uint32_t* dtab;
+        size_t ip, op, in_last, out_last, stop;
+        uint64_t bb;
+        uint32_t bc;
+    };
+    enum Round { kGoOn, kBlockEnded, kBad };
+    void load(Lane& l) const {
+        l.in = in_;
+        l.out = out_;
+        l.lit = cur_->lit;
+        l.dtab = cur_->dist;
+        l.ip = ip_;
+        l.op = op_;
+        l.in_last = in_n_ - 16;
+        l.out_last = cap_ - 320;
+        l.stop = target_;
+        l.bb = bitbuf_;
+        l.bc = bitcnt_;
+    }
+    void store(const Lane& l, Round r) {
+        ip_ = l.ip;
+        op_ = l.op;
+        bitcnt_ = l.bc;
+        bitbuf_ = l.bb & ((1ull << l.bc) - 1);  // the refill leaves stream bytes above bit `bc`: the buffer is exact again
+        if (r == kBlockEnded) phase_ = final_ ? kDone : kHeader;
+        if (r == kBad) fail();
+    }
+    static bool in_hand(const Lane& l) { return l.ip <= l.in_last && l.op <= l.out_last && l.op < l.stop; }
+    static inline __attribute__((always_inline)) Round round(Lane& l) {
         constexpr uint32_t kMask = (1u << kLitBits) - 1, kDMask = (1u << kDistBits) - 1;
-        while (ip <= in_last && op <= out_last && op < stop) {
-            bb |= load64(in + ip) << bc;  // at least 56 bits: 15 + 5 for a length, 15 + 13 for a distance
-            ip += (63 - bc) >> 3;
-            bc |= 56;
-            uint32_t e = lit[bb & kMask];
-            uint32_t len;
-            if (__builtin_expect(!(e & kKindMask), 1)) {
-                const uint32_t w = e >> 8;
-                memcpy(out + op, &w, 4);
-                op += (e >> 28) & 3;
-                len = (e >> 24) & 15;
-                bb >>= e & kBitsMask;
-                bc -= e & kBitsMask;
-            } else {
-                if ((e & kKindMask) == kKindSub) {
-                    const uint32_t sb = (e >> 24) & 15;
-                    if (sb == 0) { ok = false; break; }
-                    bb >>= kLitBits;
-                    bc -= kLitBits;
-                    e = lit[((e >> 8) & 0xFFFF) + (bb & ((1u << sb) - 1))];
-                    if (!(e & kKindMask)) {  // sub-table entries hold one symbol
-                        out[op++] = (uint8_t)(e >> 8);
-                        bb >>= e & kBitsMask;
-                        bc -= e & kBitsMask;
-                        continue;
-                    }
-                    if ((e & kKindMask) == kKindSub) { ok = false; break; }
+        uint64_t bb = l.bb | (load64(l.in + l.ip) << l.bc);  // at least 56 bits: 15 + 5 for a length, 15 + 13 for a distance
+        uint32_t bc = l.bc | 56;
+        l.ip += (63 - l.bc) >> 3;
+        uint32_t e = l.lit[bb & kMask];
+        uint32_t len;
+        size_t op = l.op;
+        if (__builtin_expect(!(e & kKindMask), 1)) {
+            const uint32_t w = e >> 8;
+            memcpy(l.out + op, &w, 4);
+            op += (e >> 28) & 3;
+            len = (e >> 24) & 15;
+            bb >>= e & kBitsMask;
+            bc -= e & kBitsMask;
+        } else {
+            if ((e & kKindMask) == kKindSub) {
+                const uint32_t sb = (e >> 24) & 15;
+                if (sb == 0) return kBad;
+                bb >>= kLitBits;
+                bc -= kLitBits;
+                e = l.lit[((e >> 8) & 0xFFFF) + (bb & ((1u << sb) - 1))];
+                if (!(e & kKindMask)) {  // sub-table entries hold one symbol
+                    l.out[op] = (uint8_t)(e >> 8);
+                    l.op = op + 1;
+                    l.bb = bb >> (e & kBitsMask);
+                    l.bc = bc - (e & kBitsMask);
+                    return kGoOn;
                 }
-                if ((e & kKindMask) == kKindEnd) {
-                    bb >>= e & kBitsMask;
-                    bc -= e & kBitsMask;
-                    phase_ = final_ ? kDone : kHeader;
-                    break;
-                }
-                len = ((e >> 8) & 0x1FF) + (uint32_t)((bb >> ((e >> 24) & 15)) & ((1u << (e >> 28)) - 1));
-                bb >>= e & kBitsMask;
-                bc -= e & kBitsMask;
+                if ((e & kKindMask) == kKindSub) return kBad;
             }
-            const uint32_t* dsel = len ? dtab : no_match;
-            uint32_t d = dsel[bb & kDMask];
-            if (__builtin_expect((d & kKindMask) == kKindSub, 0)) {
-                const uint32_t sb = (d >> 24) & 15;
-                if (sb == 0) { ok = false; break; }
-                bb >>= kDistBits;
-                bc -= kDistBits;
-                d = dtab[((d >> 8) & 0xFFFF) + (bb & ((1u << sb) - 1))];
-                if ((d & kKindMask) != kKindVal) { ok = false; break; }
+            if ((e & kKindMask) == kKindEnd) {
+                l.bb = bb >> (e & kBitsMask);
+                l.bc = bc - (e & kBitsMask);
+                return kBlockEnded;
             }
-            const size_t dist = ((d >> 8) & 0xFFFF) + (size_t)((bb >> ((d >> 24) & 15)) & ((1u << (d >> 28)) - 1));
-            bb >>= d & kBitsMask;
-            bc -= d & kBitsMask;
-            if (__builtin_expect(dist > op, 0)) { ok = false; break; }
-            uint8_t* dst = out + op;
-            const uint8_t* src = dst - dist;
-            if (__builtin_expect(dist >= 8 || dist == 0, 1)) {
-                memcpy(dst, src, 8);
-                memcpy(dst + 8, src + 8, 8);
-                for (uint32_t k = 16; k < len; k += 8) memcpy(dst + k, src + k, 8);
-            } else if (dist == 1) {
-                memset(dst, src[0], len);
-            } else {
-                for (uint32_t k = 0; k < len; ++k) dst[k] = src[k];
-            }
-            op += len;
+            len = ((e >> 8) & 0x1FF) + (uint32_t)((bb >> ((e >> 24) & 15)) & ((1u << (e >> 28)) - 1));
+            bb >>= e & kBitsMask;
+            bc -= e & kBitsMask;
         }
-        // the refill leaves stream bytes above bit `bc`: give them back so that the buffer is exact again
-        bb &= (1ull << bc) - 1;
-        ip_ = ip;
-        op_ = op;
-        bitbuf_ = bb;
-        bitcnt_ = bc;
-        return ok;
+        const uint32_t* dsel = len ? l.dtab : kNoMatch;
+        uint32_t d = dsel[bb & kDMask];
+        if (__builtin_expect((d & kKindMask) == kKindSub, 0)) {
+            const uint32_t sb = (d >> 24) & 15;
+            if (sb == 0) return kBad;
+            bb >>= kDistBits;
+            bc -= kDistBits;
+            d = l.dtab[((d >> 8) & 0xFFFF) + (bb & ((1u << sb) - 1))];
+            if ((d & kKindMask) != kKindVal) return kBad;
+        }
+        const size_t dist = ((d >> 8) & 0xFFFF) + (size_t)((bb >> ((d >> 24) & 15)) & ((1u << (d >> 28)) - 1));
+        l.bb = bb >> (d & kBitsMask);
+        l.bc = bc - (d & kBitsMask);
+        if (__builtin_expect(dist > op, 0)) return kBad;
+        uint8_t* dst = l.out + op;
+        const uint8_t* src = dst - dist;
+        if (__builtin_expect(dist >= 8 || dist == 0, 1)) {
+            memcpy(dst, src, 8);
+            memcpy(dst + 8, src + 8, 8);
+            for (uint32_t k = 16; k < len; k += 8) memcpy(dst + k, src + k, 8);
+        } else if (dist == 1) {
+            memset(dst, src[0], len);
+        } else {
+            for (uint32_t k = 0; k < len; ++k) dst[k] = src[k];
+        }
+        l.op = op + len;
+        return kGoOn;
+    }
+    bool decode_fast() {  // after prepare() said kReadyFast
+        Lane l;
+        load(l);
+        Round r = kGoOn;
+        while (in_hand(l) && (r = round(l)) == kGoOn) {}
+        store(l, r);
+        return r != kBad;
+    }
+    static void decode_fast_pair(Stream& a, Stream& b) {
+        Lane la, lb;
+        a.load(la);
+        b.load(lb);
+        Round ra = kGoOn, rb = kGoOn;
+        while (in_hand(la) && in_hand(lb)) {
+            ra = round(la);
+            rb = round(lb);
+            if (ra | rb) break;
+        }
+        a.store(la, ra);
+        b.store(lb, rb);
     }
 
     // The first and last few bytes of a stream: one entry at a time, every read and write checked.
     bool decode_careful(size_t stop) {
         const uint32_t* lit = cur_->lit;
         constexpr uint32_t kMask = (1u << kLitBits) - 1;
-        const bool fast_possible = in_n_ >= 16 && cap_ >= 320;
         while (op_ < stop) {
-            if (fast_possible && ip_ <= in_n_ - 16 && op_ <= cap_ - 320) return true;  // the fast loop can go on
+            if (fast_possible()) return true;  // the fast loop can go on
             fill();
             uint32_t e = lit[bitbuf_ & kMask];
             if ((e & kKindMask) == kKindSub) {
@@ -584,7 +659,8 @@ class Stream {
     uint64_t bitbuf_ = 0;
     uint32_t bitcnt_ = 0;
     uint8_t* out_ = nullptr;
-    size_t cap_ = 0, op_ = 0;
+    size_t cap_ = 0, op_ = 0, stop_ = 0, target_ = 0;
+    bool to_end_ = false;
     Phase phase_ = kFailed;
     bool final_ = false;
     uint32_t stored_left_ = 0;

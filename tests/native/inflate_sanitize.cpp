@@ -75,7 +75,10 @@ static std::vector<uint8_t> make_data(std::mt19937_64& rng, size_t n) {
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 300;
     std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], nullptr, 10) : 1);
-    std::unique_ptr<svx_inflate::Stream> st(new svx_inflate::Stream());
+    std::unique_ptr<svx_inflate::Stream> st(new svx_inflate::Stream()), st2(new svx_inflate::Stream());
+    std::vector<uint8_t> prev_stream, prev_want;  // the previous case: the partner of the side-by-side run
+    bool prev_ok = false;
+    size_t prev_cap = 0, pairs = 0;
     size_t accepted = 0, refused = 0, long_codes = 0;
     static const int strategies[5] = {Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED};
     static const size_t sizes[8] = {0, 1, 7, 300, 321, 5000, 40000, 65536};
@@ -122,15 +125,36 @@ int main(int argc, char** argv) {
                     fprintf(stderr, "verdicts differ: own %d zlib %d (round %d mutation %d how %d mode %d)\n", ok, z_ok, r, m, how, mode);
                     return 1;
                 }
-                if (ok && (st->produced() != want.size() || memcmp(out.get(), want.data(), want.size()) != 0)) {
+                if (ok && (st->produced() != want.size() || (!want.empty() && memcmp(out.get(), want.data(), want.size()) != 0))) {
                     fprintf(stderr, "bytes differ (round %d mutation %d)\n", r, m);
                     return 1;
                 }
                 if (mode == 0) (ok ? accepted : refused)++;
             }
+            // the same stream decoded side by side with the previous case's: each as if alone
+            if (!prev_stream.empty() || prev_cap == 0) {
+                std::unique_ptr<uint8_t[]> in2(new uint8_t[prev_stream.size() ? prev_stream.size() : 1]);
+                if (!prev_stream.empty()) memcpy(in2.get(), prev_stream.data(), prev_stream.size());
+                std::unique_ptr<uint8_t[]> oa(new uint8_t[cap ? cap : 1]), ob(new uint8_t[prev_cap ? prev_cap : 1]);
+                st->begin(in.get(), t.size());
+                st2->begin(in2.get(), prev_stream.size());
+                bool ok_a = false, ok_b = false;
+                svx_inflate::Stream::run_pair(*st, oa.get(), cap, 0, true, &ok_a, *st2, ob.get(), prev_cap, 0, true, &ok_b);
+                if (ok_a != z_ok || ok_b != prev_ok ||
+                    (ok_a && (st->produced() != want.size() || (!want.empty() && memcmp(oa.get(), want.data(), want.size()) != 0))) ||
+                    (ok_b && (st2->produced() != prev_want.size() || (!prev_want.empty() && memcmp(ob.get(), prev_want.data(), prev_want.size()) != 0)))) {
+                    fprintf(stderr, "side by side differs from alone (round %d mutation %d)\n", r, m);
+                    return 1;
+                }
+                ++pairs;
+            }
+            prev_stream = t;
+            prev_want = want;
+            prev_ok = z_ok;
+            prev_cap = cap;
         }
         long_codes += s.size() > 100;
     }
-    printf("inflate_sanitize ok: %zu accepted, %zu refused\n", accepted, refused);
+    printf("inflate_sanitize ok: %zu accepted, %zu refused, %zu side by side\n", accepted, refused, pairs);
     return accepted > 0 && refused > 0 ? 0 : 1;
 }

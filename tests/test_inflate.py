@@ -157,6 +157,57 @@ def test_damaged_streams(seed):
     assert agree_bad > 100 and agree_ok > 5
 
 
+def inflate_pair(sa, cap_a, stop_a, sb, cap_b, stop_b):
+    lib = _lib.load()
+    oa, ob = (C.c_uint8 * max(cap_a, 1))(), (C.c_uint8 * max(cap_b, 1))()
+    na, nb, ra, rb = C.c_uint64(0), C.c_uint64(0), C.c_int(7), C.c_int(7)
+    end = 2 ** 64 - 1
+    rc = lib.svx_inflate_raw_pair(sa, len(sa), oa, cap_a, end if stop_a is None else stop_a, C.byref(na), C.byref(ra),
+                                  sb, len(sb), ob, cap_b, end if stop_b is None else stop_b, C.byref(nb), C.byref(rb))
+    assert rc == 0
+    return (ra.value, bytes(oa[: na.value])), (rb.value, bytes(ob[: nb.value]))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_two_streams_side_by_side_equal_each_alone(seed):
+    """svx_inflate_raw_pair (how svx_bam_seq_slices inflates its members): whatever the two streams are — different
+    kinds and sizes, one of them damaged, whole or up to a stop — each gets what svx_inflate_raw gives it alone."""
+    rng = np.random.default_rng(500 + seed)
+    pr = random.Random(seed)
+    pool = []
+    for size in (0, 3, 400, 5000, 65536):
+        for name, data in kinds(rng, size):
+            s = deflate(data, pr.choice([1, 6, 9]), pr.choice(STRATEGIES))
+            pool.append((s, len(data)))
+            if len(s) > 8:
+                t = bytearray(s)
+                t[pr.randrange(len(t))] ^= 1 << pr.randrange(8)
+                pool.append((bytes(t), len(data)))
+                pool.append((s[: pr.randrange(len(s))], len(data)))
+    n_bad = 0
+    for _ in range(150):
+        (sa, ca), (sb, cb) = pr.choice(pool), pr.choice(pool)
+        for stops in ((None, None), (pr.randrange(ca + 1), pr.randrange(cb + 1)), (None, pr.randrange(cb + 1))):
+            got_a, got_b = inflate_pair(sa, ca, stops[0], sb, cb, stops[1])
+            for got, s, cap, stop in ((got_a, sa, ca, stops[0]), (got_b, sb, cb, stops[1])):
+                lib = _lib.load()
+                out = (C.c_uint8 * max(cap, 1))()
+                n = C.c_uint64(0)
+                if stop is None:
+                    rc = lib.svx_inflate_raw(s, len(s), out, cap, None, 0, C.byref(n))
+                    assert got == (rc, bytes(out[: n.value]))
+                else:  # alone: run to the stop only (svx_inflate_raw would go on to the end afterwards)
+                    st = (C.c_uint64 * 1)(stop)
+                    rc = lib.svx_inflate_raw(s, len(s), out, cap, st, 1, C.byref(n))
+                    whole = bytes(out[: n.value])
+                    if got[0] == 0:
+                        assert len(got[1]) >= stop and whole[: len(got[1])] == got[1][: len(whole)]
+                    else:
+                        assert rc != 0
+                n_bad += got[0] != 0
+    assert n_bad > 20
+
+
 def test_decoder_under_sanitizers(tmp_path):
     """tests/native/inflate_sanitize.cpp: the same comparison in C++ with AddressSanitizer + UBSan and heap buffers of
     exactly the sizes the decoder is told — whole, resumed and damaged streams, thousands of cases."""

@@ -63,6 +63,20 @@ for name, grp in (("SEQ members", [s for s in spans if s[1] > 25000]), ("other m
         half[0] = isz // 2
         lib.svx_inflate_raw(b, ln, out, isz // 2 + 300, half, 1, C.byref(n))  # ends in "more than cap": only the prefix is timed
     res["own_to_half"] = (time.perf_counter() - t) / len(pick) * 1e6
+    out2 = C.create_string_buffer(65536)
+    n2, ra, rb = C.c_uint64(), C.c_int(), C.c_int()
+    END = 2 ** 64 - 1
+    t = time.perf_counter()
+    for k in range(0, len(pick) - 1, 2):
+        (_, la, ia), (_, lb, ib) = pick[k], pick[k + 1]
+        lib.svx_inflate_raw_pair(blobs[k], la, out, ia, END, C.byref(n), C.byref(ra), blobs[k + 1], lb, out2, ib, END, C.byref(n2), C.byref(rb))
+        assert ra.value == 0 and rb.value == 0
+    res["own_pair"] = (time.perf_counter() - t) / (len(pick) // 2 * 2) * 1e6
+    t = time.perf_counter()
+    for k in range(0, len(pick) - 1, 2):
+        (_, la, ia), (_, lb, ib) = pick[k], pick[k + 1]
+        lib.svx_inflate_raw_pair(blobs[k], la, out, ia, ia // 2, C.byref(n), C.byref(ra), blobs[k + 1], lb, out2, ib, ib // 2, C.byref(n2), C.byref(rb))
+    res["own_pair_to_half"] = (time.perf_counter() - t) / (len(pick) // 2 * 2) * 1e6
     for b, (_, ln, isz) in list(zip(blobs, pick))[:100]:
         lib.svx_inflate_raw(b, ln, out, isz, None, 0, C.byref(n))
         assert out.raw[:isz] == zlib.decompress(b, -15)
