@@ -594,9 +594,9 @@ def collect_tables(bams, options, ctx=None):
     """CandidateTable of every bam in `bams` (the two haplotypes of a diploid sample): one device submission
     for all of them when their reference dictionaries agree."""
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
-    tl = time.perf_counter()
+    tl, cl = time.perf_counter(), time.process_time()
     _load_together(bams)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     samples = [_prepare(bam, options) for bam in bams]
     t1 = time.perf_counter()
     groups = [samples] if _same_header(bams) else [[s] for s in samples]
@@ -605,8 +605,10 @@ def collect_tables(bams, options, ctx=None):
     t2 = time.perf_counter()
     for s in samples:   # starts every sample's sequence decoding (the readers' threads) before waiting for any
         _table_of(s, options)
-    t3 = time.perf_counter()
-    LAST_TIMING.update(load_s=t0 - tl, prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=0.0)
+    t3, c3 = time.perf_counter(), time.process_time()
+    # (…_cpu_s: CPU seconds of all threads of the process — what a run costs under a CPU quota)
+    LAST_TIMING.update(load_s=t0 - tl, prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=0.0,
+                       load_cpu_s=c0 - cl, submit_and_tables_cpu_s=c3 - c0)
     tables = [_pending_sequences(s) for s in samples]
     # The pool could stay pending until PAIR builds its byte pool (SVX_LAZY_SEQS=1: the decoding then runs beside
     # PAIR's keys, sort, windows and recipes).  Measured, interleaved on one box, four pairs of five runs: medians
@@ -615,6 +617,7 @@ def collect_tables(bams, options, ctx=None):
     if not os.environ.get("SVX_LAZY_SEQS"):
         for t in tables:
             t.seqs
+        LAST_TIMING["sequences_cpu_s"] = time.process_time() - c3
     return tables
 
 

@@ -280,9 +280,22 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
 LAST_TIMING = {}  # seconds per stage of the latest pair_tables / vcf_body call (tools/, bench legs)
 
 
+_cpu_mark = [0.0]
+
+
+def _clock_start():
+    _cpu_mark[0] = time.process_time()
+    return time.perf_counter()
+
+
 def _clock(stage, t0):
-    now = time.perf_counter()
+    """Wall seconds of a stage, and beside them (`…_cpu_s`) the CPU seconds of all threads of the process: under a
+    CPU quota (cgroup cpu.max) those, not the thread count, are what a run costs."""
+    now, cpu = time.perf_counter(), time.process_time()
     LAST_TIMING[stage] = LAST_TIMING.get(stage, 0.0) + now - t0
+    key = stage[:-2] + "_cpu_s" if stage.endswith("_s") else stage + "_cpu"
+    LAST_TIMING[key] = LAST_TIMING.get(key, 0.0) + cpu - _cpu_mark[0]
+    _cpu_mark[0] = cpu
     return now
 
 
@@ -291,7 +304,7 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
     for k in [k for k in LAST_TIMING if k.startswith("pair_")]:
         del LAST_TIMING[k]
-    tc = time.perf_counter()
+    tc = _clock_start()
     base_bam = getattr(bam, "_bam", bam)
     contigs = list(base_bam.references)
     T = CandidateTable.concat([t1, t2], contigs, [base_bam.get_reference_length(c) for c in contigs])
@@ -605,7 +618,7 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
     t = table
     for k in [k for k in LAST_TIMING if k.startswith("vcf_")]:
         del LAST_TIMING[k]
-    tc = time.perf_counter()
+    tc = _clock_start()
     rows_of = lambda ti: np.flatnonzero(t.type == ti)
     kinds, rows = [], []
 

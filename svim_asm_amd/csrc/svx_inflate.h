@@ -592,15 +592,17 @@ class Stream {
         l.op = op + len;
         return kGoOn;
     }
-    bool decode_fast() {  // after prepare() said kReadyFast
+    // The loops themselves, compiled twice: for the baseline x86-64 and with BMI1/2 (shifts that take their count from
+    // any register, bzhi: about a tenth fewer instructions per round), chosen once at run time.
+    static inline __attribute__((always_inline)) bool fast_loop(Stream& s) {
         Lane l;
-        load(l);
+        s.load(l);
         Round r = kGoOn;
         while (in_hand(l) && (r = round(l)) == kGoOn) {}
-        store(l, r);
+        s.store(l, r);
         return r != kBad;
     }
-    static void decode_fast_pair(Stream& a, Stream& b) {
+    static inline __attribute__((always_inline)) void fast_loop_pair(Stream& a, Stream& b) {
         Lane la, lb;
         a.load(la);
         b.load(lb);
@@ -612,6 +614,27 @@ class Stream {
         }
         a.store(la, ra);
         b.store(lb, rb);
+    }
+#if defined(__x86_64__)
+    __attribute__((target("bmi,bmi2"))) static bool fast_loop_bmi2(Stream& s) { return fast_loop(s); }
+    __attribute__((target("bmi,bmi2"))) static void fast_loop_pair_bmi2(Stream& a, Stream& b) { fast_loop_pair(a, b); }
+    static bool have_bmi2() {
+        static const bool yes = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+        return yes;
+    }
+#else
+    static bool fast_loop_bmi2(Stream& s) { return fast_loop(s); }
+    static void fast_loop_pair_bmi2(Stream& a, Stream& b) { fast_loop_pair(a, b); }
+    static bool have_bmi2() { return false; }
+#endif
+    static bool fast_loop_base(Stream& s) { return fast_loop(s); }
+    static void fast_loop_pair_base(Stream& a, Stream& b) { fast_loop_pair(a, b); }
+    bool decode_fast() {  // after prepare() said kReadyFast
+        return have_bmi2() ? fast_loop_bmi2(*this) : fast_loop_base(*this);
+    }
+    static void decode_fast_pair(Stream& a, Stream& b) {
+        if (have_bmi2()) fast_loop_pair_bmi2(a, b);
+        else fast_loop_pair_base(a, b);
     }
 
     // The first and last few bytes of a stream: one entry at a time, every read and write checked.

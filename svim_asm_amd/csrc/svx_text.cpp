@@ -93,19 +93,18 @@ static bool fetch_one(const svx_fasta* fa, int32_t ref, int64_t start, int64_t e
         if (r <= 0) return false;
         got += (size_t)r;
     }
-    int64_t pos = start;
+    if (upper)  // one pass over everything read (a line end stays what it is), instead of a short loop per line
+        for (size_t i = 0; i < n; ++i) raw[i] = ascii_upper(raw[i]);
     const uint8_t* src = raw.data();
-    while (pos < end) {
-        const int64_t in_line = pos % lb;
-        const int64_t take = std::min<int64_t>(lb - in_line, end - pos);
-        if (upper) {
-            for (int64_t i = 0; i < take; ++i) dst[i] = ascii_upper(src[i]);
-        } else {
-            memcpy(dst, src, (size_t)take);
-        }
+    int64_t left = end - start;
+    int64_t take = std::min<int64_t>(lb - start % lb, left);  // the rest of the first line, then whole lines
+    for (;;) {
+        memcpy(dst, src, (size_t)take);
         dst += take;
-        pos += take;
-        src += take + (pos < end ? lw - lb : 0);  // over the line end
+        left -= take;
+        if (left <= 0) break;
+        src += take + (lw - lb);  // over the line end
+        take = std::min<int64_t>(lb, left);
     }
     return true;
 }
