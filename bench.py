@@ -434,6 +434,8 @@ def e2e_leg(scale, local_rank, n_devices=1):
             "phases_s": {k: best[k] for k in ("open_index_s", "collect_s", "pair_s", "vcf_s")},
             "collect_stages_s": best.get("collect_stages_s"),  # load_s: the record walks of both BAMs; sequences_wait_s: what PAIR still
             # waited for the inflate of the inserted alleles, which starts in COLLECT and runs beside PAIR's set-up
+            "cpu_seconds": best.get("cpu_seconds"),  # CPU seconds of all threads per phase, and beside them
+            "cpu_quota_cpus": r.get("cpu_quota_cpus"),  # the CPUs the box's cgroup grants per period: their quotient bounds wall_s
             "command_line_wall_s": r.get("cli_wall_s"),  # `svim-asm diploid` as a fresh process: interpreter + HIP start-up included
             "inputs_match_real_reference_run": r.get("inputs_match_real_reference_run"),
             "vcf_matches_real_reference_digest": r.get("vcf_matches_real_reference_digest"),
