@@ -116,6 +116,9 @@ def cpu_baseline(batch, args):
             dtm = time.perf_counter() - t0
         out["all_cores_value"] = n_ops * reps_mt / dtm
         out["all_cores"] = len(shards)
+        from tools.e2e_bench import cpu_quota
+        out["cpu_quota_cpus"] = cpu_quota()  # not None: the cgroup grants that many CPUs per period, however many
+        # threads run — "all_cores_value" is then the rate of that many cores (16 on the GPU pool: 15x the one-core rate)
     except Exception as e:
         out["all_cores_error"] = repr(e)
     # CPython restatement of the same loop (what the reference actually executes), small sample
