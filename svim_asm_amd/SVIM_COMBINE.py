@@ -155,15 +155,17 @@ def span_position_distance_breakends(candidate1, candidate2):
 
 
 # ------------------------------------------------------------------------------ reference windows
-def _fetch_windows(reference, contigs, lo, hi, upper):
-    """reference.fetch(contigs[i], lo[i], hi[i]) for all i: (uint8 pool, int64 offsets).  One native batch
-    for the product's FastaFile; any object with pysam's fetch() otherwise."""
+def _fetch_windows(reference, names, ids, lo, hi, upper):
+    """reference.fetch(names[ids[i]], lo[i], hi[i]) for all i: (uint8 pool, int64 offsets).  One native batch
+    for the product's FastaFile (contig ids go down as they are: no list of 10^5 names); any object with pysam's
+    fetch() otherwise."""
+    ids = np.asarray(ids)
     batch = getattr(reference, "fetch_batch", None)
     if batch is not None:
-        return batch(contigs, lo, hi, upper=upper)
+        return batch(names, lo, hi, upper=upper, ids=ids)
     parts = []
-    for c, a, b in zip(contigs, np.asarray(lo).tolist(), np.asarray(hi).tolist()):
-        s = reference.fetch(c, a, b)
+    for c, a, b in zip(ids.tolist(), np.asarray(lo).tolist(), np.asarray(hi).tolist()):
+        s = reference.fetch(names[c], a, b)
         parts.append((s.upper() if upper else s).encode("latin-1"))
     off = np.zeros(len(parts) + 1, np.int64)
     if parts:
@@ -237,7 +239,7 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
         cand = np.unique(np.concatenate((job_a[dint], job_b[dint])))
         Ls = _reference_lengths(reference, T.contigs, T.sc[cand])[T.sc[cand]]
         n_src = np.maximum(0, np.minimum(T.se[cand], Ls) - T.ss[cand])
-        pool, off = _fetch_windows(reference, [T.contigs[c] for c in T.sc[cand].tolist()], T.ss[cand], T.se[cand], False)
+        pool, off = _fetch_windows(reference, T.contigs, T.sc[cand], T.ss[cand], T.se[cand], False)
         if not np.array_equal(off[1:] - off[:-1], n_src):
             raise ValueError("reference windows shorter than the index says")
         extra_parts.append(pool)
@@ -377,7 +379,7 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
         wlo = np.maximum(0, seg_lo - 100)
         whi = np.minimum(L_part[wp], seg_hi + 100)
         tc = _clock("pair_windows_plan_s", tc)
-        pool_w, off_w = _fetch_windows(reference, [T.contigs[c] for c in p_contig[wp].tolist()], wlo, np.maximum(whi, wlo), False)
+        pool_w, off_w = _fetch_windows(reference, T.contigs, p_contig[wp], wlo, np.maximum(whi, wlo), False)
         tc = _clock("pair_windows_fetch_s", tc)
         if not np.array_equal(off_w[1:] - off_w[:-1], np.maximum(whi - wlo, 0)):
             raise ValueError("reference windows shorter than the index says")
@@ -665,7 +667,7 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
         f_lo = np.concatenate((lo[w], ss[w2]))
         f_hi = np.concatenate((hi[w], se[w2]))
         tc = _clock("vcf_entries_s", tc)
-        bases, off = _fetch_windows(reference, [t.contigs[c] for c in f_cid.tolist()], f_lo, f_hi, True)
+        bases, off = _fetch_windows(reference, t.contigs, f_cid, f_lo, f_hi, True)
         tc = _clock("vcf_fetch_s", tc)
         b_off, b_len = np.zeros(ne, np.int64), np.zeros(ne, np.int64)
         b2_off, b2_len = np.zeros(ne, np.int64), np.zeros(ne, np.int64)

@@ -52,12 +52,22 @@ class FastaFile(object):
                 self._ref_index.setdefault(name, i)
         return self._native
 
-    def fetch_batch(self, contigs, start, end, upper=True):
+    def fetch_batch(self, contigs, start, end, upper=True, ids=None):
         """fetch(contigs[i], start[i], end[i]) for all i in one native call (threads, no str objects):
-        (uint8 pool, int64 offsets [n + 1]); `upper` applies str.upper() to every slice."""
+        (uint8 pool, int64 offsets [n + 1]); `upper` applies str.upper() to every slice.  With `ids`, interval i
+        lies on contigs[ids[i]] (a table's contig names and its id column: names are looked up once each)."""
         lib, h = self._handle()
-        n = len(contigs)
-        ref = np.fromiter((self._ref_index[c] for c in contigs), dtype=np.int32, count=n)
+        if ids is not None:
+            ids = np.asarray(ids, dtype=np.int64)
+            n = len(ids)
+            used = np.unique(ids) if n else ids
+            table = np.full(len(contigs), -1, dtype=np.int32)
+            for c in used.tolist():
+                table[c] = self._ref_index[contigs[c]]   # KeyError for a contig the FASTA does not have, as fetch()
+            ref = np.ascontiguousarray(table[ids])
+        else:
+            n = len(contigs)
+            ref = np.fromiter((self._ref_index[c] for c in contigs), dtype=np.int32, count=n)
         start = np.ascontiguousarray(start, dtype=np.int64)
         end = np.ascontiguousarray(end, dtype=np.int64)
         if n and (bool((start < 0).any()) or bool((end < start).any())):

@@ -153,8 +153,13 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
         _lib.default_context(device)  # context creation / first touch outside the timed region
         runs = []
         import gc
-        for _ in range(max(1, repeat)):
+        for rep_no in range(max(1, repeat)):
             r = {}
+            prof = None
+            if os.environ.get("SVX_E2E_PROFILE") and rep_no == max(1, repeat) - 1:  # cProfile of the last repeat (main thread)
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
             gc.collect()
             gc.disable()  # as cli._run does for the whole command
             t_all = time.perf_counter()
@@ -191,6 +196,10 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             r["collect_stages_s"] = dict(SVIM_COLLECT.LAST_TIMING)
             r["product_total_s"] = time.perf_counter() - t_all
             gc.enable()
+            if prof is not None:
+                import pstats
+                prof.disable()
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
             runs.append(r)
         res["cpu_quota_cpus"] = cpu_quota()
         res.update(runs[0])
