@@ -17,7 +17,8 @@
  * over), plus the blocks of the base ranges later requested with svx_bam_seq_slices.
  * Inflate = the build's own DEFLATE decoder (svx_inflate_raw below; SVX_BAM_ZLIB=1: zlib); a member's CRC32 is
  * checked whenever the member is inflated to its end (svx_bam_set_verify: always).
- * With a `.bai` next to the BAM (the reference requires one, svim-asm:67-72) every bin
+ * With a `.bai` or a `.csi` next to the BAM — `<file>.bai`, `<stem>.bai`, `<file>.csi`, `<stem>.csi`, in htslib's
+ * order (the reference requires an index, svim-asm:67-72; pysam takes either kind) — every bin
  * chunk boundary and linear-index entry is a record boundary: the file is cut there and
  * the pieces are walked by `n_threads` host threads; the per-contig chunk ranges restrict
  * the walk to the contigs a rank owns (contig sharding).  Without a usable

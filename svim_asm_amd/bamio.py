@@ -541,8 +541,8 @@ class AlignmentFile(object):
         if self._h is not None:
             return int(self._lib.svx_bam_index_state(self._h))
         base = self.filename
-        return 2 if (os.path.exists(base + ".bai") or os.path.exists(base + ".csi") or
-                     os.path.exists(os.path.splitext(base)[0] + ".bai")) else 0
+        stem = os.path.splitext(base)[0]
+        return 2 if any(os.path.exists(p) for p in (base + ".bai", stem + ".bai", base + ".csi", stem + ".csi")) else 0
 
     def contig_spans(self):
         """Compressed bytes per contig from the index (None without a usable one)."""
@@ -977,9 +977,68 @@ def write_bam(path, references, lengths, record_blobs, sort_order="coordinate", 
             fh.write(build_bai(len(references), tid, beg, end, flag, vo, ve))
 
 
-def index_bam(path, out=None):
-    """`samtools index` for the files this package reads: walk the records once (native reader,
-    sequential without an index) and write `<path>.bai`."""
+def _reg2bin_csi(beg, end, min_shift, depth):
+    """CSI v1 specification, reg2bin for an index of `depth` levels above `min_shift`-bit leaves."""
+    end -= 1
+    s, t = min_shift, ((1 << depth * 3) - 1) // 7
+    for l in range(depth, 0, -1):
+        if beg >> s == end >> s:
+            return t + (beg >> s)
+        s += 3
+        t -= 1 << ((l - 1) * 3)
+    return 0
+
+
+def build_csi(n_ref, tid, beg, end, flag, voff, voff_end, min_shift=14, depth=5):
+    """Bytes of a `.csi` (CSI v1; what `samtools index -c` writes) for records given in file order: per sequence the
+    bins with their chunks and `loffset` (virtual offset of the first record that overlaps the bin), the metadata
+    pseudo-bin, then the count of unplaced reads; BGZF-compressed."""
+    out = [b"CSI\x01", struct.pack("<iii", min_shift, depth, 0), struct.pack("<i", n_ref)]
+    tid = np.asarray(tid, dtype=np.int64)
+    meta = ((1 << (depth + 1) * 3) - 1) // 7 + 1
+    for r in range(n_ref):
+        idx = np.nonzero(tid == r)[0]
+        if len(idx) == 0:
+            out.append(struct.pack("<i", 0))
+            continue
+        bins, order, loff, last_bin = {}, [], {}, None
+        n_mapped = n_unmapped = 0
+        for i in idx.tolist():
+            b, e = max(int(beg[i]), 0), max(int(end[i]), 1)
+            bn = _reg2bin_csi(b, e, min_shift, depth)
+            if bn == last_bin:
+                bins[bn][-1][1] = int(voff_end[i])
+            else:
+                if bn not in bins:
+                    bins[bn] = []
+                    order.append(bn)
+                bins[bn].append([int(voff[i]), int(voff_end[i])])
+            last_bin = bn
+            # every bin the record overlaps, on every level, learns the first record that reaches into it
+            s, t = min_shift, ((1 << depth * 3) - 1) // 7
+            for l in range(depth, -1, -1):
+                for k in range(b >> s, ((e - 1) >> s) + 1):
+                    loff.setdefault(t + k, int(voff[i]))
+                s += 3
+                t -= 1 << ((l - 1) * 3) if l > 0 else 0
+            if int(flag[i]) & 4:
+                n_unmapped += 1
+            else:
+                n_mapped += 1
+        out.append(struct.pack("<i", len(order) + 1))
+        for bn in order:
+            out.append(struct.pack("<IQi", bn, loff.get(bn, 0), len(bins[bn])))
+            for cb, ce in bins[bn]:
+                out.append(struct.pack("<QQ", cb, ce))
+        out.append(struct.pack("<IQi", meta, 0, 2))
+        out.append(struct.pack("<QQQQ", int(voff[idx[0]]), int(voff_end[idx[-1]]), n_mapped, n_unmapped))
+    out.append(struct.pack("<Q", int((tid < 0).sum())))
+    return bgzf_compress(b"".join(out), 6)
+
+
+def index_bam(path, out=None, csi=False, min_shift=14, depth=5):
+    """`samtools index` (csi=True: `samtools index -c`) for the files this package reads: walk the records once
+    (native reader, sequential without an index) and write `<path>.bai` / `<path>.csi`."""
     f = AlignmentFile(path, reader="native")
     # ignore whatever index is there: virtual offsets come from the walk itself
     c = f.load(None)._cols
@@ -992,11 +1051,15 @@ def index_bam(path, out=None):
     ve = np.concatenate((vo[1:], [np.uint64(eof_at << 16)])) if n else vo
     unmapped = (c["flag"] & 4) != 0
     rl = np.where((c["ref_len"] > 0) & ~unmapped, c["ref_len"], 1)
-    data = build_bai(len(f.references), c["tid"], c["pos"], c["pos"] + rl, c["flag"], vo, ve)
+    if csi:
+        data = build_csi(len(f.references), c["tid"], c["pos"], c["pos"] + rl, c["flag"], vo, ve, min_shift, depth)
+    else:
+        data = build_bai(len(f.references), c["tid"], c["pos"], c["pos"] + rl, c["flag"], vo, ve)
     f.close()
-    with open(out or (path + ".bai"), "wb") as fh:
+    out = out or (path + (".csi" if csi else ".bai"))
+    with open(out, "wb") as fh:
         fh.write(data)
-    return out or (path + ".bai")
+    return out
 
 
 if __name__ == "__main__":

@@ -533,6 +533,73 @@ bool parse_bai(const std::vector<uint8_t>& d, int32_t n_ref_expected, std::vecto
     return true;
 }
 
+// `.csi` (the coordinate-sorted index htslib writes with `samtools index -c`, needed for contigs above 512 Mbp; CSI v1
+// specification): a BGZF file of its own — magic, min_shift, depth, auxiliary bytes, then per sequence the bins with
+// a `loffset` each (no linear index).  Gives the same thing a `.bai` does here: record boundaries.
+bool inflate_all(const std::vector<uint8_t>& raw, std::vector<uint8_t>* out) {
+    Inflater inf;
+    uint64_t coff = 0;
+    out->clear();
+    for (;;) {
+        Blk blk;
+        const int rc = parse_block(raw.data(), raw.size(), coff, &blk);
+        if (rc == 1) return true;
+        if (rc < 0 || out->size() + blk.isize > (512u << 20)) return false;
+        const size_t at = out->size();
+        out->resize(at + blk.isize);
+        if (blk.isize && !inf.run(raw.data() + coff + blk.payload_off, blk.payload_len, out->data() + at, blk.isize, blk.crc))
+            return false;
+        coff += blk.bsize;
+    }
+}
+
+bool parse_csi(const std::vector<uint8_t>& raw, int32_t n_ref_expected, std::vector<RefIndex>* refs) {
+    std::vector<uint8_t> d;
+    if (!inflate_all(raw, &d)) return false;
+    const size_t n = d.size();
+    if (n < 16 || memcmp(d.data(), "CSI\1", 4) != 0) return false;
+    const int32_t min_shift = (int32_t)le32(d.data() + 4), depth = (int32_t)le32(d.data() + 8), l_aux = (int32_t)le32(d.data() + 12);
+    if (min_shift < 0 || min_shift > 31 || depth < 0 || depth > 10 || l_aux < 0 || 16ull + (uint64_t)l_aux + 4 > n) return false;
+    size_t p = 16 + (size_t)l_aux;
+    const int32_t n_ref = (int32_t)le32(d.data() + p);
+    p += 4;
+    if (n_ref != n_ref_expected) return false;
+    const uint64_t meta_bin = ((1ull << ((depth + 1) * 3)) - 1) / 7 + 1;  // metadata pseudo-bin
+    refs->assign(n_ref, RefIndex());
+    for (int32_t r = 0; r < n_ref; ++r) {
+        RefIndex& R = (*refs)[r];
+        if (p + 4 > n) return false;
+        const int32_t n_bin = (int32_t)le32(d.data() + p);
+        p += 4;
+        if (n_bin < 0) return false;
+        std::vector<uint64_t> first_overlaps;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 16 > n) return false;
+            const uint32_t bin = le32(d.data() + p);
+            const uint64_t loffset = le64(d.data() + p + 4);
+            const int32_t n_chunk = (int32_t)le32(d.data() + p + 12);
+            p += 16;
+            if (n_chunk < 0 || p + 16ull * n_chunk > n) return false;
+            for (int32_t k = 0; k < n_chunk; ++k) {
+                const uint64_t beg = le64(d.data() + p), end = le64(d.data() + p + 8);
+                p += 16;
+                if (bin == meta_bin) continue;
+                if (end < beg) return false;
+                R.points.push_back(beg);
+                R.points.push_back(end);
+                R.lo = std::min(R.lo, beg);
+                R.hi = std::max(R.hi, end);
+            }
+            if (bin != meta_bin && loffset) first_overlaps.push_back(loffset);
+        }
+        for (uint64_t v : first_overlaps)  // the first record overlapping a bin: a record boundary of this sequence
+            if (v >= R.lo && v <= R.hi) R.points.push_back(v);
+        std::sort(R.points.begin(), R.points.end());
+        R.points.erase(std::unique(R.points.begin(), R.points.end()), R.points.end());
+    }
+    return true;
+}
+
 template <typename T>
 T* dup_array(const std::vector<T>& v) {
     T* p = static_cast<T*>(malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
@@ -718,15 +785,20 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out, char
     b->first_record = c.tell();
     b->blocks_inflated += inf.n_blocks;
     // ---- index
-    const std::string p1 = b->path + ".bai";
-    std::string p2 = b->path;
-    const size_t dot = p2.rfind('.');
-    if (dot != std::string::npos) p2 = p2.substr(0, dot) + ".bai";
-    std::string bai = file_exists(p1) ? p1 : (file_exists(p2) ? p2 : "");
-    if (!bai.empty()) {
+    // <file>.bai, <file without .bam>.bai, then the same two names with .csi (htslib's order)
+    std::string stem = b->path;
+    const size_t dot = stem.rfind('.');
+    if (dot != std::string::npos) stem = stem.substr(0, dot);
+    std::string bai, csi;
+    for (const std::string& cand : {b->path + ".bai", stem + ".bai"})
+        if (bai.empty() && file_exists(cand)) bai = cand;
+    for (const std::string& cand : {b->path + ".csi", stem + ".csi"})
+        if (csi.empty() && file_exists(cand)) csi = cand;
+    if (!bai.empty() || !csi.empty()) {
         b->index_state = 2;
         std::vector<uint8_t> d;
-        if (read_file(bai, &d) && parse_bai(d, n_ref, &b->refs)) {
+        if (!bai.empty() ? (read_file(bai, &d) && parse_bai(d, n_ref, &b->refs))
+                         : (read_file(csi, &d) && parse_csi(d, n_ref, &b->refs))) {
             // consistent with the file?  every point must address a member inside the file, and
             // the first placed record of the file must be the lowest indexed position
             bool good = true, any = false;

@@ -106,7 +106,10 @@ int main(int argc, char** argv) {
         const std::string path = argv[a];
         if (walk(path.c_str(), 3, true) != 0) { fprintf(stderr, "well-formed file refused: %s\n", path.c_str()); return 1; }
         if (walk(path.c_str(), 1, false) != 0) return 1;
-        const std::vector<uint8_t> good = slurp(path), bai = slurp(path + ".bai");
+        // (a file that comes with a .csi instead of a .bai: the same treatment for that index)
+        const bool has_bai = !slurp(path + ".bai").empty();
+        const std::string ext = has_bai ? ".bai" : ".csi";
+        const std::vector<uint8_t> good = slurp(path), bai = slurp(path + ext);
         for (int m = 0; m < n_mut && !good.empty(); ++m) {
             std::vector<uint8_t> bad = good;
             const uint64_t kind = next() % 5;
@@ -129,7 +132,8 @@ int main(int argc, char** argv) {
             std::vector<uint8_t> bad_bai = bai;   // the index next to it: intact, damaged or absent
             const uint64_t ik = next() % 3;
             if (ik == 1 && !bad_bai.empty()) for (int k = 0; k < 3; ++k) bad_bai[next() % bad_bai.size()] = (uint8_t)next();
-            if (ik == 2 || bad_bai.empty()) remove((p + ".bai").c_str()); else spill(p + ".bai", bad_bai);
+            remove((p + (has_bai ? ".csi" : ".bai")).c_str());
+            if (ik == 2 || bad_bai.empty()) remove((p + ext).c_str()); else spill(p + ext, bad_bai);
             (walk(p.c_str(), 1 + (int)(next() % 4), (next() & 1) != 0) ? refused : read)++;
         }
     }

@@ -277,3 +277,34 @@ def test_decoding_against_samtools_own_text_rendering(reader):
             assert not a.has_tag("SA")
         if "NM" in tags:
             assert int(a.get_tag("NM")) == int(tags["NM"])
+
+
+@pytest.mark.parametrize("min_shift,depth", [(14, 5), (14, 6), (12, 4), (16, 3)])
+def test_csi_index_serves_like_a_bai(dataset, tmp_path, min_shift, depth):
+    """A `.csi` (CSI v1, `samtools index -c`) next to the BAM instead of a `.bai`: usable (index_state 1), same
+    records from the parallel walk, per-contig loads and contig spans work; a damaged one is ignored."""
+    d, bams = dataset
+    p = str(tmp_path / "x.bam")
+    shutil.copy(bams[0], p)
+    bamio.index_bam(p, csi=True, min_shift=min_shift, depth=depth)
+    assert os.path.exists(p + ".csi") and not os.path.exists(p + ".bai")
+    f = bamio.AlignmentFile(p)
+    assert f.index_state() == 1 and f.check_index()
+    ref = bamio.AlignmentFile(bams[0])
+    assert_same_columns(ref, f)
+    assert f.contig_spans() is not None and list(f.contig_spans() > 0) == list(ref.contig_spans() > 0)
+    one = bamio.AlignmentFile(p).load([f.references[1]])
+    want = ref._cols["tid"] == 1
+    assert len(one) == int(want.sum()) and np.array_equal(one._cols["pos"], ref._cols["pos"][want])
+    # `<stem>.csi` is found too; a `.bai` wins when both are there
+    q = str(tmp_path / "y.bam")
+    shutil.copy(bams[0], q)
+    shutil.copy(p + ".csi", str(tmp_path / "y.csi"))
+    assert bamio.AlignmentFile(q).index_state() == 1
+    # damaged: truncated, and with a flipped byte in its compressed payload
+    raw = open(p + ".csi", "rb").read()
+    for bad in (raw[: len(raw) // 2], raw[:40] + bytes([raw[40] ^ 0x55]) + raw[41:]):
+        open(p + ".csi", "wb").write(bad)
+        g = bamio.AlignmentFile(p)
+        assert g.index_state() == 2
+        assert_same_columns(ref, g)

@@ -50,6 +50,22 @@ def test_reader_is_clean_on_fixtures_and_their_damaged_copies(driver, tmp_path):
     assert " read," in out
 
 
+def test_reader_is_clean_with_csi_indices_and_their_damaged_copies(driver, tmp_path):
+    """The same with a `.csi` (BGZF-compressed CSI v1) as the index: intact, with random bytes in it, absent."""
+    import shutil as sh
+    from svim_asm_amd import bamio
+    files = []
+    for k, name in enumerate(("hap1.bam", "hap2.bam")):
+        p = str(tmp_path / ("c%d.bam" % k))
+        sh.copy(os.path.join(GOLD, "config1", name), p)
+        bamio.index_bam(p, csi=True, min_shift=14 - 2 * k, depth=5 + k)
+        files.append(p)
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    out = _run(driver, scratch, 120, files)
+    assert " read," in out
+
+
 def test_reader_is_clean_on_long_cigar_records_and_their_damaged_copies(driver, tmp_path):
     """Records of > 65 535 CIGAR operations (CG:B,I form) that span many BGZF blocks, with a real .bai."""
     from svim_asm_amd import synth_bam
