@@ -851,7 +851,7 @@ def _reg2bin(beg, end):
 
 def encode_record(qname, flag, tid, pos, mapq, cigar_words, seq, tags=None, seq_packed=None, l_seq=None):
     """One BAM alignment record (block_size prefix included).  `tags`: list of (tag, type, value)
-    with type 'Z' or 'i'.  A CIGAR of more than 65535 operations does not fit the 16-bit
+    with any SAM aux type (A c C s S i I f d Z H, and B as (subtype, values)).  A CIGAR of more than 65535 operations does not fit the 16-bit
     n_cigar_op field: it is stored as the CG:B,I array behind the placeholder `<l_seq>S<ref_len>N`
     (SAM spec §4.2.2), as samtools/htslib write it."""
     cw = np.ascontiguousarray(cigar_words, dtype="<u4")
@@ -867,6 +867,16 @@ def encode_record(qname, flag, tid, pos, mapq, cigar_words, seq, tags=None, seq_
             aux += tag.encode() + b"Z" + val.encode() + b"\x00"
         elif typ == "i":
             aux += tag.encode() + b"i" + struct.pack("<i", val)
+        elif typ == "A":
+            aux += tag.encode() + b"A" + val.encode()[:1]
+        elif typ == "H":
+            aux += tag.encode() + b"H" + val.encode() + b"\x00"
+        elif typ in _AUX_FMT:     # c C s S I f d
+            aux += tag.encode() + typ.encode() + struct.pack(_AUX_FMT[typ][0], val)
+        elif typ == "B":          # val = (subtype, values)
+            sub, vals = val
+            aux += tag.encode() + b"B" + sub.encode() + struct.pack("<i", len(vals)) + \
+                struct.pack("<%d%s" % (len(vals), _AUX_FMT[sub][0][1]), *vals)
         else:
             raise ValueError("unsupported aux type " + typ)
     stored = cw

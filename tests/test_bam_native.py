@@ -308,3 +308,38 @@ def test_csi_index_serves_like_a_bai(dataset, tmp_path, min_shift, depth):
         g = bamio.AlignmentFile(p)
         assert g.index_state() == 2
         assert_same_columns(ref, g)
+
+
+def test_sa_tag_among_every_other_aux_type(tmp_path):
+    """Records whose SA tag sits before, between and behind tags of every other aux type (A c C s S i I f d Z H and B
+    arrays of each subtype, empty and long ones): both readers find the same SA string, keep the same raw tag bytes,
+    and an array named CG is only taken for a CIGAR where the SAM specification says so."""
+    rng = np.random.default_rng(5)
+    names, lengths = ["chr1", "chr2"], [50000, 30000]
+    others = [("NM", "i", 17), ("XA", "A", "x"), ("Xc", "c", -5), ("XC", "C", 200), ("Xs", "s", -3000), ("XS", "S", 60000),
+              ("XI", "I", 4000000000), ("Xf", "f", 1.5), ("Xd", "d", 2.25), ("MD", "Z", "10A5^AC6"), ("XH", "H", "1AE301"),
+              ("B0", "B", ("c", [])), ("B1", "B", ("C", [1, 2, 255])), ("B2", "B", ("s", [-1, 300])),
+              ("B3", "B", ("S", list(range(300)))), ("B4", "B", ("i", [-7])), ("B5", "B", ("I", [1 << 31])),
+              ("B6", "B", ("f", [0.5, -2.0])), ("CG", "B", ("I", [(40 << 4) | 0, (3 << 4) | 1]))]
+    blobs, want_sa = [], []
+    for i in range(60):
+        tags = [others[k] for k in rng.permutation(len(others))[: int(rng.integers(0, len(others) + 1))]]
+        sa = None
+        if i % 3:
+            sa = "chr2,%d,%s,20M30S,60,1;" % (100 + i, "+-"[i % 2])
+            tags.insert(int(rng.integers(0, len(tags) + 1)), ("SA", "Z", sa))
+        want_sa.append(sa)
+        seq = "".join("ACGT"[b] for b in rng.integers(0, 4, 50))
+        blobs.append(bamio.encode_record("r%d" % i, 0, 0, 100 + 37 * i, 60, [(50 << 4) | 0], seq, tags=tags))
+    p = str(tmp_path / "aux.bam")
+    bamio.write_bam(p, names, lengths, blobs)
+    nat, py = bamio.AlignmentFile(p), bamio.AlignmentFile(p, reader="python")
+    assert_same_columns(py, nat)
+    for i, sa in enumerate(want_sa):
+        r = nat.record(i)
+        assert (r.get_tag("SA") if r.has_tag("SA") else None) == sa
+        assert r.cigartuples == [(0, 50)]          # the CG array is not a CIGAR here: the stored one is no placeholder
+        if r.has_tag("B3"):
+            assert r.get_tag("B3") == list(range(300))
+        if r.has_tag("Xd"):
+            assert r.get_tag("Xd") == 2.25
