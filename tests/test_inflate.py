@@ -228,3 +228,51 @@ def test_decoder_under_sanitizers(tmp_path):
     for seed in (1, 2):
         res = subprocess.run([exe, "500", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert res.returncode == 0 and "inflate_sanitize ok" in res.stdout, res.stdout[-3000:]
+
+
+def _libdeflate():
+    try:
+        L = C.CDLL("libdeflate.so.0")
+    except OSError:
+        return None
+    L.libdeflate_alloc_compressor.restype = C.c_void_p
+    L.libdeflate_alloc_compressor.argtypes = [C.c_int]
+    L.libdeflate_deflate_compress.restype = C.c_size_t
+    L.libdeflate_deflate_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.libdeflate_deflate_compress_bound.restype = C.c_size_t
+    L.libdeflate_deflate_compress_bound.argtypes = [C.c_void_p, C.c_size_t]
+    L.libdeflate_free_compressor.argtypes = [C.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 5, 6, 9, 12])
+def test_streams_written_by_libdeflate(level):
+    """htslib is usually built with libdeflate, whose compressor splits blocks and builds codes differently from
+    zlib's (optimal parsing at the high levels, its own choice of stored / fixed / dynamic blocks): its streams decode
+    to the same bytes, whole, in prefix steps and side by side — zlib's inflate being the referee."""
+    L = _libdeflate()
+    if L is None:
+        pytest.skip("libdeflate is not installed here")
+    rng = np.random.default_rng(level)
+    pr = random.Random(level)
+    comp = L.libdeflate_alloc_compressor(level)
+    assert comp
+    streams = []
+    try:
+        for size in (0, 1, 50, 4000, 65280):
+            for name, data in kinds(rng, size):
+                bound = L.libdeflate_deflate_compress_bound(comp, len(data))
+                buf = C.create_string_buffer(bound + 16)
+                n = L.libdeflate_deflate_compress(comp, data, len(data), buf, bound + 16)
+                assert n > 0
+                s = buf.raw[:n]
+                assert zlib.decompress(s, -15) == data
+                streams.append((s, data))
+                assert inflate(s, len(data)) == (0, data), (name, size)
+                stops = sorted(pr.randrange(0, len(data) + 1) for _ in range(3))
+                assert inflate(s, len(data), stops) == (0, data), (name, size, stops)
+    finally:
+        L.libdeflate_free_compressor(comp)
+    for _ in range(40):
+        (sa, da), (sb, db) = pr.choice(streams), pr.choice(streams)
+        assert inflate_pair(sa, len(da), None, sb, len(db), None) == ((0, da), (0, db))
