@@ -28,31 +28,54 @@
 
 namespace svx_inflate {
 
-constexpr int kLitBits = 11;   // index bits of the primary literal/length table (10 / 11 / 12 measured: 11)
+constexpr int kLitBits = 12;   // index bits of the primary literal/length table, at most; a block chooses 11 or 12 (lit_bits_for)
 constexpr int kDistBits = 9;   // … of the primary distance table
 constexpr int kPreBits = 7;    // the code-length code has no longer codes
-constexpr int kLitSize = (1 << kLitBits) + 288 * (1 << (15 - kLitBits));  // + one sub-table per longer code, at most
+constexpr int kLitBitsMin = 11;
+constexpr int kLitSize = (1 << kLitBits) + 288 * (1 << (15 - kLitBitsMin));  // + one sub-table per longer code, at most
 constexpr int kDistSize = (1 << kDistBits) + 32 * 64;  // + one 6-bit sub-table per code longer than 9 bits, at most
 
-// Table entry (32 bits).  [5:0] = ALL the stream bits the entry consumes (codes and extra bits: an x86 shift takes its
-// count modulo 64, so the entry itself is the shift count), [7:6] kind:
-//   kind 0  literal/length table: up to two literals, then perhaps a short match — [15:8], [23:16] the literal
-//           bytes, [29:28] how many, [27:24] the length (3..10: the codes without extra bits) of a match that follows
-//           them, 0 = none.  No literals + a length = a short match on its own.
-//           distance table: the all-zero entry = "no match" (see decode_fast)
+// Table entries (32 bits).  [5:0] = ALL the stream bits the entry consumes (codes and extra bits: an x86 shift takes
+// its count modulo 64, so the entry itself is the shift count).
+//
+// Distance and code-length tables, and the literal/length table while it is built — [7:6] kind:
+//   kind 0  one literal: [15:8] the byte                    (the all-zero entry of a distance table = "no match")
 //   kind 1  a value with extra bits: [27:24] bits of the code itself, [31:28] number of extra bits (they follow the
-//           code in the stream), [23:8] base — a length (literal/length table), a distance (distance table) or a
-//           code-length symbol (no extra bits)
+//           code in the stream), [23:8] base — a length, a distance or a code-length symbol
 //   kind 2  end of block
 //   kind 3  sub-table: [23:8] first entry, [27:24] index bits; index bits 0 = invalid code
 constexpr uint32_t kKindLit = 0u << 6, kKindVal = 1u << 6, kKindEnd = 2u << 6, kKindSub = 3u << 6, kKindMask = 3u << 6;
 constexpr uint32_t kInvalid = kKindSub;  // consumes nothing, index bits 0
 constexpr uint32_t kBitsMask = 63;
+//
+// The finished literal/length table (pack_entries) — [5:0] != 0: a "fast" entry,
+//   [7:6]    number of literals, 0..3; their bytes in [15:8], [23:16], [31:24]
+//   [27:24]  with fewer than three literals: the length (3..10, the codes without extra bits) of a match that follows
+//            them, 0 = none.  No literals + a length = a short match on its own.
+// [5:0] == 0: everything else — [7:6] kind as above, [13:8] the bits it consumes,
+//   kind 1  a length with extra bits: [17:14] bits of the code, [20:18] number of extra bits, [29:21] base
+//   kind 2  end of block
+//   kind 3  sub-table: [17:14] index bits (0 = invalid code), [31:18] first entry
+inline uint32_t l_total(uint32_t e) { return (e >> 8) & 63; }
+inline uint32_t l_code_bits(uint32_t e) { return (e >> 14) & 15; }   // kind 3: index bits of the sub-table
+inline uint32_t l_extra_bits(uint32_t e) { return (e >> 18) & 7; }
+inline uint32_t l_base(uint32_t e) { return (e >> 21) & 0x1FF; }
+inline uint32_t l_sub_start(uint32_t e) { return e >> 18; }
+inline uint32_t l_from_building(uint32_t e) {  // an entry as build_table leaves it → its final form
+    const uint32_t bits = e & kBitsMask;
+    switch (e & kKindMask) {
+        case kKindLit: return bits | (1u << 6) | (((e >> 8) & 0xFF) << 8);
+        case kKindVal: return kKindVal | (bits << 8) | (((e >> 24) & 15) << 14) | ((e >> 28) << 18) | (((e >> 8) & 0x1FF) << 21);
+        case kKindEnd: return kKindEnd | (bits << 8);
+        default: return kKindSub | (((e >> 24) & 15) << 14) | (((e >> 8) & 0xFFFF) << 18);
+    }
+}
 
 // the distance table of a round without a match (internal linkage: no GOT detour in a shared library)
 static const uint32_t kNoMatch[1 << kDistBits] = {0};
 
 struct Tables {
+    int lit_bits;  // index bits of this block's primary literal/length table
     uint32_t lit[kLitSize];
     uint32_t dist[kDistSize];
 };
@@ -75,14 +98,15 @@ inline uint32_t entry_of(uint32_t payload, uint32_t code_bits) {
 // stream bits (LSB first), sub-tables behind it for longer codes.  payload[s] = entry of symbol s without its bit
 // count.  false: over-subscribed, or incomplete in a way zlib refuses.
 inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int cap, const uint32_t* payload,
-                        bool single_code_ok) {
+                        bool single_code_ok, bool lit_form = false) {
     uint16_t count[16] = {0};
     for (int s = 0; s < n; ++s) ++count[lens[s]];
     int max = 15;
     while (max > 0 && !count[max]) --max;
     const int primary = 1 << tb;
+    const uint32_t invalid = lit_form ? l_from_building(kInvalid) : kInvalid;
     if (max == 0) {  // no symbols at all: every look-up is an invalid code
-        for (int i = 0; i < primary; ++i) tab[i] = kInvalid;
+        for (int i = 0; i < primary; ++i) tab[i] = invalid;
         return true;
     }
     int left = 1;
@@ -93,7 +117,7 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
     }
     if (left > 0) {
         if (!(single_code_ok && max == 1)) return false;
-        for (int i = 0; i < primary; ++i) tab[i] = kInvalid;
+        for (int i = 0; i < primary; ++i) tab[i] = invalid;
     }
     uint16_t offs[17];
     offs[1] = 0;
@@ -110,7 +134,8 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
     const int direct = max < tb ? max : tb;
     for (int len = 1; len <= direct; ++len) {
         for (int k = 0; k < count[len]; ++k, ++code) {
-            const uint32_t e = entry_of(payload[sorted[idx++]], (uint32_t)len);
+            uint32_t e = entry_of(payload[sorted[idx++]], (uint32_t)len);
+            if (lit_form) e = l_from_building(e);
             for (uint32_t i = bit_reverse(code, len); i < (uint32_t)primary; i += 1u << len) tab[i] = e;
         }
         code <<= 1;
@@ -152,8 +177,9 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
         const int start = next_free;
         next_free += 1 << sb;
         if (next_free > cap) return false;
-        for (int i = start; i < next_free; ++i) tab[i] = kInvalid;
-        tab[bit_reverse(prefix, tb)] = kKindSub | ((uint32_t)start << 8) | ((uint32_t)sb << 24) | (uint32_t)tb;
+        for (int i = start; i < next_free; ++i) tab[i] = invalid;
+        const uint32_t sub = kKindSub | ((uint32_t)start << 8) | ((uint32_t)sb << 24) | (uint32_t)tb;
+        tab[bit_reverse(prefix, tb)] = lit_form ? l_from_building(sub) : sub;
         for (;;) {  // place the group's codes
             if (in_len == count[len]) {
                 if (len == max) { ++len; break; }
@@ -164,7 +190,8 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
             }
             if ((code >> (len - tb)) != prefix) break;
             const int rest = len - tb;
-            const uint32_t e = entry_of(payload[sorted[idx++]], (uint32_t)rest);
+            uint32_t e = entry_of(payload[sorted[idx++]], (uint32_t)rest);
+            if (lit_form) e = l_from_building(e);
             for (uint32_t i = bit_reverse(code & ((1u << rest) - 1), rest); i < (1u << sb); i += 1u << rest)
                 tab[start + i] = e;
             ++code;
@@ -174,47 +201,59 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
     return true;
 }
 
-// Second pass over the primary literal/length table.  What the SEQ members of a BAM are made of — 4–5-bit literals
-// and matches of three to five bytes in about equal numbers, in no predictable order — costs a one-symbol-per-look-up
-// decoder a mispredicted branch per symbol.  So an entry takes along what follows its first symbol as far as the
-// index bits reach: up to two literals and the length code of a short match; the fast loop
-// then runs the same straight-line code for every such entry (decode_fast).
-inline void pack_entries(uint32_t* tab) {
+// Second pass over the literal/length table (built in its final form, build_table(lit_form)): a primary entry takes
+// along what follows its first symbol as far as the index bits reach.  What the SEQ members of a BAM are made of costs a
+// one-symbol-per-look-up decoder a mispredicted branch per symbol: zlib writes them as 4–5-bit literals and matches of
+// three to five bytes in about equal numbers, in no predictable order; libdeflate (what htslib is usually built
+// with) as 4-bit literals almost only.  So an entry holds up to three literals, or up to two literals and the length
+// code of a short match behind them; the fast loop then runs the same straight-line code for every such entry
+// (Stream::round).
+inline void pack_entries(uint32_t* tab, int tb) {
     uint32_t single[1 << kLitBits];
-    memcpy(single, tab, sizeof(single));
+    memcpy(single, tab, sizeof(uint32_t) << tb);
     auto short_length = [](uint32_t e) {  // a length code without extra bits, length <= 10
-        return (e & kKindMask) == kKindVal && (e >> 28) == 0 && ((e >> 8) & 0x1FF) <= 10;
+        return !(e & kBitsMask) && (e & kKindMask) == kKindVal && l_extra_bits(e) == 0 && l_base(e) <= 10;
     };
-    for (uint32_t i = 0; i < (1u << kLitBits); ++i) {
+    for (uint32_t i = 0; i < (1u << tb); ++i) {
         const uint32_t e1 = single[i];
-        uint32_t bits = e1 & kBitsMask, cnt = 0, bytes = 0, mlen = 0;
+        uint32_t bits, cnt = 0, bytes = 0, mlen = 0;
         if (short_length(e1)) {
-            mlen = (e1 >> 8) & 0x1FF;
-        } else if (!(e1 & kKindMask)) {
+            bits = l_total(e1);
+            mlen = l_base(e1);
+        } else if (e1 & kBitsMask) {  // one literal
+            bits = e1 & kBitsMask;
             bytes = (e1 >> 8) & 0xFF;
             cnt = 1;
             for (;;) {
                 const uint32_t e = single[i >> bits];
-                const uint32_t l = e & kBitsMask;
-                if (bits + l > (uint32_t)kLitBits) break;
-                if (!(e & kKindMask)) {
-                    if (cnt == 2) break;
-                    bytes |= ((e >> 8) & 0xFF) << 8;
-                    cnt = 2;
+                if (e & kBitsMask) {
+                    const uint32_t l = e & kBitsMask;
+                    if (cnt == 3 || bits + l > (uint32_t)tb) break;
+                    bytes |= ((e >> 8) & 0xFF) << (8 * cnt);
+                    ++cnt;
                     bits += l;
                     continue;
                 }
-                if (short_length(e)) {
-                    mlen = (e >> 8) & 0x1FF;
-                    bits += l;
+                if (cnt < 3 && short_length(e) && bits + l_total(e) <= (uint32_t)tb) {
+                    mlen = l_base(e);
+                    bits += l_total(e);
                 }
                 break;
             }
         } else {
             continue;
         }
-        tab[i] = bits | kKindLit | (bytes << 8) | (mlen << 24) | (cnt << 28);
+        tab[i] = bits | (cnt << 6) | (bytes << 8) | (cnt < 3 ? mlen << 24 : 0);
     }
+}
+
+// Index bits for a block with these literal/length code lengths: 12 when its literals are 4-bit codes for the most
+// part (three of them then share an entry: what libdeflate makes of SEQ bytes), 11 otherwise (half the table to build
+// and to pack; zlib's mix of 4-5-bit literals and short matches gains nothing from the twelfth bit).
+inline int lit_bits_for(const uint8_t* lens) {
+    int short_literals = 0;
+    for (int s = 0; s < 256; ++s) short_literals += lens[s] != 0 && lens[s] <= 4;
+    return short_literals >= 12 ? kLitBits : kLitBitsMin;
 }
 
 struct SymbolPayloads {
@@ -228,7 +267,7 @@ struct SymbolPayloads {
         static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769,
                                            1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
         static const uint8_t dextra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-        for (uint32_t s = 0; s < 256; ++s) lit[s] = kKindLit | (1u << 28) | (s << 8);
+        for (uint32_t s = 0; s < 256; ++s) lit[s] = kKindLit | (s << 8);
         lit[256] = kKindEnd;
         for (int s = 257; s < 286; ++s) lit[s] = kKindVal | ((uint32_t)lbase[s - 257] << 8) | ((uint32_t)lextra[s - 257] << 28);
         lit[286] = lit[287] = kInvalid;  // in the fixed code, never valid in a stream
@@ -247,8 +286,9 @@ inline const Tables& fixed_tables() {
         Tables f;
         uint8_t lens[288];
         for (int s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-        build_table(lens, 288, kLitBits, f.lit, kLitSize, payloads().lit, false);
-        pack_entries(f.lit);
+        f.lit_bits = kLitBitsMin;
+        build_table(lens, 288, f.lit_bits, f.lit, kLitSize, payloads().lit, false, true);
+        pack_entries(f.lit, f.lit_bits);
         for (int s = 0; s < 32; ++s) lens[s] = 5;
         build_table(lens, 32, kDistBits, f.dist, kDistSize, payloads().dist, false);
         return f;
@@ -450,8 +490,9 @@ class Stream {
         uint8_t padded[288];
         memcpy(padded, lens, nlit);
         memset(padded + nlit, 0, 288 - nlit);
-        if (!build_table(padded, 288, kLitBits, own_.lit, kLitSize, payloads().lit, true)) return false;
-        pack_entries(own_.lit);
+        own_.lit_bits = lit_bits_for(padded);
+        if (!build_table(padded, 288, own_.lit_bits, own_.lit, kLitSize, payloads().lit, true, true)) return false;
+        pack_entries(own_.lit, own_.lit_bits);
         uint8_t dl[32] = {0};
         memcpy(dl, lens + nlit, ndist);
         if (!build_table(dl, 32, kDistBits, own_.dist, kDistSize, payloads().dist, true)) return false;
@@ -499,7 +540,7 @@ class Stream {
         const uint32_t* dtab;
         size_t ip, op, in_last, out_last, stop;
         uint64_t bb;
-        uint32_t bc;
+        uint32_t bc, lit_bits, lit_mask;
     };
     enum Round { kGoOn, kBlockEnded, kBad };
     void load(Lane& l) const {
@@ -514,6 +555,8 @@ class Stream {
         l.stop = target_;
         l.bb = bitbuf_;
         l.bc = bitcnt_;
+        l.lit_bits = (uint32_t)cur_->lit_bits;
+        l.lit_mask = (1u << cur_->lit_bits) - 1;
     }
     void store(const Lane& l, Round r) {
         ip_ = l.ip;
@@ -525,28 +568,49 @@ class Stream {
     }
     static bool in_hand(const Lane& l) { return l.ip <= l.in_last && l.op <= l.out_last && l.op < l.stop; }
     static inline __attribute__((always_inline)) Round round(Lane& l) {
-        constexpr uint32_t kMask = (1u << kLitBits) - 1, kDMask = (1u << kDistBits) - 1;
+        constexpr uint32_t kDMask = (1u << kDistBits) - 1;
+        const uint32_t kMask = l.lit_mask;
         uint64_t bb = l.bb | (load64(l.in + l.ip) << l.bc);  // at least 56 bits: 15 + 5 for a length, 15 + 13 for a distance
         uint32_t bc = l.bc | 56;
         l.ip += (63 - l.bc) >> 3;
         uint32_t e = l.lit[bb & kMask];
         uint32_t len;
         size_t op = l.op;
-        if (__builtin_expect(!(e & kKindMask), 1)) {
+        if (__builtin_expect(e & kBitsMask, 1)) {
             const uint32_t w = e >> 8;
             memcpy(l.out + op, &w, 4);
-            op += (e >> 28) & 3;
-            len = (e >> 24) & 15;
+            const uint32_t cnt = (e >> 6) & 3;
+            op += cnt;
             bb >>= e & kBitsMask;
             bc -= e & kBitsMask;
+            if (cnt == 3) {
+                // three literals and nothing else: the whole round.  (Streams of literals only — what libdeflate makes
+                // of SEQ bytes — take this way every time, the literal/match mix of zlib's next to never: the branch
+                // predicts either way, and the distance half below is not run for nothing.)  Up to three more such
+                // entries are taken from the bits already in hand.
+                for (int k = 0; k < 3; ++k) {
+                    e = l.lit[bb & kMask];
+                    if ((e & 0xFF) <= (3u << 6)) break;   // not a fast entry of three literals (low byte: 0xC0 + its bits)
+                    const uint32_t w2 = e >> 8;
+                    memcpy(l.out + op, &w2, 4);
+                    op += 3;
+                    bb >>= e & kBitsMask;
+                    bc -= e & kBitsMask;
+                }
+                l.op = op;
+                l.bb = bb;
+                l.bc = bc;
+                return kGoOn;
+            }
+            len = (e >> 24) & 15;
         } else {
             if ((e & kKindMask) == kKindSub) {
-                const uint32_t sb = (e >> 24) & 15;
+                const uint32_t sb = l_code_bits(e);
                 if (sb == 0) return kBad;
-                bb >>= kLitBits;
-                bc -= kLitBits;
-                e = l.lit[((e >> 8) & 0xFFFF) + (bb & ((1u << sb) - 1))];
-                if (!(e & kKindMask)) {  // sub-table entries hold one symbol
+                bb >>= l.lit_bits;
+                bc -= l.lit_bits;
+                e = l.lit[l_sub_start(e) + (bb & ((1u << sb) - 1))];
+                if (e & kBitsMask) {  // sub-table entries hold one symbol: here a literal
                     l.out[op] = (uint8_t)(e >> 8);
                     l.op = op + 1;
                     l.bb = bb >> (e & kBitsMask);
@@ -556,13 +620,14 @@ class Stream {
                 if ((e & kKindMask) == kKindSub) return kBad;
             }
             if ((e & kKindMask) == kKindEnd) {
-                l.bb = bb >> (e & kBitsMask);
-                l.bc = bc - (e & kBitsMask);
+                l.bb = bb >> l_total(e);
+                l.bc = bc - l_total(e);
                 return kBlockEnded;
             }
-            len = ((e >> 8) & 0x1FF) + (uint32_t)((bb >> ((e >> 24) & 15)) & ((1u << (e >> 28)) - 1));
-            bb >>= e & kBitsMask;
-            bc -= e & kBitsMask;
+            if ((e & kKindMask) != kKindVal) return kBad;
+            len = l_base(e) + (uint32_t)((bb >> l_code_bits(e)) & ((1u << l_extra_bits(e)) - 1));
+            bb >>= l_total(e);
+            bc -= l_total(e);
         }
         const uint32_t* dsel = len ? l.dtab : kNoMatch;
         uint32_t d = dsel[bb & kDMask];
@@ -640,35 +705,37 @@ class Stream {
     // The first and last few bytes of a stream: one entry at a time, every read and write checked.
     bool decode_careful(size_t stop) {
         const uint32_t* lit = cur_->lit;
-        constexpr uint32_t kMask = (1u << kLitBits) - 1;
+        const uint32_t lit_bits = (uint32_t)cur_->lit_bits, kMask = (1u << lit_bits) - 1;
         while (op_ < stop) {
             if (fast_possible()) return true;  // the fast loop can go on
             fill();
             uint32_t e = lit[bitbuf_ & kMask];
-            if ((e & kKindMask) == kKindSub) {
-                const uint32_t sb = (e >> 24) & 15;
-                if (sb == 0 || (uint32_t)kLitBits > bitcnt_) return false;
-                bitbuf_ >>= kLitBits;
-                bitcnt_ -= kLitBits;
-                e = lit[((e >> 8) & 0xFFFF) + (bitbuf_ & ((1u << sb) - 1))];
-                if ((e & kKindMask) == kKindSub) return false;
+            if (!(e & kBitsMask) && (e & kKindMask) == kKindSub) {
+                const uint32_t sb = l_code_bits(e);
+                if (sb == 0 || lit_bits > bitcnt_) return false;
+                bitbuf_ >>= lit_bits;
+                bitcnt_ -= lit_bits;
+                e = lit[l_sub_start(e) + (bitbuf_ & ((1u << sb) - 1))];
+                if (!(e & kBitsMask) && (e & kKindMask) == kKindSub) return false;
             }
-            const uint32_t all = e & kBitsMask;
+            const uint32_t all = (e & kBitsMask) ? (e & kBitsMask) : l_total(e);
             if (all > bitcnt_) return false;
             uint32_t len;
-            if (!(e & kKindMask)) {
-                const uint32_t cnt = (e >> 28) & 3;
+            if (e & kBitsMask) {
+                const uint32_t cnt = (e >> 6) & 3;
                 if (cnt > cap_ - op_) return false;
                 for (uint32_t k = 0; k < cnt; ++k) out_[op_ + k] = (uint8_t)(e >> (8 + 8 * k));
                 op_ += cnt;
-                len = (e >> 24) & 15;
+                len = cnt == 3 ? 0 : (e >> 24) & 15;
             } else if ((e & kKindMask) == kKindEnd) {
                 bitbuf_ >>= all;
                 bitcnt_ -= all;
                 phase_ = final_ ? kDone : kHeader;
                 return true;
+            } else if ((e & kKindMask) == kKindVal) {
+                len = l_base(e) + (uint32_t)((bitbuf_ >> l_code_bits(e)) & ((1u << l_extra_bits(e)) - 1));
             } else {
-                len = ((e >> 8) & 0x1FF) + (uint32_t)((bitbuf_ >> ((e >> 24) & 15)) & ((1u << (e >> 28)) - 1));
+                return false;
             }
             bitbuf_ >>= all;
             bitcnt_ -= all;

@@ -2,7 +2,9 @@
 """Inflate probe (GPU box or build container): per-member cost of the build's DEFLATE decoder (svx_inflate_raw)
 beside zlib and, when installed, libdeflate, on the BGZF members of one BAM — SEQ members (poorly compressible:
 > 25 000 B compressed) and the others apart — whole and up to the member's middle.
-    python tools/inflate_probe.py DIR/hap1.bam [n_members]"""
+With a third argument N the SEQ members are first re-compressed by libdeflate at level N (htslib is usually built
+with libdeflate; its level-6 streams are 4-bit literals almost only, where zlib's are literals and short matches).
+    python tools/inflate_probe.py DIR/hap1.bam [n_members [libdeflate_level]]"""
 import ctypes as C
 import os
 import random
@@ -31,6 +33,13 @@ try:
     ld = L.libdeflate_alloc_decompressor()
 except OSError:
     L = None
+relevel = int(sys.argv[3]) if len(sys.argv) > 3 else None
+if relevel is not None and L is not None:
+    L.libdeflate_alloc_compressor.restype = C.c_void_p
+    L.libdeflate_alloc_compressor.argtypes = [C.c_int]
+    L.libdeflate_deflate_compress.restype = C.c_size_t
+    L.libdeflate_deflate_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    comp = L.libdeflate_alloc_compressor(relevel)
 out = C.create_string_buffer(65536)
 got, n = C.c_size_t(), C.c_uint64()
 half = (C.c_uint64 * 1)()
@@ -40,6 +49,16 @@ for name, grp in (("SEQ members", [s for s in spans if s[1] > 25000]), ("other m
     random.seed(1)
     pick = random.sample(grp, min(n_pick, len(grp)))
     blobs = [raw[st:st + ln] for st, ln, _ in pick]
+    if relevel is not None and L is not None and name.startswith("SEQ"):
+        again = []
+        for b, (st, ln, isz) in zip(blobs, pick):
+            data = zlib.decompress(b, -15)
+            buf = C.create_string_buffer(70000)
+            k = L.libdeflate_deflate_compress(comp, data, len(data), buf, 70000)
+            again.append(buf.raw[:k])
+        blobs = again
+        pick = [(0, len(b), isz) for b, (_, _, isz) in zip(blobs, pick)]
+        name = "SEQ members re-compressed by libdeflate level %d" % relevel
     res = {}
     t = time.perf_counter()
     for b in blobs:
