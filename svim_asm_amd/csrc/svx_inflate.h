@@ -98,7 +98,7 @@ inline uint32_t entry_of(uint32_t payload, uint32_t code_bits) {
 // stream bits (LSB first), sub-tables behind it for longer codes.  payload[s] = entry of symbol s without its bit
 // count.  false: over-subscribed, or incomplete in a way zlib refuses.
 inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int cap, const uint32_t* payload,
-                        bool single_code_ok, bool lit_form = false) {
+                        bool single_code_ok, bool lit_form = false, uint32_t* firsts = nullptr, int* n_firsts = nullptr) {
     uint16_t count[16] = {0};
     for (int s = 0; s < n; ++s) ++count[lens[s]];
     int max = 15;
@@ -136,7 +136,9 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
         for (int k = 0; k < count[len]; ++k, ++code) {
             uint32_t e = entry_of(payload[sorted[idx++]], (uint32_t)len);
             if (lit_form) e = l_from_building(e);
-            for (uint32_t i = bit_reverse(code, len); i < (uint32_t)primary; i += 1u << len) tab[i] = e;
+            const uint32_t rev = bit_reverse(code, len);
+            if (firsts) firsts[(*n_firsts)++] = rev | ((uint32_t)len << 16);
+            for (uint32_t i = rev; i < (uint32_t)primary; i += 1u << len) tab[i] = e;
         }
         code <<= 1;
     }
@@ -208,42 +210,56 @@ inline bool build_table(const uint8_t* lens, int n, int tb, uint32_t* tab, int c
 // with) as 4-bit literals almost only.  So an entry holds up to three literals, or up to two literals and the length
 // code of a short match behind them; the fast loop then runs the same straight-line code for every such entry
 // (Stream::round).
-inline void pack_entries(uint32_t* tab, int tb) {
-    uint32_t single[1 << kLitBits];
-    memcpy(single, tab, sizeof(uint32_t) << tb);
+inline void pack_entries(uint32_t* tab, int tb, const uint32_t* firsts, int n_firsts) {
     auto short_length = [](uint32_t e) {  // a length code without extra bits, length <= 10
         return !(e & kBitsMask) && (e & kKindMask) == kKindVal && l_extra_bits(e) == 0 && l_base(e) <= 10;
     };
-    for (uint32_t i = 0; i < (1u << tb); ++i) {
-        const uint32_t e1 = single[i];
-        uint32_t bits, cnt = 0, bytes = 0, mlen = 0;
-        if (short_length(e1)) {
-            bits = l_total(e1);
-            mlen = l_base(e1);
-        } else if (e1 & kBitsMask) {  // one literal
-            bits = e1 & kBitsMask;
-            bytes = (e1 >> 8) & 0xFF;
-            cnt = 1;
-            for (;;) {
-                const uint32_t e = single[i >> bits];
-                if (e & kBitsMask) {
-                    const uint32_t l = e & kBitsMask;
-                    if (cnt == 3 || bits + l > (uint32_t)tb) break;
-                    bytes |= ((e >> 8) & 0xFF) << (8 * cnt);
-                    ++cnt;
-                    bits += l;
-                    continue;
-                }
-                if (cnt < 3 && short_length(e) && bits + l_total(e) <= (uint32_t)tb) {
-                    mlen = l_base(e);
+    // What can follow a first literal of L bits depends only on the tb - L index bits behind it, not on the literal:
+    // the continuations are worked out once per budget b = tb - L (2^b of them, kept at cont[2^b ...]) — from the
+    // table as build_table left it, one symbol per entry — and every entry that starts with a literal then becomes
+    // its literal plus the continuation of its remaining bits.  A continuation: [5:0] bits, [7:6] further literals
+    // (0..2), [15:8] the first of them, [23:16] the second — or the length of a short match when fewer than two
+    // literals came before it.
+    uint32_t cont[1 << kLitBits];
+    uint32_t budgets = 0;
+    for (int k = 0; k < n_firsts; ++k)
+        if (tab[firsts[k] & 0xFFFF] & kBitsMask) budgets |= 1u << ((uint32_t)tb - (firsts[k] >> 16));
+    for (uint32_t budget = 0; budget < (uint32_t)tb; ++budget) {
+        if (!(budgets >> budget & 1)) continue;
+        for (uint32_t r = 0; r < (1u << budget); ++r) {
+            uint32_t bits = 0, cnt = 0, a = 0, b2 = 0;
+            uint32_t e = tab[r];
+            if ((e & kBitsMask) && (e & kBitsMask) <= budget) {
+                cnt = 1;
+                a = (e >> 8) & 0xFF;
+                bits = e & kBitsMask;
+                e = tab[r >> bits];
+                if ((e & kBitsMask) && bits + (e & kBitsMask) <= budget) {
+                    cnt = 2;
+                    b2 = (e >> 8) & 0xFF;
+                    bits += e & kBitsMask;
+                } else if (short_length(e) && bits + l_total(e) <= budget) {
+                    b2 = l_base(e);
                     bits += l_total(e);
                 }
-                break;
+            } else if (short_length(e) && l_total(e) <= budget) {
+                b2 = l_base(e);
+                bits = l_total(e);
             }
-        } else {
-            continue;
+            cont[(1u << budget) + r] = bits | (cnt << 6) | (a << 8) | (b2 << 16);
         }
-        tab[i] = bits | (cnt << 6) | (bytes << 8) | (cnt < 3 ? mlen << 24 : 0);
+    }
+    for (int k = 0; k < n_firsts; ++k) {  // the symbols whose codes index the table directly, each with its replicas
+        const uint32_t rev = firsts[k] & 0xFFFF, l1 = firsts[k] >> 16;
+        const uint32_t e1 = tab[rev];
+        if (e1 & kBitsMask) {  // a literal: bits | 1 << 6 | byte << 8
+            const uint32_t budget = (uint32_t)tb - l1;
+            const uint32_t* c = cont + (1u << budget);
+            for (uint32_t r = 0; r < (1u << budget); ++r) tab[rev | (r << l1)] = e1 + (c[r] & 0xFF) + ((c[r] >> 8) << 16);
+        } else if (short_length(e1)) {
+            const uint32_t e = l_total(e1) | (l_base(e1) << 24);
+            for (uint32_t i = rev; i < (1u << tb); i += 1u << l1) tab[i] = e;
+        }
     }
 }
 
@@ -287,8 +303,10 @@ inline const Tables& fixed_tables() {
         uint8_t lens[288];
         for (int s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
         f.lit_bits = kLitBitsMin;
-        build_table(lens, 288, f.lit_bits, f.lit, kLitSize, payloads().lit, false, true);
-        pack_entries(f.lit, f.lit_bits);
+        uint32_t firsts[288];
+        int n_firsts = 0;
+        build_table(lens, 288, f.lit_bits, f.lit, kLitSize, payloads().lit, false, true, firsts, &n_firsts);
+        pack_entries(f.lit, f.lit_bits, firsts, n_firsts);
         for (int s = 0; s < 32; ++s) lens[s] = 5;
         build_table(lens, 32, kDistBits, f.dist, kDistSize, payloads().dist, false);
         return f;
@@ -491,8 +509,10 @@ class Stream {
         memcpy(padded, lens, nlit);
         memset(padded + nlit, 0, 288 - nlit);
         own_.lit_bits = lit_bits_for(padded);
-        if (!build_table(padded, 288, own_.lit_bits, own_.lit, kLitSize, payloads().lit, true, true)) return false;
-        pack_entries(own_.lit, own_.lit_bits);
+        uint32_t firsts[288];
+        int n_firsts = 0;
+        if (!build_table(padded, 288, own_.lit_bits, own_.lit, kLitSize, payloads().lit, true, true, firsts, &n_firsts)) return false;
+        pack_entries(own_.lit, own_.lit_bits, firsts, n_firsts);
         uint8_t dl[32] = {0};
         memcpy(dl, lens + nlit, ndist);
         if (!build_table(dl, 32, kDistBits, own_.dist, kDistSize, payloads().dist, true)) return false;
