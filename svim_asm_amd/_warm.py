@@ -30,6 +30,34 @@ def restrict_to_local_rank():
     return _state["restricted"]
 
 
+def restrict_to_device(device):
+    """Single-process run (no launcher): show the process only the device it was asked to use, which then is device 0
+    — on a node with eight GPUs the HIP runtime otherwise brings up all of them before the first kernel of a command
+    that lives for half a second.  Returns the device index to use from now on.  Left alone: a multi-rank launch
+    (restrict_to_local_rank); a list of visible devices the caller set is narrowed to its entry, not overridden."""
+    if "restricted" in _state:
+        return _state["restricted"]
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("LOCAL_RANK") is not None:
+        return device
+    listed = os.environ.get("HIP_VISIBLE_DEVICES")
+    if listed is not None:
+        # a list the caller set: device d is its d-th entry; narrow the list to that entry (one entry: nothing to do)
+        entries = [e for e in listed.split(",") if e.strip()]
+        if len(entries) <= 1 or int(device) >= len(entries):
+            return device
+        os.environ["HIP_VISIBLE_DEVICES"] = entries[int(device)].strip()
+    else:
+        os.environ["HIP_VISIBLE_DEVICES"] = str(int(device))  # (indexes what ROCR_VISIBLE_DEVICES leaves visible, if set)
+    _state["restricted"] = 0
+    _state["physical"] = int(device)
+    return 0
+
+
+def logical_device(device):
+    """The index under which the device the user named is visible after restrict_to_device."""
+    return _state["restricted"] if _state.get("physical") == int(device) and "restricted" in _state else device
+
+
 def start(device, lib_path):
     """Begin creating the context of `device` in the background (no-op when already started)."""
     if _state["thread"] is not None or not os.path.exists(lib_path):

@@ -113,6 +113,9 @@ def main(arguments=None):
         print("Please choose one of the two modes ('haploid' or 'diploid'). See --help for more information.")
         return
     distributed = _init_distributed(options)
+    if not distributed:
+        from svim_asm_amd import _warm
+        options.device = _warm.logical_device(getattr(options, "device", 0) or 0)  # (bin/svim-asm may have narrowed the view)
     _warm_device(getattr(options, "device", 0) or 0)
     try:
         return _main(options)
