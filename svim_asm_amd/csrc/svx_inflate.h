@@ -1,15 +1,17 @@
 // svx_inflate.h — raw DEFLATE (RFC 1951) decoder of the BAM ingest, host C++.
 //
 // Why not zlib / libdeflate alone: the members of an assembly-to-reference BAM are SEQ bytes for the most part — two
-// 4-bit bases per byte, sixteen byte values that are about equally likely.  A deflate writer turns them into 4–5-bit
+// 4-bit bases per byte, sixteen byte values that are about equally likely.  zlib's deflate turns them into 4–5-bit
 // literals and, in about equal number, matches of three or four bytes at distances anywhere in the window, in no
-// predictable order: a 64 KiB member is ≈ 15 000 matches and ≈ 16 000 literals.  A decoder that takes one symbol per
-// table look-up and branches on its kind pays a mispredicted branch on almost every one of them (zlib ≈ 200,
-// libdeflate ≈ 160 µs per member on the GPU box's EPYC 9575F; here ≈ 120).  Here an entry of the primary table holds
-// up to two literals and the length of a short match behind them — whatever fits the index bits — and the fast
-// loop runs the same straight-line code for every such entry (pack_entries, decode_fast).  And the decoder stops and
-// resumes at any output position: an inserted-sequence slice lies somewhere inside a member and only the bytes up
-// to its end are wanted (svx_bam_seq_slices), which libdeflate cannot do.
+// predictable order (a 64 KiB member: ≈ 15 000 matches, ≈ 16 000 literals); libdeflate's — what htslib is usually
+// built with — into 4-bit literals almost only.  A decoder that takes one symbol per table look-up and branches on
+// its kind pays a mispredicted branch per symbol on the first kind of stream.  Here an entry of the primary table
+// holds up to three literals, or up to two literals and the length of a short match behind them — whatever fits the
+// index bits — and the fast loop runs the same straight-line code for every such entry, two streams side by side
+// (pack_entries, Stream::round, Stream::run_pair).  Per member on the GPU box's EPYC 9575F: zlib-written 208 µs with
+// zlib, 166 with libdeflate, 91 / 75 here (alone / side by side); libdeflate-written 121, 115, 103 / 93.  And the
+// decoder stops and resumes at any output position: an inserted-sequence slice lies somewhere inside a member and only
+// the bytes up to its end are wanted (svx_bam_seq_slices), which libdeflate cannot do.
 //
 // The reference gets here through pysam → htslib → zlib (SVIM_COLLECT.py:68 `bam.fetch`, SVIM_intra.py:40
 // `alignment.query_sequence`); the format is the published one, nothing of htslib's is restated.
@@ -28,10 +30,10 @@
 
 namespace svx_inflate {
 
-constexpr int kLitBits = 12;   // index bits of the primary literal/length table, at most; a block chooses 11 or 12 (lit_bits_for)
-constexpr int kDistBits = 9;   // … of the primary distance table
-constexpr int kPreBits = 7;    // the code-length code has no longer codes
-constexpr int kLitBitsMin = 11;
+constexpr int kLitBits = 12;     // index bits of the primary literal/length table: a block chooses 12 or
+constexpr int kLitBitsMin = 11;  // 11 (lit_bits_for)
+constexpr int kDistBits = 9;     // … of the primary distance table
+constexpr int kPreBits = 7;      // the code-length code has no longer codes
 constexpr int kLitSize = (1 << kLitBits) + 288 * (1 << (15 - kLitBitsMin));  // + one sub-table per longer code, at most
 constexpr int kDistSize = (1 << kDistBits) + 32 * 64;  // + one 6-bit sub-table per code longer than 9 bits, at most
 
