@@ -437,6 +437,8 @@ def e2e_leg(scale, local_rank, n_devices=1):
             "phases_s": {k: best[k] for k in ("open_index_s", "collect_s", "pair_s", "vcf_s")},
             "collect_stages_s": best.get("collect_stages_s"),  # load_s: the record walks of both BAMs; sequences_wait_s: what PAIR still
             # waited for the inflate of the inserted alleles, which starts in COLLECT and runs beside PAIR's set-up
+            "wall_s_whole_members_crc32": r.get("whole_members_crc32_total_s"),  # one more pass with svx_bam_set_verify(1): every
+            # touched BGZF member inflated completely and CRC32-checked, as htslib does (the default inflates what is needed)
             "cpu_seconds": best.get("cpu_seconds"),  # CPU seconds of all threads per phase, and beside them
             "cpu_quota_cpus": r.get("cpu_quota_cpus"),  # the CPUs the box's cgroup grants per period: their quotient bounds wall_s
             "command_line_wall_s": r.get("cli_wall_s"),  # `svim-asm diploid` as a fresh process: interpreter + HIP start-up included
