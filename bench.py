@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-steady", action="store_true", help="skip the 200 further steps behind the timed region "
                     "(`sustained` in the line)")
+    ap.add_argument("--prewarm-ms", type=float, default=0.0, help="diagnostic: keep the device busy with a torch fill loop "
+                    "for this long right before the warm-up steps (is the slow start of the timed region the device's clocks?)")
     ap.add_argument("--step-trace", type=int, default=0, help="diagnostic: after the timed region leave the device idle "
                     "for two seconds, then run this many steps one by one (synchronised) and print their times to stderr")
     ap.add_argument("--samples", type=int, default=256, help="haplotype samples (assemblies) per GPU per step")
@@ -595,6 +597,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     torch.cuda.synchronize(dev)  # uploads ran on torch's stream; the contexts use their own
+    if args.prewarm_ms > 0:
+        junk = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+            junk.fill_(1)
+            torch.cuda.synchronize(dev)
+        del junk
     for _ in range(args.warmup):
         step()
     barrier()
