@@ -332,7 +332,7 @@ def file_digest(path):
 
 
 def write_dataset(outdir, seed=1, contigs=CONFIG1_CONTIGS, diploid=True, n_shared=25, n_private=6,
-                  median_aln=30000, mean_m=2000, dense_cluster=True, with_splits=True, min_gap=1500):
+                  median_aln=30000, mean_m=2000, dense_cluster=True, with_splits=True, min_gap=1500, level=1):
     """FASTA + one or two haplotype BAMs under `outdir`; returns their paths."""
     import os
     os.makedirs(outdir, exist_ok=True)
@@ -356,6 +356,6 @@ def write_dataset(outdir, seed=1, contigs=CONFIG1_CONTIGS, diploid=True, n_share
         recs = simulate_haplotype(seed + 3000 + h, genome, contigs, events, median_aln, mean_m, tag="h%d" % (h + 1),
                                   with_splits=with_splits)
         path = os.path.join(outdir, "hap%d.bam" % (h + 1))
-        write_bam(path, contigs, recs)
+        write_bam(path, contigs, recs, level=level)  # (deflate level of the BGZF members; the records do not depend on it)
         bams.append(path)
     return fasta, bams

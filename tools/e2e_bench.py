@@ -103,7 +103,7 @@ def run_ranks(argv, world_size, n_devices=1, timeout=900):
 
 
 def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None, threads=0, repeat=1, device=0,
-            ranks=(1, 2, 4), n_devices=1, mean_m=2000, in_process=True, seed=3, min_gap=1500):
+            ranks=(1, 2, 4), n_devices=1, mean_m=2000, in_process=True, seed=3, min_gap=1500, bam_level=1):
     """Generate (or reuse) the dataset, run the product pipeline `repeat` times in this process with phase
     clocks (in_process=False: the caller must not touch the GPU — only the child processes run), then the
     command line as fresh processes (1 rank and the sharded runs), then the checker."""
@@ -115,7 +115,7 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
         out = dataset
         fasta, bams = os.path.join(out, "ref.fa"), [os.path.join(out, "hap1.bam"), os.path.join(out, "hap2.bam")]
     else:
-        fasta, bams = synth_bam.write_dataset(out, **dataset_args(scale, sv_per_mbp, mean_m, seed, min_gap))
+        fasta, bams = synth_bam.write_dataset(out, level=bam_level, **dataset_args(scale, sv_per_mbp, mean_m, seed, min_gap))
     res["generate_s"] = time.perf_counter() - t0
     res["genome_bp"] = int(sum(max(60000, int(l * scale)) for l in __import__("svim_asm_amd.synth", fromlist=["x"]).GRCH38_LENGTHS))
     res["bam_bytes"] = [os.path.getsize(b) for b in bams]
@@ -305,6 +305,8 @@ def main():
                     "oracle/make_golden.py config5 (10x small-indel density, crowded partitions, > 131072 candidates)")
     ap.add_argument("--with-oracle", action="store_true", help="run the CPU oracle pipeline even when the real reference's digest is available")
     ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
+    ap.add_argument("--bam-level", type=int, default=1, help="zlib level of the BGZF members of the generated BAMs (1: the "
+                    "goldens' writer; 6: what samtools writes by default — the records, and so the expected VCF, are the same)")
     ap.add_argument("--threads", type=int, default=0, help="ingest threads (0: one per hardware thread, at most 64)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the product pipeline, report the best run too")
     ap.add_argument("--ranks", default="1,2,4", help="rank counts of the command-line runs")
@@ -317,7 +319,7 @@ def main():
     print(json.dumps(run_e2e(args.scale, args.keep, args.sv_per_mbp, True if args.with_oracle else None, args.dataset,
                              args.threads, args.repeat, ranks=tuple(int(x) for x in args.ranks.split(",") if x),
                              n_devices=args.devices, mean_m=args.mean_m, in_process=not args.no_in_process, seed=seed,
-                             min_gap=min_gap)))
+                             min_gap=min_gap, bam_level=args.bam_level)))
 
 
 if __name__ == "__main__":
