@@ -164,9 +164,44 @@ class BgzfLazy(object):
         return (hdr << 16) | (off - int(self._uoff[i]))
 
 
+_LIBDEFLATE = [None]
+
+
+def _libdeflate_compress(chunk, level):
+    """Raw DEFLATE stream of `chunk` by libdeflate (levels 100 + n of the writers; what an htslib built with libdeflate
+    puts into its BGZF members), or None where the library is not installed."""
+    import ctypes as C
+    import threading
+    if _LIBDEFLATE[0] is None:
+        try:
+            lib = C.CDLL("libdeflate.so.0")
+            lib.libdeflate_alloc_compressor.restype = C.c_void_p
+            lib.libdeflate_alloc_compressor.argtypes = [C.c_int]
+            lib.libdeflate_deflate_compress.restype = C.c_size_t
+            lib.libdeflate_deflate_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            _LIBDEFLATE[0] = (lib, threading.local())
+        except OSError:
+            _LIBDEFLATE[0] = False
+    if not _LIBDEFLATE[0]:
+        return None
+    lib, tls = _LIBDEFLATE[0]
+    comps = tls.__dict__.setdefault("comps", {})
+    if level not in comps:
+        comps[level] = lib.libdeflate_alloc_compressor(level)   # one per thread and level, kept
+    data = bytes(chunk)
+    buf = C.create_string_buffer(len(data) + 1024)
+    n = lib.libdeflate_deflate_compress(comps[level], data, len(data), buf, len(data) + 1024)
+    return buf.raw[:n] if n else None
+
+
 def _bgzf_member(chunk, level):
-    co = zlib.compressobj(level, zlib.DEFLATED, -15)
-    comp = co.compress(chunk) + co.flush()
+    comp = None
+    if level >= 100:  # 100 + n: libdeflate at level n (falls back to zlib at min(n, 9) where it is not installed)
+        comp = _libdeflate_compress(chunk, level - 100)
+        level = min(level - 100, 9)
+    if comp is None:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
     return b"".join((struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, len(comp) + 25), comp,
                      struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))))
 

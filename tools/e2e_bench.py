@@ -306,7 +306,8 @@ def main():
     ap.add_argument("--with-oracle", action="store_true", help="run the CPU oracle pipeline even when the real reference's digest is available")
     ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
     ap.add_argument("--bam-level", type=int, default=1, help="zlib level of the BGZF members of the generated BAMs (1: the "
-                    "goldens' writer; 6: what samtools writes by default — the records, and so the expected VCF, are the same)")
+                    "goldens' writer; 6: what samtools writes by default; 100 + n: libdeflate at level n, what an htslib built with "
+                    "libdeflate writes — the records, and so the expected VCF, are the same)")
     ap.add_argument("--threads", type=int, default=0, help="ingest threads (0: one per hardware thread, at most 64)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the product pipeline, report the best run too")
     ap.add_argument("--ranks", default="1,2,4", help="rank counts of the command-line runs")
