@@ -265,13 +265,19 @@ inline void pack_entries(uint32_t* tab, int tb, const uint32_t* firsts, int n_fi
     }
 }
 
-// Index bits for a block with these literal/length code lengths: 12 when its literals are 4-bit codes for the most
-// part (three of them then share an entry: what libdeflate makes of SEQ bytes), 11 otherwise (half the table to build
-// and to pack; zlib's mix of 4-5-bit literals and short matches gains nothing from the twelfth bit).
+// Index bits for a block with these literal/length code lengths: 12 when it is literals for the most part and they are
+// 4-bit codes (three of them then share an entry, and the fast loop takes runs of such entries without the distance
+// half: what libdeflate makes of SEQ bytes) — that is, twelve or more literals have codes of at most 4 bits and no
+// length code is shorter than 6 bits (a match less than every 30th symbol or so); 11 otherwise (half the table to
+// build and to pack; zlib's mix of 4-5-bit literals and short matches gains nothing from the twelfth bit, and a
+// "does a match follow" branch would mispredict on it).
 inline int lit_bits_for(const uint8_t* lens) {
     int short_literals = 0;
     for (int s = 0; s < 256; ++s) short_literals += lens[s] != 0 && lens[s] <= 4;
-    return short_literals >= 12 ? kLitBits : kLitBitsMin;
+    if (short_literals < 12) return kLitBitsMin;
+    for (int s = 257; s < 286; ++s)
+        if (lens[s] != 0 && lens[s] < 6) return kLitBitsMin;
+    return kLitBits;
 }
 
 struct SymbolPayloads {
@@ -605,26 +611,27 @@ class Stream {
             op += cnt;
             bb >>= e & kBitsMask;
             bc -= e & kBitsMask;
-            if (cnt == 3) {
-                // three literals and nothing else: the whole round.  (Streams of literals only — what libdeflate makes
-                // of SEQ bytes — take this way every time, the literal/match mix of zlib's next to never: the branch
-                // predicts either way, and the distance half below is not run for nothing.)  Up to three more such
-                // entries are taken from the bits already in hand.
-                for (int k = 0; k < 3; ++k) {
-                    e = l.lit[bb & kMask];
-                    if ((e & 0xFF) <= (3u << 6)) break;   // not a fast entry of three literals (low byte: 0xC0 + its bits)
-                    const uint32_t w2 = e >> 8;
-                    memcpy(l.out + op, &w2, 4);
-                    op += 3;
-                    bb >>= e & kBitsMask;
-                    bc -= e & kBitsMask;
+            len = cnt == 3 ? 0 : (e >> 24) & 15;
+            // (the order of the tests matters: "three literals" is rare and "a block of literals" constant within a block
+            //  in zlib's mix, where "no match follows" alone would be a coin toss for the branch predictor)
+            if (cnt == 3 || (l.lit_bits == (uint32_t)kLitBits && len == 0)) {
+                if (l.lit_bits == (uint32_t)kLitBits) {
+                    for (int k = 0; k < 3; ++k) {
+                        e = l.lit[bb & kMask];
+                        const uint32_t c2 = (e >> 6) & 3;
+                        if (!(e & kBitsMask) || (c2 != 3 && ((e >> 24) & 15))) break;  // not literals only
+                        const uint32_t w2 = e >> 8;
+                        memcpy(l.out + op, &w2, 4);
+                        op += c2;
+                        bb >>= e & kBitsMask;
+                        bc -= e & kBitsMask;
+                    }
                 }
                 l.op = op;
                 l.bb = bb;
                 l.bc = bc;
                 return kGoOn;
             }
-            len = (e >> 24) & 15;
         } else {
             if ((e & kKindMask) == kKindSub) {
                 const uint32_t sb = l_code_bits(e);
