@@ -9,7 +9,7 @@
 // holds up to three literals, or up to two literals and the length of a short match behind them — whatever fits the
 // index bits — and the fast loop runs the same straight-line code for every such entry, two streams side by side
 // (pack_entries, Stream::round, Stream::run_pair).  Per member on the GPU box's EPYC 9575F: zlib-written 208 µs with
-// zlib, 166 with libdeflate, 91 / 75 here (alone / side by side); libdeflate-written 121, 115, 103 / 93.  And the
+// zlib, 166 with libdeflate, 88 / 74 here (alone / side by side); libdeflate-written 119, 114, 66 / 57.  And the
 // decoder stops and resumes at any output position: an inserted-sequence slice lies somewhere inside a member and only
 // the bytes up to its end are wanted (svx_bam_seq_slices), which libdeflate cannot do.
 //
