@@ -117,3 +117,55 @@ def test_cli_reproduces_reference_vcf_medium_options(svx_ctx, medium_dataset, tm
     cli.main(["diploid", str(tmp_path), bams[0], bams[1], fasta] + META["option_runs"][name]["options"])
     got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
     assert got == _expected(name)
+
+
+@pytest.mark.parametrize("how", ["zlib-6", "libdeflate-6", "whole-members-crc32", "csi-index"])
+def test_host_path_on_other_writers_files_with_the_oracle_as_device(monkeypatch, tmp_path, how):
+    """The CPU twin of the test below: reader, host logic and VCF writer of the product with the device answered by the
+    oracle (no GPU)."""
+    from tests import helpers
+    helpers.oracle_backed_device(monkeypatch)
+    _other_writers_case(tmp_path, how)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["zlib-6", "libdeflate-6", "whole-members-crc32", "csi-index"])
+def test_cli_reproduces_reference_vcf_on_other_writers_files(svx_ctx, tmp_path, how):
+    _other_writers_case(tmp_path, how)
+
+
+def _other_writers_case(tmp_path, how):
+    """The same records in files as other writers make them — BGZF members deflated by zlib at level 6 (samtools'
+    default), by libdeflate at level 6 (an htslib built with libdeflate: 4-bit literals almost only, the decoder's
+    12-bit tables and literal runs) —, read with whole-member verification, or indexed by a `.csi`: the product
+    CLI writes the REAL reference's VCF for each."""
+    from svim_asm_amd import bamio, cli, synth, synth_bam
+    prm = META["params"]
+    contigs = tuple((n, max(60000, int(l * prm["scale"]))) for n, l in zip(synth.GRCH38_NAMES, synth.GRCH38_LENGTHS))
+    level = {"zlib-6": 6, "libdeflate-6": 106}.get(how, 1)
+    d = str(tmp_path / "data")
+    fasta, bams = synth_bam.write_dataset(d, seed=prm["seed"], contigs=contigs, n_shared=prm["n_shared"],
+                                          n_private=prm["n_private"], median_aln=prm["median_aln"], mean_m=prm["mean_m"],
+                                          level=level)
+    from tests import helpers
+    helpers.assert_inputs_are_the_golden_ones(META, [fasta] + bams)   # digests of the uncompressed content
+    env = {}
+    if how == "whole-members-crc32":
+        env["SVX_BAM_VERIFY"] = "1"
+    if how == "csi-index":
+        for b in bams:
+            os.remove(b + ".bai")
+            bamio.index_bam(b, csi=True, min_shift=14, depth=6)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        out = tmp_path / "wd"
+        cli.main(["diploid", str(out), bams[0], bams[1], fasta])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    got = "".join(l for l in open(out / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == expected_vcf()
