@@ -273,6 +273,22 @@ def random_candidates(rng, names, lengths, seqs, n, hap_tag):
     return out
 
 
+def constructed_again(tuples, lens):
+    """Candidate tuples as they are after one more pass through their constructor.  The differential harnesses hand
+    the product (or the reference) objects built from the tuples with `build_candidate` — the tuples' second
+    construction, random_candidates made them with the oracle's constructors — and the oracle the tuples themselves.
+    Every constructor is idempotent except CandidateBreakend on a breakend whose two ends are the same position: it
+    swaps the ends and flips both directions every time (SVCandidate.py:352-373, `<` on both comparisons), so the
+    oracle's side must have been through it as often as the other side."""
+    from oracle import svim_oracle as O
+    out = []
+    for t in tuples:
+        if t[0] == "BND":
+            t = O.cand_bnd(t[1], t[2], t[3], t[4], t[5], t[6], t[7], lens, t[8])
+        out.append(t)
+    return out
+
+
 def run_cli_ranks(argv, world_size, timeout=600):
     """Run `svim-asm <argv>` as `world_size` fresh processes (one rank each, all on HIP device 0 — the
     GPU box has one GPU), the way torch.distributed.run would start them.  Every child makes its own

@@ -86,7 +86,8 @@ def test_pair_candidates_matches_oracle(svx_ctx, seed):
     c1 = [helpers.build_candidate(t, bam, SVCandidate) for t in t1]
     c2 = [helpers.build_candidate(t, bam, SVCandidate) for t in t2]
     got = [helpers.candidate_tuple(c) for c in SVIM_COMBINE.pair_candidates(c1, c2, ref, bam, o)]
-    exp = svim_oracle.pair_candidates(t1, t2, ref.fetch, NAMES, lengths, dict(zip(NAMES, lengths)), o,
+    lens = dict(zip(NAMES, lengths))
+    exp = svim_oracle.pair_candidates(helpers.constructed_again(t1, lens), helpers.constructed_again(t2, lens), ref.fetch, NAMES, lengths, lens, o,
                                       edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
     assert got == exp
     assert {c[-1] for c in got} == {"1/1", "1/0", "0/1"}

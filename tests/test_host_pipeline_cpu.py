@@ -56,7 +56,8 @@ def test_pair_candidates_matches_oracle(seed):
     c1 = [helpers.build_candidate(t, bam, SVCandidate) for t in t1]
     c2 = [helpers.build_candidate(t, bam, SVCandidate) for t in t2]
     got = [helpers.candidate_tuple(c) for c in SVIM_COMBINE.pair_candidates(c1, c2, ref, bam, o)]
-    exp = svim_oracle.pair_candidates(t1, t2, ref.fetch, NAMES, lengths, dict(zip(NAMES, lengths)), o,
+    lens = dict(zip(NAMES, lengths))
+    exp = svim_oracle.pair_candidates(helpers.constructed_again(t1, lens), helpers.constructed_again(t2, lens), ref.fetch, NAMES, lengths, lens, o,
                                       edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
     assert got == exp
 
@@ -127,3 +128,22 @@ def test_two_haplotypes_with_differently_ordered_headers():
     exp = svim_oracle.pair_candidates(exp1, exp2, ref.fetch, NAMES, LENGTHS, dict(zip(NAMES, LENGTHS)), o,
                                       edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
     assert got == exp
+
+
+def test_breakend_whose_ends_coincide_flips_at_every_construction():
+    """CandidateBreakend keeps its ends only when source < dest (contig, then position, both strict): ends on the same
+    position are swapped and both directions flipped by every construction — the one in COLLECT and the one PAIR makes
+    for its output (SVCandidate.py:352-373, SVIM_COMBINE.py:340-366).  Found by tools/fuzz_pipeline.py seed 980353
+    (as a disagreement of the harness's two sides, the product agreeing with the real reference)."""
+    lengths = [30000] * len(NAMES)
+    lens = dict(zip(NAMES, lengths))
+    bam = helpers.FakeBam(NAMES, lengths, [])
+    ref = helpers.FakeFasta({n: "A" * 30000 for n in NAMES})
+    raw = ("BND", "chr10", 3154, "fwd", "chr10", 3154, "fwd", ("r",), "1/1")
+    once = helpers.build_candidate(raw, bam, SVCandidate)
+    assert (once.source_direction, once.dest_direction) == ("rev", "rev")
+    out = SVIM_COMBINE.pair_candidates([], [once], ref, bam, helpers.options())
+    assert [helpers.candidate_tuple(c) for c in out] == [("BND", "chr10", 3154, "fwd", "chr10", 3154, "fwd", ("r",), "0/1")]
+    exp = svim_oracle.pair_candidates([], helpers.constructed_again([raw], lens), ref.fetch, NAMES, lengths, lens,
+                                      helpers.options())
+    assert [tuple(x) for x in exp] == [("BND", "chr10", 3154, "fwd", "chr10", 3154, "fwd", ("r",), "0/1")]

@@ -124,7 +124,7 @@ def test_pair_and_vcf_match_reference(ref, seed):
     exp = [helpers.candidate_tuple(c) for c in exp_objs]
     ref_lens = dict(zip(NAMES, lengths))
     from oracle import orc
-    got = svim_oracle.pair_candidates(t1, t2, fasta.fetch, NAMES, lengths, ref_lens, o,
+    got = svim_oracle.pair_candidates(helpers.constructed_again(t1, ref_lens), helpers.constructed_again(t2, ref_lens), fasta.fetch, NAMES, lengths, ref_lens, o,
                                       edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
     assert got == exp
     assert {c[-1] for c in got} == {"1/1", "1/0", "0/1"}

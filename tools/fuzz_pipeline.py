@@ -57,7 +57,8 @@ def pair_case(seed):
     c1 = [helpers.build_candidate(t, bam, SVCandidate) for t in t1]
     c2 = [helpers.build_candidate(t, bam, SVCandidate) for t in t2]
     got = [helpers.candidate_tuple(c) for c in SVIM_COMBINE.pair_candidates(c1, c2, ref, bam, o)]
-    exp = svim_oracle.pair_candidates(t1, t2, ref.fetch, NAMES, lengths, dict(zip(NAMES, lengths)), o,
+    lens = dict(zip(NAMES, lengths))
+    exp = svim_oracle.pair_candidates(helpers.constructed_again(t1, lens), helpers.constructed_again(t2, lens), ref.fetch, NAMES, lengths, lens, o,
                                       edit=lambda a, b: orc.edit_distance(a.encode(), b.encode()))
     return got == exp, "pair med %d pmd %d n %d/%d" % (o.max_edit_distance, o.partition_max_distance, len(t1), len(t2))
 
