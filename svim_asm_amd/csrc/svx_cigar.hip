@@ -227,7 +227,13 @@ __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_b
 #define SVX_STAGE 48
 #endif
 constexpr int kStage = SVX_STAGE;  // finished records staged in LDS per wave before one burst to the slab (>= kQueue)
-constexpr int kQueue = 2 * kLaneOps;  // signatures one round may queue in LDS (one flush lane each)
+#ifndef SVX_QUEUE
+#define SVX_QUEUE 32
+#endif
+constexpr int kQueue = SVX_QUEUE;  // signatures one round may queue in LDS (one flush lane each, so at most 64)
+static_assert(kQueue <= 64, "one flush lane per queued signature");
+// LDS words per wave for the start mask, which the queue re-uses once the mask has moved to registers
+constexpr int kHeadWords = (kTileOps / 32) > kQueue * 4 ? (kTileOps / 32) : kQueue * 4;
 static_assert(kStage >= kQueue, "one round's records must fit the stage buffer");
 constexpr uint32_t kDescForceDense = 1u << 30;  // descriptor flag: a round overflowed the queue
 
@@ -241,12 +247,17 @@ struct WalkOut {
     uint32_t n_queued;        // wave-uniform: signatures queued this round (WALK_QUEUE)
 };
 
-// Everything WALK_DIRECT needs to finish a signature on the spot.
+// Everything WALK_DIRECT needs to finish a signature on the spot.  The alignment index is carried along the
+// walk (it advances at the lane's own alignment starts) together with that alignment's ref_start, so a
+// signature costs its five stores and no load; only batches with empty alignments (`dup`: two starts on one
+// op, which the start mask cannot count) search aln_off, and only at a start.
 struct DirectCtx {
     uint32_t in_r, in_d;  // lane carry-in (since the last start before the lane)
     uint64_t out0;        // output slot of this lane's first signature
     uint32_t a_lo;
     uint64_t g_lane0;     // global op index of the lane's op 0
+    uint32_t aln0, rs0;   // alignment of the op before the lane's first one (0xFFFFFFFF: none) and its ref_start
+    bool dup;
 };
 
 // Lane-local walk (SVIM_intra.py:13-29).  The 16 words stay in LDS (`myx`, 4 per uint4) and the
@@ -269,6 +280,7 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
     const uint32_t thr = p.min_len >= (1u << 28) ? 0xFFFFFFFFu : (p.min_len ? p.min_len << 4 : 1u);
     uint32_t rr = 0, rd = 0, base_r = 0, base_d = 0, n_emit = 0, qn = 0;
     uint32_t hs = 0;  // this lane has passed an alignment start
+    uint32_t aln_cur = dc.aln0, rs_cur = dc.rs0;  // WALK_DIRECT only
 #ifdef SVX_EXP_NOWALK  // perf experiment only: memory + scan floor without the per-op work
     { const uint4 v = myx[swz]; WalkOut o; o.tot_r = v.x; o.tot_d = v.y; o.tail_r = v.z; o.tail_d = v.w; o.n_emit = 0; o.n_queued = 0; return o; }
 #endif
@@ -286,7 +298,13 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
             else { op = wv[t] & 15u; len = wv[t] >> 4; }
             if (__builtin_expect(((hu4 >> t) & 1u) != 0u, 0)) {  // scalar test: some lane starts an alignment at this slot
                 asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch, not two selects per op
-                if ((hm4 >> t) & 1u) { base_r = rr; base_d = rd; hs = 1u; }
+                if ((hm4 >> t) & 1u) {
+                    base_r = rr; base_d = rd; hs = 1u;
+                    if (WALK == WALK_DIRECT) {
+                        aln_cur = dc.dup ? find_aln(p.aln_off, p.n_aln, dc.a_lo, dc.g_lane0 + (uint32_t)(4 * j + t)) : aln_cur + 1u;
+                        rs_cur = p.ref_start ? (uint32_t)p.ref_start[aln_cur] : 0u;
+                    }
+                }
             }
             // I or D with len >= min_len (inclusive threshold, :18,:22): compares straight into
             // scalar masks; the per-lane predicate is only derived inside the rarely taken branch
@@ -316,8 +334,18 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
                     } else if (WALK == WALK_DIRECT) {
                         const uint32_t ref = rr - base_r + (hs ? 0u : dc.in_r);
                         const uint32_t rdp = rd - base_d + (hs ? 0u : dc.in_d);
-                        const uint32_t aln = find_aln(p.aln_off, p.n_aln, dc.a_lo, dc.g_lane0 + i);
-                        store_final(p, dc.out0 + n_emit, aln, ref, rdp, len, (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS);
+                        const uint64_t slot = dc.out0 + n_emit;
+#ifdef SVX_EXP_DENSE_FIND  // ablation (profiles/README.md): round 3's per-signature search + ref_start gather
+                        aln_cur = find_aln(p.aln_off, p.n_aln, dc.a_lo, dc.g_lane0 + i);
+                        rs_cur = p.ref_start ? (uint32_t)p.ref_start[aln_cur] : 0u;
+#endif
+                        if (slot < p.cap) {
+                            p.out.aln[slot] = aln_cur;
+                            p.out.ref_pos[slot] = ref + rs_cur;
+                            p.out.read_pos[slot] = rdp;
+                            p.out.len[slot] = len;
+                            p.out.type[slot] = (uint8_t)((op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS);
+                        }
                     }
                     ++n_emit;
                 }
@@ -435,7 +463,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
     // per-round signature queue (kQueue * 16 B == the mask's 512 B) — 5.25 KiB of LDS per wave keeps
     // six 4-wave workgroups on a CU
     static_assert(kLaneOps == 16 && kRounds <= 4, "the queue aliases the start mask: 16 ops per lane, at most 4 rounds");
-    static_assert(kQueue * sizeof(uint4) <= (kTileOps / 32) * sizeof(uint32_t), "queue must fit the start mask's LDS");
+    static_assert(kQueue * sizeof(uint4) <= kHeadWords * sizeof(uint32_t), "queue must fit the start mask's LDS");
     uint32_t hm01 = 0, hm23 = 0;
     if (kLaneOps == 16 && kRounds <= 4) {
         const uint32_t sh = ((uint32_t)lane & 1u) * 16u, wi = (uint32_t)lane >> 1;
@@ -521,6 +549,7 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
 
         DirectCtx dc;
         dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
+        dc.aln0 = 0; dc.rs0 = 0; dc.dup = dup;
         constexpr int kWalk1 = (MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS;
         const WalkOut wo = (!SOA && fast24) ? walk16<kWalk1, SOA, !SOA>(p, myx, swz, opw, hm, HU, lane, queue, dc)
                                             : walk16<kWalk1, SOA, false>(p, myx, swz, opw, hm, HU, lane, queue, dc);
@@ -591,6 +620,11 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
             if (C) {  // dense tile: second walk finishes each signature on the spot
                 dc.in_r = in_r; dc.in_d = in_d;
                 dc.out0 = (uint64_t)obase + tile_cnt + xc;
+                // the alignment the lane's first op continues: a_lo - 1 + the starts before the lane inside the tile
+                // (none before the batch's first op: that op is a start itself)
+                dc.aln0 = !dup ? a_lo + heads_before + (xch >> 16) - 1u
+                               : (dc.g_lane0 ? find_aln(p.aln_off, p.n_aln, a_lo, dc.g_lane0 - 1u) : 0xFFFFFFFFu);
+                dc.rs0 = (p.ref_start && dc.aln0 < p.n_aln) ? (uint32_t)p.ref_start[dc.aln0] : 0u;
                 (void)walk16<WALK_DIRECT, SOA, false>(p, myx, swz, opw, hm, HU, lane, queue, dc);
             }
         }
@@ -654,7 +688,7 @@ __global__ __launch_bounds__(256) void k_tile_alo(const uint64_t* __restrict__ a
 template <bool SOA, int TILE_OPS, int ALO>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kTileOps / 32];  // start mask, then the queue
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];  // start mask, then the queue
     __shared__ uint4 s_stage[kWaves][kStage];
     // the wave index is wave-uniform: tell the compiler so that tile indices, loop bounds and
     // carries live in SGPRs and the tile/round loops are scalar branches
@@ -818,17 +852,130 @@ __global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) {
     }
 }
 
-// ---- D: dense tiles (more than kSlab signatures: adversarial all-indel CIGARs, or a tiny min_len)
-// are re-walked with carry-in and output base known.  Always launched — the host cannot know —
-// and empty in the common case (every workgroup reads the count and leaves). ----
+// ---- D: dense tiles (more than kSlab signatures, or a round that overflowed the queue: SV-dense stretches of
+// an assembly, satellite arrays, a tiny min_len) are re-walked with carry-in and output base known.  Always
+// launched — the host cannot know — and empty in the common case (every workgroup reads the count and leaves).
+// One WORKGROUP per dense tile, one wave per round of 1024 ops: the four rounds are walked side by side (totals
+// walk + wave scan), exchange their totals through LDS — the carry chain across the rounds is four scalar steps —
+// and emit side by side.  (Round 3 gave a tile to one wave, which walked the rounds one after the other and
+// searched aln_off once per signature: 25 us per tile, 73 us for the product's full-size sample.) ----
+struct RoundTotals {
+    uint32_t r, d, tail_r, tail_d, cnt, heads, seen, pad;
+};
+
+template <bool SOA>
+__device__ __forceinline__ void dense_tile_wg(const CigarArgs& p, const uint32_t tile, const int wave, const int lane,
+                                              uint4* xp, uint32_t* hmask, uint32_t* s_dup, RoundTotals* s_round,
+                                              const TileIn& in) {
+    static_assert(kRounds == kWaves && kLaneOps == 16, "one wave per round");
+    const uint64_t g0 = (uint64_t)tile * kTileOps;
+    const uint64_t tile_end = (g0 + kTileOps < p.n_ops) ? g0 + kTileOps : p.n_ops;
+    const uint32_t tile_len = (uint32_t)(tile_end - g0);
+    const uint32_t ro = (uint32_t)wave * kRoundOps;
+    const bool live = ro < tile_len;  // wave-uniform: the ragged last tile may not reach this wave's round
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.cigar + g0, tile_len * 4u);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(SOA ? (const void*)(p.op + g0) : (const void*)p.cigar,
+                                                  SOA ? ((tile_len + 3u) & ~3u) : 0u);
+    uint4 q[kLU];
+    uint32_t qo[kLU] = {};
+    if (live) load_round<SOA>(rs_c, rs_o, tile_len, ro, lane, q, qo);
+    // ---- the tile's start mask, built by the whole workgroup
+    const int tid = wave * 64 + lane;
+    if (tid < kTileOps / 32) hmask[tid] = 0;
+    if (tid == 0) *s_dup = 0;
+    __syncthreads();
+    for (uint64_t a = (uint64_t)in.a_lo + tid;; a += 64 * kWaves) {
+        bool inside = false;
+        if (a < p.n_aln) {
+            const uint64_t off = p.aln_off[a];
+            if (off < tile_end) {
+                inside = true;
+                const uint32_t bit = (uint32_t)(off - g0);
+                if ((atomicOr(&hmask[bit >> 5], 1u << (bit & 31)) >> (bit & 31)) & 1u) *s_dup = 1u;
+            }
+        }
+        if (!__syncthreads_and(inside ? 1 : 0)) break;  // offsets ascend: a thread past the tile ends the sweep
+    }
+    __syncthreads();
+    const bool dup = *s_dup != 0;
+    const uint32_t lbase = ro + (uint32_t)lane * kLaneOps;
+    const uint32_t hm = (hmask[lbase >> 5] >> (lbase & 31)) & 0xFFFFu;
+    const uint32_t HU = wave_or_u32(hm);
+    uint32_t pr = 0, pd = 0, sc = 0, qr = 0, qd = 0;
+    uint64_t H = 0;
+    uint32_t opw[kLU];
+#pragma unroll
+    for (int k = 0; k < kLU; ++k) opw[k] = qo[k];
+    const uint4* myx = xp + lane * kLU;
+    const int swz = xswz(lane);
+    DirectCtx dc;
+    dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = in.a_lo; dc.g_lane0 = g0 + lbase; dc.aln0 = 0; dc.rs0 = 0; dc.dup = dup;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < kLU; ++k) {
+            const int i = k * 64 + lane;
+            const int c = i / kLU;
+            xp[c * kLU + ((i & (kLU - 1)) ^ xswz(c))] = q[k];
+        }
+        wave_lds_sync();
+        const WalkOut wo = walk16<WALK_TOTALS, SOA, false>(p, myx, swz, opw, hm, HU, lane, nullptr, dc);
+        pr = wo.tot_r; pd = wo.tot_d; sc = wo.n_emit | ((uint32_t)__popc(hm) << 16);
+#define SVX_ADD3_STEP(CTRL, RM) \
+        pr += dpp0<CTRL, RM>(pr); pd += dpp0<CTRL, RM>(pd); sc += dpp0<CTRL, RM>(sc);
+        SVX_ADD3_STEP(kDppShr1, 0xF) SVX_ADD3_STEP(kDppShr2, 0xF) SVX_ADD3_STEP(kDppShr4, 0xF)
+        SVX_ADD3_STEP(kDppShr8, 0xF) SVX_ADD3_STEP(kDppBcast15, 0xA) SVX_ADD3_STEP(kDppBcast31, 0xC)
+#undef SVX_ADD3_STEP
+        H = __builtin_amdgcn_ballot_w64(hm != 0);
+        qr = wo.tail_r - pr; qd = wo.tail_d - pd;
+    }
+    if (lane == 0) {
+        RoundTotals t;
+        const uint32_t R = __builtin_amdgcn_readlane(pr, 63), D = __builtin_amdgcn_readlane(pd, 63);
+        const uint32_t CH = __builtin_amdgcn_readlane(sc, 63);
+        const int hlast = H ? 63 - __clzll((long long)H) : 0;
+        t.r = R; t.d = D; t.cnt = CH & 0xFFFFu; t.heads = CH >> 16; t.seen = H ? 1u : 0u; t.pad = 0;
+        t.tail_r = R + __builtin_amdgcn_readlane(qr, hlast);
+        t.tail_d = D + __builtin_amdgcn_readlane(qd, hlast);
+        s_round[wave] = t;
+    }
+    __syncthreads();
+    // ---- carry into this wave's round: fold the rounds before it (wave-uniform scalars)
+    uint32_t carry_r = in.carry_r, carry_d = in.carry_d, cnt_before = 0, heads_before = 0;
+    for (int k = 0; k < wave; ++k) {
+        const RoundTotals t = s_round[k];
+        if (t.seen) { carry_r = t.tail_r; carry_d = t.tail_d; }
+        else { carry_r += t.r; carry_d += t.d; }
+        cnt_before += t.cnt;
+        heads_before += t.heads;
+    }
+    if (live && (__builtin_amdgcn_readlane(sc, 63) & 0xFFFFu)) {
+        const uint32_t xr = dpp0<kDppWaveShr1, 0xF>(pr), xd = dpp0<kDppWaveShr1, 0xF>(pd), xch = dpp0<kDppWaveShr1, 0xF>(sc);
+        const uint64_t hl = H & ((1ull << lane) - 1ull);
+        const bool xf = hl != 0;
+        const int hsrc = xf ? 63 - __clzll((long long)hl) : 0;
+        const uint32_t gq_r = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qr);
+        const uint32_t gq_d = (uint32_t)__builtin_amdgcn_ds_bpermute(hsrc << 2, (int)qd);
+        dc.in_r = xr + (xf ? gq_r : carry_r);
+        dc.in_d = xd + (xf ? gq_d : carry_d);
+        dc.out0 = (uint64_t)in.obase + cnt_before + (xch & 0xFFFFu);
+        dc.aln0 = !dup ? in.a_lo + heads_before + (xch >> 16) - 1u
+                       : (dc.g_lane0 ? find_aln(p.aln_off, p.n_aln, in.a_lo, dc.g_lane0 - 1u) : 0xFFFFFFFFu);
+        dc.rs0 = (p.ref_start && dc.aln0 < p.n_aln) ? (uint32_t)p.ref_start[dc.aln0] : 0u;
+        (void)walk16<WALK_DIRECT, SOA, false>(p, myx, swz, opw, hm, HU, lane, nullptr, dc);
+    }
+    __syncthreads();  // the mask, the totals and the transpose buffers are rewritten for the next tile
+}
+
 template <bool SOA>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_dense(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kTileOps / 32];
+    __shared__ uint32_t s_mask[kTileOps / 32];
+    __shared__ RoundTotals s_round[kWaves];
+    __shared__ uint32_t s_dup;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t n_dense = p.n_dense[2];
-    for (uint32_t work = blockIdx.x * kWaves + wave; work < n_dense; work += gridDim.x * kWaves) {
+    for (uint32_t work = blockIdx.x; work < n_dense; work += gridDim.x) {
         const uint32_t tile = p.dense_list[work];
         const uint4 bp = p.blk_prefix[tile / kScanBlock];
         const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
@@ -838,8 +985,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_dense
         in.carry_r = local_head ? lr : lr + bp.y;
         in.carry_d = local_head ? ld : ld + bp.z;
         in.obase = (lb & 0x7FFFFFFFu) + bp.w;
-        process_tile<MODE_DIRECT, SOA, kTileOps, ALO_GIVEN>(p, tile, lane, s_xpose[wave], s_head[wave],
-                                                                   reinterpret_cast<uint4*>(s_head[wave]), nullptr, in);
+        dense_tile_wg<SOA>(p, tile, wave, lane, s_xpose[wave], s_mask, &s_dup, s_round, in);
     }
 }
 
@@ -859,7 +1005,7 @@ template <bool SOA>
 __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_t* __restrict__ n_out) {
     __shared__ uint32_t s_cr[kSmallMaxTiles], s_cd[kSmallMaxTiles], s_ob[kSmallMaxTiles];
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kTileOps / 32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];
     __shared__ uint32_t s_f[4], s_r[4], s_d[4], s_c[4];
     static_assert(kWaves == 4, "256 threads");
     const int tid = threadIdx.x, lane = tid & 63;
