@@ -63,10 +63,18 @@ int svx_device_count(void);
 
 /* svx_cigar_extract* run batches of at most `max_ops` CIGAR ops in TWO kernel launches (tiles of 1024
  * ops; every workgroup of the second kernel scans all tile descriptors itself): the operating point of
- * the svim-asm CLI, one BAM of an assembly per call (~1.5 M ops), where five dependent launches cost
- * more than the work.  Larger batches take the streaming path (tiles of 4096 ops, five launches).
- * Default and upper limit 2^21 ops; 0 disables the small-batch path.  Results are identical on both. */
+ * the svim-asm CLI — one BAM of an assembly (~1.5 M ops) or both haplotype BAMs of a diploid sample
+ * (~6 M ops) per call —, where five dependent launches cost more than the work.  Larger batches take the
+ * streaming path (tiles of 4096 ops, five launches).  Default and upper limit 2^23 ops; 0 disables the
+ * small-batch path.  Results are identical on both. */
 int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
+/* svx_collect_batch* send the split-segment chain of a submission (segment rows -> decision tree -> post-passes,
+ * SVIM_inter.py:62-340) out as ONE kernel: inside the first launch of the small-batch CIGAR path, or as one launch
+ * behind the streaming path.  on != 0 restores the single-purpose launches (svx_segments_rows_dev,
+ * svx_segments_classify_dev, svx_segments_postpass_dev behind svx_cigar_extract_dev) — same results; kept for
+ * comparison and for submissions whose reads are too uneven for one scratch slice size, which take it by
+ * themselves.  Default off. */
+int svx_ctx_set_split_chain(svx_ctx* ctx, int on);
 /* svx_pair_partition* sort batches of at most `max_candidates` keys in ONE kernel launch (buckets by the
  * leading key bits, every window of buckets sorted inside one workgroup's LDS — merged when the window
  * arrives as a few sorted runs, as PAIR's two haplotype lists do, counted otherwise —, two arrival barriers
@@ -100,6 +108,12 @@ int svx_dev_download(svx_ctx* ctx, void* dst, const void* d_src, size_t bytes);
  * elapsed GPU time of the last call is returned in milliseconds. */
 int svx_ctx_set_timing(svx_ctx* ctx, int enabled);
 int svx_ctx_last_kernel_ms(svx_ctx* ctx, float* ms_total, float* ms_dominant);
+/* Measurement aid: the read-only streaming rate this device sustains right now — `reps` passes of a kernel that
+ * reads d_buf[0 .. bytes) once per pass with the loads of the CIGAR stream (16 bytes per lane, four in flight,
+ * nontemporal) and writes nothing; *ms_per_pass = HIP-event time / reps.  bytes / that time is the second
+ * denominator a read-mostly kernel's achieved GB/s is quoted against (a device-to-device copy is not a
+ * ceiling for such a kernel).  Synchronises the stream.  d_buf 16-byte aligned. */
+int svx_hbm_read_probe_dev(svx_ctx* ctx, const void* d_buf, size_t bytes, uint32_t reps, float* ms_per_pass);
 
 /* Pipelining independent batches over two contexts: make everything enqueued on `ctx` from now on
  * wait until the streaming (dominant) kernel of `other`'s most recent svx_cigar_extract*_dev call

@@ -114,6 +114,8 @@ SYMBOLS = {
     "svx_version": (C.c_char_p, []),
     "svx_device_count": (C.c_int, []),
     "svx_ctx_set_small_batch_ops": (C.c_int, [_P, C.c_uint64]),
+    "svx_hbm_read_probe_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
+    "svx_ctx_set_split_chain": (C.c_int, [_P, C.c_int]),
     "svx_ctx_set_pair_single_launch_max": (C.c_int, [_P, C.c_uint32]),
     "svx_ctx_set_edit_wavefront_cap": (C.c_int, [_P, C.c_uint32]),
     "svx_ctx_set_pair_wait_free": (C.c_int, [_P, C.c_int]),
@@ -248,6 +250,10 @@ class Context:
         """Largest batch (CIGAR ops) of the small-batch (two-launch) path; 0 forces the streaming path."""
         self._check(self.lib.svx_ctx_set_small_batch_ops(self.h, int(max_ops)))
 
+    def set_split_chain(self, on=True):
+        """The split-segment chain of collect_batch as three single-purpose launches instead of one fused kernel."""
+        self._check(self.lib.svx_ctx_set_split_chain(self.h, 1 if on else 0))
+
     def set_pair_single_launch_max(self, max_candidates):
         """Largest batch (candidates) of the one-launch pair sort; 0 forces the radix path."""
         self._check(self.lib.svx_ctx_set_pair_single_launch_max(self.h, int(max_candidates)))
@@ -275,6 +281,12 @@ class Context:
 
     def set_timing(self, on=True):
         self._check(self.lib.svx_ctx_set_timing(self.h, 1 if on else 0))
+
+    def hbm_read_probe(self, d_ptr, nbytes, reps=5):
+        """GB/s of a read-only nontemporal stream over a resident buffer (svx_hbm_read_probe_dev)."""
+        ms = C.c_float()
+        self._check(self.lib.svx_hbm_read_probe_dev(self.h, d_ptr, int(nbytes), int(reps), C.byref(ms)))
+        return nbytes / (ms.value * 1e-3) / 1e9
 
     def last_kernel_ms(self):
         t, d = C.c_float(), C.c_float()

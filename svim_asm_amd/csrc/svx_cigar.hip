@@ -31,6 +31,8 @@
 // own 16 tiles and re-walks the dense ones (see the comment above that kernel).
 // Output order = (alignment, op) order by construction (prefix sums, no atomically-ordered appends).
 #include "svx_internal.h"
+#include "svx_postpass_dev.h"
+#include "svx_segments_dev.h"
 
 namespace {
 
@@ -72,6 +74,7 @@ struct CigarArgs {
     uint32_t n_tiles;
     uint32_t min_len;
     uint4* desc;
+    uint4* desc4;  // small-batch path: one folded descriptor per workgroup of four tiles
     uint4* slab;
     uint32_t* out_base;
     uint32_t* carry_ref;
@@ -224,11 +227,11 @@ __device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rc, __amdgpu_b
 #define SVX_TILE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
 #ifndef SVX_STAGE
-#define SVX_STAGE 48
+#define SVX_STAGE 64
 #endif
 constexpr int kStage = SVX_STAGE;  // finished records staged in LDS per wave before one burst to the slab (>= kQueue)
 #ifndef SVX_QUEUE
-#define SVX_QUEUE 32
+#define SVX_QUEUE 64  // (32 until round 3: a fifth of the 1024-op rounds of an SV-dense contig overflowed it)
 #endif
 constexpr int kQueue = SVX_QUEUE;  // signatures one round may queue in LDS (one flush lane each, so at most 64)
 static_assert(kQueue <= 64, "one flush lane per queued signature");
@@ -400,7 +403,7 @@ struct TileIn {
 // One tile (TILE_OPS <= 4096 ops) processed by one wave.  MODE_STAGE: signatures go to the tile's slab
 // with tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
 template <int MODE, bool SOA, int TILE_OPS, int ALO>
-__device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t tile, const int lane, uint4* xp,
+__device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t tile, const int lane, uint4* xp,
                                              uint32_t* hmask, uint4* queue, uint4* stage, const TileIn& in) {
     static_assert(TILE_OPS % kRoundOps == 0 && TILE_OPS <= kTileOps, "a tile is 1..kRounds whole rounds");
     uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
@@ -663,9 +666,27 @@ __device__ __forceinline__ void process_tile(const CigarArgs& p, const uint32_t 
         const uint32_t hi = tile_cnt - stage_base < (uint32_t)kStage ? tile_cnt : stage_base + (uint32_t)kStage;
         drain(hi);
     }
-    if (MODE == MODE_STAGE && lane == 0) {
-        p.desc[tile] = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31),
-                                  carry_r, carry_d, a_lo);
+    const uint4 dsc = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31), carry_r, carry_d, a_lo);
+    if (MODE == MODE_STAGE && lane == 0) p.desc[tile] = dsc;
+    return dsc;  // wave-uniform
+}
+
+// Small-batch path: the four tiles of a workgroup fold their descriptors into one (segmented sum in tile order),
+// so that the scan every workgroup of k_cigar_finish_small runs covers a quarter of the entries.
+__device__ __forceinline__ void fold_group_desc(const CigarArgs& p, uint4* s_agg, const int wave, const int lane, const uint4 dsc,
+                                                const uint32_t group) {
+    if (lane == 0) s_agg[wave] = dsc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t f = 0, r = 0, d = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; ++k) {
+            const uint4 v = s_agg[k];
+            if (v.x >> 31) { f = 1; r = v.y; d = v.z; }
+            else { r += v.y; d += v.z; }
+            c += v.x & 0x3FFFFFFFu;
+        }
+        p.desc4[group] = make_uint4(c | (f << 31), r, d, 0u);
     }
 }
 
@@ -694,8 +715,18 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
     // carries live in SGPRs and the tile/round loops are scalar branches
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
+    if (TILE_OPS == kRoundOps) {  // small-batch path (one round per tile): the grid covers every tile once
+        __shared__ uint4 s_agg[kWaves];
+        const uint32_t tile = blockIdx.x * kWaves + wave;
+        uint4 dsc = make_uint4(0, 0, 0, 0);
+        if (tile < p.n_tiles)
+            dsc = process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
+                                                              reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
+        fold_group_desc(p, s_agg, wave, lane, dsc, blockIdx.x);
+        return;
+    }
     for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves)
-        process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
+        (void)process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
                                                                   reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
 }
 
@@ -966,154 +997,6 @@ __device__ __forceinline__ void dense_tile_wg(const CigarArgs& p, const uint32_t
     __syncthreads();  // the mask, the totals and the transpose buffers are rewritten for the next tile
 }
 
-template <bool SOA>
-__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_dense(CigarArgs p) {
-    __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ uint32_t s_mask[kTileOps / 32];
-    __shared__ RoundTotals s_round[kWaves];
-    __shared__ uint32_t s_dup;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const uint32_t n_dense = p.n_dense[2];
-    for (uint32_t work = blockIdx.x; work < n_dense; work += gridDim.x) {
-        const uint32_t tile = p.dense_list[work];
-        const uint4 bp = p.blk_prefix[tile / kScanBlock];
-        const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
-        const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
-        TileIn in;
-        in.a_lo = p.tile_alo[tile];
-        in.carry_r = local_head ? lr : lr + bp.y;
-        in.carry_d = local_head ? ld : ld + bp.z;
-        in.obase = (lb & 0x7FFFFFFFu) + bp.w;
-        dense_tile_wg<SOA>(p, tile, wave, lane, s_xpose[wave], s_mask, &s_dup, s_round, in);
-    }
-}
-
-// ---- two-launch path for small batches (one BAM of a human assembly: ~1.5 M ops) ----
-// Five dependent launches cost more than the work itself below a chip-load of tiles, and a tile
-// of 4096 ops per wave leaves most of the chip idle.  Here: k_cigar_tiles with tiles of 1024 ops
-// (one round per wave: 4x the waves for the same batch) and the tile's start index from a 64-ary
-// search instead of a table kernel; then ONE kernel in which every workgroup scans ALL tile
-// descriptors itself (at most 2048 x 16 B, L2-resident: cheaper than a scan kernel plus a launch
-// gap, and no tickets, fences or waiting), copies the records of its own 16 tiles to the final SoA
-// and re-walks those of them that are dense.
-constexpr int kSmallTileOps = kRoundOps;            // 1024 ops
-constexpr uint32_t kSmallMaxTiles = 2048;           // batches up to 2 M ops take this path
-constexpr int kSmallPer = kSmallMaxTiles / 256;     // descriptors per thread in the scan
-
-template <bool SOA>
-__global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_t* __restrict__ n_out) {
-    __shared__ uint32_t s_cr[kSmallMaxTiles], s_cd[kSmallMaxTiles], s_ob[kSmallMaxTiles];
-    __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];
-    __shared__ uint32_t s_f[4], s_r[4], s_d[4], s_c[4];
-    static_assert(kWaves == 4, "256 threads");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- the tile this thread's 16-lane group finishes: its records are requested before the scan
-    const uint32_t tile = blockIdx.x * (256u / kFinLanes) + tid / kFinLanes;
-    const uint32_t l = tid % kFinLanes;
-    const bool mine = tile < p.n_tiles;
-    uint4 spec[kFinSpec];
-#pragma unroll
-    for (int k = 0; k < kFinSpec; ++k)
-        spec[k] = mine ? p.slab[(uint64_t)tile * kSlab + l + k * kFinLanes] : make_uint4(0, 0, 0, 0);
-    const uint4 dsc = mine ? p.desc[tile] : make_uint4(0, 0, 0, 0);
-
-    // ---- segmented exclusive scan over all descriptors: kSmallPer consecutive ones per thread
-    uint32_t lr[kSmallPer], ld[kSmallPer], lc[kSmallPer], lf = 0;  // exclusive inside the thread; lf: bit i = a start before item i
-    uint32_t f = 0, sr = 0, sd = 0, sc = 0;
-    {
-        uint4 d[kSmallPer];
-#pragma unroll
-        for (int i = 0; i < kSmallPer; ++i) {
-            const uint32_t t = (uint32_t)tid * kSmallPer + i;
-            d[i] = t < p.n_tiles ? p.desc[t] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < kSmallPer; ++i) {
-            lr[i] = sr; ld[i] = sd; lc[i] = sc;
-            lf |= f << i;
-            if (d[i].x >> 31) { f = 1; sr = d[i].y; sd = d[i].z; }
-            else { sr += d[i].y; sd += d[i].z; }
-            sc += d[i].x & 0x3FFFFFFFu;
-        }
-    }
-    const uint32_t tf = f, tr = sr, td = sd, tc = sc;  // this thread's aggregate
-    SVX_SEG_SCAN()
-    if (lane == 63) { s_f[wave] = f; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
-    __syncthreads();
-    uint32_t pr_ = 0, pd_ = 0, pc = 0, ar = 0, ad = 0, ac = 0;
-    for (int w2 = 0; w2 < 4; ++w2) {
-        if (w2 == wave) { pr_ = ar; pd_ = ad; pc = ac; }
-        if (s_f[w2]) { ar = s_r[w2]; ad = s_d[w2]; }
-        else { ar += s_r[w2]; ad += s_d[w2]; }
-        ac += s_c[w2];
-    }
-    const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
-                   xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
-    const uint32_t Tr = xf ? xr : pr_ + xr, Td = xf ? xd : pd_ + xd, Tc = pc + xc;  // exclusive over the threads before
-    (void)tf; (void)tr; (void)td; (void)tc;
-#pragma unroll
-    for (int i = 0; i < kSmallPer; ++i) {
-        const uint32_t t = (uint32_t)tid * kSmallPer + i;
-        const bool own = (lf >> i) & 1u;  // a start inside this thread's earlier items
-        s_cr[t] = own ? lr[i] : Tr + lr[i];
-        s_cd[t] = own ? ld[i] : Td + ld[i];
-        s_ob[t] = Tc + lc[i];
-    }
-    if (blockIdx.x == 0 && tid == 255) *n_out = (uint64_t)ac;
-    __syncthreads();
-
-    // ---- finish, sparse tiles (as k_cigar_finish): 16 lanes per tile
-    const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
-    const bool dense = cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense);
-    if (mine && cnt && !dense) {
-        const uint32_t cr = s_cr[tile], cd = s_cd[tile];
-        const uint64_t ob = s_ob[tile];
-        uint32_t rs[kFinSpec];
-#pragma unroll
-        for (int k = 0; k < kFinSpec; ++k)
-            rs[k] = (l + k * kFinLanes < cnt && p.ref_start) ? (uint32_t)p.ref_start[spec[k].x] : 0u;
-#pragma unroll
-        for (int k = 0; k < kFinSpec; ++k) {
-            const uint32_t r = l + k * kFinLanes;
-            if (r < cnt && ob + r < p.cap) {
-                const uint4 rec = spec[k];
-                const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
-                p.out.aln[ob + r] = rec.x;
-                p.out.ref_pos[ob + r] = rec.y + (prec ? cr : 0u) + rs[k];
-                p.out.read_pos[ob + r] = rec.z + (prec ? cd : 0u);
-                p.out.len[ob + r] = len;
-                p.out.type[ob + r] = (uint8_t)type;
-            }
-        }
-        for (uint32_t r = l + kFinSpec * kFinLanes; r < cnt; r += kFinLanes) {
-            const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
-            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
-            store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
-        }
-    }
-    // ---- dense tiles among this workgroup's 16 (rare): one wave each, re-walked with carry-in and
-    // output base known
-    const uint32_t t0 = blockIdx.x * (256u / kFinLanes);
-    for (uint32_t j = wave; j < 256u / kFinLanes; j += kWaves) {
-        const uint32_t t = t0 + j;
-        if (t >= p.n_tiles) break;
-        const uint4 dd = p.desc[t];  // wave-uniform
-        const uint32_t c = __builtin_amdgcn_readfirstlane(dd.x);
-        if ((c & 0x3FFFFFFFu) > (uint32_t)kSlab || (c & kDescForceDense)) {
-            TileIn in;
-            in.a_lo = __builtin_amdgcn_readfirstlane(dd.w);
-            in.carry_r = s_cr[t];
-            in.carry_d = s_cd[t];
-            in.obase = s_ob[t];
-            process_tile<MODE_DIRECT, SOA, kSmallTileOps, ALO_GIVEN>(p, t, lane, s_xpose[wave], s_head[wave],
-                                                                            reinterpret_cast<uint4*>(s_head[wave]), nullptr, in);
-        }
-    }
-}
-
 // ---- per-alignment CIGAR statistics: one wave per alignment ----
 struct StatsArgs {
     const uint32_t* cigar;
@@ -1131,6 +1014,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 struct AlnStats {
     uint32_t lead, ref, qal, rl, hard;
 };
+constexpr int kStatLoads = 8;  // CIGAR words a lane requests before it uses the first
 
 // Statistics of the alignment whose ops are cigar[b .. e), computed by one wave (every lane returns the same):
 // lead = Σ leading S (skipping H), ref = Σ{M,D,N,=,X}, qal = Σ{M,I,=,X}, rl = Σ{M,I,S,=,X,H}, hard = Σ H.
@@ -1156,15 +1040,157 @@ __device__ __forceinline__ AlnStats wave_alignment_stats(const uint32_t* cigar, 
         }
     }
     uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
-    for (uint64_t i = b + lane; i < e; i += 64) {
-        const uint32_t w = cigar[i], op = w & 15u, len = w >> 4;
-        if ((0x18Du >> op) & 1u) ref += len;   // M D N = X  (htslib bam_endpos)
-        if ((0x183u >> op) & 1u) qal += len;   // M I = X
-        if ((0x1B3u >> op) & 1u) rl += len;    // M I S H = X (infer_read_length)
-        if (op == 5u) hard += len;
+    for (uint64_t i0 = b; i0 < e; i0 += kStatLoads * 64) {  // kStatLoads loads in flight per lane: the loop is a chain of round trips
+        uint32_t w[kStatLoads];
+#pragma unroll
+        for (int k = 0; k < kStatLoads; ++k) {
+            const uint64_t i = i0 + (uint64_t)(k * 64 + lane);
+            w[k] = i < e ? cigar[i] : 0xFu;  // op 15: counts for nothing
+        }
+#pragma unroll
+        for (int k = 0; k < kStatLoads; ++k) {
+            const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+            if ((0x18Du >> op) & 1u) ref += len;   // M D N = X  (htslib bam_endpos)
+            if ((0x183u >> op) & 1u) qal += len;   // M I = X
+            if ((0x1B3u >> op) & 1u) rl += len;    // M I S H = X (infer_read_length)
+            if (op == 5u) hard += len;
+        }
     }
     r.lead = lead;
     r.ref = wave_sum(ref); r.qal = wave_sum(qal); r.rl = wave_sum(rl); r.hard = wave_sum(hard);
+    return r;
+}
+
+// The same statistics for 64 / W alignments at once: every aligned group of W lanes of the wave owns one alignment
+// (b, e uniform inside a group; every lane of a group returns the group's result).  All 64 lanes must call it
+// together.  SA-derived segments are three ops long: a whole wave per segment wastes 61 lanes and, worse, one
+// chain of dependent loads per wave; W = 16 runs four chains per wave.
+template <int W>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+template <int W>
+__device__ __forceinline__ AlnStats group_alignment_stats(const uint32_t* cigar, const uint64_t b, const uint64_t e, const int lane) {
+    static_assert(W == 8 || W == 16 || W == 32, "sub-wave groups");
+    const int gl = lane & (W - 1), gshift = lane & ~(W - 1);
+    uint32_t lead = 0;
+    {
+        uint64_t i = b;
+        bool done = b >= e;
+        while (__any(!done)) {
+            const uint64_t j = i + gl;
+            const bool in = !done && j < e;
+            const uint32_t w = in ? cigar[j] : 0u;  // op 0 (M) terminates the prefix
+            const uint32_t op = w & 15u;
+            const bool clip = in && (op == 4u || op == 5u);
+            const uint32_t nb = (uint32_t)(__ballot(!clip) >> gshift) & ((1u << W) - 1u);
+            const int first = nb ? __ffs((int)nb) - 1 : W;
+            lead += group_sum<W>((in && gl < first && op == 4u) ? (w >> 4) : 0u);
+            if (!done) {
+                i += W;
+                done = first < W || i >= e;
+            }
+        }
+    }
+    uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
+    for (uint64_t i0 = b; i0 < e; i0 += kStatLoads * W) {
+        uint32_t w[kStatLoads];
+#pragma unroll
+        for (int k = 0; k < kStatLoads; ++k) {
+            const uint64_t i = i0 + (uint64_t)(k * W + gl);
+            w[k] = i < e ? cigar[i] : 0xFu;  // op 15: counts for nothing
+        }
+#pragma unroll
+        for (int k = 0; k < kStatLoads; ++k) {
+            const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+            if ((0x18Du >> op) & 1u) ref += len;
+            if ((0x183u >> op) & 1u) qal += len;
+            if ((0x1B3u >> op) & 1u) rl += len;
+            if (op == 5u) hard += len;
+        }
+    }
+    AlnStats r;
+    r.lead = lead;
+    r.ref = group_sum<W>(ref); r.qal = group_sum<W>(qal); r.rl = group_sum<W>(rl); r.hard = group_sum<W>(hard);
+    return r;
+}
+
+// ... and for an alignment of at most kTinyOps ops by ONE lane (an SA-derived segment is S M S): 64 alignments per
+// wave, every load of a lane issued before the first is used.
+constexpr int kTinyOps = 8;
+__device__ __forceinline__ AlnStats lane_alignment_stats(const uint32_t* cigar, const uint64_t b, const uint32_t n) {
+    uint32_t w[kTinyOps];
+#pragma unroll
+    for (int k = 0; k < kTinyOps; ++k) w[k] = (uint32_t)k < n ? cigar[b + k] : 0xFu;
+    AlnStats r;
+    r.lead = r.ref = r.qal = r.rl = r.hard = 0;
+    bool prefix = true;
+#pragma unroll
+    for (int k = 0; k < kTinyOps; ++k) {
+        const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+        const bool real = (uint32_t)k < n;
+        prefix = prefix && real && (op == 4u || op == 5u);
+        if (prefix && op == 4u) r.lead += len;
+        if ((0x18Du >> op) & 1u) r.ref += len;
+        if ((0x183u >> op) & 1u) r.qal += len;
+        if ((0x1B3u >> op) & 1u) r.rl += len;
+        if (op == 5u) r.hard += len;
+    }
+    return r;
+}
+
+// ... and for ONE long alignment by the whole workgroup (256 threads, kStatLoads loads in flight per thread): a
+// chimeric read's primary is a whole assembly contig — 10^4 to 10^6 ops.  s_part: 4 x 4 words of LDS.
+__device__ __forceinline__ AlnStats block_alignment_stats(const uint32_t* cigar, const uint64_t b, const uint64_t e, const int tid,
+                                                          uint32_t* s_part) {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
+    for (uint64_t i0 = b; i0 < e; i0 += kStatLoads * 256) {
+        uint32_t w[kStatLoads];
+#pragma unroll
+        for (int k = 0; k < kStatLoads; ++k) {
+            const uint64_t i = i0 + (uint64_t)k * 256 + tid;
+            w[k] = i < e ? cigar[i] : 0xFu;  // op 15: counts for nothing
+        }
+#pragma unroll
+        for (int k = 0; k < kStatLoads; ++k) {
+            const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+            if ((0x18Du >> op) & 1u) ref += len;
+            if ((0x183u >> op) & 1u) qal += len;
+            if ((0x1B3u >> op) & 1u) rl += len;
+            if (op == 5u) hard += len;
+        }
+    }
+    ref = wave_sum(ref); qal = wave_sum(qal); rl = wave_sum(rl); hard = wave_sum(hard);
+    __syncthreads();  // s_part may still be read from the call before
+    if (lane == 0) { s_part[wave * 4 + 0] = ref; s_part[wave * 4 + 1] = qal; s_part[wave * 4 + 2] = rl; s_part[wave * 4 + 3] = hard; }
+    __syncthreads();
+    AlnStats r;
+    r.ref = s_part[0] + s_part[4] + s_part[8] + s_part[12];
+    r.qal = s_part[1] + s_part[5] + s_part[9] + s_part[13];
+    r.rl = s_part[2] + s_part[6] + s_part[10] + s_part[14];
+    r.hard = s_part[3] + s_part[7] + s_part[11] + s_part[15];
+    // leading soft clips: a prefix of the ops; every wave computes it redundantly (no further exchange)
+    uint32_t lead = 0;
+    {
+        uint64_t i = b;
+        bool done = false;
+        while (!done && i < e) {
+            const uint64_t j = i + lane;
+            const uint32_t w = (j < e) ? cigar[j] : 0u;
+            const uint32_t op = w & 15u;
+            const bool clip = (j < e) && (op == 4u || op == 5u);
+            const uint64_t nb = __ballot(!clip);
+            const int first = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
+            lead += wave_sum((lane < first && op == 4u && j < e) ? (w >> 4) : 0u);
+            done = first < 64;
+            i += 64;
+        }
+    }
+    r.lead = lead;
     return r;
 }
 
@@ -1198,26 +1224,29 @@ struct SegRowArgs {
     int32_t* read_len;         // per read: infer_read_length() of its first segment (the primary)
 };
 
+// the row of SVIM_inter.py:66-81 for segment j from its alignment's CIGAR statistics
+__device__ __forceinline__ svx_seg segment_row(const SegRowArgs& p, const uint32_t j, const AlnStats& st) {
+    const int32_t q_start = (int32_t)st.lead;
+    const int32_t over = p.seg_qend[j];
+    const int32_t q_end = over >= 0 ? over : (int32_t)(st.lead + st.qal);
+    const int32_t rl = (int32_t)st.rl;
+    const bool rev = p.seg_rev[j] != 0;
+    svx_seg s;
+    s.q_start = rev ? rl - q_end : q_start;      // :68-73 (query coordinates flipped for reverse records)
+    s.q_end = rev ? rl - q_start : q_end;
+    s.ref_id = p.seg_tid[j];
+    s.ref_start = p.seg_pos[j];
+    s.ref_end = p.seg_pos[j] + (int32_t)(st.ref ? st.ref : 1u);  // htslib bam_endpos
+    s.is_reverse = rev ? 1 : 0;
+    return s;
+}
+
 __global__ __launch_bounds__(256) void k_segment_rows(SegRowArgs p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t j = blockIdx.x * 4 + wave; j < p.n_segs; j += gridDim.x * 4) {
         const uint32_t a = p.seg_src[j];
         const AlnStats st = wave_alignment_stats(p.cigar, p.aln_off[a], p.aln_off[a + 1], lane);
-        if (lane == 0) {
-            const int32_t q_start = (int32_t)st.lead;
-            const int32_t over = p.seg_qend[j];
-            const int32_t q_end = over >= 0 ? over : (int32_t)(st.lead + st.qal);
-            const int32_t rl = (int32_t)st.rl;
-            const bool rev = p.seg_rev[j] != 0;
-            svx_seg s;
-            s.q_start = rev ? rl - q_end : q_start;      // :68-73 (query coordinates flipped for reverse records)
-            s.q_end = rev ? rl - q_start : q_end;
-            s.ref_id = p.seg_tid[j];
-            s.ref_start = p.seg_pos[j];
-            s.ref_end = p.seg_pos[j] + (int32_t)(st.ref ? st.ref : 1u);  // htslib bam_endpos
-            s.is_reverse = rev ? 1 : 0;
-            p.segs[j] = s;
-        }
+        if (lane == 0) p.segs[j] = segment_row(p, j, st);
     }
     // read_len[r] = read length of read r's primary = its first segment; recomputed by the wave that owns it
     for (uint32_t r = blockIdx.x * 4 + wave; r < p.n_reads; r += gridDim.x * 4) {
@@ -1232,11 +1261,426 @@ __global__ __launch_bounds__(256) void k_segment_rows(SegRowArgs p) {
     }
 }
 
+// ---- the split-segment chain of one submission (SVIM_inter.py:62-340) inside the launches of the CIGAR path: a
+// workgroup owns `reads_per_block` consecutive chimeric reads.  Stage A (in the tile launch): the segment rows
+// (sixteen lanes per segment: CIGAR statistics -> svx_seg, :66-81; alignments beyond kLongOps by the whole
+// workgroup), a workgroup barrier, the adjacent-pair decision tree (eight lanes per read, :83-258).  Stage B (in
+// the last launch of the path): the three post-passes (one lane per read, :260-338).  The rows travel through HBM
+// and are read back by the workgroup that wrote them, i.e. from the same CU's cache, behind the barrier; the raw
+// records are an output anyway.  Round 3 ran the chain as three launches of 4-7 us each behind the CIGAR path.
+struct A3Args {
+    int32_t* seg_rl;  // per segment: infer_read_length() of its alignment (the tree takes a read's length from its first segment)
+    SegRowArgs rows;
+    svx_seg_dev::SegArgs tree;
+    svx_post_dev::PostArgs post;
+    uint32_t reads_per_block;
+};
+
+enum { A3_ROWS_TREE = 1, A3_POST = 2 };
+
+constexpr int kMidOps = 512;     // up to here: sixteen lanes per alignment (four round trips of kStatLoads words per lane)
+constexpr int kLongOps = 8192;   // up to here: a wave per alignment; beyond: the whole workgroup
+constexpr int kLongList = 60;
+struct A3Lds {
+    uint32_t n_long, long_list[kLongList], part[16];
+};
+
+template <int STAGES>
+__device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t blk, A3Lds* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n_reads = a.rows.n_reads;
+    const uint32_t per = (STAGES & A3_ROWS_TREE) ? a.reads_per_block : 256u;  // the post-passes: one lane per read
+    const uint32_t r_lo = blk * per;
+    if (r_lo >= n_reads) return;
+    const uint32_t r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
+    if (STAGES & A3_ROWS_TREE) {
+        // ---- rows: the segments of the block's reads, sixteen lanes each; alignments beyond kLongOps are noted and
+        // walked by the whole workgroup afterwards, one at a time
+        // ---- rows.  One THREAD per segment fetches the segment's CIGAR range; tiny alignments (SA-derived: S M S)
+        // are finished by that lane, the others by sixteen lanes each, four at a time per wave, and alignments
+        // beyond kLongOps (a primary is a whole assembly contig) by the whole workgroup, one at a time.
+        uint32_t* s_part = lds->part;
+        const SegRowArgs& p = a.rows;
+        const uint32_t j_lo = p.read_off[r_lo], j_hi = p.read_off[r_hi];
+        if (tid == 0) lds->n_long = 0;
+        __syncthreads();
+        constexpr int W = 16;
+        const int gl = lane & (W - 1), grp = lane / W;
+        for (uint32_t j0 = j_lo; j0 < j_hi; j0 += 256) {
+            // consecutive segments go to different waves: a read's primary is the expensive one
+            const uint32_t j = j0 + (uint32_t)lane * kWaves + (uint32_t)wave;
+            const bool live = j < j_hi;
+            uint64_t cb = 0, ce = 0;
+            if (live) {
+                const uint32_t src = p.seg_src[j];
+                cb = p.aln_off[src];
+                ce = p.aln_off[src + 1];
+            }
+            const uint64_t n = ce - cb;
+            const bool tiny = live && n <= (uint64_t)kTinyOps, big = live && n > (uint64_t)kMidOps;
+            if (tiny) {
+                const AlnStats st = lane_alignment_stats(p.cigar, cb, (uint32_t)n);
+                p.segs[j] = segment_row(p, j, st);
+                a.seg_rl[j] = (int32_t)st.rl;
+            }
+            const bool huge = big && n > (uint64_t)kLongOps;
+            if (huge) {  // noted for the whole workgroup
+                const uint32_t at = atomicAdd(&lds->n_long, 1u);
+                if (at < (uint32_t)kLongList) lds->long_list[at] = j;
+            }
+            // the mid-sized ones of this wave, four per pass: group g takes the (4 * pass + g)-th of them
+            uint64_t mid = __ballot(live && !tiny && !big);
+            while (mid) {  // wave-uniform
+                uint64_t m = mid;
+                int owner = -1;
+#pragma unroll
+                for (int g = 0; g < 64 / W; ++g) {
+                    const int bit = m ? __ffsll((unsigned long long)m) - 1 : -1;
+                    if (bit >= 0) m &= m - 1;
+                    if (g == grp) owner = bit;
+                }
+                mid = m;
+                const int from = owner >= 0 ? owner : lane;
+                const uint32_t jb = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)j);
+                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)(uint32_t)cb);
+                const uint32_t b_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)(uint32_t)(cb >> 32));
+                const uint32_t nn = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)(uint32_t)n);
+                const uint64_t gb = ((uint64_t)b_hi << 32) | b_lo;
+                const AlnStats st = group_alignment_stats<W>(p.cigar, gb, owner >= 0 ? gb + nn : gb, lane);
+                if (owner >= 0 && gl == 0) {
+                    p.segs[jb] = segment_row(p, jb, st);
+                    a.seg_rl[jb] = (int32_t)st.rl;
+                }
+            }
+            // ... and the ones beyond kMidOps (up to kLongOps) by the whole wave, one after the other
+            uint64_t bigs = __ballot(big && !huge);
+            while (bigs) {  // wave-uniform
+                const int owner = __ffsll((unsigned long long)bigs) - 1;
+                bigs &= bigs - 1;
+                const uint32_t jb = (uint32_t)__builtin_amdgcn_readlane((int)j, owner);
+                const uint64_t gb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cb >> 32), owner) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cb, owner);
+                const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)n, owner);
+                const AlnStats st = wave_alignment_stats(p.cigar, gb, gb + nn, lane);
+                if (lane == 0) {
+                    p.segs[jb] = segment_row(p, jb, st);
+                    a.seg_rl[jb] = (int32_t)st.rl;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n_long = lds->n_long;
+        const uint32_t n_long_listed = n_long < (uint32_t)kLongList ? n_long : (uint32_t)kLongList;
+        for (uint32_t k = 0; k < n_long_listed; ++k) {  // workgroup-uniform
+            const uint32_t j = lds->long_list[k];
+            const uint32_t src = p.seg_src[j];
+            const AlnStats st = block_alignment_stats(p.cigar, p.aln_off[src], p.aln_off[src + 1], tid, s_part);
+            if (tid == 0) {
+                p.segs[j] = segment_row(p, j, st);
+                a.seg_rl[j] = (int32_t)st.rl;
+            }
+        }
+        if (n_long > (uint32_t)kLongList) {  // more than the list holds: the rest wave by wave
+            for (uint32_t j = j_lo + wave; j < j_hi; j += 4) {
+                const uint32_t src = p.seg_src[j];
+                const uint64_t cb = p.aln_off[src], ce = p.aln_off[src + 1];
+                if (ce - cb <= (uint64_t)kLongOps) continue;
+                bool listed = false;
+                for (int q = 0; q < kLongList; ++q) listed = listed || lds->long_list[q] == j;
+                if (listed) continue;
+                const AlnStats st = wave_alignment_stats(p.cigar, cb, ce, lane);
+                if (lane == 0) {
+                    p.segs[j] = segment_row(p, j, st);
+                    a.seg_rl[j] = (int32_t)st.rl;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- decision tree: eight lanes per read
+        const int tl = lane & (svx_seg_dev::kGroup - 1), gbase = lane & ~(svx_seg_dev::kGroup - 1);
+        for (uint32_t r0 = r_lo; r0 < r_hi; r0 += 256 / svx_seg_dev::kGroup) {
+            const uint32_t r = r0 + tid / svx_seg_dev::kGroup;
+            svx_seg_dev::segments_group(a.tree, r, r < r_hi, tl, gbase);
+        }
+    }
+    // ---- post-passes: one lane per read
+    if (STAGES & A3_POST)
+        for (uint32_t r = r_lo + tid; r < r_hi; r += 256) svx_post_dev::post_one_read(a.post, r);
+}
+
+// The dense-tile launch of the streaming path (dense_tile_wg above); with WITH_POST its first n_a3_blocks workgroups
+// run the post-passes of the split-segment chain instead — the launch is empty in the common case anyway.
+template <bool SOA, bool WITH_POST>
+__global__ __launch_bounds__(64 * kWaves) void k_cigar_dense(CigarArgs p, A3Args a3, uint32_t n_a3_blocks) {
+    if (WITH_POST && blockIdx.x < n_a3_blocks) {  // workgroup-uniform
+        a3_chain_block<A3_POST>(a3, blockIdx.x, nullptr);
+        return;
+    }
+    __shared__ uint4 s_xpose[kWaves][kXposeU4];
+    __shared__ uint32_t s_mask[kTileOps / 32];
+    __shared__ RoundTotals s_round[kWaves];
+    __shared__ uint32_t s_dup;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_dense = p.n_dense[2];
+    const uint32_t first = WITH_POST ? n_a3_blocks : 0u;
+    for (uint32_t work = blockIdx.x - first; work < n_dense; work += gridDim.x - first) {
+        const uint32_t tile = p.dense_list[work];
+        const uint4 bp = p.blk_prefix[tile / kScanBlock];
+        const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
+        const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
+        TileIn in;
+        in.a_lo = p.tile_alo[tile];
+        in.carry_r = local_head ? lr : lr + bp.y;
+        in.carry_d = local_head ? ld : ld + bp.z;
+        in.obase = (lb & 0x7FFFFFFFu) + bp.w;
+        dense_tile_wg<SOA>(p, tile, wave, lane, s_xpose[wave], s_mask, &s_dup, s_round, in);
+    }
+}
+
+// ---- two-launch path for small batches (one BAM of a human assembly: ~1.5 M ops) ----
+// Five dependent launches cost more than the work itself below a chip-load of tiles, and a tile
+// of 4096 ops per wave leaves most of the chip idle.  Here: k_cigar_tiles with tiles of 1024 ops
+// (one round per wave: 4x the waves for the same batch) and the tile's start index from a 64-ary
+// search instead of a table kernel; then ONE kernel in which every workgroup scans ALL tile
+// descriptors itself (at most 2048 x 16 B, L2-resident: cheaper than a scan kernel plus a launch
+// gap, and no tickets, fences or waiting), copies the records of its own 16 tiles to the final SoA
+// and re-walks those of them that are dense.
+constexpr int kSmallTileOps = kRoundOps;            // 1024 ops
+constexpr int kSmallPer = 8;                        // folded descriptors per thread in the scan
+constexpr uint32_t kSmallMaxGroups = 256u * kSmallPer;   // groups of kWaves tiles (one per workgroup of the tile kernel)
+constexpr uint32_t kSmallMaxTiles = kSmallMaxGroups * kWaves;  // batches up to 8 M ops take this path
+constexpr uint32_t kFinTiles = 256u / 16u;          // tiles a workgroup finishes (16 lanes each): kWaves groups
+static_assert(kFinTiles == 4u * kWaves && kWaves == 4, "a wave of the finish kernel owns one group of four tiles");
+
+template <bool SOA, bool WITH_POST>
+__global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_t* __restrict__ n_out, A3Args a3, uint32_t n_a3_blocks) {
+    if (WITH_POST && blockIdx.x < n_a3_blocks) {  // workgroup-uniform: the post-passes of the split-segment chain
+        a3_chain_block<A3_POST>(a3, blockIdx.x, nullptr);
+        return;
+    }
+    const uint32_t block = WITH_POST ? blockIdx.x - n_a3_blocks : blockIdx.x;
+    __shared__ uint32_t s_cr[kWaves], s_cd[kWaves], s_ob[kWaves];  // exclusive prefix of this workgroup's four groups
+    __shared__ uint4 s_dense[kFinTiles];
+    __shared__ uint32_t s_dense_alo[kFinTiles], s_n_dense;
+    __shared__ uint4 s_xpose[kWaves][kXposeU4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];
+    __shared__ uint32_t s_f[4], s_r[4], s_d[4], s_c[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- the tile this thread's 16-lane group finishes: its records are requested before the scan
+    const uint32_t t0 = block * kFinTiles, g0 = block * kWaves;
+    const uint32_t tile = t0 + tid / kFinLanes;
+    const uint32_t l = tid % kFinLanes;
+    const bool mine = tile < p.n_tiles;
+    uint4 spec[kFinSpec];
+#pragma unroll
+    for (int k = 0; k < kFinSpec; ++k)
+        spec[k] = mine ? p.slab[(uint64_t)tile * kSlab + l + k * kFinLanes] : make_uint4(0, 0, 0, 0);
+    const uint4 dsc = mine ? p.desc[tile] : make_uint4(0, 0, 0, 0);
+
+    // ---- segmented exclusive scan over the folded descriptors of ALL groups (one per four tiles, written by the
+    // tile kernel's workgroups): kSmallPer consecutive ones per thread, DPP scan across the workgroup; only the
+    // prefixes of this workgroup's own four groups are kept
+    const uint32_t n_groups = (p.n_tiles + kWaves - 1) / kWaves;
+    uint32_t f = 0, sr = 0, sd = 0, sc = 0;
+    uint4 d[kSmallPer];
+#pragma unroll
+    for (int i = 0; i < kSmallPer; ++i) {
+        const uint32_t g = (uint32_t)tid * kSmallPer + i;
+        d[i] = g < n_groups ? p.desc4[g] : make_uint4(0, 0, 0, 0);
+    }
+    uint32_t lr[kSmallPer], ld[kSmallPer], lc[kSmallPer], lf = 0;  // exclusive inside the thread; lf: bit i = a start before item i
+#pragma unroll
+    for (int i = 0; i < kSmallPer; ++i) {
+        lr[i] = sr; ld[i] = sd; lc[i] = sc;
+        lf |= f << i;
+        if (d[i].x >> 31) { f = 1; sr = d[i].y; sd = d[i].z; }
+        else { sr += d[i].y; sd += d[i].z; }
+        sc += d[i].x & 0x3FFFFFFFu;
+    }
+    SVX_SEG_SCAN()
+    if (lane == 63) { s_f[wave] = f; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
+    __syncthreads();
+    uint32_t pr_ = 0, pd_ = 0, pc = 0, ar = 0, ad = 0, ac = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+        if (w2 == wave) { pr_ = ar; pd_ = ad; pc = ac; }
+        if (s_f[w2]) { ar = s_r[w2]; ad = s_d[w2]; }
+        else { ar += s_r[w2]; ad += s_d[w2]; }
+        ac += s_c[w2];
+    }
+    const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
+                   xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
+    const uint32_t Tr = xf ? xr : pr_ + xr, Td = xf ? xd : pd_ + xd, Tc = pc + xc;  // exclusive over the threads before
+#pragma unroll
+    for (int i = 0; i < kSmallPer; ++i) {
+        const uint32_t g = (uint32_t)tid * kSmallPer + i;
+        if (g - g0 < (uint32_t)kWaves) {
+            const bool own = (lf >> i) & 1u;  // a start inside this thread's earlier items
+            s_cr[g - g0] = own ? lr[i] : Tr + lr[i];
+            s_cd[g - g0] = own ? ld[i] : Td + ld[i];
+            s_ob[g - g0] = Tc + lc[i];
+        }
+    }
+    if (block == 0 && tid == 255) *n_out = (uint64_t)ac;
+    __syncthreads();
+    // ---- inside the group (= this wave's four tiles, 16 lanes each): fold the tiles before mine
+    uint32_t t_cr = s_cr[wave], t_cd = s_cd[wave], t_ob = s_ob[wave];
+    {
+        const int k_mine = lane / kFinLanes;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t vx = __builtin_amdgcn_readlane(dsc.x, k * kFinLanes), vy = __builtin_amdgcn_readlane(dsc.y, k * kFinLanes),
+                           vz = __builtin_amdgcn_readlane(dsc.z, k * kFinLanes);
+            if (k < k_mine) {
+                if (vx >> 31) { t_cr = vy; t_cd = vz; }
+                else { t_cr += vy; t_cd += vz; }
+                t_ob += vx & 0x3FFFFFFFu;
+            }
+        }
+    }
+
+    // ---- finish, sparse tiles (as k_cigar_finish): 16 lanes per tile
+    const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
+    const bool dense = cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense);
+    if (mine && cnt && !dense) {
+        const uint32_t cr = t_cr, cd = t_cd;
+        const uint64_t ob = t_ob;
+        uint32_t rs[kFinSpec];
+#pragma unroll
+        for (int k = 0; k < kFinSpec; ++k)
+            rs[k] = (l + k * kFinLanes < cnt && p.ref_start) ? (uint32_t)p.ref_start[spec[k].x] : 0u;
+#pragma unroll
+        for (int k = 0; k < kFinSpec; ++k) {
+            const uint32_t r = l + k * kFinLanes;
+            if (r < cnt && ob + r < p.cap) {
+                const uint4 rec = spec[k];
+                const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+                p.out.aln[ob + r] = rec.x;
+                p.out.ref_pos[ob + r] = rec.y + (prec ? cr : 0u) + rs[k];
+                p.out.read_pos[ob + r] = rec.z + (prec ? cd : 0u);
+                p.out.len[ob + r] = len;
+                p.out.type[ob + r] = (uint8_t)type;
+            }
+        }
+        for (uint32_t r = l + kFinSpec * kFinLanes; r < cnt; r += kFinLanes) {
+            const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
+            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+            store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
+        }
+    }
+    // ---- dense tiles among this workgroup's sixteen (a round that overflowed the queue, a tile beyond the slab): listed
+    // in LDS and re-walked with carry-in and output base known, one wave each, the waves taking turns
+    if (tid == 0) s_n_dense = 0;
+    __syncthreads();
+    if (mine && dense && l == 0) {
+        const uint32_t at = atomicAdd(&s_n_dense, 1u);
+        s_dense[at] = make_uint4(tile, t_cr, t_cd, t_ob);
+        s_dense_alo[at] = dsc.w;
+    }
+    __syncthreads();
+    const uint32_t n_dense = s_n_dense;
+    for (uint32_t i = wave; i < n_dense; i += kWaves) {
+        const uint4 e = s_dense[i];
+        TileIn in;
+        in.a_lo = s_dense_alo[i];
+        in.carry_r = e.y;
+        in.carry_d = e.z;
+        in.obase = e.w;
+        (void)process_tile<MODE_DIRECT, SOA, kSmallTileOps, ALO_GIVEN>(p, e.x, lane, s_xpose[wave], s_head[wave],
+                                                                              reinterpret_cast<uint4*>(s_head[wave]), nullptr, in);
+    }
+}
+
+// The small-batch path's two launches carry the chain inside them: the first one the rows and the decision tree
+// beside the tile workgroups of k_cigar_tiles, the second one (k_cigar_finish_small) the post-passes beside the
+// finishing workgroups — the chain's workgroups first in each grid, they are the longer dependent sequences.  So
+// a1+a2 and a3 of a sample overlap without a second stream and its cross-stream events, and the register-hungry
+// post-pass code (float64 linkage) stays out of the kernel whose occupancy matters.
+template <bool SOA, int TILE_OPS, int ALO>
+__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks,
+                                                                              uint32_t a3_stride) {
+    __shared__ uint4 s_xpose[kWaves][kXposeU4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];
+    __shared__ uint4 s_stage[kWaves][kStage];
+    // which workgroups carry the chain: the first n_a3_blocks (a3_stride == 0: small batches, the chain is the
+    // longer dependent sequence) or every a3_stride-th one (streaming path: the latency-bound chain spreads over
+    // the run of the bandwidth-bound tile workgroups)
+    uint32_t tile_block, a3_block;
+    bool is_a3;
+    if (a3_stride == 0) {
+        is_a3 = blockIdx.x < n_a3_blocks;
+        a3_block = blockIdx.x;
+        tile_block = blockIdx.x - n_a3_blocks;
+    } else {
+        const uint32_t q = blockIdx.x / a3_stride, rem = blockIdx.x % a3_stride;
+        is_a3 = rem == 0 && q < n_a3_blocks;
+        a3_block = q;
+        const uint32_t before = q + (rem ? 1u : 0u);  // chain workgroups in front of this one
+        tile_block = blockIdx.x - (before < n_a3_blocks ? before : n_a3_blocks);
+    }
+    if (is_a3) {  // workgroup-uniform
+        __shared__ A3Lds lds;
+        a3_chain_block<A3_ROWS_TREE>(a, a3_block, &lds);
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile = tile_block * kWaves + wave;
+    uint4 dsc = make_uint4(0, 0, 0, 0);
+    if (tile < p.n_tiles)
+        dsc = process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
+                                                          reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
+    if (TILE_OPS == kSmallTileOps) {
+        __shared__ uint4 s_agg[kWaves];
+        fold_group_desc(p, s_agg, wave, lane, dsc, tile_block);
+    }
+}
+
+// Fills the chain's arguments from a plan; takes the tree's and the post-passes' scratch from the workspace
+// (reserved by the caller together with the CIGAR path's).
+void a3_fill(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, const svx_a3_plan& q, uint64_t post_stride,
+             A3Args* a) {
+    a->rows = SegRowArgs{d_cigar, d_aln_off, q.d_seg_src, q.d_seg_tid, q.d_seg_pos, q.d_seg_rev, q.d_seg_qend, q.n_segs,
+                         q.d_read_off, q.n_reads, q.d_segs, q.d_read_len};
+    a->seg_rl = svx_ws_take<int32_t>(ctx, q.n_segs ? q.n_segs : 1);
+    a->tree.segs = q.d_segs;
+    a->tree.seg_rl = a->seg_rl;
+    a->tree.read_len_out = q.d_read_len;
+    a->tree.sorted = svx_ws_take<svx_seg>(ctx, q.n_segs ? q.n_segs : 1);
+    a->tree.read_off = q.d_read_off;
+    a->tree.read_len = q.d_read_len;
+    a->tree.n_reads = q.n_reads;
+    a->tree.o = q.params;
+    a->tree.out = q.d_raw;
+    svx_post_dev::PostArgs& o = a->post;
+    o.raw = q.d_raw; o.read_off = q.d_read_off; o.n_reads = q.n_reads; o.contig_rank = q.d_contig_rank; o.n_contigs = q.n_contigs;
+    o.min_sv = q.params.min_sv_size; o.max_sv = q.params.max_sv_size;
+    o.out = q.d_post; o.out_off = q.d_post_off; o.out_cnt = q.d_post_cnt;
+    o.scratch = svx_ws_take<char>(ctx, (size_t)q.n_reads * post_stride);
+    o.scratch_off = nullptr;
+    o.scratch_stride = post_stride;
+    // reads per workgroup of the rows + tree stage: two while the grid stays small (the shortest dependent sequence
+    // per workgroup), up to sixteen — about 48 segments, twelve per wave, of which a read's primary is the mid-sized
+    // or long one: one pass of four sixteen-lane groups per wave — for a cohort's reads
+#ifndef SVX_A3_READS_DIV
+#define SVX_A3_READS_DIV 1024u
+#endif
+#ifndef SVX_A3_READS_MAX
+#define SVX_A3_READS_MAX 16u
+#endif
+    const uint32_t per = q.n_reads / SVX_A3_READS_DIV;
+    a->reads_per_block = per < 2u ? 2u : (per > SVX_A3_READS_MAX ? SVX_A3_READS_MAX : per);
+}
+
+// a3 != nullptr: the split-segment chain of the same submission goes out with the CIGAR path — inside the tile
+// launch on the small-batch path, as one launch behind it on the streaming path (svx_collect_batch_dev).
 template <bool SOA>
 int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const uint8_t* d_op,
                            uint64_t n_ops, const uint64_t* d_aln_off, uint32_t n_aln,
                            const int32_t* d_ref_start, uint32_t min_len, svx_sig_soa d_out,
-                           uint64_t cap, uint64_t* d_n_out) {
+                           uint64_t cap, uint64_t* d_n_out, const svx_a3_plan* a3 = nullptr) {
     if (!ctx || !d_n_out) return SVX_E_INVALID;
     if (n_ops >= (1ull << 32)) {
         SVX_SET_ERR(ctx, "n_ops=%llu exceeds the 2^32-1 per-call limit; split the batch",
@@ -1246,7 +1690,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     SVX_HIP(ctx, hipSetDevice(ctx->device));
     if (n_ops == 0 || n_aln == 0) {
         SVX_HIP(ctx, hipMemsetAsync(d_n_out, 0, sizeof(uint64_t), ctx->stream));
-        return SVX_OK;
+        return a3 ? SVX_E_INVALID : SVX_OK;
     }
     if (!d_cigar_or_len || !d_aln_off || (SOA && !d_op)) return SVX_E_INVALID;
     if (cap > 0 && (!d_out.aln || !d_out.ref_pos || !d_out.read_pos || !d_out.len || !d_out.type))
@@ -1259,7 +1703,10 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const bool small = n_ops <= (uint64_t)kSmallMaxTiles * kSmallTileOps && n_ops <= ctx->small_batch_ops;
     const uint32_t n_tiles = small ? (uint32_t)((n_ops + kSmallTileOps - 1) / kSmallTileOps)
                                    : (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
-    int rc = svx_ws_reserve(ctx, svx_cigar_extract_ws_need(ctx, n_ops));
+    size_t need = svx_cigar_extract_ws_need(ctx, n_ops);
+    if (a3) need += svx_take_bytes(a3->n_segs ? a3->n_segs : 1, sizeof(svx_seg)) + svx_take_bytes(a3->n_segs ? a3->n_segs : 1, 4) +
+                    svx_take_bytes((size_t)a3->n_reads * a3->post_stride, 1);
+    int rc = svx_ws_reserve(ctx, need);
     if (rc != SVX_OK) return rc;
 
     CigarArgs a;
@@ -1273,6 +1720,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     a.min_len = min_len;
     a.n_dense = reinterpret_cast<uint32_t*>(ctx->ws);  // workspace header: zero at allocation, self-cleaning
     a.desc = svx_ws_take<uint4>(ctx, n_tiles);
+    a.desc4 = svx_ws_take<uint4>(ctx, (n_tiles + kWaves - 1) / kWaves);
     a.slab = svx_ws_take<uint4>(ctx, (size_t)n_tiles * kSlab);
     a.out_base = svx_ws_take<uint32_t>(ctx, n_tiles);
     a.carry_ref = svx_ws_take<uint32_t>(ctx, n_tiles);
@@ -1284,14 +1732,27 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     a.blk_prefix = svx_ws_take<uint4>(ctx, n_scan_blocks);
     a.out = d_out;
     a.cap = cap;
+    A3Args c;
+    memset(&c, 0, sizeof(c));
+    uint32_t n_a3_blocks = 0, n_post_blocks = 0;
+    if (a3) {
+        a3_fill(ctx, d_cigar_or_len, d_aln_off, *a3, a3->post_stride, &c);
+        n_a3_blocks = (a3->n_reads + c.reads_per_block - 1) / c.reads_per_block;
+        n_post_blocks = (a3->n_reads + 255u) / 256u;
+    }
 
-    if (small) {  // two launches: tiles of 1024 ops; scan + finish + dense tiles
+    if (small) {  // two launches: tiles of 1024 ops (+ the split-segment chain); scan + finish + dense tiles
         rc = svx_timing_begin(ctx);
         if (rc != SVX_OK) return rc;
         rc = svx_timing_mark(ctx, 1);
         if (rc != SVX_OK) return rc;
-        hipLaunchKernelGGL((k_cigar_tiles<SOA, kSmallTileOps, ALO_SEARCH>), dim3((n_tiles + kWaves - 1) / kWaves),
-                           dim3(64 * kWaves), 0, ctx->stream, a);
+        const uint32_t tile_blocks = (n_tiles + kWaves - 1) / kWaves;
+        if (a3)
+            hipLaunchKernelGGL((k_tiles_a3<SOA, kSmallTileOps, ALO_SEARCH>), dim3(n_a3_blocks + tile_blocks), dim3(64 * kWaves), 0,
+                               ctx->stream, a, c, n_a3_blocks, 0u);
+        else
+            hipLaunchKernelGGL((k_cigar_tiles<SOA, kSmallTileOps, ALO_SEARCH>), dim3(tile_blocks), dim3(64 * kWaves), 0,
+                               ctx->stream, a);
         rc = svx_timing_mark(ctx, 2);
         if (rc != SVX_OK) return rc;
         if (ctx->want_dom) {
@@ -1299,8 +1760,12 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
             SVX_HIP(ctx, hipEventRecord(ctx->ev_dom, ctx->stream));
             ctx->ev_dom_recorded = true;
         }
-        hipLaunchKernelGGL((k_cigar_finish_small<SOA>), dim3((n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes)), dim3(256),
-                           0, ctx->stream, a, d_n_out);
+        const uint32_t fin_blocks = (n_tiles + kFinTiles - 1) / kFinTiles;
+        if (a3)
+            hipLaunchKernelGGL((k_cigar_finish_small<SOA, true>), dim3(n_post_blocks + fin_blocks), dim3(256), 0, ctx->stream, a, d_n_out,
+                               c, n_post_blocks);
+        else
+            hipLaunchKernelGGL((k_cigar_finish_small<SOA, false>), dim3(fin_blocks), dim3(256), 0, ctx->stream, a, d_n_out, c, 0u);
         SVX_HIP(ctx, hipGetLastError());
         return svx_timing_end(ctx);
     }
@@ -1308,17 +1773,18 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t blocks_cap = (uint32_t)ctx->n_cu * 8u;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
-#ifdef SVX_EXP_STREAM_SEARCH  // experiment (profiles/README.md): the small path's wave search instead of the table kernel
-    rc = svx_timing_mark(ctx, 1);
-    if (rc != SVX_OK) return rc;
-    hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_SEARCH>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
-#else
     hipLaunchKernelGGL(k_tile_alo, dim3((n_aln + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
                        a.tile_alo);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-    hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
-#endif
+    if (a3) {  // the chain's rows and decision tree ride inside the streaming launch, every stride-th workgroup
+        const uint32_t total = blocks_all + n_a3_blocks;
+        const uint32_t stride = total / n_a3_blocks ? total / n_a3_blocks : 1u;
+        hipLaunchKernelGGL((k_tiles_a3<SOA, kTileOps, ALO_TABLE>), dim3(total), dim3(64 * kWaves), 0, ctx->stream, a, c, n_a3_blocks,
+                           stride);
+    } else {
+        hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
+    }
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)
@@ -1331,8 +1797,12 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
                        a.blk_prefix, a.n_dense + 1, d_n_out);
     hipLaunchKernelGGL(k_cigar_finish, dim3((n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes)), dim3(256), 0,
                        ctx->stream, a);
-    hipLaunchKernelGGL((k_cigar_dense<SOA>), dim3(blocks_all < blocks_cap ? blocks_all : blocks_cap), dim3(64 * kWaves),
-                       0, ctx->stream, a);
+    const uint32_t dense_blocks = n_tiles < blocks_cap ? n_tiles : blocks_cap;
+    if (a3)  // ... and its post-passes inside the dense-tile launch
+        hipLaunchKernelGGL((k_cigar_dense<SOA, true>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c,
+                           n_post_blocks);
+    else
+        hipLaunchKernelGGL((k_cigar_dense<SOA, false>), dim3(dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c, 0u);
     SVX_HIP(ctx, hipGetLastError());
     return svx_timing_end(ctx);
 }
@@ -1422,6 +1892,13 @@ extern "C" int svx_cigar_extract_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint
                                          min_len, d_out, cap, d_n_out);
 }
 
+int svx_cigar_extract_chain_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint64_t n_ops, const uint64_t* d_aln_off, uint32_t n_aln,
+                                const int32_t* d_ref_start, uint32_t min_len, svx_sig_soa d_out, uint64_t cap,
+                                uint64_t* d_n_out, const svx_a3_plan* a3) {
+    return cigar_extract_dev_impl<false>(ctx, d_cigar, nullptr, n_ops, d_aln_off, n_aln, d_ref_start, min_len, d_out, cap,
+                                         d_n_out, a3);
+}
+
 extern "C" int svx_cigar_extract_soa_dev(svx_ctx* ctx, const uint8_t* d_op, const uint32_t* d_len,
                                          uint64_t n_ops, const uint64_t* d_aln_off, uint32_t n_aln,
                                          const int32_t* d_ref_start, uint32_t min_len,
@@ -1499,7 +1976,8 @@ size_t svx_cigar_extract_ws_need(const svx_ctx* ctx, uint64_t n_ops) {
     const bool small = n_ops <= (uint64_t)kSmallMaxTiles * kSmallTileOps && n_ops <= ctx->small_batch_ops;
     const uint32_t n_tiles = small ? (uint32_t)((n_ops + kSmallTileOps - 1) / kSmallTileOps)
                                    : (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
-    return svx_take_bytes(n_tiles, sizeof(uint4)) + svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
+    return svx_take_bytes(n_tiles, sizeof(uint4)) + svx_take_bytes((n_tiles + kWaves - 1) / kWaves, sizeof(uint4)) +
+           svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
            5 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
            2 * svx_take_bytes((n_tiles + kScanBlock - 1) / kScanBlock, sizeof(uint4));
 }

@@ -59,9 +59,34 @@ extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
     if (chain && (!d->read_off || !d->d_read_off || !d->post_off || !d->d_post_off || !d->d_post_cnt || !d->d_segs ||
                   !d->d_read_len || !d->d_raw || !d->d_seg_src))
         return SVX_E_INVALID;
-    int rc = svx_cigar_extract_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len, d->d_sig,
-                                   d->sig_cap, d->d_n_sig);
-    if (rc != SVX_OK || !chain) return rc;
+    if (!chain)
+        return svx_cigar_extract_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len, d->d_sig,
+                                     d->sig_cap, d->d_n_sig);
+    if (!d->d_seg_tid || !d->d_seg_pos || !d->d_seg_rev || !d->d_seg_qend || (d->n_contigs && !d->d_contig_rank)) return SVX_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(d->d_segs) & 7u) || (reinterpret_cast<uintptr_t>(d->d_raw) & 15u)) {
+        SVX_SET_ERR(ctx, "d_segs must be 8-byte aligned and d_raw 16-byte aligned");
+        return SVX_E_INVALID;
+    }
+    if (d->read_off[d->n_reads] != d->n_segs) return SVX_E_INVALID;
+    uint64_t stride = 0;
+    int rc = svx_postpass_plan(ctx, d->read_off, d->n_reads, d->post_off, &stride);
+    if (rc != SVX_OK) return rc;
+    if (d->post_off[d->n_reads] && !d->d_post) return SVX_E_INVALID;
+    if (stride && !ctx->split_chain) {
+        // the chain goes out with the CIGAR path: inside its tile launch (small batches) or as one launch behind it
+        svx_a3_plan q;
+        q.d_seg_src = d->d_seg_src; q.d_seg_tid = d->d_seg_tid; q.d_seg_pos = d->d_seg_pos; q.d_seg_rev = d->d_seg_rev;
+        q.d_seg_qend = d->d_seg_qend; q.n_segs = d->n_segs; q.d_read_off = d->d_read_off; q.n_reads = d->n_reads;
+        q.d_contig_rank = d->d_contig_rank; q.n_contigs = d->n_contigs; q.params = d->params; q.d_segs = d->d_segs;
+        q.d_read_len = d->d_read_len; q.d_raw = d->d_raw; q.d_post = d->d_post; q.d_post_off = d->d_post_off;
+        q.d_post_cnt = d->d_post_cnt; q.post_stride = stride;
+        return svx_cigar_extract_chain_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len,
+                                           d->d_sig, d->sig_cap, d->d_n_sig, &q);
+    }
+    // reads too uneven for one scratch slice size (or svx_ctx_set_split_chain): the single-purpose launches
+    rc = svx_cigar_extract_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len, d->d_sig,
+                               d->sig_cap, d->d_n_sig);
+    if (rc != SVX_OK) return rc;
     rc = svx_segments_rows_dev(ctx, d->d_cigar, d->d_aln_off, d->d_seg_src, d->d_seg_tid, d->d_seg_pos, d->d_seg_rev,
                                d->d_seg_qend, d->n_segs, d->d_read_off, d->n_reads, d->d_segs, d->d_read_len);
     if (rc != SVX_OK) return rc;

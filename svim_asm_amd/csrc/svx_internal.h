@@ -39,7 +39,8 @@ struct svx_ctx {
     bool pair_wait_free = false;       // svx_ctx_set_pair_wait_free: sort on the plan without waits inside a launch
     uint32_t pair_retries = 0;         // host-pointer calls that were re-run on that plan after a wait ran out
     uint32_t pair_single_max = 131072;  // svx_ctx_set_pair_single_launch_max: largest batch of the one-launch pair sort
-    uint64_t small_batch_ops = 1ull << 21;  // svx_ctx_set_small_batch_ops: largest batch of the single-launch CIGAR path
+    uint64_t small_batch_ops = 1ull << 23;  // svx_ctx_set_small_batch_ops: largest batch of the two-launch CIGAR path
+    bool split_chain = false;               // svx_ctx_set_split_chain: the split-segment chain as three launches
     char err[512] = {0};
 };
 
@@ -71,6 +72,35 @@ int svx_stage_reserve(svx_ctx* ctx, size_t total);
 // workspace bytes svx_cigar_extract*_dev / svx_segments_postpass_dev reserve for a batch (svx_collect_batch_dev sums them)
 size_t svx_cigar_extract_ws_need(const svx_ctx* ctx, uint64_t n_ops);
 size_t svx_postpass_ws_need(const uint32_t* read_off, uint32_t n_reads);
+
+// The split-segment chain of one submission (the a3 fields of svx_collect_dev) with the per-read scratch slice
+// size of its post-passes (svx_postpass_plan); svx_cigar_extract_chain_dev sends it out with the CIGAR path.
+struct svx_a3_plan {
+    const uint32_t* d_seg_src;
+    const int32_t* d_seg_tid;
+    const int32_t* d_seg_pos;
+    const uint8_t* d_seg_rev;
+    const int32_t* d_seg_qend;
+    uint32_t n_segs;
+    const uint32_t* d_read_off;
+    uint32_t n_reads;
+    const int32_t* d_contig_rank;
+    uint32_t n_contigs;
+    svx_seg_params params;
+    svx_seg* d_segs;
+    int32_t* d_read_len;
+    svx_raw* d_raw;
+    svx_post* d_post;
+    const uint64_t* d_post_off;
+    uint32_t* d_post_cnt;
+    uint64_t post_stride;
+};
+// Validates the host copies of read_off / out_off like svx_segments_postpass_dev and returns the uniform scratch
+// slice size of the post-passes (0: the reads are too uneven for one size — take the separate launches).
+int svx_postpass_plan(svx_ctx* ctx, const uint32_t* read_off, uint32_t n_reads, const uint64_t* out_off, uint64_t* stride);
+int svx_cigar_extract_chain_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint64_t n_ops, const uint64_t* d_aln_off, uint32_t n_aln,
+                                const int32_t* d_ref_start, uint32_t min_len, svx_sig_soa d_out, uint64_t cap,
+                                uint64_t* d_n_out, const svx_a3_plan* a3);
 
 template <typename T>
 static inline T* svx_ws_take(svx_ctx* ctx, size_t count) {

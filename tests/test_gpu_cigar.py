@@ -14,12 +14,12 @@ KEYS = ("aln", "ref_pos", "read_pos", "len", "type")
 
 @pytest.fixture(autouse=True, params=["small_batch", "streaming"])
 def cigar_path(request, svx_ctx):
-    """Every test of this module runs on both kernel paths: batches up to 2^21 ops in two launches
+    """Every test of this module runs on both kernel paths: batches up to 2^23 ops in two launches
     (tiles of 1024 ops, k_cigar_finish_small) and the five-launch streaming path (tiles of 4096 ops) that
     larger batches take — forced here with svx_ctx_set_small_batch_ops(0)."""
-    svx_ctx.set_small_batch_ops(0 if request.param == "streaming" else 1 << 21)
+    svx_ctx.set_small_batch_ops(0 if request.param == "streaming" else 1 << 23)
     yield request.param
-    svx_ctx.set_small_batch_ops(1 << 21)
+    svx_ctx.set_small_batch_ops(1 << 23)
 
 
 def pack(tuples):
@@ -234,6 +234,20 @@ def test_full_size_configs_match_oracle(svx_ctx, cfg):
     same = np.diff(got["aln"].astype(np.int64)) == 0
     assert np.all(np.diff(got["read_pos"].astype(np.int64))[same] >= 0)
     assert np.all(np.diff(got["ref_pos"].astype(np.int64))[same] >= 0)
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=31, mean_m=2000, sv_frac=0.015, ops_target=5_000_000),
+                                 dict(seed=32, mean_m=2000, sv_frac=0.09, ops_target=3_000_000),
+                                 dict(seed=33, mean_m=200, sv_frac=0.5, ops_target=8_000_000)])
+def test_diploid_sized_and_sv_dense_batches(svx_ctx, cfg):
+    """Both haplotype BAMs of a diploid sample in one batch (2-8 M ops: on the two-launch path every workgroup
+    of k_cigar_finish_small folds its share of up to 8192 descriptors in four chunks), at the SV density of the
+    full-size synthetic sample's small contigs (a fifth of the tiles leave the staged path: rounds with more
+    signatures than the queue holds, tiles beyond the slab) and at satellite density (every tile dense)."""
+    b = synth.synth_cigar_batch(**cfg)
+    assert (1 << 21) < len(b["cigar"]) < (1 << 23)
+    got = svx_ctx.cigar_extract(b["cigar"], b["aln_off"], b["ref_start"], 40)
+    assert_same(got, orc.cigar_extract(b["cigar"], b["aln_off"], b["ref_start"], 40))
 
 
 def test_cohort_batch_equals_per_sample_concat(svx_ctx):

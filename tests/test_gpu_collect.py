@@ -18,6 +18,16 @@ pytestmark = pytest.mark.gpu
 PARAMS = (40, 100000, 50, 50, 50, 50)
 
 
+@pytest.fixture(autouse=True, params=["fused_chain", "split_chain"])
+def chain_form(request, svx_ctx):
+    """Every test of this module runs with the split-segment chain of a submission as ONE kernel (inside the tile
+    launch of the small-batch path, behind the streaming path) and as the three single-purpose launches
+    (svx_ctx_set_split_chain)."""
+    svx_ctx.set_split_chain(request.param == "split_chain")
+    yield request.param
+    svx_ctx.set_split_chain(False)
+
+
 def random_batch(rng, n_aln, n_parts=2, n_reads=40, max_supp=4, long_read=False):
     """Records with random CIGARs split over `n_parts` pools, and chimeric reads whose segments name pool records
     (primaries) and extra alignments (SA-derived)."""
@@ -89,7 +99,7 @@ def test_streaming_path_and_capacity_retry(svx_ctx):
     try:
         same(call(svx_ctx.collect_batch, b, 1), call(svx_ctx.collect_batch_composed, b, 1))
     finally:
-        svx_ctx.set_small_batch_ops(1 << 21)
+        svx_ctx.set_small_batch_ops(1 << 23)
 
 
 def test_empty_and_degenerate_batches(svx_ctx):

@@ -57,7 +57,7 @@ def test_timing_brackets_the_last_device_call(svx_ctx):
         svx_ctx.last_kernel_ms()  # nothing timed yet
     svx_ctx.set_timing(True)
     try:
-        for ops in (1 << 21, 0):  # both kernel paths
+        for ops in (1 << 23, 0):  # both kernel paths
             svx_ctx.set_small_batch_ops(ops)
             _run(svx_ctx, b, len(cig), len(off) - 1, cap)
             svx_ctx.sync()
@@ -66,7 +66,7 @@ def test_timing_brackets_the_last_device_call(svx_ctx):
             _check(b, exp)
     finally:
         svx_ctx.set_timing(False)
-        svx_ctx.set_small_batch_ops(1 << 21)
+        svx_ctx.set_small_batch_ops(1 << 23)
 
 
 def test_two_contexts_pipelined_with_wait_dominant():
@@ -76,6 +76,7 @@ def test_two_contexts_pipelined_with_wait_dominant():
     rng = np.random.default_rng(4)
     cases = []
     for ctx in (a, b):
+        ctx.set_small_batch_ops(1 << 21)
         cig, off, rs = synth.random_cigar_case(rng, 30000, max_ops=400)  # > 2 M ops: streaming path
         exp = orc.cigar_extract(cig, off, rs, 40)
         cap = len(exp["aln"]) + 8

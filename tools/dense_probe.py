@@ -64,8 +64,8 @@ def main():
         cap = n_sig + 16
         o = [ctx.dev_array(nbytes=4 * cap) for _ in range(4)] + [ctx.dev_array(nbytes=cap), ctx.dev_array(np.zeros(1, np.uint64))]
         outs = tuple(x.ptr for x in o[:5])
-        for path, small in (("streaming", 0), ("small", 1 << 21)):
-            if small and n_ops > small:
+        for path, small in (("streaming", 0), ("small", 1 << 23)):
+            if small and n_ops > small:  # beyond the two-launch path
                 continue
             ctx.set_small_batch_ops(small)
             tile = 1024 if small else 4096
@@ -97,7 +97,7 @@ def main():
             print(json.dumps(out[-1]), flush=True)
         for x in [d_c, d_o, d_r] + o:
             x.free()
-    ctx.set_small_batch_ops(1 << 21)
+    ctx.set_small_batch_ops(1 << 23)
     if not all(r["bit_exact_vs_oracle"] for r in out):
         raise SystemExit("dense_probe: output differs from the oracle")
 

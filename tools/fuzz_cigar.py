@@ -59,7 +59,7 @@ def main():
         exp = orc.cigar_extract(cig, off, rs, min_len)
         soa = rng.random() < 0.3
         streaming = rng.random() < 0.5  # both kernel paths: small-batch (two launches) and streaming (five)
-        ctx.set_small_batch_ops(0 if streaming else 1 << 21)
+        ctx.set_small_batch_ops(0 if streaming else 1 << 23)
         if soa:
             got = ctx.cigar_extract((cig >> 4).astype(np.uint32), off, rs, min_len, op=(cig & 15).astype(np.uint8))
         else:

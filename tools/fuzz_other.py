@@ -220,12 +220,12 @@ def fuzz_collect(ctx, rng):
     prm = (int(rng.choice([1, 40, 50, 1000])), int(rng.choice([20, 1000, 100000, 1 << 30])),
            int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])))
     streaming = bool(rng.random() < 0.25)
-    ctx.set_small_batch_ops(0 if streaming else 1 << 21)
+    ctx.set_small_batch_ops(0 if streaming else 1 << 23)
     try:
         got = tcol.call(ctx.collect_batch, b, min_len, prm)
         exp = tcol.call(ctx.collect_batch_composed, b, min_len, prm)
     finally:
-        ctx.set_small_batch_ops(1 << 21)
+        ctx.set_small_batch_ops(1 << 23)
     try:
         tcol.same(got, exp)
         ok = True
