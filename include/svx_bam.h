@@ -57,19 +57,22 @@ int svx_bam_header(const svx_bam* bam, const char** text, uint64_t* l_text, int3
 int svx_bam_reference(const svx_bam* bam, int32_t tid, const char** name, int32_t* length);
 
 /* 0: no index file; 1: .bai parsed and consistent with the file (parallel + per-contig walks);
- * 2: an index file exists but cannot be used (.csi, stub or inconsistent .bai): sequential walk.
+ * 2: an index file exists but cannot be used (stub, inconsistent .bai / .csi): sequential walk.  (A .csi of any
+ *    min_shift / depth is parsed and serves like a .bai: state 1.)
  * `check_index()` of the reference (svim-asm:67) only needs != 0. */
 int svx_bam_index_state(const svx_bam* bam);
 /* Compressed bytes the index attributes to each contig (0 for contigs without records): the
  * weights of the contig → rank plan.  span[n_ref].  SVX_E_INVALID when index_state != 1. */
 int svx_bam_contig_spans(const svx_bam* bam, uint64_t* span);
 
-/* What is inflated of a member that is needed: by default only as far as the last byte asked for (a record walk stops
- * right behind a record's CIGAR instead of going on into its SEQ bytes: a third of the CPU time; a sequence slice: half
- * of it) — the CRC32 of a member is then checked only when the member happens to be inflated to its end.  on != 0:
- * every touched member is inflated completely and its CRC32 checked, as htslib does under the reference
- * (bgzf_read_block).  The default of a new handle is off, or on with SVX_BAM_VERIFY=1 in the environment.  Either way
- * a malformed DEFLATE stream, a stream longer than its ISIZE or a stream that ends early is an error. */
+/* What is inflated of a member that is needed.  Default (on != 0): every member a walk or a sequence slice touches
+ * is inflated completely and its CRC32 checked, as htslib does under the reference (bgzf_read_block behind
+ * bam.fetch, SVIM_COLLECT.py:65-68) — a damaged member is an error, never silently different variants.
+ * on == 0 (opt-in; also SVX_BAM_VERIFY=0 in the environment, `svim-asm --no_bgzf_crc`): a member is inflated only
+ * as far as the last byte asked for (a record walk stops right behind a record's CIGAR instead of going on into
+ * its SEQ bytes, a sequence slice at its last base: half the CPU time of the ingest) and its CRC32 is checked only
+ * when it happens to be inflated to its end.  Either way a malformed DEFLATE stream, a stream longer than its
+ * ISIZE or a stream that ends early is an error. */
 int svx_bam_set_verify(svx_bam* bam, int on);
 
 /* Page-lock the CIGAR pool of later svx_bam_load calls in the context of HIP device `device`

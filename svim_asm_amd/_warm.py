@@ -40,6 +40,9 @@ def restrict_to_device(device):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("LOCAL_RANK") is not None:
         return device
     listed = os.environ.get("HIP_VISIBLE_DEVICES")
+    if listed is None and os.environ.get("CUDA_VISIBLE_DEVICES") is not None:
+        # the HIP runtime honours this name too: treat the caller's list the same way
+        listed = os.environ["CUDA_VISIBLE_DEVICES"]
     if listed is not None:
         # a list the caller set: device d is its d-th entry; narrow the list to that entry (one entry: nothing to do)
         entries = [e for e in listed.split(",") if e.strip()]
@@ -54,8 +57,16 @@ def restrict_to_device(device):
 
 
 def logical_device(device):
-    """The index under which the device the user named is visible after restrict_to_device."""
-    return _state["restricted"] if _state.get("physical") == int(device) and "restricted" in _state else device
+    """The index under which the device the user named is visible after restrict_to_device.  A process that was
+    narrowed to one device and is then asked for another cannot serve the request: that is an error here, not a
+    failed context creation later."""
+    if "physical" in _state and "restricted" in _state:
+        if _state["physical"] != int(device):
+            raise RuntimeError("this process was restricted to device %d before the HIP runtime started and cannot use "
+                               "device %d (bin/svim-asm derives the device from --device on the command line)"
+                               % (_state["physical"], int(device)))
+        return _state["restricted"]
+    return device
 
 
 def start(device, lib_path):

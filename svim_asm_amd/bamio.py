@@ -514,8 +514,9 @@ class AlignmentFile(object):
     `load(contigs)` restricts the walk to the contigs a rank owns; anything that touches the
     records loads the whole file on demand.  reader="python" selects the pure-Python walker
     (kept as the differential reference of the native one; also via SVX_BAM_READER=python).
-    verify=True inflates every touched BGZF member completely and checks its CRC32 (what htslib does); the default
-    stops at the last byte needed (svx_bam_set_verify, include/svx_bam.h)."""
+    verify (default True, or what SVX_BAM_VERIFY says): every touched BGZF member is inflated completely and its CRC32
+    checked (what htslib does under the reference); verify=False stops at the last byte needed and checks a member
+    only when it happens to be inflated to its end (svx_bam_set_verify, include/svx_bam.h)."""
 
     def __init__(self, path, mode="rb", threads=None, reader=None, device=None, verify=None):
         self.filename = path

@@ -19,7 +19,8 @@ TYPE_LABELS = (("DEL", "deletion"), ("INV", "inversion"), ("INS", "insertion"), 
 
 def _open_file(path, options):
     return bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
-                               threads=bamio.ingest_threads(2 if options.sub == "diploid" else 1))
+                               threads=bamio.ingest_threads(2 if options.sub == "diploid" else 1),
+                               verify=False if getattr(options, "no_bgzf_crc", False) else None)
 
 
 def _open_ahead(path, options):
@@ -214,6 +215,11 @@ def _run_steps(options):
     logging.info("****************** STEP {0}: OUTPUT ******************".format(2 if options.sub == "haploid" else 3))
     for key, label in TYPE_LABELS:
         logging.info("Found {0} {1} candidates.".format(int(counts[TYPE_ORDER.index(key)]), label))
+    # the inserted-sequence bytes are decoded beside PAIR; with --symbolic_alleles (and on ranks other than 0) nobody
+    # reads them — but a damaged BGZF member among them must still fail the run, as it would under pysam
+    _ = sv_candidates.seqs
+    if options.sub == "diploid":
+        _ = sv_candidates1.seqs, sv_candidates2.seqs
     if shard.world()[0] != 0:
         return  # every rank holds the full result; rank 0 writes it
     logging.info("Write SV candidates..")

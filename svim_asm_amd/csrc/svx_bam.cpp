@@ -692,7 +692,7 @@ struct svx_bam {
     std::vector<uint8_t> aux;
     uint64_t blocks_inflated = 0, blocks_spanned = 0;
     int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
-    bool verify = false;  // inflate whole members and check their CRC32 (svx_bam_set_verify)
+    bool verify = true;   // inflate whole members and check their CRC32 (svx_bam_set_verify); the default
     Pool pool;
 
     void free_cigar() {
@@ -723,7 +723,7 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out, char
     b->n_threads = n_threads;
     {
         const char* v = getenv("SVX_BAM_VERIFY");
-        b->verify = v && v[0] == '1';
+        b->verify = !(v && v[0] == '0');  // default on: what htslib does under the reference
     }
     b->fd = open(path, O_RDONLY);
     struct stat st;

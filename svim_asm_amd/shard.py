@@ -14,9 +14,10 @@ rank pairs the key contigs it owns and the results are merged type by type in co
 The path has no device-side exchange step (no RCCL collective is justified for a few MB of host
 columns).  One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run sets them.
 The exchange itself needs no torch: rank 0 listens on a unix-domain socket named after the job
-(MASTER_PORT), the others connect, one pickled message each way per all-gather.  When the caller
-has initialised a torch.distributed process group (the CPU tests do, with gloo), that group's
-all_gather_object is used instead.
+(MASTER_PORT + run id) inside a directory only the user can enter, checks every peer's uid, and the
+tables travel as length-prefixed blobs of typed arrays (CandidateTable.to_wire) — nothing is unpickled.
+When the caller has initialised a torch.distributed process group (the CPU tests do, with gloo), that
+group's all_gather_object is used instead.
 """
 import os
 import sys
@@ -48,59 +49,182 @@ def world():
     return (int(os.environ.get("RANK", "0")), size) if size > 1 else (0, 1)
 
 
+def _rendezvous_path():
+    """Path of the job's exchange socket: inside a directory only this user can enter (mode 0700, owned by the
+    user, checked), named after the job (MASTER_PORT + run id, or SVX_RENDEZVOUS)."""
+    import hashlib
+    import stat
+    import tempfile
+    uid = os.getuid()
+    base = os.environ.get("XDG_RUNTIME_DIR")
+    if not (base and os.path.isdir(base) and os.stat(base).st_uid == uid):
+        base = tempfile.gettempdir()
+    d = os.path.join(base, "svx-%d" % uid)
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != uid or (st.st_mode & 0o077):
+        raise RuntimeError("%s must be a directory owned by uid %d with mode 0700 (found mode %o, uid %d): refusing to "
+                           "exchange candidate tables through it" % (d, uid, st.st_mode & 0o7777, st.st_uid))
+    job = os.environ.get("SVX_RENDEZVOUS") or "svx-%s-%s" % (os.environ.get("MASTER_PORT", "0"),
+                                                              os.environ.get("TORCHELASTIC_RUN_ID", "job"))
+    return os.path.join(d, hashlib.sha256(job.encode()).hexdigest()[:24] + ".sock")
+
+
+def _send_msg(sock, parts):
+    """One message = 8-byte count of parts, then every part as 8-byte length + bytes."""
+    import struct
+    sock.sendall(struct.pack("<Q", len(parts)))
+    for p in parts:
+        sock.sendall(struct.pack("<Q", len(p)))
+        sock.sendall(p)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray(n)
+    view, got = memoryview(buf), 0
+    while got < n:
+        k = sock.recv_into(view[got:], n - got)
+        if k == 0:
+            raise ConnectionError("peer closed the exchange socket")
+        got += k
+    return buf
+
+
+def _recv_msg(sock, max_bytes=1 << 40):
+    import struct
+    (n_parts,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n_parts > 1 << 20:
+        raise ValueError("exchange message with %d parts" % n_parts)
+    parts = []
+    for _ in range(n_parts):
+        (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+        if n > max_bytes:
+            raise ValueError("exchange message part of %d bytes" % n)
+        parts.append(bytes(_recv_exact(sock, n)))
+    return parts
+
+
+def _encode(obj):
+    """(status, payload) of _gather_or_raise as message parts: b"ok" + one wire blob per table, or b"error" + text.
+    No pickle: what a peer sends can only become tables (CandidateTable.from_wire) or a string."""
+    status, payload = obj
+    if status == "error":
+        return [b"error", str(payload).encode("utf-8", "replace")]
+    tables = payload if isinstance(payload, (list, tuple)) else [payload]
+    return [b"ok", b"L" if isinstance(payload, (list, tuple)) else b"1"] + [t.to_wire() for t in tables]
+
+
+def _decode(parts):
+    if parts[0] == b"error":
+        return ("error", parts[1].decode("utf-8", "replace"))
+    if parts[0] != b"ok" or len(parts) < 2 or parts[1] not in (b"L", b"1"):
+        raise ValueError("malformed exchange message")
+    tables = [CandidateTable.from_wire(p) for p in parts[2:]]
+    return ("ok", tables if parts[1] == b"L" else tables[0])
+
+
 class _SocketGroup(object):
-    """all_gather of picklable objects over a unix-domain socket: rank 0 collects and redistributes."""
+    """all_gather of (status, tables) over a unix-domain socket: rank 0 collects and redistributes.  The socket
+    is a path inside a directory of mode 0700 owned by the user, every peer's uid is checked (SO_PEERCRED), and
+    the messages are length-prefixed table blobs (CandidateTable.to_wire) — nothing is unpickled."""
 
     def __init__(self, rank, size, timeout=120.0):
-        from multiprocessing.connection import Client, Listener
+        import socket
         self.rank, self.size = rank, size
-        job = os.environ.get("SVX_RENDEZVOUS") or "svx-%s-%s-%d" % (
-            os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.getuid())
-        address = "\0" + job  # abstract namespace: nothing to unlink, gone with the processes
-        key = job.encode()
+        self.path = _rendezvous_path()
         if rank == 0:
-            self.listener = Listener(address, family="AF_UNIX", authkey=key)
+            if os.path.exists(self.path):
+                probe = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    probe.connect(self.path)
+                except OSError:
+                    os.unlink(self.path)  # left behind by a job that died
+                else:
+                    probe.close()
+                    raise RuntimeError("another job of this user is using the rendezvous %s (same MASTER_PORT and run id): "
+                                       "set SVX_RENDEZVOUS to a unique name" % self.path)
+                finally:
+                    probe.close()
+            self.listener = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            old = os.umask(0o177)
+            try:
+                self.listener.bind(self.path)
+            finally:
+                os.umask(old)
+            self.listener.listen(size)
+            self.listener.settimeout(timeout)  # a rank that never shows up must not block rank 0 for ever
             self.peers = [None] * size
-            try:  # a rank that never shows up must not block rank 0 for ever
-                self.listener._listener._socket.settimeout(timeout)
-            except AttributeError:
-                pass
             for _ in range(size - 1):
                 try:
-                    conn = self.listener.accept()
+                    conn, _ = self.listener.accept()
                 except OSError as e:  # socket.timeout
+                    self.close()
                     raise RuntimeError("rank 0: only %d of %d ranks reached the exchange within %.0f s (%s)"
                                        % (1 + sum(p is not None for p in self.peers), size, timeout, e))
-                self.peers[conn.recv()] = conn
+                self._check_peer(conn)
+                conn.settimeout(None)
+                r = int(_recv_msg(conn, 64)[0])
+                if not 0 < r < size or self.peers[r] is not None:
+                    conn.close()
+                    raise RuntimeError("rank 0: a peer announced itself as rank %d of %d" % (r, size))
+                self.peers[r] = conn
         else:
             deadline = time.time() + timeout
             while True:
+                self.conn = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
                 try:
-                    self.conn = Client(address, family="AF_UNIX", authkey=key)
+                    self.conn.connect(self.path)
                     break
                 except (ConnectionRefusedError, FileNotFoundError):
+                    self.conn.close()
                     if time.time() > deadline:
                         raise RuntimeError("rank %d: rank 0 did not open the exchange socket within %.0f s" % (rank, timeout))
                     time.sleep(0.005)
-            self.conn.send(rank)
+            self._check_peer(self.conn)
+            _send_msg(self.conn, [str(rank).encode()])
+
+    @staticmethod
+    def _check_peer(conn):
+        import socket
+        import struct
+        if hasattr(socket, "SO_PEERCRED"):
+            _pid, uid, _gid = struct.unpack("3i", conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+            if uid != os.getuid():
+                conn.close()
+                raise RuntimeError("exchange socket: peer runs as uid %d, this job as %d" % (uid, os.getuid()))
 
     def all_gather(self, obj):
+        mine = _encode(obj)
         if self.rank == 0:
-            everything = [obj] + [None] * (self.size - 1)
+            everything = [mine] + [None] * (self.size - 1)
             for r in range(1, self.size):
-                everything[r] = self.peers[r].recv()
+                everything[r] = _recv_msg(self.peers[r])
+            flat = [str(len(m)).encode() for m in everything] + [p for m in everything for p in m]
             for r in range(1, self.size):
-                self.peers[r].send(everything)
-            return everything
-        self.conn.send(obj)
-        return self.conn.recv()
+                _send_msg(self.peers[r], flat)
+            return [obj] + [_decode(m) for m in everything[1:]]
+        _send_msg(self.conn, mine)
+        flat = _recv_msg(self.conn)
+        counts = [int(x) for x in flat[:self.size]]
+        out, at = [], self.size
+        for r, c in enumerate(counts):
+            out.append(obj if r == self.rank else _decode(flat[at:at + c]))
+            at += c
+        return out
 
     def close(self):
         if self.rank == 0:
-            for c in self.peers[1:]:
+            for c in getattr(self, "peers", [])[1:]:
                 if c is not None:
                     c.close()
             self.listener.close()
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
         else:
             self.conn.close()
 

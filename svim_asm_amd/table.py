@@ -130,6 +130,59 @@ class CandidateTable(object):
         state["_seqs"] = self.seqs
         return state
 
+    # ------------------------------------------------------------------ wire format (rank exchange, shard.py)
+    # A table as ONE bytes object without pickle: 8-byte header length, a JSON header (contig names, genotype strings,
+    # name / dtype / length of every array), then the arrays' bytes back to back.  Reading it back can only ever
+    # produce numpy arrays of the dtypes listed here, strings and ints — nothing executable.
+    _WIRE_EXTRA = (("r_off", np.int64), ("r_flat", np.int64), ("contig_len", np.int64), ("rec_tid", None))
+
+    def to_wire(self):
+        import json
+        import struct
+        arrays = [(k, np.ascontiguousarray(getattr(self, k), dtype=dt)) for k, dt in _COLUMNS]
+        for k, dt in self._WIRE_EXTRA:
+            v = getattr(self, k, None)
+            if v is not None:
+                arrays.append((k, np.ascontiguousarray(v, dtype=dt)))
+        arrays.append(("names_off", np.ascontiguousarray(self.names.off, dtype=np.int64)))
+        arrays.append(("names_pool", np.frombuffer(bytes(self.names.pool[:int(self.names.off[-1])]), dtype=np.uint8)))
+        arrays.append(("seqs", np.ascontiguousarray(self.seqs, dtype=np.uint8)))
+        head = json.dumps({"contigs": self.contigs, "genotypes": self.genotypes,
+                           "arrays": [[k, a.dtype.str, int(a.size)] for k, a in arrays]}).encode()
+        return b"".join([struct.pack("<Q", len(head)), head] + [a.tobytes() for _, a in arrays])
+
+    @staticmethod
+    def from_wire(blob):
+        import json
+        import struct
+        view = memoryview(blob)
+        (n_head,) = struct.unpack_from("<Q", view, 0)
+        if n_head > len(view) - 8:
+            raise ValueError("truncated table message")
+        head = json.loads(bytes(view[8:8 + n_head]).decode())
+        allowed = {np.dtype(t).str for t in ("u1", "<i4", "<i8", "<u4", "<u8")}
+        at, got = 8 + n_head, {}
+        for k, dt, n in head["arrays"]:
+            if dt not in allowed or not isinstance(n, int) or n < 0:
+                raise ValueError("table message: array %r of type %r" % (k, dt))
+            nbytes = n * np.dtype(dt).itemsize
+            if at + nbytes > len(view):
+                raise ValueError("truncated table message")
+            got[str(k)] = np.frombuffer(view[at:at + nbytes], dtype=dt).copy()
+            at += nbytes
+        contigs = [str(c) for c in head["contigs"]]
+        t = CandidateTable(contigs, got["contig_len"], 0, NamePool(got["names_pool"].tobytes(), got["names_off"]),
+                           got["seqs"], [str(g) for g in head["genotypes"]])
+        n = len(got["type"])
+        for k, dt in _COLUMNS:
+            if len(got[k]) != n:
+                raise ValueError("table message: column %s has %d rows, type has %d" % (k, len(got[k]), n))
+            setattr(t, k, got[k].astype(dt, copy=False))
+        t.r_off, t.r_flat = got["r_off"], got["r_flat"]
+        if "rec_tid" in got:
+            t.rec_tid = got["rec_tid"]
+        return t
+
     # ------------------------------------------------------------------ row algebra
     def _like(self, n):
         out = CandidateTable(self.contigs, self.contig_len, n, self.names, None, self.genotypes)

@@ -203,9 +203,10 @@ def test_corrupt_input_is_rejected(dataset, tmp_path):
     open(cut, "wb").write(data[:len(data) // 2 + 123])
     with pytest.raises(ValueError):
         bamio.AlignmentFile(cut).load()
-    # a flipped payload byte in a member that holds record headers: with verify=True (whole members, CRC32 as under
-    # htslib) always an error; by default an error when the damage lies inside the bytes the walk needs and the stream
-    # no longer decodes, and the pristine file's records when it lies behind them
+    # a flipped payload byte in a member that holds record headers: by default (whole members, CRC32 as under htslib)
+    # ALWAYS an error — also when the damage lies in the unread tail of the member, behind the last byte a record walk
+    # needs; with verify=False (the opt-out) an error when it lies inside the bytes the walk needs and the stream no
+    # longer decodes, and the pristine file's records when it lies behind them
     spans = bamio._bgzf_block_spans(data)
     pristine = bamio.AlignmentFile(bams[0])
     member = int(pristine._cols["voffset"][2]) >> 16
@@ -218,9 +219,11 @@ def test_corrupt_input_is_rejected(dataset, tmp_path):
         open(flip, "wb").write(bytes(bad))
         shutil.copy(bams[0] + ".bai", flip + ".bai")
         with pytest.raises(ValueError):
+            bamio.AlignmentFile(flip).load()
+        with pytest.raises(ValueError):
             bamio.AlignmentFile(flip, verify=True).load()
         try:
-            got = bamio.AlignmentFile(flip).load()
+            got = bamio.AlignmentFile(flip, verify=False).load()
         except ValueError:
             outcomes.add("refused")
         else:

@@ -105,6 +105,53 @@ def test_cli_reproduces_reference_vcf_config1(tmp_path, name):
     assert got == open(os.path.join(GOLD, "config1", name + ".vcf")).read()
 
 
+def test_cli_refuses_a_member_damaged_behind_the_bytes_it_needs(tmp_path):
+    """htslib checks the CRC32 of every BGZF block it reads (bgzf_read_block under bam.fetch, SVIM_COLLECT.py:65-68): the
+    reference aborts on a damaged block.  So does the product by default — also when the damage lies in the tail of a
+    member, BEHIND the last byte a record walk or a sequence slice needs (literal bytes of a stored or little-compressed
+    block changed: the stream still decodes) — and no VCF is written; with --no_bgzf_crc the same run goes through."""
+    import shutil
+    from svim_asm_amd import bamio, cli
+    src = os.path.join(GOLD, "config1")
+    d = tmp_path / "in"
+    shutil.copytree(src, d)
+    bam = str(d / "hap1.bam")
+    data = bytearray(open(bam, "rb").read())
+    spans = bamio._bgzf_block_spans(bytes(data))
+    # the last bytes of the deflate payload of the biggest member: the end of its SEQ / QUAL bytes
+    st, ln = max(((sp[0], sp[1]) for sp in spans if sp[2]), key=lambda x: x[1])
+    # find a damage that still inflates (so only the CRC32 can notice it)
+    import zlib
+    good = zlib.decompress(bytes(data[st:st + ln]), -15)
+    done = False
+    for back in range(3, min(ln, 4000)):
+        for bit in (1, 2, 4, 8, 16, 32, 64, 128):
+            trial = bytearray(data[st:st + ln])
+            trial[ln - back] ^= bit
+            try:
+                out = zlib.decompress(bytes(trial), -15)
+            except zlib.error:
+                continue
+            if len(out) == len(good) and out != good and out[:len(good) // 2] == good[:len(good) // 2]:
+                data[st + ln - back] ^= bit
+                done = True
+                break
+        if done:
+            break
+    assert done, "no damage found that leaves a valid deflate stream"
+    open(bam, "wb").write(bytes(data))
+    argv = ["diploid", str(tmp_path / "wd"), bam, str(d / "hap2.bam"), str(d / "ref.fa")]
+    with pytest.raises(ValueError):
+        cli.main(argv)
+    assert not os.path.exists(tmp_path / "wd" / "variants.vcf")
+    # the opt-out reads only what it needs and does not notice damage behind it ... or notices it, when the damaged
+    # bytes are among the ones it needs: either way never a crash
+    try:
+        cli.main(argv[:1] + [str(tmp_path / "wd2")] + argv[2:] + ["--no_bgzf_crc"])
+    except ValueError:
+        pass
+
+
 def test_two_haplotypes_with_differently_ordered_headers():
     """The two BAMs of a diploid run need not list their contigs in the same order: COLLECT then submits them
     separately (contig ids mean different things) and PAIR re-expresses the second table's contig ids by NAME in the

@@ -119,7 +119,7 @@ def test_cli_reproduces_reference_vcf_medium_options(svx_ctx, medium_dataset, tm
     assert got == _expected(name)
 
 
-@pytest.mark.parametrize("how", ["zlib-6", "libdeflate-6", "whole-members-crc32", "csi-index"])
+@pytest.mark.parametrize("how", ["zlib-6", "libdeflate-6", "prefix-only-no-crc", "csi-index"])
 def test_host_path_on_other_writers_files_with_the_oracle_as_device(monkeypatch, tmp_path, how):
     """The CPU twin of the test below: reader, host logic and VCF writer of the product with the device answered by the
     oracle (no GPU)."""
@@ -129,7 +129,7 @@ def test_host_path_on_other_writers_files_with_the_oracle_as_device(monkeypatch,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("how", ["zlib-6", "libdeflate-6", "whole-members-crc32", "csi-index"])
+@pytest.mark.parametrize("how", ["zlib-6", "libdeflate-6", "prefix-only-no-crc", "csi-index"])
 def test_cli_reproduces_reference_vcf_on_other_writers_files(svx_ctx, tmp_path, how):
     _other_writers_case(tmp_path, how)
 
@@ -137,7 +137,7 @@ def test_cli_reproduces_reference_vcf_on_other_writers_files(svx_ctx, tmp_path, 
 def _other_writers_case(tmp_path, how):
     """The same records in files as other writers make them — BGZF members deflated by zlib at level 6 (samtools'
     default), by libdeflate at level 6 (an htslib built with libdeflate: 4-bit literals almost only, the decoder's
-    12-bit tables and literal runs) —, read with whole-member verification, or indexed by a `.csi`: the product
+    12-bit tables and literal runs) —, read with the opt-out of the whole-member CRC32 check, or indexed by a `.csi`: the product
     CLI writes the REAL reference's VCF for each."""
     from svim_asm_amd import bamio, cli, synth, synth_bam
     prm = META["params"]
@@ -150,8 +150,8 @@ def _other_writers_case(tmp_path, how):
     from tests import helpers
     helpers.assert_inputs_are_the_golden_ones(META, [fasta] + bams)   # digests of the uncompressed content
     env = {}
-    if how == "whole-members-crc32":
-        env["SVX_BAM_VERIFY"] = "1"
+    if how == "prefix-only-no-crc":
+        env["SVX_BAM_VERIFY"] = "0"
     if how == "csi-index":
         for b in bams:
             os.remove(b + ".bai")

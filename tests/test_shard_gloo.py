@@ -93,3 +93,27 @@ def test_sharded_collect_and_pair_equal_single_process(transport):
         assert c2 == exp2, "rank %d collect order differs (hap 2)" % rank
         assert paired == exp_pair, "rank %d pair order differs" % rank
         assert 0 < n1 < total, "rank %d indexed %d of %d records: contig-restricted ingest" % (rank, n1, total)
+
+
+def test_exchange_socket_lives_in_a_private_directory(tmp_path, monkeypatch):
+    """The rank exchange binds a PATH socket inside <tmp>/svx-<uid>, a directory that must belong to the user and be
+    closed to everybody else (mode 0700): a directory somebody else could enter — or pre-create — is refused instead of
+    used.  (The peers' uid is checked on top of that, SO_PEERCRED, and the messages are typed arrays, never pickles.)"""
+    import stat
+    from svim_asm_amd import shard
+    monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    monkeypatch.setattr(tempfile, "tempdir", None)
+    monkeypatch.setenv("MASTER_PORT", "12345")
+    path = shard._rendezvous_path()
+    d = os.path.dirname(path)
+    assert d == str(tmp_path / ("svx-%d" % os.getuid())) and path.endswith(".sock")
+    assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    monkeypatch.setenv("MASTER_PORT", "12346")
+    assert shard._rendezvous_path() != path  # another job, another socket
+    os.chmod(d, 0o755)
+    with pytest.raises(RuntimeError):
+        shard._rendezvous_path()
+    os.chmod(d, 0o700)
+    monkeypatch.setattr(tempfile, "tempdir", None)

@@ -50,6 +50,41 @@ def test_objects_round_trip_through_the_table(seed):
     assert both.counts_by_type().tolist() == [sum(1 for c in objs + objs[:40] if c.type == ty) for ty in TYPE_ORDER]
 
 
+def test_wire_format_round_trip_and_refusals():
+    """A table travels between ranks as typed arrays behind a JSON header (CandidateTable.to_wire): it comes back row
+    for row; a message that is cut, names a type the format does not know or whose columns disagree is refused —
+    nothing in it is ever unpickled or executed."""
+    import json
+    import struct
+    rng = np.random.default_rng(9)
+    seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=l)) for n, l in zip(NAMES, LENGTHS)}
+    bam, tuples, objs = _random_objects(rng, 120, seqs)
+    objs[5].reads = objs[5].reads + ["another_read"]
+    objs[9].genotype = "0/1"
+    t = CandidateTable.from_objects(objs, bam)
+    t.rec_tid = np.arange(len(t), dtype=np.int64) % len(NAMES)
+    blob = t.to_wire()
+    assert isinstance(blob, bytes) and b"pickle" not in blob[:200]
+    back = CandidateTable.from_wire(blob)
+    assert [helpers.candidate_tuple(c) for c in back.objects()] == [helpers.candidate_tuple(c) for c in objs]
+    assert np.array_equal(back.rec_tid, t.rec_tid) and back.contigs == t.contigs and back.genotypes == t.genotypes
+    empty = CandidateTable.from_wire(CandidateTable(NAMES, LENGTHS).to_wire())
+    assert len(empty) == 0 and empty.contigs == NAMES
+    with pytest.raises(ValueError):
+        CandidateTable.from_wire(blob[:len(blob) // 2])
+    (n_head,) = struct.unpack_from("<Q", blob, 0)
+    head = json.loads(blob[8:8 + n_head])
+    head["arrays"][0][1] = "|O"  # an object array: never
+    bad_head = json.dumps(head).encode()
+    with pytest.raises(ValueError):
+        CandidateTable.from_wire(struct.pack("<Q", len(bad_head)) + bad_head + blob[8 + n_head:])
+    head = json.loads(blob[8:8 + n_head])
+    head["arrays"][1][2] -= 1  # one column a row short
+    bad_head = json.dumps(head).encode()
+    with pytest.raises(ValueError):
+        CandidateTable.from_wire(struct.pack("<Q", len(bad_head)) + bad_head + blob[8 + n_head:])
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_constructors_on_columns_equal_the_object_constructors(seed):
     rng = np.random.default_rng(100 + seed)
