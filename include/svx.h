@@ -519,6 +519,14 @@ int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t poo
  * the stages of the distance computation are planned from read-backs (which pairs the wavefront pass resolved). */
 int svx_haplotype_distance_batch_dev(svx_ctx* ctx, const uint8_t* d_pool, uint64_t pool_bytes,
                                      const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist);
+/* One call for a PAIR step's whole batch: k_max[p] per pair — the threshold for the pairs of two-member partitions
+ * ("<= max_edit_distance?" is all pair_haplotypes needs of them, SVIM_COMBINE.py:120-139), 0xFFFFFFFF (exact) for
+ * the pairs of larger partitions, whose dendrogram above the cut decides scipy's label order.  One upload of the
+ * pool, one haplotype assembly, one wavefront pass and one bit-vector pass for all of them.  The waits inside the
+ * call sleep on a blocking event instead of spinning on the stream. */
+int svx_haplotype_distance_batch_mixed(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
+                                       const svx_hap_piece* pieces, uint32_t n_pairs, const uint32_t* k_max,
+                                       uint32_t* dist);
 
 /*
  * Batched complete linkage + flat cut: for every partition p (n_members[p] candidates, condensed

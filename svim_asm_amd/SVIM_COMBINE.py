@@ -395,19 +395,12 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
         # above the cut (hence scipy's cluster label order) is the reference's.  Any threshold the reference
         # accepts: a negative one pairs nothing, one beyond 32 bits everything
         k_max = max(min(max(int(threshold), -1), 0xFFFFFFFE), 0)
-        dist = np.zeros(len(job_a), np.float64)
-        thr, exa = np.flatnonzero(job_two), np.flatnonzero(~job_two)
-        if len(thr) and len(exa):
-            pool = ctx.resident(pool)  # one upload of the windows and alleles serves both batches
-        if len(thr):
-            d = ctx.haplotype_distance_batch(pool, pieces[thr].reshape(-1), k_max).astype(np.float64)
-            d[d == float(0xFFFFFFFF)] = k_max + 1  # "more than the threshold" is all that is known, and all that matters
-            dist[thr] = d
-        if len(exa):
-            dist[exa] = ctx.haplotype_distance_batch(pool, pieces[exa].reshape(-1), 0xFFFFFFFF).astype(np.float64)
-        free = getattr(pool, "free", None)
-        if free is not None:
-            free()
+        # one call for both kinds of pairs (per-pair threshold; 0xFFFFFFFF = exact): one upload of the windows and
+        # alleles, one assembly of the haplotype strings, one wavefront pass and one bit-vector pass
+        per_pair = np.where(job_two, np.uint32(k_max), np.uint32(0xFFFFFFFF)).astype(np.uint32)
+        dist = ctx.haplotype_distance_batch_mixed(pool, pieces.reshape(-1), per_pair).astype(np.float64)
+        over = job_two & (dist == float(0xFFFFFFFF))
+        dist[over] = k_max + 1  # "more than the threshold" is all that is known, and all that matters
         tc = _clock("pair_distances_s", tc)
     # condensed distance vectors per size class (row-major pairs (i < j), :131-133), then the clusters
     at = 0

@@ -154,6 +154,7 @@ SYMBOLS = {
     "svx_edit_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_uint32,
                                           _P]),
     "svx_haplotype_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P]),
+    "svx_haplotype_distance_batch_mixed": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, _P]),
     "svx_linkage_cut_batch": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_double, _P]),
     # native BAM ingest (include/svx_bam.h)
     "svx_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P), C.c_char_p, C.c_size_t]),
@@ -528,6 +529,20 @@ class Context:
             pool = _as(pool, np.uint8)
             self._check(self.lib.svx_haplotype_distance_batch(self.h, _ptr(pool), len(pool), _ptr(pieces), n,
                                                               int(k_max) & 0xFFFFFFFF, _ptr(dist)))
+        return dist
+
+    def haplotype_distance_batch_mixed(self, pool, pieces, k_max):
+        """haplotype_distance_batch with one threshold per pair (0xFFFFFFFF: exact) — a PAIR step's thresholded and
+        exact pairs in ONE call (svx_haplotype_distance_batch_mixed)."""
+        pieces = np.ascontiguousarray(pieces, dtype=HAP_PIECE_DTYPE)
+        k_max = np.ascontiguousarray(k_max, dtype=np.uint32)
+        if len(pieces) != 6 * len(k_max):
+            raise SvxError(SVX_E_INVALID, "6 pieces and one threshold per pair")
+        dist = np.zeros(len(k_max), np.uint32)
+        if len(k_max):
+            pool = _as(pool, np.uint8)
+            self._check(self.lib.svx_haplotype_distance_batch_mixed(self.h, _ptr(pool), len(pool), _ptr(pieces), len(k_max),
+                                                                    _ptr(k_max), _ptr(dist)))
         return dist
 
     def linkage_cut_batch(self, dist, n_members, cutoff):

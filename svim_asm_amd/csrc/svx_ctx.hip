@@ -53,6 +53,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* ctx) {
     for (int i = 0; i < 4; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_dom) (void)hipEventDestroy(ctx->ev_dom);
+    if (ctx->ev_block) (void)hipEventDestroy(ctx->ev_block);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -115,6 +116,13 @@ int svx_ws_reserve(svx_ctx* ctx, size_t total) {
     // allocation, left at zero by the kernels that use them); per-call scratch starts after it
     ctx->ws_used = 4096;
     return grow(ctx, &ctx->ws, &ctx->ws_bytes, total + 4096);
+}
+int svx_wait_blocking(svx_ctx* ctx) {
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->ev_block) SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_block, hipEventBlockingSync | hipEventDisableTiming));
+    SVX_HIP(ctx, hipEventRecord(ctx->ev_block, ctx->stream));
+    SVX_HIP(ctx, hipEventSynchronize(ctx->ev_block));
+    return SVX_OK;
 }
 int svx_stage_reserve(svx_ctx* ctx, size_t total) {
     ctx->stage_used = 0;

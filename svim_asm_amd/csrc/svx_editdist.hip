@@ -41,6 +41,9 @@
 
 namespace {
 
+#ifndef SVX_ED_PREFETCH
+#define SVX_ED_PREFETCH 0  // 1: text chunks requested a whole chunk ahead — measured slower (5.76 vs 5.51 ms, profiles/README.md)
+#endif
 constexpr uint32_t kStripRows = 64 * 64;
 constexpr uint32_t kUnproven = 0x80000000u;   // flag: D' > band and cells were cut (upper bound only)
 constexpr uint32_t kAlphabet = 0xFFFFFFFEu;   // marker: pattern alphabet exceeds this instantiation
@@ -136,6 +139,71 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         s_in = p.stream + p.stream_off[w];
         s_out = s_in + words;
     }
+    if (n_strips == 1) {
+        // ---- the pattern fits one strip (<= 4096 rows: every pair of the PAIR step but the contig-sized alleles): no band,
+        // no boundary stream, the top row's horizontal delta is +1 everywhere — a leaner step: the score is accumulated by
+        // every lane without a branch (only lane `last` holds the matrix's last row), the activity test is one subtract
+        // and one compare against a per-lane limit, the horizontal deltas are split with bit operations.
+        const uint32_t nblk = (m + 63) / 64, last = nblk - 1, outbit = (m - 1) & 63;
+        for (uint32_t c = 0; c <= min(sigma, (uint32_t)CAP); ++c) peq[c * 64 + lane] = 0;
+        peq[CAP * 64 + lane] = 0;
+        if (lane < nblk) {
+            const uint32_t r0 = 64 * lane;
+            for (uint32_t r = 0; r < 64 && r0 + r < m; ++r) peq[cmap[P[r0 + r]] * 64 + lane] |= 1ull << r;
+        }
+        wave_lds_fence();
+        const uint32_t nsteps = n + nblk - 1;
+        const uint32_t lim = lane < nblk ? n : 0u;          // steps this lane is active for, from step `lane` on
+        const uint32_t sh = lane == last ? outbit : 63u;
+        uint64_t Pv = ~0ull, Mv = 0;
+        uint32_t val = m, hout_prev = 0, code_cur = CAP, codechunk = CAP;
+        // text symbols: 64 per register chunk; the chunk after the current one is requested a whole chunk ahead (its
+        // bytes at step 0 of a chunk, their symbol codes at step 32) so that no step waits for memory
+        auto fetch_raw = [&](uint32_t t0) -> uint32_t {
+            const uint32_t col = 1 + t0 + lane;
+            return col <= n ? (uint32_t)T[col - 1] : 0x100u;
+        };
+        auto to_code = [&](uint32_t raw) -> uint32_t { return raw < 0x100u ? (uint32_t)cmap[raw] : (uint32_t)CAP; };
+        codechunk = to_code(fetch_raw(0));
+        uint32_t raw_ahead = 0x100u, code_ahead = CAP;
+        code_cur = shr1_in((uint32_t)__builtin_amdgcn_readlane((int)codechunk, 0), code_cur);
+        uint64_t eq_cur = peq[code_cur * 64 + lane];
+        for (uint32_t t = 0; t < nsteps; ++t) {
+#if SVX_ED_PREFETCH
+            if ((t & 63) == 0) raw_ahead = fetch_raw(t + 64);
+            if ((t & 63) == 32) code_ahead = to_code(raw_ahead);
+            if ((t & 63) == 63) codechunk = code_ahead;
+#else
+            if ((t & 63) == 63) { raw_ahead = fetch_raw(t + 1); code_ahead = to_code(raw_ahead); codechunk = code_ahead; }
+#endif
+            const uint32_t fresh_c = (uint32_t)__builtin_amdgcn_readlane((int)codechunk, (int)((t + 1) & 63));
+            const uint32_t code_next = shr1_in(fresh_c, code_cur);
+            const uint64_t eq_next = peq[code_next * 64 + lane];
+            const uint32_t hin = shr1_in(1u, hout_prev);     // lane 0: the top row, +1
+            const bool active = (t - lane) < lim;            // (t < lane wraps to a huge value)
+            const uint64_t hneg = hin >> 1, hpos = hin & 1u;
+            uint64_t Eq = eq_cur;
+            const uint64_t Xv = Eq | Mv;
+            Eq |= hneg;
+            const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint64_t Ph = Mv | ~(Xh | Pv);
+            uint64_t Mh = Pv & Xh;
+            const uint32_t ho = (uint32_t)((Ph >> sh) & 1ull) | ((uint32_t)((Mh >> sh) & 1ull) << 1);
+            Ph = (Ph << 1) | hpos;
+            Mh = (Mh << 1) | hneg;
+            if (active) {
+                Pv = Mh | ~(Xv | Ph);
+                Mv = Ph & Xv;
+                hout_prev = ho;
+                val += (ho & 1u) - (ho >> 1);
+            }
+            code_cur = code_next;
+            eq_cur = eq_next;
+        }
+        const uint32_t result1 = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)last);
+        if (lane == 0) p.dist[pi] = result1;
+        return;
+    }
     uint32_t base = 0;           // D'[last row of the strip][c_lo - 1]
     uint32_t prev_c_hi = 0;
     uint32_t carried = 0;        // D'[last row of the previous strip][c_lo of this strip - 1]
@@ -183,58 +251,74 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         uint32_t hout_prev = 0, code_cur = CAP;
         uint32_t codechunk = CAP, hchunk = 1;
         uint64_t eq_cur = 0;
-        auto load_chunk = [&](uint32_t t0) {
+        // text symbols and incoming deltas: 64 per register chunk, the next chunk requested a whole chunk ahead
+        uint32_t raw_ahead = 0x100u, code_ahead = CAP, h_ahead = 1;
+        uint64_t hword_ahead = 0;
+        auto fetch_raw = [&](uint32_t t0) {
             const uint32_t col = c_lo + t0 + lane;
-            codechunk = CAP;
-            hchunk = 1;  // +1: top row of the matrix, or columns the previous strip did not visit
-            if (col <= c_hi) {
-                codechunk = cmap[T[col - 1]];
-                if (s > 0 && col <= prev_c_hi) {
-                    const uint64_t wv = s_in[(col - 1) >> 5];
-                    hchunk = (uint32_t)(wv >> (2 * ((col - 1) & 31))) & 3u;
-                }
-            }
+            raw_ahead = col <= c_hi ? (uint32_t)T[col - 1] : 0x100u;
+            hword_ahead = (col <= c_hi && s > 0 && col <= prev_c_hi) ? s_in[(col - 1) >> 5] : ~0ull;
         };
-        load_chunk(0);
+        auto decode_ahead = [&](uint32_t t0) {
+            const uint32_t col = c_lo + t0 + lane;
+            code_ahead = raw_ahead < 0x100u ? (uint32_t)cmap[raw_ahead] : (uint32_t)CAP;
+            // +1: top row of the matrix, or columns the previous strip did not visit
+            h_ahead = (col <= c_hi && s > 0 && col <= prev_c_hi) ? (uint32_t)(hword_ahead >> (2 * ((col - 1) & 31))) & 3u : 1u;
+        };
+        fetch_raw(0);
+        decode_ahead(0);
+        codechunk = code_ahead;
+        hchunk = h_ahead;
         code_cur = shr1_in((uint32_t)__builtin_amdgcn_readlane((int)codechunk, 0), code_cur);
         eq_cur = peq[code_cur * 64 + lane];
+        // (the lean step of the single-strip path above, plus what a strip boundary needs: the incoming deltas of the
+        //  strip above, the packed outgoing ones — only lane `last`'s are real; every lane shifts by lane `last`'s
+        //  column, a scalar — and the score at the column where the next strip starts)
+        const uint32_t lim = lane < nblk ? ncols : 0u;
+        const uint32_t sh = lane == last ? outbit : 63u;
+        const uint32_t t_cap = (cap_col != 0xFFFFFFFFu && cap_col >= c_lo) ? cap_col - c_lo + last : 0xFFFFFFFFu;
         for (uint32_t t = 0; t < nsteps; ++t) {
             const uint32_t tl = t & 63;
             const uint32_t fresh_h = (uint32_t)__builtin_amdgcn_readlane((int)hchunk, (int)tl);
             // next step's symbol and match vector (independent of this step's recurrence)
-            if (tl == 63) load_chunk(t + 1);
+#if SVX_ED_PREFETCH
+            if (tl == 0) fetch_raw(t + 64);
+            if (tl == 32) decode_ahead(t + 32);
+            if (tl == 63) { codechunk = code_ahead; hchunk = h_ahead; }
+#else
+            if (tl == 63) { fetch_raw(t + 1); decode_ahead(t + 1); codechunk = code_ahead; hchunk = h_ahead; }
+#endif
             const uint32_t fresh_c = (uint32_t)__builtin_amdgcn_readlane((int)codechunk, (int)((t + 1) & 63));
             const uint32_t code_next = shr1_in(fresh_c, code_cur);
             const uint64_t eq_next = peq[code_next * 64 + lane];
 
             const uint32_t hin = shr1_in(fresh_h, hout_prev);
-            const bool active = lane < nblk && t >= lane && (t - lane) < ncols;
-            const uint64_t hneg = hin == 2 ? 1ull : 0ull, hpos = hin == 1 ? 1ull : 0ull;
+            const bool active = (t - lane) < lim;  // (t < lane wraps to a huge value)
+            const uint64_t hneg = hin >> 1, hpos = hin & 1u;
             uint64_t Eq = eq_cur;
             const uint64_t Xv = Eq | Mv;
             Eq |= hneg;
             const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             uint64_t Ph = Mv | ~(Xh | Pv);
             uint64_t Mh = Pv & Xh;
-            const uint32_t sh = lane == last ? outbit : 63u;
-            const uint32_t ho = ((Ph >> sh) & 1ull) ? 1u : (((Mh >> sh) & 1ull) ? 2u : 0u);
+            const uint32_t ho = (uint32_t)((Ph >> sh) & 1ull) | ((uint32_t)((Mh >> sh) & 1ull) << 1);
             Ph = (Ph << 1) | hpos;
             Mh = (Mh << 1) | hneg;
+            uint32_t ho_a = 0;
             if (active) {
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
                 hout_prev = ho;
+                val += (ho & 1u) - (ho >> 1);
+                ho_a = ho;
             }
-            if (active && lane == last) {
-                const uint32_t col = c_lo + t - lane;
-                val += (ho == 1u ? 1u : 0u) - (ho == 2u ? 1u : 0u);
-                if (col == cap_col) captured = val;
-                if (s_out) {
-                    acc |= (uint64_t)ho << (2 * ((col - 1) & 31));
-                    if (((col - 1) & 31) == 31 || col == c_hi) {
-                        s_out[(col - 1) >> 5] = acc;
-                        acc = 0;
-                    }
+            captured = t == t_cap ? val : captured;
+            if (s_out && t >= last) {  // wave-uniform: lane `last` is at column col_last
+                const uint32_t col_last = c_lo + t - last;
+                acc |= (uint64_t)ho_a << (2 * ((col_last - 1) & 31));
+                if (((col_last - 1) & 31) == 31 || col_last == c_hi) {
+                    if (lane == last) s_out[(col_last - 1) >> 5] = acc;
+                    acc = 0;
                 }
             }
             code_cur = code_next;
@@ -479,10 +563,12 @@ static size_t ed_stage_need(uint32_t n_pairs, const EdPlan& plan) {
 
 // d_seq: the sequence pool in HBM (already uploaded / built on the context's stream); the stage region
 // must have been reserved with ed_stage_need() bytes still free
+// k_of != nullptr: per-pair threshold (0xFFFFFFFF = exact) instead of the one k_max for all
 static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, const uint32_t* a_len,
                   const uint64_t* b_off, const uint32_t* b_len, uint32_t n_pairs, uint32_t k_max, uint32_t* dist,
-                  const EdPlan& plan) {
-    const bool exact = (k_max == 0xFFFFFFFFu);
+                  const EdPlan& plan, const uint32_t* k_of = nullptr) {
+    auto kmax_of = [&](uint32_t i) { return k_of ? k_of[i] : k_max; };
+    auto exact_of = [&](uint32_t i) { return kmax_of(i) == 0xFFFFFFFFu; };
     const std::vector<uint32_t>& order = plan.order;
     int rc;
     EdArgs a;
@@ -512,7 +598,8 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
     // band per pair: the threshold itself, or (exact request) 256 widened per pair below
-    std::vector<uint32_t> band_of(n_pairs, exact ? 256u : k_max);
+    std::vector<uint32_t> band_of(n_pairs);
+    for (uint32_t i = 0; i < n_pairs; ++i) band_of[i] = exact_of(i) ? 256u : kmax_of(i);
     std::vector<uint32_t> todo = order, big, again, lst_band;
     std::vector<uint64_t> lst_soff;
     // ---- wavefront pass: resolves every pair whose distance is small next to its length
@@ -528,7 +615,7 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
             // 1/64 the same within noise, the near-identical batches of the bench unchanged (profiles/README.md)
             uint64_t c = std::max<uint64_t>(64, ((uint64_t)a_len[i] + b_len[i]) / 32);
             c = std::min<uint64_t>(c, ctx->wfa_cap);
-            if (!exact) c = std::min<uint64_t>(c, k_max);
+            if (!exact_of(i)) c = std::min<uint64_t>(c, kmax_of(i));
             lst_band[w] = (uint32_t)c;
             lds_cap = std::max(lds_cap, (uint32_t)c);
         }
@@ -544,13 +631,13 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
         hipLaunchKernelGGL(k_edit_wfa, dim3(n_pairs), dim3(64), lds, ctx->stream, wa, lds_cap);
         SVX_HIP(ctx, hipGetLastError());
         SVX_HIP(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        { int wrc = svx_wait_blocking(ctx); if (wrc != SVX_OK) return wrc; }
         todo.clear();
         for (uint32_t w = 0; w < n_pairs; ++w) {
             const uint32_t i = order[w];
             if (!(dist[i] & kUnproven)) continue;                  // exact distance <= cap
-            if (!exact && lst_band[w] >= k_max) continue;          // distance > k_max: all the caller asked
-            band_of[i] = exact ? std::max<uint32_t>(256u, 2 * lst_band[w]) : k_max;   // distance > cap is known
+            if (!exact_of(i) && lst_band[w] >= kmax_of(i)) continue;          // distance > k_max: all the caller asked
+            band_of[i] = exact_of(i) ? std::max<uint32_t>(256u, 2 * lst_band[w]) : kmax_of(i);   // distance > cap is known
             todo.push_back(i);
         }
     }
@@ -578,7 +665,7 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
                 hipLaunchKernelGGL(k_edit_myers<256>, dim3(a.n), dim3(64), lds_bytes<256>(), ctx->stream, a);
             SVX_HIP(ctx, hipGetLastError());
             SVX_HIP(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-            SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            { int wrc = svx_wait_blocking(ctx); if (wrc != SVX_OK) return wrc; }
             if (pass == 0) {
                 big.clear();
                 for (uint32_t i : todo)
@@ -592,8 +679,8 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
             }
         again.clear();
         for (uint32_t i : todo)
-            if (dist[i] & kUnproven) again.push_back(i);
-        if (!exact || again.empty()) break;
+            if ((dist[i] & kUnproven) && exact_of(i)) again.push_back(i);
+        if (again.empty()) break;
         // exact request: widen the band of each unresolved pair.  Its result D' is an upper bound of
         // the distance, so a band of D' is certain to resolve it; 4x the old band is tried first
         // when that is narrower (the bound can be far above the distance)
@@ -611,7 +698,7 @@ static int ed_run(svx_ctx* ctx, const uint8_t* d_seq, const uint64_t* a_off, con
     if (rc != SVX_OK) return rc;
     for (uint32_t i = 0; i < n_pairs; ++i) {
         if (dist[i] & kUnproven) dist[i] = 0xFFFFFFFFu;          // only "> k_max" is known (threshold request)
-        else if (!exact && dist[i] > k_max) dist[i] = 0xFFFFFFFFu;
+        else if (!exact_of(i) && dist[i] > kmax_of(i)) dist[i] = 0xFFFFFFFFu;
     }
     return SVX_OK;
 }
@@ -638,7 +725,8 @@ extern "C" int svx_edit_distance_batch(svx_ctx* ctx, const uint8_t* seq, uint64_
 
 // pool: host bytes staged to HBM by this call, or (d_pool_resident != nullptr) already there
 static int hap_distance_impl(svx_ctx* ctx, const uint8_t* pool, const uint8_t* d_pool_resident, bool resident, uint64_t pool_bytes,
-                             const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist) {
+                             const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist,
+                             const uint32_t* k_of = nullptr) {
     if (!ctx) return SVX_E_INVALID;
     if (n_pairs == 0) return SVX_OK;
     if (!pieces || !dist || (pool_bytes && !(resident ? d_pool_resident : pool))) return SVX_E_INVALID;
@@ -688,7 +776,7 @@ static int hap_distance_impl(svx_ctx* ctx, const uint8_t* pool, const uint8_t* d
     h.pool = d_pool; h.pieces = d_pc; h.str_off = d_soff; h.out = d_str; h.n_strings = n_strings;
     hipLaunchKernelGGL(k_hap_build, dim3(n_strings), dim3(256), 0, ctx->stream, h);
     SVX_HIP(ctx, hipGetLastError());
-    return ed_run(ctx, d_str, a_off.data(), a_len.data(), b_off.data(), b_len.data(), n_pairs, k_max, dist, plan);
+    return ed_run(ctx, d_str, a_off.data(), a_len.data(), b_off.data(), b_len.data(), n_pairs, k_max, dist, plan, k_of);
 }
 
 extern "C" int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
@@ -701,4 +789,11 @@ extern "C" int svx_haplotype_distance_batch_dev(svx_ctx* ctx, const uint8_t* d_p
                                                 const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max,
                                                 uint32_t* dist) {
     return hap_distance_impl(ctx, nullptr, d_pool, true, pool_bytes, pieces, n_pairs, k_max, dist);
+}
+
+extern "C" int svx_haplotype_distance_batch_mixed(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
+                                                  const svx_hap_piece* pieces, uint32_t n_pairs, const uint32_t* k_max,
+                                                  uint32_t* dist) {
+    if (n_pairs && !k_max) return SVX_E_INVALID;
+    return hap_distance_impl(ctx, pool, nullptr, false, pool_bytes, pieces, n_pairs, 0, dist, k_max);
 }

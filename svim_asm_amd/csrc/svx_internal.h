@@ -28,6 +28,7 @@ struct svx_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     // recorded right after the streaming kernel of every cigar call (svx_ctx_wait_dominant)
+    hipEvent_t ev_block = nullptr;  // svx_wait_blocking
     hipEvent_t ev_dom = nullptr;
     bool ev_dom_recorded = false;
     bool want_dom = false;
@@ -118,6 +119,10 @@ static inline size_t svx_take_bytes(size_t count, size_t elem) {
     return svx_align_up(count * elem, 256) + 256;
 }
 
+// Wait for everything enqueued on the context's stream WITHOUT spinning: an event created with hipEventBlockingSync
+// puts the thread to sleep until the device signals (hipStreamSynchronize burns a CPU for the whole wait: under a
+// CPU quota, milliseconds of kernel time then cost the host's other threads their share).
+int svx_wait_blocking(svx_ctx* ctx);
 int svx_timing_begin(svx_ctx* ctx);           // records ev[0]
 int svx_timing_mark(svx_ctx* ctx, int which); // records ev[which] (1: dominant start, 2: dominant end)
 int svx_timing_end(svx_ctx* ctx);             // records ev[3]

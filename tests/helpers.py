@@ -430,6 +430,11 @@ class OracleBackedContext(object):
             out.append(d if d <= k_max else 0xFFFFFFFF)
         return np.array(out, dtype=np.uint32)
 
+    def haplotype_distance_batch_mixed(self, pool, pieces, k_max):
+        exact = self.haplotype_distance_batch(pool, pieces)
+        k_max = np.asarray(k_max, dtype=np.uint32)
+        return np.where(exact <= k_max, exact, np.uint32(0xFFFFFFFF)).astype(np.uint32)
+
     def linkage_cut_batch(self, dist, n_members, cutoff):
         out, at = [], 0
         for n in n_members:

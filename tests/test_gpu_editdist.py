@@ -253,6 +253,10 @@ def test_haplotype_distance_batch_assembles_like_the_reference(svx_ctx):
     assert got.tolist() == exp
     thr = svx_ctx.haplotype_distance_batch(pool, pieces, 200)
     assert all((g == e) if e <= 200 else g == 0xFFFFFFFF for g, e in zip(thr.tolist(), exp))
+    # one call with a threshold per pair (the PAIR step's form): 0xFFFFFFFF = exact, else "exact when <= k"
+    per_pair = rng.choice(np.array([0xFFFFFFFF, 200, 0, 37, 1 << 31], dtype=np.uint32), size=n_pairs)
+    mixed = svx_ctx.haplotype_distance_batch_mixed(pool, pieces, per_pair)
+    assert all((g == e) if e <= int(k) else g == 0xFFFFFFFF for g, e, k in zip(mixed.tolist(), exp, per_pair.tolist()))
     # a piece that reads past the pool is rejected, not read
     bad = pieces[:6].copy()
     bad[2] = (len(pool) - 10, 100, 1, 1)
