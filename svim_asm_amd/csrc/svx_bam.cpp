@@ -1089,7 +1089,8 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
                 b->ref_len.push_back(ch.ref_len[i]); b->flag.push_back(ch.flag[i]); b->mapq.push_back(ch.mapq[i]);
                 b->voffset.push_back(ch.voffset[i]); b->seq_coff.push_back(ch.seq_coff[i]);
                 b->seq_uoff.push_back(ch.seq_uoff[i]);
-                memcpy(b->cigar + cw, ch.cigar.data() + co, (size_t)ch.n_cig[i] * 4);
+                if (ch.n_cig[i])  // (a chunk of records without CIGARs — unplaced reads — has no CIGAR buffer at all)
+                    memcpy(b->cigar + cw, ch.cigar.data() + co, (size_t)ch.n_cig[i] * 4);
                 cw += ch.n_cig[i];
                 b->cigar_off.push_back(cw);
                 b->names.insert(b->names.end(), ch.names.begin() + no, ch.names.begin() + no + ch.name_len[i]);

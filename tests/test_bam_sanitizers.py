@@ -76,3 +76,18 @@ def test_reader_is_clean_on_long_cigar_records_and_their_damaged_copies(driver, 
                                       n_shared=prm["n_shared"], n_private=prm["n_private"], median_aln=prm["median_aln"],
                                       mean_m=prm["mean_m"])
     _run(driver, tmp_path, 40, list(bams))
+
+
+def test_reader_is_clean_on_spec_written_files_and_their_damaged_copies(driver, tmp_path):
+    """The awkward cases of tests/test_bam_spec_cases.py — files written from the SAM specification alone by
+    tests/spec_bam_writer.py: records across many members, empty members, every aux type around SA, stored members,
+    a split block_size field, bins of every level, .bai with and without pseudo-bins — and damaged copies of them."""
+    from tests import test_bam_spec_cases as cases
+    d = tmp_path / "spec"
+    d.mkdir()
+    files = [cases.write_case(d, name)[0] for name in sorted(cases.CASES) if name not in ("largest_members", "cigar_of_70000_operations")]
+    assert len(files) >= 20
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    out = _run(driver, scratch, 25, files)
+    assert " read," in out
