@@ -439,6 +439,26 @@ typedef struct svx_collect_dev {
 
 int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d);
 
+/* ------------------------------------------------------------ f-1 on the device (prototype) ------ */
+/*
+ * BGZF members inflated and checked on the device: what htslib's bgzf_read_block does under every record the
+ * reference reads (pysam bam.fetch, SVIM_COLLECT.py:65-68) — inflate the member's raw DEFLATE payload, compare
+ * the CRC32 and the length with the member's trailer.  One lane per member, all members of a call in one launch.
+ *   d_in                 compressed payloads (the bytes between a member's header and its 8-byte trailer), anywhere
+ *                        in one buffer: member m is d_in[d_in_off[m] .. + d_in_len[m]); the buffer must be readable 3 bytes
+ *                        past the end of any member (input words are fetched whole)
+ *   d_isize, d_crc       the trailer's ISIZE (<= 65536) and CRC32 of every member
+ *   d_out, d_out_off     member m's bytes are written to d_out[d_out_off[m] .. + d_isize[m]); the stretches must be
+ *                        separated by at least 8 bytes (and d_out end 8 bytes behind the last one): match copies move
+ *                        whole 8-byte words and may touch up to 7 bytes behind a member's end
+ *   d_status             per member: 0 ok; 1 malformed stream; 2 length != ISIZE; 3 CRC32 mismatch; 4 input ended early.
+ *                        Nothing outside a member's own input and output stretch is ever read or written.
+ * Asynchronous on the context's stream.
+ */
+int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                         const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
+                         const uint64_t* d_out_off, uint32_t* d_status);
+
 /* ------------------------------------------------------------ a5 + a6 ------ */
 /*
  * Pair sort + partition: form_partitions (SVIM_COMBINE.py:15-32).

@@ -114,6 +114,7 @@ SYMBOLS = {
     "svx_version": (C.c_char_p, []),
     "svx_device_count": (C.c_int, []),
     "svx_ctx_set_small_batch_ops": (C.c_int, [_P, C.c_uint64]),
+    "svx_bgzf_inflate_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "svx_hbm_read_probe_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
     "svx_ctx_set_split_chain": (C.c_int, [_P, C.c_int]),
     "svx_ctx_set_pair_single_launch_max": (C.c_int, [_P, C.c_uint32]),
@@ -282,6 +283,42 @@ class Context:
 
     def set_timing(self, on=True):
         self._check(self.lib.svx_ctx_set_timing(self.h, 1 if on else 0))
+
+    def bgzf_inflate(self, payloads, isize, crc, keep_output=True):
+        """Inflate + CRC-check BGZF member payloads on the device (svx_bgzf_inflate_dev; prototype).  payloads: list of
+        bytes-like raw DEFLATE streams; isize / crc: the members' trailers.  Returns (status u32[n], outputs or None,
+        kernel milliseconds)."""
+        n = len(payloads)
+        in_len = np.array([len(p) for p in payloads], dtype=np.uint32)
+        in_off = np.zeros(n, np.uint64)
+        if n > 1:
+            np.cumsum(((in_len[:-1].astype(np.uint64) + 3) // 4) * 4, out=in_off[1:])
+        total_in = int(in_off[-1] + in_len[-1]) if n else 0
+        blob = np.zeros(total_in + 8, np.uint8)
+        for p, o, l in zip(payloads, in_off.tolist(), in_len.tolist()):
+            blob[o:o + l] = np.frombuffer(p, dtype=np.uint8)
+        isize = np.ascontiguousarray(isize, dtype=np.uint32)
+        crc = np.ascontiguousarray(crc, dtype=np.uint32)
+        out_off = np.zeros(n, np.uint64)
+        if n > 1:
+            np.cumsum(((isize[:-1].astype(np.uint64) + 8 + 15) // 16) * 16, out=out_off[1:])  # >= 8 bytes between members
+        total_out = int(out_off[-1] + isize[-1]) if n else 0
+        d = [self.dev_array(x) for x in (blob, in_off, in_len, isize, crc, out_off)]
+        d_out, d_st = self.dev_array(nbytes=total_out + 16), self.dev_array(np.full(n, 0xFFFFFFFF, np.uint32))
+        self.set_timing(True)
+        self._check(self.lib.svx_bgzf_inflate_dev(self.h, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, n, d_out.ptr,
+                                                  d[5].ptr, d_st.ptr))
+        self.sync()
+        ms = self.last_kernel_ms()[1]
+        self.set_timing(False)
+        status = d_st.download(np.uint32)
+        outs = None
+        if keep_output:
+            flat = d_out.download(np.uint8)
+            outs = [flat[int(o):int(o) + int(l)].tobytes() for o, l in zip(out_off.tolist(), isize.tolist())]
+        for x in d + [d_out, d_st]:
+            x.free()
+        return status, outs, ms
 
     def hbm_read_probe(self, d_ptr, nbytes, reps=5):
         """GB/s of a read-only nontemporal stream over a resident buffer (svx_hbm_read_probe_dev)."""

@@ -1,0 +1,95 @@
+"""svx_bgzf_inflate_dev (prototype): BGZF member payloads inflated and CRC32-checked on the
+device, one lane per member, against zlib — what htslib's bgzf_read_block does under every record the reference
+reads (SVIM_COLLECT.py:65-68).  Bytes identical for every zlib level / strategy over several kinds of data, stored
+and fixed-code members, members of the config-1 golden BAMs; damaged members are flagged, never read past."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from svim_asm_amd import bamio
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "config1")
+
+
+def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
+    return c.compress(data) + c.flush()
+
+
+def kinds(rng):
+    seq = rng.choice(np.frombuffer(bytes([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88, 0xFF]),
+                                   np.uint8), size=60000).tobytes()            # 4-bit packed bases, as a SEQ field
+    text = (b"chr1\t12345\tsvim_asm.DEL.7\tACGTNNNN\t<DEL>\t.\tPASS\tSVTYPE=DEL;END=12400;SVLEN=-55\tGT\t0/1\n" * 700)[:65000]
+    return {"seq": seq, "text": text, "zeros": bytes(65536), "random": rng.integers(0, 256, 65536, dtype=np.uint8).tobytes(),
+            "tiny": b"A", "empty": b"", "runs": b"".join(bytes([int(x)]) * int(n) for x, n in zip(rng.integers(0, 256, 400), rng.integers(1, 300, 400)))[:65536]}
+
+
+def test_every_level_and_strategy_matches_zlib(svx_ctx):
+    rng = np.random.default_rng(1)
+    payloads, expect = [], []
+    for name, data in kinds(rng).items():
+        for level in (0, 1, 2, 4, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                for mem in (1, 9):
+                    payloads.append(deflate(data, level, strategy, mem))
+                    expect.append(data)
+    isize = [len(d) for d in expect]
+    crc = [zlib.crc32(d) & 0xFFFFFFFF for d in expect]
+    status, outs, _ = svx_ctx.bgzf_inflate(payloads, isize, crc)
+    assert status.tolist() == [0] * len(payloads)
+    assert all(o == e for o, e in zip(outs, expect))
+
+
+def test_members_of_the_golden_bams(svx_ctx):
+    payloads, isize, crc, expect = [], [], [], []
+    for name in ("hap1.bam", "hap2.bam"):
+        raw = open(os.path.join(GOLD, name), "rb").read()
+        for st, ln, isz, *_ in bamio._bgzf_block_spans(raw):
+            member_end = st + ln
+            payloads.append(raw[st:member_end])
+            expect.append(zlib.decompress(raw[st:member_end], -15) if isz else b"")
+            isize.append(isz)
+            crc.append(zlib.crc32(expect[-1]) & 0xFFFFFFFF)
+    assert len(payloads) > 20
+    status, outs, _ = svx_ctx.bgzf_inflate(payloads, isize, crc)
+    assert status.tolist() == [0] * len(payloads)
+    assert all(o == e for o, e in zip(outs, expect))
+
+
+def test_damaged_members_are_flagged(svx_ctx):
+    """Flipped bits, truncated input, wrong trailer values: the status says so (zlib's verdict where zlib can tell,
+    the CRC32 where only the checksum can), the neighbours in the same launch are untouched."""
+    rng = np.random.default_rng(2)
+    data = kinds(rng)
+    base = [(deflate(d, lvl), d) for d in (data["seq"], data["text"], data["runs"]) for lvl in (1, 6)]
+    payloads, isize, crc, want_ok, expect = [], [], [], [], []
+    for p, d in base:  # intact controls
+        payloads.append(p); isize.append(len(d)); crc.append(zlib.crc32(d) & 0xFFFFFFFF); want_ok.append(True); expect.append(d)
+    for trial in range(200):
+        p, d = base[trial % len(base)]
+        bad = bytearray(p)
+        kind = trial % 4
+        good_isize, good_crc = len(d), zlib.crc32(d) & 0xFFFFFFFF
+        if kind == 0:
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            bad = bad[:int(rng.integers(1, len(bad)))]
+        elif kind == 2:
+            good_crc ^= 1 << int(rng.integers(0, 32))
+        else:
+            good_isize = max(0, good_isize + int(rng.choice([-1, 1, -100, 7])))
+        try:
+            out = zlib.decompress(bytes(bad), -15)
+            same = out == d and len(out) == good_isize and (zlib.crc32(out) & 0xFFFFFFFF) == good_crc
+        except zlib.error:
+            same = False
+        payloads.append(bytes(bad)); isize.append(good_isize); crc.append(good_crc); want_ok.append(same); expect.append(d)
+    status, outs, _ = svx_ctx.bgzf_inflate(payloads, isize, crc)
+    for k, (st, ok) in enumerate(zip(status.tolist(), want_ok)):
+        assert (st == 0) == ok, (k, st, ok)
+        if ok:
+            assert outs[k] == expect[k]
