@@ -818,27 +818,47 @@ def main():
     else:
         total_ops = n_ops
 
-    # ---- roofline of the dominant kernel (k_cigar_tiles): HIP events on its launch stream around
-    # every launch of the a1+a2 path (context 0; event pairs bracket the kernel itself) ----
+    # ---- roofline of the dominant kernel: HIP events on its launch stream around every launch of the step's own
+    # sequence (context 0; the event pair brackets the kernel itself).  With --step collect that kernel is
+    # k_tiles_a3<4096>: the streaming tile workgroups of a1+a2 WITH the rows + decision-tree workgroups of the
+    # split-segment chain among them; the a1+a2-only launch (k_cigar_tiles, what svx_cigar_extract_dev enqueues) is
+    # timed beside it ----
     torch.cuda.synchronize(dev)
-    ctx.set_timing(True)
-    k_ms, p_ms = [], []
-    for _ in range(max(5, min(20, args.steps))):
-        ctx.cigar_extract_dev(d_cig_ptr, n_ops, d_off_ptr, n_aln, d_rs_ptr, args.min_sv_size, outs, cap, d_n_ptr, d_op=d_op_ptr)
-        ctx.sync()
-        tot_ms, dom_ms = ctx.last_kernel_ms()
-        k_ms.append(dom_ms)
-        p_ms.append(tot_ms)
-    ctx.set_timing(False)
-    k_avg = float(np.mean(k_ms)) * 1e-3
-    p_avg = float(np.mean(p_ms)) * 1e-3
     op_bytes = 5 if args.layout == "soa" else 4  # packed u32 per op; SoA: a u8 op code next to the u32 length
     algo_bytes = op_bytes * n_ops + 16 * n_aln + 17 * n_sig  # SURVEY.md §8(d), whole a1+a2 path
-    # what the dominant kernel itself moves of those: the op stream, aln_off, its slab records (16 B per
+    # what the tile workgroups themselves move of those: the op stream, aln_off, the slab records (16 B per
     # signature) and one 16-B descriptor + one 4-B start index per tile; the 17-B final records are written by
     # the finish kernel and only count for the path figure
     n_tiles = (n_ops + 4095) // 4096
-    kernel_bytes = op_bytes * n_ops + 8 * n_aln + 16 * n_sig + 20 * n_tiles
+    tile_bytes = op_bytes * n_ops + 8 * n_aln + 16 * n_sig + 20 * n_tiles
+
+    def timed(fn):
+        ctx.set_timing(True)
+        k_ms, p_ms = [], []
+        for _ in range(max(5, min(20, args.steps))):
+            fn()
+            ctx.sync()
+            tot_ms, dom_ms = ctx.last_kernel_ms()
+            k_ms.append(dom_ms)
+            p_ms.append(tot_ms)
+        ctx.set_timing(False)
+        return float(np.mean(k_ms)) * 1e-3, float(np.mean(p_ms)) * 1e-3
+
+    def a1a2_only():
+        ctx.cigar_extract_dev(d_cig_ptr, n_ops, d_off_ptr, n_aln, d_rs_ptr, args.min_sv_size, outs, cap, d_n_ptr, d_op=d_op_ptr)
+    tiles_k, tiles_p = timed(a1a2_only)
+    chain_bytes = 0
+    if args.step == "collect":
+        # bytes of the chain's stage A inside the same launch: the CIGARs of the segments' alignments (4 B per op), per
+        # segment its table row in (seg_src, two offsets, tid, pos, rev, qend: 33 B), the 24-B row and the read length
+        # out and in again, the 32-B raw record out; per read two offsets and its length
+        seg_ops = int((batch["aln_off"][1:] - batch["aln_off"][:-1])[case["seg_src"][case["seg_src"] < n_aln].astype(np.int64)].sum()) + \
+            int(len(case["extra_cigar"]))
+        chain_bytes = 4 * seg_ops + (33 + 2 * 28 + 32) * n_segs + 12 * n_reads
+        k_avg, p_avg = timed(rc0.step)
+        kernel_bytes = tile_bytes + chain_bytes
+    else:
+        k_avg, p_avg, kernel_bytes = tiles_k, tiles_p, tile_bytes
     achieved = kernel_bytes / k_avg / 1e9
 
     # second denominator: the read-only nontemporal stream this box sustains over the very buffer
@@ -872,7 +892,7 @@ def main():
     if rank == 0:
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        wl_key = "config%d_x%d_%s" % (args.config, args.samples, args.layout)
+        wl_key = "config%d_x%d_%s%s" % (args.config, args.samples, args.layout, "_collect" if args.step == "collect" else "")
         if os.path.exists(tpath):
             try:
                 entry = json.load(open(tpath)).get(wl_key, {})
@@ -917,12 +937,18 @@ def main():
                 "parallelism": "sample/contig shards x%d, no data-path collective" % world,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_cigar_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "k_tiles_a3<false, 4096, 0>" if args.step == "collect" else "k_cigar_tiles<false, 4096, 0>",
+                "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel_bytes_per_launch": kernel_bytes, "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_bytes_per_launch": kernel_bytes, "algorithmic_bytes_per_launch": algo_bytes + chain_bytes,
+                "chain_bytes_in_the_launch": chain_bytes,
                 "kernel_ms": k_avg * 1e3,
-                "path_ms": p_avg * 1e3, "path_achieved": algo_bytes / p_avg / 1e9,
-                "path_frac": algo_bytes / p_avg / 1e9 / HBM_PEAK_GBS,
+                "path_ms": p_avg * 1e3, "path_achieved": (algo_bytes + chain_bytes) / p_avg / 1e9,
+                "path_frac": (algo_bytes + chain_bytes) / p_avg / 1e9 / HBM_PEAK_GBS,
+                "a1a2_only": {"kernel": "k_cigar_tiles<false, 4096, 0>", "note": "svx_cigar_extract_dev alone (no chimeric reads in the "
+                              "launch): the figure rounds 1-3 quoted", "kernel_ms": tiles_k * 1e3, "kernel_bytes_per_launch": tile_bytes,
+                              "achieved": tile_bytes / tiles_k / 1e9, "frac": tile_bytes / tiles_k / 1e9 / HBM_PEAK_GBS,
+                              "path_ms": tiles_p * 1e3, "path_frac": algo_bytes / tiles_p / 1e9 / HBM_PEAK_GBS},
                 "read_ceiling": read_gbs, "frac_of_read_ceiling": (achieved / read_gbs) if read_gbs else None,
                 "read_ceiling_note": "read-only nontemporal stream over the same resident CIGAR buffer, measured in this run "
                                      "(svx_hbm_read_probe_dev)",

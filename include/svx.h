@@ -86,6 +86,11 @@ int svx_ctx_set_split_chain(svx_ctx* ctx, int on);
  * the wait-free plan (below) and succeeds; for the asynchronous entry points the next svx_ctx_sync returns
  * SVX_E_HIP, the outputs of that call are invalid, the context stays usable. */
 int svx_ctx_set_pair_single_launch_max(svx_ctx* ctx, uint32_t max_candidates);
+/* For callers of the asynchronous svx_pair_partition_dev*: 1 when the SVX_E_HIP that the latest svx_ctx_sync (or a
+ * later call on the context) returned was a wait between workgroups that ran out — the outputs of that call are
+ * invalid, the context is usable, and the same call enqueued again after svx_ctx_set_pair_wait_free(ctx, 1) cannot
+ * fail that way (what svx_pair_partition does by itself for host-pointer callers).  Reading clears the flag. */
+int svx_ctx_barrier_timed_out(svx_ctx* ctx);
 /* The plan that never waits between workgroups inside a launch: radix passes (P + 1 launches) and the partition
  * sweep as two launches.  Slower than the plans above and independent of who else is resident on the device.
  * svx_pair_partition (host pointers, synchronous) falls back to it by itself when a wait of the faster plans

@@ -590,16 +590,38 @@ def _load_together(bams):
 LAST_TIMING = {}  # seconds per stage of the latest collect_tables call (tools/, bench legs)
 
 
+MAX_OPS_PER_SUBMISSION = (1 << 32) - 1024  # svx_collect_batch takes fewer than 2^32 CIGAR ops per call (include/svx.h)
+
+
+def _submission_groups(samples, same_header, max_ops=None):
+    """Which samples go out together: all of them in ONE submission when their reference dictionaries agree — also
+    the BAMs of many samples of a cohort —, cut into several wherever the op count of a submission (records + SA-derived
+    segments) would reach the device entry's limit; one submission per file otherwise."""
+    max_ops = MAX_OPS_PER_SUBMISSION if max_ops is None else max_ops
+    if not same_header:
+        return [[s] for s in samples]
+    groups, ops = [[]], 0
+    for s in samples:
+        n = int(s.rec.cig_off[-1]) + int(sum(len(w) for w in s.extra_words))
+        if groups[-1] and ops + n > max_ops:
+            groups.append([])
+            ops = 0
+        groups[-1].append(s)
+        ops += n
+    return groups
+
+
 def collect_tables(bams, options, ctx=None):
-    """CandidateTable of every bam in `bams` (the two haplotypes of a diploid sample): one device submission
-    for all of them when their reference dictionaries agree."""
+    """CandidateTable of every bam in `bams` (the two haplotypes of a diploid sample, or the BAMs of a whole cohort
+    of samples: svim_asm_amd/cohort.py): one device submission for all of them when their reference dictionaries
+    agree, several where one would exceed the 2^32-op limit of svx_collect_batch."""
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
     tl, cl = time.perf_counter(), time.process_time()
     _load_together(bams)
     t0, c0 = time.perf_counter(), time.process_time()
     samples = [_prepare(bam, options) for bam in bams]
     t1 = time.perf_counter()
-    groups = [samples] if _same_header(bams) else [[s] for s in samples]
+    groups = _submission_groups(samples, _same_header(bams))
     for group in groups:
         _submit(group, options, ctx)
     t2 = time.perf_counter()

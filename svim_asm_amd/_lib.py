@@ -118,6 +118,7 @@ SYMBOLS = {
     "svx_hbm_read_probe_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
     "svx_ctx_set_split_chain": (C.c_int, [_P, C.c_int]),
     "svx_ctx_set_pair_single_launch_max": (C.c_int, [_P, C.c_uint32]),
+    "svx_ctx_barrier_timed_out": (C.c_int, [_P]),
     "svx_ctx_set_edit_wavefront_cap": (C.c_int, [_P, C.c_uint32]),
     "svx_ctx_set_pair_wait_free": (C.c_int, [_P, C.c_int]),
     "svx_ctx_pair_retries": (C.c_int, [_P]),
@@ -263,6 +264,10 @@ class Context:
     def set_pair_wait_free(self, on=True):
         """Sort on the plan without waits between workgroups inside a launch (radix passes + two-launch sweep)."""
         self._check(self.lib.svx_ctx_set_pair_wait_free(self.h, 1 if on else 0))
+
+    def barrier_timed_out(self):
+        """True once after a sync failed because a wait between workgroups ran out (svx_ctx_barrier_timed_out)."""
+        return bool(self.lib.svx_ctx_barrier_timed_out(self.h))
 
     def pair_retries(self):
         """Host-pointer pair_partition calls re-run on the wait-free plan after a wait of the fast plans ran out."""

@@ -73,6 +73,7 @@ int svx_barrier_check(svx_ctx* ctx) {
     if (!note) return SVX_OK;
     SVX_HIP(ctx, hipMemset(ctx->ws, 0, 4096));  // counters of the broken launch included
     ctx->pair_launches = 0;
+    ctx->barrier_timed_out = true;  // svx_ctx_barrier_timed_out: the caller of a _dev entry may re-enqueue wait-free
     SVX_SET_ERR(ctx, "svx_pair_partition: a wait between workgroups ran out (more than four contexts sorting on one "
                      "device?); the results of that call are invalid");
     return SVX_E_HIP;
@@ -133,6 +134,13 @@ extern "C" int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops) {
     if (!ctx) return SVX_E_INVALID;
     ctx->small_batch_ops = max_ops;
     return SVX_OK;
+}
+
+extern "C" int svx_ctx_barrier_timed_out(svx_ctx* ctx) {
+    if (!ctx) return 0;
+    const bool was = ctx->barrier_timed_out;
+    ctx->barrier_timed_out = false;
+    return was ? 1 : 0;
 }
 
 extern "C" int svx_ctx_set_split_chain(svx_ctx* ctx, int on) {

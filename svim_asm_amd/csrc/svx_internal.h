@@ -35,6 +35,7 @@ struct svx_ctx {
     int n_cu = 256;
     uint32_t wfa_cap = 1024;  // svx_ctx_set_edit_wavefront_cap: edits the wavefront pass of the edit distance resolves
     bool barrier_pending = false;      // a kernel with a grid barrier went out since the last svx_barrier_check
+    bool barrier_timed_out = false;    // the last failed svx_ctx_sync was a wait between workgroups that ran out
     bool pair_lds_set = false;         // k_pair_single's dynamic-LDS limit raised on this context's device
     uint32_t pair_launches = 0;        // launches of k_pair_single so far: which set of arrival counters is next
     bool pair_wait_free = false;       // svx_ctx_set_pair_wait_free: sort on the plan without waits inside a launch

@@ -140,8 +140,9 @@ try:
     raise SystemExit("svx_ctx_sync did not report the failed launch")
 except _lib.SvxError as e:
     assert "ran out" in str(e), str(e)
+assert ctx.barrier_timed_out() and not ctx.barrier_timed_out()   # the caller-visible flag, cleared by reading it
 ctx.sync()
-# ... and an asynchronous caller that cannot be re-run behind its back selects the wait-free plan itself
+# ... and an asynchronous caller that cannot be re-run behind its back sees the flag and selects the wait-free plan itself
 ctx.set_pair_wait_free(True)
 ctx._check(ctx.lib.svx_pair_partition_dev_bits(ctx.h, d_k.ptr, len(big), 1000, int(np.bitwise_or.reduce(big)), d_p.ptr,
                                                d_id.ptr, d_np.ptr))

@@ -190,3 +190,31 @@ def test_large_alleles_pair_like_the_oracle(svx_ctx):
     a, b = (1, helpers.build_candidate(t1[0], bam, SVCandidate)), (2, helpers.build_candidate(t2[0], bam, SVCandidate))
     h = SVIM_COMBINE.haplotype_pair(a[1], b[1], ref)
     assert SVIM_COMBINE.compute_distance(a, b, ref) == orc.edit_distance(h[0].encode(), h[1].encode()) > 16000
+
+
+def test_cohort_command_writes_the_single_sample_vcfs(svx_ctx, tmp_path):
+    """svim-asm-cohort: three diploid samples (the config-1 BAMs in both orders) — COLLECT of all six BAMs as ONE
+    device submission — write, per sample, the VCF the real reference wrote for that sample alone; and the same with
+    the submission cut into several by the op-count limit (here lowered to a few thousand ops)."""
+    from svim_asm_amd import SVIM_COLLECT, cohort
+    g = os.path.join(GOLD, "config1")
+    rows = [("s1", "hap1.bam", "hap2.bam", "diploid_default"), ("s2", "hap2.bam", "hap1.bam", None), ("s3", "hap1.bam", "hap2.bam", "diploid_default")]
+    manifest = tmp_path / "cohort.tsv"
+    manifest.write_text("# working_dir bam1 bam2\n" + "".join("%s %s %s\n" % (tmp_path / wd, os.path.join(g, a), os.path.join(g, b)) for wd, a, b, _ in rows))
+    for limit in (None, 4000):
+        old = SVIM_COLLECT.MAX_OPS_PER_SUBMISSION
+        if limit:
+            SVIM_COLLECT.MAX_OPS_PER_SUBMISSION = limit
+        try:
+            assert cohort.main(["diploid", str(manifest), os.path.join(g, "ref.fa")]) == 0
+        finally:
+            SVIM_COLLECT.MAX_OPS_PER_SUBMISSION = old
+        for wd, a, b, golden in rows:
+            got = "".join(l for l in open(tmp_path / wd / "variants.vcf") if not l.startswith("##fileDate="))
+            if golden:
+                assert got == open(os.path.join(g, golden + ".vcf")).read()
+            else:  # the swapped order has no golden of its own: the single-sample command is the reference
+                single = tmp_path / "single"
+                cli.main(["diploid", str(single), os.path.join(g, a), os.path.join(g, b), os.path.join(g, "ref.fa")])
+                assert got == "".join(l for l in open(single / "variants.vcf") if not l.startswith("##fileDate="))
+            os.remove(tmp_path / wd / "variants.vcf")

@@ -194,3 +194,21 @@ def test_breakend_whose_ends_coincide_flips_at_every_construction():
     exp = svim_oracle.pair_candidates([], helpers.constructed_again([raw], lens), ref.fetch, NAMES, lengths, lens,
                                       helpers.options())
     assert [tuple(x) for x in exp] == [("BND", "chr10", 3154, "fwd", "chr10", 3154, "fwd", ("r",), "0/1")]
+
+
+def test_submission_groups_respect_the_op_limit():
+    """COLLECT cuts a cohort into several submissions where one would reach svx_collect_batch's 2^32-op limit."""
+    class Rec(object):
+        def __init__(self, n):
+            self.cig_off = np.array([0, n], np.int64)
+
+    class S(object):
+        def __init__(self, n, extra):
+            self.rec, self.extra_words = Rec(n), [np.zeros(e, np.uint32) for e in extra]
+    samples = [S(1000, [3, 3]), S(3000, []), S(500, [10]), S(2000, [1]), S(100, [])]
+    groups = SVIM_COLLECT._submission_groups(samples, True, max_ops=4000)
+    assert [[samples.index(s) for s in g] for g in groups] == [[0], [1, 2], [3, 4]]
+    assert SVIM_COLLECT._submission_groups(samples, True) == [samples]           # far below 2^32: one submission
+    assert SVIM_COLLECT._submission_groups(samples, False) == [[s] for s in samples]  # headers differ: one per file
+    big = [S((1 << 31) + 5, []), S((1 << 31) + 5, []), S(7, [])]
+    assert [len(g) for g in SVIM_COLLECT._submission_groups(big, True)] == [1, 2]

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collect PMC counters of the bench kernels in separate passes (rocprofv3 --pmc; no sys/hip tracing).
-# usage: tools/pmc.sh <outdir> [bench args...]
+# usage: tools/pmc.sh <outdir> [bench args...]          PMC_CMD="tools/collect_probe.py product_point" tools/pmc.sh <outdir>
+# (PMC_CMD: another python program instead of bench.py; the program itself follows rocprofv3's `--`, no wrapper)
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
@@ -9,7 +10,11 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out" -o pass$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > /dev/null 2>> "$out/err.txt"
+  if [ -n "$PMC_CMD" ]; then
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out" -o pass$i -- python3 $PMC_CMD > /dev/null 2>> "$out/err.txt"
+  else
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out" -o pass$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > /dev/null 2>> "$out/err.txt"
+  fi
 done
 python3 - "$out" <<'PY'
 import csv, collections, glob, json, re, sys

@@ -4,7 +4,7 @@
 #   hip_api_stats.csv   rocprofv3 --hip-trace --stats: how many hipMemcpy* / hipStreamSynchronize the command issues
 #   kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
 cd /tmp && export TMPDIR=/tmp SVX_ORDERLY_EXIT=1; cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/${1:-r03_cli}; mkdir -p $out
+out=gpurun_out/${1:-r04_cli}; mkdir -p $out
 d=/tmp/svx_cli_dataset
 python3 tools/e2e_bench.py --scale ${2:-1.0} --keep $d --ranks 1 --repeat 2 > $out/e2e.json 2> $out/e2e.err
 rocprofv3 --hip-trace --stats --output-format csv -d $out/hip -o s -- python3 bin/svim-asm diploid $d/wd_prof_hip $d/hap1.bam $d/hap2.bam $d/ref.fa > $out/cli_hip.log 2>&1
