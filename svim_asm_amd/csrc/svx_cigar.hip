@@ -1451,8 +1451,13 @@ constexpr int kSmallTileOps = kRoundOps;            // 1024 ops
 constexpr int kSmallPer = 8;                        // folded descriptors per thread in the scan
 constexpr uint32_t kSmallMaxGroups = 256u * kSmallPer;   // groups of kWaves tiles (one per workgroup of the tile kernel)
 constexpr uint32_t kSmallMaxTiles = kSmallMaxGroups * kWaves;  // batches up to 8 M ops take this path
-constexpr uint32_t kFinTiles = 256u / 16u;          // tiles a workgroup finishes (16 lanes each): kWaves groups
-static_assert(kFinTiles == 4u * kWaves && kWaves == 4, "a wave of the finish kernel owns one group of four tiles");
+#ifndef SVX_FIN_GROUPS
+#define SVX_FIN_GROUPS 4
+#endif
+constexpr uint32_t kFinGroups = SVX_FIN_GROUPS;     // groups of four tiles a workgroup finishes: one per wave, at most kWaves
+constexpr uint32_t kFinTiles = 4u * kFinGroups;     // (16 lanes per tile; with fewer than four groups the other waves only help
+                                                    //  with the workgroup's dense tiles)
+static_assert(kFinGroups >= 1 && kFinGroups <= (uint32_t)kWaves && kWaves == 4, "a wave of the finish kernel owns one group of four tiles");
 
 template <bool SOA, bool WITH_POST>
 __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_t* __restrict__ n_out, A3Args a3, uint32_t n_a3_blocks) {
@@ -1461,7 +1466,7 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
         return;
     }
     const uint32_t block = WITH_POST ? blockIdx.x - n_a3_blocks : blockIdx.x;
-    __shared__ uint32_t s_cr[kWaves], s_cd[kWaves], s_ob[kWaves];  // exclusive prefix of this workgroup's four groups
+    __shared__ uint32_t s_cr[kWaves], s_cd[kWaves], s_ob[kWaves];  // exclusive prefix of this workgroup's groups
     __shared__ uint4 s_dense[kFinTiles];
     __shared__ uint32_t s_dense_alo[kFinTiles], s_n_dense;
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
@@ -1470,10 +1475,10 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- the tile this thread's 16-lane group finishes: its records are requested before the scan
-    const uint32_t t0 = block * kFinTiles, g0 = block * kWaves;
+    const uint32_t t0 = block * kFinTiles, g0 = block * kFinGroups;
     const uint32_t tile = t0 + tid / kFinLanes;
     const uint32_t l = tid % kFinLanes;
-    const bool mine = tile < p.n_tiles;
+    const bool mine = (uint32_t)tid < kFinTiles * kFinLanes && tile < p.n_tiles;
     uint4 spec[kFinSpec];
 #pragma unroll
     for (int k = 0; k < kFinSpec; ++k)
@@ -1516,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
 #pragma unroll
     for (int i = 0; i < kSmallPer; ++i) {
         const uint32_t g = (uint32_t)tid * kSmallPer + i;
-        if (g - g0 < (uint32_t)kWaves) {
+        if (g - g0 < kFinGroups) {
             const bool own = (lf >> i) & 1u;  // a start inside this thread's earlier items
             s_cr[g - g0] = own ? lr[i] : Tr + lr[i];
             s_cd[g - g0] = own ? ld[i] : Td + ld[i];
