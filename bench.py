@@ -302,10 +302,12 @@ def collect_leg(args, local_rank, torch, batches, what, seed):
                                  case["extra_off"], case["seg_src"], case["seg_tid"], case["seg_pos"], case["seg_rev"],
                                  case["seg_qend"], case["read_off"], case["rank"], (args.min_sv_size, 100000, 50, 50, 50, 50))
     sig, raw, post, first = host_call()
-    t0 = time.perf_counter()
+    host_t = []
     for _ in range(20):
+        t0 = time.perf_counter()
         host_call()
-    host_ms = (time.perf_counter() - t0) / 20 * 1e3
+        host_t.append(time.perf_counter() - t0)
+    host_ms = float(np.median(host_t)) * 1e3  # (median: a single call that meets a page fault storm is 10x the others)
     # ---- the same kernel sequence with everything resident: one stream, no host round trip inside a step
     rc = ResidentCollect(ctx, b, case, args.min_sv_size)
     for _ in range(20):
@@ -337,9 +339,9 @@ def collect_leg(args, local_rank, torch, batches, what, seed):
                     + ("two launches — k_tiles_a3 (a1+a2 tiles of 1024 ops beside the segment rows and the decision tree of the "
                        "split-segment chain) and k_cigar_finish_small (descriptor scan + final records beside the chain's "
                        "post-passes)" if small else
-                       "the five launches of the streaming CIGAR path + k_a3_chain")
+                       "the five launches of the streaming CIGAR path, the chain inside the finish and dense launches")
                     + " — what svx_collect_batch enqueues between its uploads and its read-backs",
-            "launches": 2 if small else 6,
+            "launches": 2 if small else 5,
             "ms_per_step": dt * 1e3, "value": n_ops / dt, "unit": "CIGAR ops/s",
             "algorithmic_bytes": algo, "a3_bytes": (24 + 32) * case["n_segs"], "achieved": algo / dt / 1e9,
             "frac": algo / dt / 1e9 / HBM_PEAK_GBS,
@@ -542,7 +544,7 @@ def e2e_leg(scale, local_rank, n_devices=1):
     from tools import e2e_bench
     ranks = sorted(set([1, 2, 4] + ([n_devices] if n_devices > 1 else [])))
     samples = sorted(set([2, 4] + ([n_devices] if n_devices > 1 else [])))
-    r = e2e_bench.run_e2e(scale=scale, repeat=3, device=local_rank, ranks=ranks, n_devices=n_devices, samples=samples)
+    r = e2e_bench.run_e2e(scale=scale, repeat=5, device=local_rank, ranks=ranks, n_devices=n_devices, samples=samples)
     best, med = r.get("best_run", r), r.get("median_run", r)
     runs = r.get("all_runs_total_s") or [r["product_total_s"]]
     return {"workload": "svim-asm diploid, BASELINE config 3 at %.3g x GRCh38 contig lengths (%d bp, 2 BAMs of %d / %d bytes, "
@@ -573,7 +575,7 @@ def e2e_leg(scale, local_rank, n_devices=1):
             "ingest_threads": r["ingest_threads"], "index_state": r["index_state"], "generate_s": r["generate_s"],
             "devices": n_devices,
             "note": "outside the timed region of `value`; the pipeline functions called in this process the way cli._run "
-                    "calls them (garbage collector off for the run, as the command does); wall_s = median of 3"}, \
+                    "calls them (garbage collector off for the run, as the command does); wall_s = median of 5 (the first of them cold)"}, \
            {"workload": "the same sample through the real command line as R fresh rank processes (contigs LPT-packed over "
                         "the ranks, one table exchange after COLLECT and one after PAIR, rank 0 writes the VCF); ranks "
                         "share the %d visible device(s)" % n_devices,
@@ -819,10 +821,9 @@ def main():
         total_ops = n_ops
 
     # ---- roofline of the dominant kernel: HIP events on its launch stream around every launch of the step's own
-    # sequence (context 0; the event pair brackets the kernel itself).  With --step collect that kernel is
-    # k_tiles_a3<4096>: the streaming tile workgroups of a1+a2 WITH the rows + decision-tree workgroups of the
-    # split-segment chain among them; the a1+a2-only launch (k_cigar_tiles, what svx_cigar_extract_dev enqueues) is
-    # timed beside it ----
+    # sequence (context 0; the event pair brackets the kernel itself).  The dominant kernel of the step is the streaming
+    # tile launch k_cigar_tiles<4096> — with --step collect the split-segment chain rides in the finish and dense
+    # launches behind it, so the chain's bytes count for the PATH figure, not for this kernel ----
     torch.cuda.synchronize(dev)
     op_bytes = 5 if args.layout == "soa" else 4  # packed u32 per op; SoA: a u8 op code next to the u32 length
     algo_bytes = op_bytes * n_ops + 16 * n_aln + 17 * n_sig  # SURVEY.md §8(d), whole a1+a2 path
@@ -856,7 +857,7 @@ def main():
             int(len(case["extra_cigar"]))
         chain_bytes = 4 * seg_ops + (33 + 2 * 28 + 32) * n_segs + 12 * n_reads
         k_avg, p_avg = timed(rc0.step)
-        kernel_bytes = tile_bytes + chain_bytes
+        kernel_bytes = tile_bytes
     else:
         k_avg, p_avg, kernel_bytes = tiles_k, tiles_p, tile_bytes
     achieved = kernel_bytes / k_avg / 1e9
@@ -892,7 +893,7 @@ def main():
     if rank == 0:
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        wl_key = "config%d_x%d_%s%s" % (args.config, args.samples, args.layout, "_collect" if args.step == "collect" else "")
+        wl_key = "config%d_x%d_%s" % (args.config, args.samples, args.layout)
         if os.path.exists(tpath):
             try:
                 entry = json.load(open(tpath)).get(wl_key, {})
@@ -928,25 +929,27 @@ def main():
                 "ops_per_step_per_gpu": n_ops, "alignments_per_step_per_gpu": n_aln,
                 "signatures_per_step_per_gpu": n_sig, "chimeric_reads_per_step_per_gpu": n_reads,
                 "segments_per_step_per_gpu": n_segs, "min_sv_size": args.min_sv_size,
-                "step": ("svx_collect_batch_dev on ONE stream (the product's submission: svx_cigar_extract_dev — five launches of "
-                         "the streaming path — + the split-segment chain k_a3_chain: segment rows from the SA-derived CIGARs -> "
-                         "decision tree -> post-passes)%s" if args.step == "collect" else
+                "step": ("svx_collect_batch_dev on ONE stream (the product's submission: the five launches of the streaming CIGAR "
+                         "path with the split-segment chain inside the last two — segment rows from the SA-derived CIGARs and the "
+                         "decision tree in the finish launch, the post-passes in the dense-tile launch)%s" if args.step == "collect" else
                          "VARIANT --step split: a1+a2 svx_cigar_extract_dev (stream 1%s) + a bare svx_segments_classify_dev over "
                          "random segment rows (own stream); not what the product submits")
                         % ("; two contexts alternate between steps" if args.pipeline else ""),
                 "parallelism": "sample/contig shards x%d, no data-path collective" % world,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_tiles_a3<false, 4096, 0>" if args.step == "collect" else "k_cigar_tiles<false, 4096, 0>",
+                "bound": "hbm", "kernel": "k_cigar_tiles<false, 4096, 0>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_bytes_per_launch": kernel_bytes, "algorithmic_bytes_per_launch": algo_bytes + chain_bytes,
-                "chain_bytes_in_the_launch": chain_bytes,
+                "chain_bytes_in_the_path": chain_bytes,  # the split-segment chain's stage A (in the finish launch): the segments'
+                # CIGARs read again + rows / raw records / table entries
                 "kernel_ms": k_avg * 1e3,
                 "path_ms": p_avg * 1e3, "path_achieved": (algo_bytes + chain_bytes) / p_avg / 1e9,
                 "path_frac": (algo_bytes + chain_bytes) / p_avg / 1e9 / HBM_PEAK_GBS,
                 "a1a2_only": {"kernel": "k_cigar_tiles<false, 4096, 0>", "note": "svx_cigar_extract_dev alone (no chimeric reads in the "
-                              "launch): the figure rounds 1-3 quoted", "kernel_ms": tiles_k * 1e3, "kernel_bytes_per_launch": tile_bytes,
+                              "submission: no chain in the finish and dense launches): the call rounds 1-3 timed", "kernel_ms": tiles_k * 1e3,
+                              "kernel_bytes_per_launch": tile_bytes,
                               "achieved": tile_bytes / tiles_k / 1e9, "frac": tile_bytes / tiles_k / 1e9 / HBM_PEAK_GBS,
                               "path_ms": tiles_p * 1e3, "path_frac": algo_bytes / tiles_p / 1e9 / HBM_PEAK_GBS},
                 "read_ceiling": read_gbs, "frac_of_read_ceiling": (achieved / read_gbs) if read_gbs else None,

@@ -840,8 +840,8 @@ constexpr int kFinLanes = 16;
 #define SVX_FINSPEC 3
 #endif
 constexpr int kFinSpec = SVX_FINSPEC;  // records per lane requested together with the descriptor (48 per tile)
-__global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) {
-    const uint32_t tile = blockIdx.x * (256u / kFinLanes) + threadIdx.x / kFinLanes;
+__device__ __forceinline__ void cigar_finish_block(const CigarArgs& p, const uint32_t block) {
+    const uint32_t tile = block * (256u / kFinLanes) + threadIdx.x / kFinLanes;
     const uint32_t l = threadIdx.x % kFinLanes;
     if (tile >= p.n_tiles) return;
     // speculative: slots past the tile's count hold stale bytes and are never used
@@ -882,6 +882,8 @@ __global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) {
         store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
     }
 }
+
+__global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) { cigar_finish_block(p, blockIdx.x); }
 
 // ---- D: dense tiles (more than kSlab signatures, or a round that overflowed the queue: SV-dense stretches of
 // an assembly, satellite arrays, a tiny min_len) are re-walked with carry-in and output base known.  Always
@@ -1019,33 +1021,17 @@ constexpr int kStatLoads = 8;  // CIGAR words a lane requests before it uses the
 // Statistics of the alignment whose ops are cigar[b .. e), computed by one wave (every lane returns the same):
 // lead = Σ leading S (skipping H), ref = Σ{M,D,N,=,X}, qal = Σ{M,I,=,X}, rl = Σ{M,I,S,=,X,H}, hard = Σ H.
 __device__ __forceinline__ AlnStats wave_alignment_stats(const uint32_t* cigar, uint64_t b, uint64_t e, int lane) {
-    AlnStats r;
-    // leading soft clips: S ops before the first op that is neither S nor H
-    // (pysam getQueryStart)
-    uint32_t lead = 0;
-    {
-        uint64_t i = b;
-        bool done = false;
-        while (!done && i < e) {
-            uint64_t j = i + lane;
-            uint32_t w = (j < e) ? cigar[j] : 0u;  // op 0 (M) terminates the prefix
-            uint32_t op = w & 15u;
-            bool clip = (j < e) && (op == 4u || op == 5u);
-            uint64_t nb = __ballot(!clip);
-            int first = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
-            uint32_t s = (lane < first && op == 4u && j < e) ? (w >> 4) : 0u;
-            lead += wave_sum(s);
-            done = first < 64;
-            i += 64;
-        }
-    }
-    uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
+    // lead: S ops before the first op that is neither S nor H (pysam getQueryStart) — taken from the
+    // words of the main loop's rounds while the prefix is still open (in practice: the first round), so that it costs
+    // no round trip of its own
+    uint32_t lead = 0, ref = 0, qal = 0, rl = 0, hard = 0;
+    bool open = true;  // wave-uniform
     for (uint64_t i0 = b; i0 < e; i0 += kStatLoads * 64) {  // kStatLoads loads in flight per lane: the loop is a chain of round trips
         uint32_t w[kStatLoads];
 #pragma unroll
         for (int k = 0; k < kStatLoads; ++k) {
             const uint64_t i = i0 + (uint64_t)(k * 64 + lane);
-            w[k] = i < e ? cigar[i] : 0xFu;  // op 15: counts for nothing
+            w[k] = i < e ? cigar[i] : 0xFu;  // op 15: counts for nothing, ends the prefix
         }
 #pragma unroll
         for (int k = 0; k < kStatLoads; ++k) {
@@ -1055,76 +1041,32 @@ __device__ __forceinline__ AlnStats wave_alignment_stats(const uint32_t* cigar, 
             if ((0x1B3u >> op) & 1u) rl += len;    // M I S H = X (infer_read_length)
             if (op == 5u) hard += len;
         }
-    }
-    r.lead = lead;
-    r.ref = wave_sum(ref); r.qal = wave_sum(qal); r.rl = wave_sum(rl); r.hard = wave_sum(hard);
-    return r;
-}
-
-// The same statistics for 64 / W alignments at once: every aligned group of W lanes of the wave owns one alignment
-// (b, e uniform inside a group; every lane of a group returns the group's result).  All 64 lanes must call it
-// together.  SA-derived segments are three ops long: a whole wave per segment wastes 61 lanes and, worse, one
-// chain of dependent loads per wave; W = 16 runs four chains per wave.
-template <int W>
-__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+        if (open) {
 #pragma unroll
-    for (int d = W / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-
-template <int W>
-__device__ __forceinline__ AlnStats group_alignment_stats(const uint32_t* cigar, const uint64_t b, const uint64_t e, const int lane) {
-    static_assert(W == 8 || W == 16 || W == 32, "sub-wave groups");
-    const int gl = lane & (W - 1), gshift = lane & ~(W - 1);
-    uint32_t lead = 0;
-    {
-        uint64_t i = b;
-        bool done = b >= e;
-        while (__any(!done)) {
-            const uint64_t j = i + gl;
-            const bool in = !done && j < e;
-            const uint32_t w = in ? cigar[j] : 0u;  // op 0 (M) terminates the prefix
-            const uint32_t op = w & 15u;
-            const bool clip = in && (op == 4u || op == 5u);
-            const uint32_t nb = (uint32_t)(__ballot(!clip) >> gshift) & ((1u << W) - 1u);
-            const int first = nb ? __ffs((int)nb) - 1 : W;
-            lead += group_sum<W>((in && gl < first && op == 4u) ? (w >> 4) : 0u);
-            if (!done) {
-                i += W;
-                done = first < W || i >= e;
+            for (int k = 0; k < kStatLoads; ++k) {
+                const uint32_t op = w[k] & 15u;
+                const uint64_t nb = __ballot(!(op == 4u || op == 5u));
+                const int first = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
+                if (open && lane < first && op == 4u) lead += w[k] >> 4;
+                open = open && nb == 0;
             }
         }
     }
-    uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
-    for (uint64_t i0 = b; i0 < e; i0 += kStatLoads * W) {
-        uint32_t w[kStatLoads];
-#pragma unroll
-        for (int k = 0; k < kStatLoads; ++k) {
-            const uint64_t i = i0 + (uint64_t)(k * W + gl);
-            w[k] = i < e ? cigar[i] : 0xFu;  // op 15: counts for nothing
-        }
-#pragma unroll
-        for (int k = 0; k < kStatLoads; ++k) {
-            const uint32_t op = w[k] & 15u, len = w[k] >> 4;
-            if ((0x18Du >> op) & 1u) ref += len;
-            if ((0x183u >> op) & 1u) qal += len;
-            if ((0x1B3u >> op) & 1u) rl += len;
-            if (op == 5u) hard += len;
-        }
-    }
     AlnStats r;
-    r.lead = lead;
-    r.ref = group_sum<W>(ref); r.qal = group_sum<W>(qal); r.rl = group_sum<W>(rl); r.hard = group_sum<W>(hard);
+    r.lead = wave_sum(lead);
+    r.ref = wave_sum(ref); r.qal = wave_sum(qal); r.rl = wave_sum(rl); r.hard = wave_sum(hard);
     return r;
 }
 
 // ... and for an alignment of at most kTinyOps ops by ONE lane (an SA-derived segment is S M S): 64 alignments per
 // wave, every load of a lane issued before the first is used.
 constexpr int kTinyOps = 8;
-__device__ __forceinline__ AlnStats lane_alignment_stats(const uint32_t* cigar, const uint64_t b, const uint32_t n) {
-    uint32_t w[kTinyOps];
+// (two halves, so that a caller can put other work between the loads and their use)
+__device__ __forceinline__ void lane_alignment_load(const uint32_t* cigar, const uint64_t b, const uint32_t n, uint32_t (&w)[kTinyOps]) {
 #pragma unroll
     for (int k = 0; k < kTinyOps; ++k) w[k] = (uint32_t)k < n ? cigar[b + k] : 0xFu;
+}
+__device__ __forceinline__ AlnStats lane_alignment_stats(const uint32_t (&w)[kTinyOps], const uint32_t n) {
     AlnStats r;
     r.lead = r.ref = r.qal = r.rl = r.hard = 0;
     bool prefix = true;
@@ -1278,12 +1220,37 @@ struct A3Args {
 
 enum { A3_ROWS_TREE = 1, A3_POST = 2 };
 
-constexpr int kMidOps = 512;     // up to here: sixteen lanes per alignment (four round trips of kStatLoads words per lane)
-constexpr int kLongOps = 8192;   // up to here: a wave per alignment; beyond: the whole workgroup
+// Rows of the alignments beyond kTinyOps: the workgroup cuts them into CHUNKS of kChunkOps ops (kStatLoads words per
+// lane of a 16-lane group), lists the chunks in LDS and deals the list out to its sixteen groups in contiguous,
+// equally long ranges — every group is busy for the same number of steps whatever the sizes are, and a long alignment
+// is shared by several groups.  A group keeps its sums in registers while consecutive chunks belong to one alignment
+// and adds them to the alignment's LDS accumulators when that changes.
+constexpr int kChunkOps = kStatLoads * 16;            // 128
+constexpr int kLongOps = 2048;                        // up to here: chunks; beyond: the whole workgroup, 2048 ops per round trip
+constexpr int kChunksPerAln = kLongOps / kChunkOps;   // 16
+// (The round's first version went by size classes — sixteen lanes per alignment up to 512 ops, four alignments side by
+// side per wave; a wave per alignment up to 8192, one after the other — and was bound by VALU issue at about 30 % lane
+// utilisation: four alignments side by side run for the longest of them, and a workgroup waits for the wave with the
+// most long ones.  k_finish_a3 on the cohort of 256 samples: 74.8 us by classes, 53.5 us by chunks;
+// profiles/r04_ab_chain_rows.txt.)
 constexpr int kLongList = 60;
 struct A3Lds {
     uint32_t n_long, long_list[kLongList], part[16];
+    uint32_t n_chunks;
+    uint32_t open[8];              // bit per slot: the whole first chunk was clips (the owner then walks the prefix itself)
+    uint32_t cb_lo[256], cb_hi[256], n_ops[256];   // per slot = thread of the batch of 256 segments
+    uint32_t acc[5][256];          // lead, ref, qal, rl, hard
+    uint16_t chunk[256 * kChunksPerAln];           // slot | chunk number << 8
 };
+
+// sum over an aligned row of 16 lanes, every lane gets it (four DPP adds)
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return v;
+}
 
 template <int STAGES>
 __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t blk, A3Lds* lds) {
@@ -1295,21 +1262,25 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
     if (r_lo >= n_reads) return;
     const uint32_t r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
     if (STAGES & A3_ROWS_TREE) {
-        // ---- rows: the segments of the block's reads, sixteen lanes each; alignments beyond kLongOps are noted and
-        // walked by the whole workgroup afterwards, one at a time
         // ---- rows.  One THREAD per segment fetches the segment's CIGAR range; tiny alignments (SA-derived: S M S)
-        // are finished by that lane, the others by sixteen lanes each, four at a time per wave, and alignments
-        // beyond kLongOps (a primary is a whole assembly contig) by the whole workgroup, one at a time.
+        // are finished by that lane, the others go through the chunk list (above), and alignments beyond kLongOps (a
+        // primary can be a whole assembly contig) are walked by the whole workgroup, one at a time.
         uint32_t* s_part = lds->part;
         const SegRowArgs& p = a.rows;
         const uint32_t j_lo = p.read_off[r_lo], j_hi = p.read_off[r_hi];
         if (tid == 0) lds->n_long = 0;
+        if (tid == 0) lds->n_chunks = 0;
+        if (tid < 8) lds->open[tid] = 0;
+        // the tree's own read_off words, requested now: one round trip less behind the rows
+        const uint32_t r_tree = r_lo + (uint32_t)tid / svx_seg_dev::kGroup;
+        uint32_t tree_b = 0, tree_e = 0;
+        if (r_tree < r_hi) { tree_b = p.read_off[r_tree]; tree_e = p.read_off[r_tree + 1]; }
         __syncthreads();
-        constexpr int W = 16;
-        const int gl = lane & (W - 1), grp = lane / W;
+        const int gl = lane & 15;
+        const int gid = __builtin_amdgcn_readfirstlane(wave) * 4 + (lane >> 4);  // group of sixteen lanes in the workgroup
+        const int gshift = lane & ~15;
         for (uint32_t j0 = j_lo; j0 < j_hi; j0 += 256) {
-            // consecutive segments go to different waves: a read's primary is the expensive one
-            const uint32_t j = j0 + (uint32_t)lane * kWaves + (uint32_t)wave;
+            const uint32_t j = j0 + (uint32_t)tid;
             const bool live = j < j_hi;
             uint64_t cb = 0, ce = 0;
             if (live) {
@@ -1318,55 +1289,120 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
                 ce = p.aln_off[src + 1];
             }
             const uint64_t n = ce - cb;
-            const bool tiny = live && n <= (uint64_t)kTinyOps, big = live && n > (uint64_t)kMidOps;
-            if (tiny) {
-                const AlnStats st = lane_alignment_stats(p.cigar, cb, (uint32_t)n);
-                p.segs[j] = segment_row(p, j, st);
-                a.seg_rl[j] = (int32_t)st.rl;
-            }
-            const bool huge = big && n > (uint64_t)kLongOps;
+            const bool tiny = live && n <= (uint64_t)kTinyOps, huge = live && n > (uint64_t)kLongOps;
+            const bool chunked = live && !tiny && !huge;
+            uint32_t tw[kTinyOps];
+            lane_alignment_load(p.cigar, cb, tiny ? (uint32_t)n : 0u, tw);
             if (huge) {  // noted for the whole workgroup
                 const uint32_t at = atomicAdd(&lds->n_long, 1u);
                 if (at < (uint32_t)kLongList) lds->long_list[at] = j;
             }
-            // the mid-sized ones of this wave, four per pass: group g takes the (4 * pass + g)-th of them
-            uint64_t mid = __ballot(live && !tiny && !big);
-            while (mid) {  // wave-uniform
-                uint64_t m = mid;
-                int owner = -1;
+            if (chunked) {
+                lds->cb_lo[tid] = (uint32_t)cb;
+                lds->cb_hi[tid] = (uint32_t)(cb >> 32);
+                lds->n_ops[tid] = (uint32_t)n;
 #pragma unroll
-                for (int g = 0; g < 64 / W; ++g) {
-                    const int bit = m ? __ffsll((unsigned long long)m) - 1 : -1;
-                    if (bit >= 0) m &= m - 1;
-                    if (g == grp) owner = bit;
-                }
-                mid = m;
-                const int from = owner >= 0 ? owner : lane;
-                const uint32_t jb = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)j);
-                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)(uint32_t)cb);
-                const uint32_t b_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)(uint32_t)(cb >> 32));
-                const uint32_t nn = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)(uint32_t)n);
-                const uint64_t gb = ((uint64_t)b_hi << 32) | b_lo;
-                const AlnStats st = group_alignment_stats<W>(p.cigar, gb, owner >= 0 ? gb + nn : gb, lane);
-                if (owner >= 0 && gl == 0) {
-                    p.segs[jb] = segment_row(p, jb, st);
-                    a.seg_rl[jb] = (int32_t)st.rl;
+                for (int q = 0; q < 5; ++q) lds->acc[q][tid] = 0;
+                const uint32_t nch = ((uint32_t)n + (uint32_t)kChunkOps - 1u) / (uint32_t)kChunkOps;
+                const uint32_t at = atomicAdd(&lds->n_chunks, nch);
+                for (uint32_t c = 0; c < nch; ++c) lds->chunk[at + c] = (uint16_t)((uint32_t)tid | (c << 8));
+            }
+            if (tiny) {
+                const AlnStats st = lane_alignment_stats(tw, (uint32_t)n);
+                p.segs[j] = segment_row(p, j, st);
+                a.seg_rl[j] = (int32_t)st.rl;
+            }
+            __syncthreads();
+            {
+#ifdef SVX_EXP_A3_NOCHUNK  // timing ablation: wrong rows
+                const uint32_t total = 0;
+#else
+                const uint32_t total = lds->n_chunks;
+#endif
+                const uint32_t per_group = (total + 15u) / 16u;
+                const uint32_t c_lo = (uint32_t)gid * per_group;
+                const uint32_t c_hi = c_lo + per_group < total ? c_lo + per_group : total;
+                uint32_t cur = ~0u;  // group-uniform: the slot the register sums belong to
+                uint32_t lead = 0, ref = 0, qal = 0, rl = 0, hard = 0;
+                uint64_t cbv = 0;
+                uint32_t nv = 0;
+                for (uint32_t c = c_lo;; ++c) {  // group-uniform; one step past the end: the last flush
+                    const bool more = c < c_hi;
+                    const uint32_t ent = more ? (uint32_t)lds->chunk[c] : 0u;
+                    const uint32_t slot = more ? (ent & 255u) : ~0u;
+                    if (slot != cur) {
+                        if (cur != ~0u) {
+                            lead = row16_sum(lead); ref = row16_sum(ref); qal = row16_sum(qal); rl = row16_sum(rl); hard = row16_sum(hard);
+                            if (gl == 0) {
+                                if (lead) atomicAdd(&lds->acc[0][cur], lead);
+                                atomicAdd(&lds->acc[1][cur], ref);
+                                atomicAdd(&lds->acc[2][cur], qal);
+                                atomicAdd(&lds->acc[3][cur], rl);
+                                if (hard) atomicAdd(&lds->acc[4][cur], hard);
+                            }
+                        }
+                        if (more) {
+                            cur = slot;
+                            lead = ref = qal = rl = hard = 0;
+                            cbv = ((uint64_t)lds->cb_hi[slot] << 32) | lds->cb_lo[slot];
+                            nv = lds->n_ops[slot];
+                        }
+                    }
+                    if (!more) break;
+                    const uint32_t ci = ent >> 8;
+                    const uint32_t rel0 = ci * (uint32_t)kChunkOps + (uint32_t)gl;
+                    const uint32_t* src = p.cigar + cbv + rel0;
+                    uint32_t w[kStatLoads];
+#pragma unroll
+                    for (int k = 0; k < kStatLoads; ++k) w[k] = rel0 + (uint32_t)(k * 16) < nv ? src[k * 16] : 0xFu;  // op 15: counts for nothing
+#pragma unroll
+                    for (int k = 0; k < kStatLoads; ++k) {
+                        // one bit of a 16-entry table per sum, as a mask (v_bfe_i32 takes its offset from the low five
+                        // bits: the table twice, the lowest length bit picks either copy)
+                        const uint32_t len = w[k] >> 4, sel = w[k] & 31u;
+                        ref += len & (uint32_t)__builtin_amdgcn_sbfe(0x018D018D, sel, 1);   // M D N = X
+                        qal += len & (uint32_t)__builtin_amdgcn_sbfe(0x01830183, sel, 1);   // M I = X
+                        rl += len & (uint32_t)__builtin_amdgcn_sbfe(0x01B301B3, sel, 1);    // M I S H = X
+                        hard += len & (uint32_t)__builtin_amdgcn_sbfe(0x00200020, sel, 1);  // H
+                    }
+                    if (ci == 0) {  // the prefix of clips: position order k, lane
+                        bool open = true;
+#pragma unroll
+                        for (int k = 0; k < kStatLoads; ++k) {
+                            if (open) {
+                                const uint32_t op = w[k] & 15u;
+                                const uint32_t nb = (uint32_t)(__ballot(!(op == 4u || op == 5u)) >> gshift) & 0xFFFFu;
+                                const int first = nb ? __ffs((int)nb) - 1 : 16;
+                                if (gl < first && op == 4u) lead += w[k] >> 4;
+                                open = nb == 0;
+                            }
+                        }
+                        // (words behind the end read as op 15 and close the prefix: still open = 128 clips and more ops)
+                        if (open && gl == 0) atomicOr(&lds->open[cur >> 5], 1u << (cur & 31u));
+                    }
                 }
             }
-            // ... and the ones beyond kMidOps (up to kLongOps) by the whole wave, one after the other
-            uint64_t bigs = __ballot(big && !huge);
-            while (bigs) {  // wave-uniform
-                const int owner = __ffsll((unsigned long long)bigs) - 1;
-                bigs &= bigs - 1;
-                const uint32_t jb = (uint32_t)__builtin_amdgcn_readlane((int)j, owner);
-                const uint64_t gb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cb >> 32), owner) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cb, owner);
-                const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)n, owner);
-                const AlnStats st = wave_alignment_stats(p.cigar, gb, gb + nn, lane);
-                if (lane == 0) {
-                    p.segs[jb] = segment_row(p, jb, st);
-                    a.seg_rl[jb] = (int32_t)st.rl;
+            __syncthreads();
+            if (chunked) {
+                AlnStats st;
+                st.lead = lds->acc[0][tid]; st.ref = lds->acc[1][tid]; st.qal = lds->acc[2][tid]; st.rl = lds->acc[3][tid];
+                st.hard = lds->acc[4][tid];
+                if ((lds->open[tid >> 5] >> (tid & 31)) & 1u) {  // S ops before the first op that is neither S nor H, by this lane
+                    st.lead = 0;
+                    for (uint64_t i = cb; i < ce; ++i) {
+                        const uint32_t w = p.cigar[i], op = w & 15u;
+                        if (op != 4u && op != 5u) break;
+                        if (op == 4u) st.lead += w >> 4;
+                    }
                 }
+                p.segs[j] = segment_row(p, j, st);
+                a.seg_rl[j] = (int32_t)st.rl;
+            }
+            if (j0 + 256 < j_hi) {  // workgroup-uniform: another batch of segments
+                __syncthreads();
+                if (tid == 0) lds->n_chunks = 0;
+                if (tid < 8) lds->open[tid] = 0;
+                __syncthreads();
             }
         }
         __syncthreads();
@@ -1398,10 +1434,14 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
         }
         __syncthreads();
         // ---- decision tree: eight lanes per read
+#ifdef SVX_EXP_A3_NOTREE
+        return;
+#endif
         const int tl = lane & (svx_seg_dev::kGroup - 1), gbase = lane & ~(svx_seg_dev::kGroup - 1);
         for (uint32_t r0 = r_lo; r0 < r_hi; r0 += 256 / svx_seg_dev::kGroup) {
             const uint32_t r = r0 + tid / svx_seg_dev::kGroup;
-            svx_seg_dev::segments_group(a.tree, r, r < r_hi, tl, gbase);
+            if (r0 == r_lo) svx_seg_dev::segments_group(a.tree, r, r < r_hi, tl, gbase, tree_b, tree_e);
+            else svx_seg_dev::segments_group(a.tree, r, r < r_hi, tl, gbase);
         }
     }
     // ---- post-passes: one lane per read
@@ -1606,9 +1646,15 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
 template <bool SOA, int TILE_OPS, int ALO>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks,
                                                                               uint32_t a3_stride) {
-    __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];
-    __shared__ uint4 s_stage[kWaves][kStage];
+    // a workgroup is either a chain workgroup or a tile workgroup: one LDS block, two layouts
+    struct TileLds {
+        uint4 xpose[kWaves][kXposeU4];
+        __attribute__((aligned(16))) uint32_t head[kWaves][kHeadWords];
+        uint4 stage[kWaves][kStage];
+    };
+    constexpr size_t kLdsBytes = sizeof(TileLds) > sizeof(A3Lds) ? sizeof(TileLds) : sizeof(A3Lds);
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLdsBytes];
+    TileLds& tl = *reinterpret_cast<TileLds*>(s_raw);
     // which workgroups carry the chain: the first n_a3_blocks (a3_stride == 0: small batches, the chain is the
     // longer dependent sequence) or every a3_stride-th one (streaming path: the latency-bound chain spreads over
     // the run of the bandwidth-bound tile workgroups)
@@ -1626,8 +1672,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(Ci
         tile_block = blockIdx.x - (before < n_a3_blocks ? before : n_a3_blocks);
     }
     if (is_a3) {  // workgroup-uniform
-        __shared__ A3Lds lds;
-        a3_chain_block<A3_ROWS_TREE>(a, a3_block, &lds);
+        a3_chain_block<A3_ROWS_TREE>(a, a3_block, reinterpret_cast<A3Lds*>(s_raw));
         return;
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1635,12 +1680,57 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(Ci
     const uint32_t tile = tile_block * kWaves + wave;
     uint4 dsc = make_uint4(0, 0, 0, 0);
     if (tile < p.n_tiles)
-        dsc = process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
-                                                          reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
+        dsc = process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, tl.xpose[wave], tl.head[wave],
+                                                          reinterpret_cast<uint4*>(tl.head[wave]), tl.stage[wave], TileIn());
     if (TILE_OPS == kSmallTileOps) {
         __shared__ uint4 s_agg[kWaves];
         fold_group_desc(p, s_agg, wave, lane, dsc, tile_block);
     }
+}
+
+// Streaming path: the chain's stage A rides inside the FINISH launch (the chain's workgroups first: they are the longer
+// dependent sequences), its stage B inside the dense-tile launch; the bandwidth-bound streaming launch stays pure.
+// (-DSVX_A3_IN_FINISH=0 puts stage A among the tile workgroups of the streaming launch instead, k_tiles_a3<4096>:
+// the chain workgroups then hold slots of the tile workgroups; interleaved A/B, n = 4: step 0.3936 vs 0.3877 ms,
+// profiles/r04_ab_chain_placement.txt.  Inside this launch the chain's workgroups first is the best order: dealt
+// out between the finishing workgroups 62 us instead of 54, behind them 63.)
+#ifndef SVX_FIN_A3_WAVES
+#define SVX_FIN_A3_WAVES 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SVX_FIN_A3_WAVES, 8)))
+void k_finish_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks, uint32_t a3_stride) {
+    // every a3_stride-th workgroup carries the chain (both kinds are sequences of round trips: side by side from the
+    // first moment of the launch they hide each other's waits; a3_stride == 1: the chain's workgroups first)
+    uint32_t fin_block, a3_block;
+    bool is_a3;
+    if (a3_stride <= 1) {
+#ifdef SVX_FIN_A3_LAST
+        const uint32_t n_fin = gridDim.x - n_a3_blocks;
+        is_a3 = blockIdx.x >= n_fin;
+        a3_block = blockIdx.x - n_fin;
+        fin_block = blockIdx.x;
+#else
+        is_a3 = blockIdx.x < n_a3_blocks;
+        a3_block = blockIdx.x;
+        fin_block = blockIdx.x - n_a3_blocks;
+#endif
+    } else {
+        const uint32_t q = blockIdx.x / a3_stride, rem = blockIdx.x % a3_stride;
+        is_a3 = rem == 0 && q < n_a3_blocks;
+        a3_block = q;
+        const uint32_t before = q + (rem ? 1u : 0u);  // chain workgroups in front of this one
+        fin_block = blockIdx.x - (before < n_a3_blocks ? before : n_a3_blocks);
+    }
+    if (is_a3) {  // workgroup-uniform
+#ifndef SVX_EXP_FIN_ONLY
+        __shared__ A3Lds lds;
+        a3_chain_block<A3_ROWS_TREE>(a, a3_block, &lds);
+#endif
+        return;
+    }
+#ifndef SVX_EXP_A3_ONLY
+    cigar_finish_block(p, fin_block);
+#endif
 }
 
 // Fills the chain's arguments from a plan; takes the tree's and the post-passes' scratch from the workspace
@@ -1667,13 +1757,15 @@ void a3_fill(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, c
     o.scratch_off = nullptr;
     o.scratch_stride = post_stride;
     // reads per workgroup of the rows + tree stage: two while the grid stays small (the shortest dependent sequence
-    // per workgroup), up to sixteen — about 48 segments, twelve per wave, of which a read's primary is the mid-sized
-    // or long one: one pass of four sixteen-lane groups per wave — for a cohort's reads
+    // per workgroup), up to 32 for a cohort's reads — about 100 segments and 100 chunks, six per sixteen-lane group,
+    // and the 2 000 workgroups of a cohort of 256 samples are all resident at once (8 per CU).  Measured on that
+    // cohort, k_finish_a3: 8 reads 67.7 us, 16: 55.3, 24: 56.4, 32: 53.5, 48: 57.1, 64: 59.1
+    // (profiles/r04_ab_chain_rows.txt)
 #ifndef SVX_A3_READS_DIV
 #define SVX_A3_READS_DIV 1024u
 #endif
 #ifndef SVX_A3_READS_MAX
-#define SVX_A3_READS_MAX 16u
+#define SVX_A3_READS_MAX 32u
 #endif
     const uint32_t per = q.n_reads / SVX_A3_READS_DIV;
     a->reads_per_block = per < 2u ? 2u : (per > SVX_A3_READS_MAX ? SVX_A3_READS_MAX : per);
@@ -1782,7 +1874,10 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
                        a.tile_alo);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-    if (a3) {  // the chain's rows and decision tree ride inside the streaming launch, every stride-th workgroup
+#ifndef SVX_A3_IN_FINISH
+#define SVX_A3_IN_FINISH 1  // 0: among the tile workgroups of the streaming launch (k_tiles_a3<4096>): 1.5 % slower per step
+#endif
+    if (a3 && !SVX_A3_IN_FINISH) {  // the chain's rows and decision tree ride inside the streaming launch, every stride-th workgroup
         const uint32_t total = blocks_all + n_a3_blocks;
         const uint32_t stride = total / n_a3_blocks ? total / n_a3_blocks : 1u;
         hipLaunchKernelGGL((k_tiles_a3<SOA, kTileOps, ALO_TABLE>), dim3(total), dim3(64 * kWaves), 0, ctx->stream, a, c, n_a3_blocks,
@@ -1800,8 +1895,17 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     hipLaunchKernelGGL(k_desc_scan, dim3(n_scan_blocks), dim3(kScanBlock), 0, ctx->stream, a.desc, n_tiles,
                        a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
                        a.blk_prefix, a.n_dense + 1, d_n_out);
-    hipLaunchKernelGGL(k_cigar_finish, dim3((n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes)), dim3(256), 0,
-                       ctx->stream, a);
+    const uint32_t finish_blocks = (n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes);
+    if (a3 && SVX_A3_IN_FINISH)
+    {
+#ifndef SVX_FIN_A3_INTERLEAVE
+#define SVX_FIN_A3_INTERLEAVE 0
+#endif
+        const uint32_t stride = SVX_FIN_A3_INTERLEAVE && n_a3_blocks ? (n_a3_blocks + finish_blocks) / n_a3_blocks : 1u;
+        hipLaunchKernelGGL(k_finish_a3, dim3(n_a3_blocks + finish_blocks), dim3(256), 0, ctx->stream, a, c, n_a3_blocks, stride);
+    }
+    else
+        hipLaunchKernelGGL(k_cigar_finish, dim3(finish_blocks), dim3(256), 0, ctx->stream, a);
     const uint32_t dense_blocks = n_tiles < blocks_cap ? n_tiles : blocks_cap;
     if (a3)  // ... and its post-passes inside the dense-tile launch
         hipLaunchKernelGGL((k_cigar_dense<SOA, true>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c,

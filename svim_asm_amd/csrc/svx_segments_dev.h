@@ -155,9 +155,9 @@ constexpr int kGroup = 8;
 
 // One read per group of eight lanes (`gl` = lane inside the group, `gbase` = the group's first lane of the wave);
 // all 64 lanes of the wave call this together (the ranking uses width-8 shuffles).
-__device__ __forceinline__ void segments_group(const SegArgs& p, const uint32_t r, const bool live, const int gl, const int gbase) {
-    uint32_t b = 0, e = 0;
-    if (live) { b = p.read_off[r]; e = p.read_off[r + 1]; }
+// (b, e = read_off[r], read_off[r + 1], zero for a group that is not live)
+__device__ __forceinline__ void segments_group(const SegArgs& p, const uint32_t r, const bool live, const int gl, const int gbase,
+                                               const uint32_t b, const uint32_t e) {
     const uint32_t k = e > b ? e - b : 0;
     const bool small = k <= (uint32_t)kGroup;
     if (!small && gl == 0) segments_serial(p, r);
@@ -203,6 +203,12 @@ __device__ __forceinline__ void segments_group(const SegArgs& p, const uint32_t 
         o[0] = make_uint4((uint32_t)v.kind, (uint32_t)v.a0, (uint32_t)v.a1, (uint32_t)v.a2);
         o[1] = make_uint4((uint32_t)v.a3, (uint32_t)v.a4, (uint32_t)v.a5, 0u);
     }
+}
+
+__device__ __forceinline__ void segments_group(const SegArgs& p, const uint32_t r, const bool live, const int gl, const int gbase) {
+    uint32_t b = 0, e = 0;
+    if (live) { b = p.read_off[r]; e = p.read_off[r + 1]; }
+    segments_group(p, r, live, gl, gbase, b, e);
 }
 
 }  // namespace svx_seg_dev

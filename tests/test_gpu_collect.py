@@ -242,3 +242,95 @@ def test_collect_batch_dev_on_resident_buffers(svx_ctx):
     assert np.array_equal(np.concatenate(([0], np.cumsum(cnt))), exp_first)
     take = np.repeat(post_off[:-1].astype(np.int64) - exp_first[:-1], cnt) + np.arange(int(exp_first[-1]))
     assert np.array_equal(d_post.download(np.int32).reshape(-1, 8)[take], exp_post.view(np.int32).reshape(-1, 8))
+
+
+def _sized_cigar(rng, n, lead):
+    """n ops: `lead` leading clips (S and H mixed), then random ops of every code (clips in the middle too)."""
+    ops = [(int(rng.choice([4, 5])), int(rng.integers(1, 50))) for _ in range(min(lead, n))]
+    while len(ops) < n:
+        ops.append((int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15])), int(rng.integers(1, 2000))))
+    return np.array([(l << 4) | o for o, l in ops], dtype=np.uint32)
+
+
+@pytest.mark.parametrize("streaming", [False, True])
+def test_chain_rows_across_alignment_sizes(svx_ctx, streaming):
+    """The rows of the fused chain against the oracle's CIGAR statistics for alignments around every size boundary of
+    the kernel (a lane up to 8 ops, chunks of 128 ops up to 2048, the whole workgroup beyond), with clip prefixes that
+    end inside the first word, run through the whole first chunk (128, 129, 300 clips) or are the whole alignment, one
+    read with several hundred segments (more than one batch of 256 per workgroup)."""
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 8, 9, 15, 16, 17, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 2047, 2048, 2049, 4095, 4096, 4097,
+             8192, 8193, 20000, 70000]
+    words = []
+    for n in sizes:
+        for lead in (0, 1, 2, 3):
+            words.append(_sized_cigar(rng, n, lead))
+    for lead, n in ((127, 400), (128, 400), (129, 400), (300, 1000), (200, 200), (128, 128), (2048, 2048), (1500, 2049), (9, 9)):
+        words.append(_sized_cigar(rng, n, lead))
+    n_aln = len(words)
+    aln_off = np.concatenate(([0], np.cumsum([len(w) for w in words]))).astype(np.uint64)
+    n_ops = int(aln_off[-1])
+    ref_start = rng.integers(0, 1 << 27, size=n_aln).astype(np.int32)
+    # reads: every alignment once as a primary with one or two SA-derived segments; then one read whose 700 segments
+    # name alignments of every size
+    extra, seg_src, counts = [], [], []
+    for a in range(n_aln):
+        k = 1 + a % 2
+        seg_src.append(a)
+        for _ in range(k):
+            seg_src.append(n_aln + len(extra))
+            extra.append(_sized_cigar(rng, 3, 1))
+        counts.append(1 + k)
+    small = [a for a in range(n_aln) if len(words[a]) <= 5000]
+    many = [int(rng.choice(small)) for _ in range(700)]
+    seg_src += many
+    counts.append(len(many))
+    seg_src = np.array(seg_src, np.uint32)
+    n_segs, n_reads = len(seg_src), len(counts)
+    read_off = np.concatenate(([0], np.cumsum(counts))).astype(np.uint32)
+    seg_tid = rng.integers(0, 4, size=n_segs).astype(np.int32)
+    seg_pos = rng.integers(0, 1 << 27, size=n_segs).astype(np.int32)
+    seg_rev = (rng.random(n_segs) < 0.3).astype(np.uint8)
+    seg_qend = np.where(rng.random(n_segs) < 0.3, rng.integers(0, 5000, size=n_segs), -1).astype(np.int32)
+    extra_off = np.concatenate(([0], np.cumsum([len(w) for w in extra]))).astype(np.uint64)
+    cigar = np.concatenate(words + extra)
+    off = np.concatenate((aln_off, n_ops + extra_off[1:])).astype(np.uint64)
+    rank = np.array([2, 0, 3, 1], dtype=np.int32)
+    slots = np.diff(read_off.astype(np.int64))
+    post_off = np.concatenate(([0], np.cumsum(slots * (slots + 3) // 2))).astype(np.uint64)
+    # expectation: the oracle's statistics -> rows (host formula of the binding)
+    st_all = orc.cigar_stats(cigar, off)
+    st = {k: st_all[k].astype(np.int64)[seg_src.astype(np.int64)] for k in ("ref_len", "q_start", "q_end", "read_len")}
+    exp_segs, exp_rl = _lib.segment_rows(st, seg_tid, seg_pos, seg_rev, seg_qend, read_off)
+    exp_sig = orc.cigar_extract(cigar[:n_ops], aln_off, ref_start, 40)
+    ctx = svx_ctx
+    ctx.set_small_batch_ops(0 if streaming else 1 << 23)
+    try:
+        for phase in (0,):
+            d_all = ctx.dev_array(cigar)
+            d = {k: ctx.dev_array(v) for k, v in dict(off=off, rs=ref_start, src=seg_src, tid=seg_tid, pos=seg_pos, rev=seg_rev,
+                                                       qend=seg_qend, roff=read_off, rank=rank, poff=post_off).items()}
+            cap = len(exp_sig["aln"]) + 5
+            o = [ctx.dev_array(nbytes=4 * cap) for _ in range(4)] + [ctx.dev_array(nbytes=cap), ctx.dev_array(np.zeros(1, np.uint64))]
+            d_segs, d_rl = ctx.dev_array(nbytes=24 * n_segs), ctx.dev_array(nbytes=4 * n_reads)
+            d_raw, d_post, d_cnt = ctx.dev_array(nbytes=32 * n_segs), ctx.dev_array(nbytes=32 * int(post_off[-1])), ctx.dev_array(nbytes=4 * n_reads)
+            dv = _lib.CollectDev(d_cigar=d_all.ptr + 4 * phase, n_ops=n_ops, d_aln_off=d["off"].ptr, n_aln=n_aln, n_extra=len(extra),
+                                 d_ref_start=d["rs"].ptr, min_len=40, d_seg_src=d["src"].ptr, d_seg_tid=d["tid"].ptr,
+                                 d_seg_pos=d["pos"].ptr, d_seg_rev=d["rev"].ptr, d_seg_qend=d["qend"].ptr, n_segs=n_segs,
+                                 read_off=read_off.ctypes.data, d_read_off=d["roff"].ptr, n_reads=n_reads, d_contig_rank=d["rank"].ptr,
+                                 n_contigs=len(rank), params=_lib.SegParams(*PARAMS), d_sig=_lib.SigSoa(*[x.ptr for x in o[:5]]),
+                                 sig_cap=cap, d_n_sig=o[5].ptr, d_segs=d_segs.ptr, d_read_len=d_rl.ptr, d_raw=d_raw.ptr,
+                                 d_post=d_post.ptr, post_off=post_off.ctypes.data, d_post_off=d["poff"].ptr, d_post_cnt=d_cnt.ptr)
+            ctx._check(ctx.lib.svx_collect_batch_dev(ctx.h, C.byref(dv)))
+            ctx.sync()
+            got = d_segs.download(np.int32).reshape(-1, 6)
+            bad = np.nonzero((got != exp_segs.view(np.int32).reshape(-1, 6)).any(axis=1))[0]
+            assert len(bad) == 0, (phase, bad[:5], [int(off[seg_src[j] + 1] - off[seg_src[j]]) for j in bad[:5]])
+            assert np.array_equal(d_rl.download(np.int32), exp_rl)
+            n = int(o[5].download(np.uint64)[0])
+            assert n == len(exp_sig["aln"])
+            assert np.array_equal(o[1].download(np.uint32, n), exp_sig["ref_pos"])
+            raw = ctx.segments_classify(exp_segs, read_off, exp_rl, PARAMS)
+            assert np.array_equal(d_raw.download(np.int32).reshape(-1, 8), raw.view(np.int32).reshape(-1, 8))
+    finally:
+        ctx.set_small_batch_ops(1 << 23)
