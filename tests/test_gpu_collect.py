@@ -28,11 +28,25 @@ def chain_form(request, svx_ctx):
     svx_ctx.set_split_chain(False)
 
 
-def random_batch(rng, n_aln, n_parts=2, n_reads=40, max_supp=4, long_read=False):
+def long_cigar(rng, n, lead=None):
+    """n packed ops of every code (clips in the middle too) behind `lead` leading clips (default: 0-3, sometimes many)."""
+    if lead is None:
+        lead = int(rng.integers(0, 4)) if rng.random() < 0.9 else int(rng.integers(0, n + 1))
+    lead = min(lead, n)
+    ops = rng.choice(np.array([0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15], np.uint32), size=n)
+    ops[:lead] = rng.choice(np.array([4, 5], np.uint32), size=lead)
+    return ((rng.integers(1, 2000, size=n).astype(np.uint32) << 4) | ops).astype(np.uint32)
+
+
+def random_batch(rng, n_aln, n_parts=2, n_reads=40, max_supp=4, long_read=False, long_aln=0.0, long_max=6000):
     """Records with random CIGARs split over `n_parts` pools, and chimeric reads whose segments name pool records
-    (primaries) and extra alignments (SA-derived)."""
+    (primaries) and extra alignments (SA-derived).  `long_aln`: fraction of the records whose CIGAR has 9 .. `long_max`
+    ops (log-uniform) instead of 1-60."""
     tuples = [helpers.random_cigar(rng, int(rng.integers(1, 60)), hard=bool(rng.random() < 0.15)) for _ in range(n_aln)]
     words = [np.array([(l << 4) | o for o, l in t], dtype=np.uint32) for t in tuples]
+    if long_aln > 0:
+        for a in np.nonzero(rng.random(n_aln) < long_aln)[0].tolist():
+            words[a] = long_cigar(rng, int(np.exp(rng.uniform(np.log(9), np.log(long_max)))))
     cut = sorted(rng.integers(0, n_aln + 1, size=n_parts - 1).tolist())
     bounds = [0] + cut + [n_aln]
     parts = [np.concatenate(words[a:b]) if b > a else np.zeros(0, np.uint32) for a, b in zip(bounds, bounds[1:])]
@@ -88,6 +102,20 @@ def test_one_submission_equals_the_single_purpose_calls(svx_ctx, seed):
         o = orc.cigar_extract(cigar, b["aln_off"], b["ref_start"], min_len)
         for k in o:
             assert np.array_equal(got[0][k], o[k]), k
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_submission_with_long_primaries(svx_ctx, seed):
+    """Chimeric reads whose primaries run from a handful to thousands of ops (the chunk list of the fused chain, the
+    whole-workgroup walk beyond 2048 ops), both CIGAR paths."""
+    rng = np.random.default_rng(300 + seed)
+    b = random_batch(rng, n_aln=int(rng.choice([40, 400])), n_parts=2, n_reads=int(rng.choice([30, 400])), max_supp=3,
+                     long_read=seed % 2 == 1, long_aln=0.5, long_max=int(rng.choice([600, 9000])))
+    svx_ctx.set_small_batch_ops(0 if seed >= 2 else 1 << 23)
+    try:
+        same(call(svx_ctx.collect_batch, b), call(svx_ctx.collect_batch_composed, b))
+    finally:
+        svx_ctx.set_small_batch_ops(1 << 23)
 
 
 def test_streaming_path_and_capacity_retry(svx_ctx):

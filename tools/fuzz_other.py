@@ -215,7 +215,8 @@ def fuzz_collect(ctx, rng):
     import test_gpu_collect as tcol
     b = tcol.random_batch(rng, n_aln=int(rng.choice([1, 2, 50, 800, 6000])), n_parts=int(rng.choice([1, 2, 3, 5])),
                           n_reads=int(rng.choice([0, 1, 7, 300, 2000])), max_supp=int(rng.choice([1, 3, 7, 12])),
-                          long_read=bool(rng.random() < 0.3))
+                          long_read=bool(rng.random() < 0.3), long_aln=float(rng.choice([0.0, 0.0, 0.2, 0.8])),
+                          long_max=int(rng.choice([300, 3000, 12000])))
     min_len = int(rng.choice([1, 30, 40, 500]))
     prm = (int(rng.choice([1, 40, 50, 1000])), int(rng.choice([20, 1000, 100000, 1 << 30])),
            int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])))
