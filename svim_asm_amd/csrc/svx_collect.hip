@@ -73,7 +73,7 @@ extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
     if (rc != SVX_OK) return rc;
     if (d->post_off[d->n_reads] && !d->d_post) return SVX_E_INVALID;
     if (stride && !ctx->split_chain) {
-        // the chain goes out with the CIGAR path: inside its tile launch (small batches) or as one launch behind it
+        // the chain goes out with the CIGAR path, inside two of its launches (svx_cigar.hip, a3_chain_block)
         svx_a3_plan q;
         q.d_seg_src = d->d_seg_src; q.d_seg_tid = d->d_seg_tid; q.d_seg_pos = d->d_seg_pos; q.d_seg_rev = d->d_seg_rev;
         q.d_seg_qend = d->d_seg_qend; q.n_segs = d->n_segs; q.d_read_off = d->d_read_off; q.n_reads = d->n_reads;
