@@ -1204,10 +1204,11 @@ __global__ __launch_bounds__(256) void k_segment_rows(SegRowArgs p) {
 }
 
 // ---- the split-segment chain of one submission (SVIM_inter.py:62-340) inside the launches of the CIGAR path: a
-// workgroup owns `reads_per_block` consecutive chimeric reads.  Stage A (in the tile launch): the segment rows
-// (sixteen lanes per segment: CIGAR statistics -> svx_seg, :66-81; alignments beyond kLongOps by the whole
-// workgroup), a workgroup barrier, the adjacent-pair decision tree (eight lanes per read, :83-258).  Stage B (in
-// the last launch of the path): the three post-passes (one lane per read, :260-338).  The rows travel through HBM
+// workgroup owns `reads_per_block` consecutive chimeric reads.  Stage A (in the tile launch of the two-launch path,
+// in the finish launch of the streaming path): the segment rows (CIGAR statistics -> svx_seg, :66-81: a lane per
+// tiny alignment, the workgroup's chunk list for the others, the whole workgroup beyond kLongOps), a workgroup
+// barrier, the adjacent-pair decision tree (eight lanes per read, :83-258).  Stage B (in the last launch of the
+// path): the three post-passes (one lane per read, :260-338).  The rows travel through HBM
 // and are read back by the workgroup that wrote them, i.e. from the same CU's cache, behind the barrier; the raw
 // records are an output anyway.  Round 3 ran the chain as three launches of 4-7 us each behind the CIGAR path.
 struct A3Args {
@@ -1771,8 +1772,9 @@ void a3_fill(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, c
     a->reads_per_block = per < 2u ? 2u : (per > SVX_A3_READS_MAX ? SVX_A3_READS_MAX : per);
 }
 
-// a3 != nullptr: the split-segment chain of the same submission goes out with the CIGAR path — inside the tile
-// launch on the small-batch path, as one launch behind it on the streaming path (svx_collect_batch_dev).
+// a3 != nullptr: the split-segment chain of the same submission goes out with the CIGAR path — inside the tile and
+// finish launches of the small-batch path, inside the finish and dense-tile launches of the streaming path
+// (svx_collect_batch_dev).
 template <bool SOA>
 int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const uint8_t* d_op,
                            uint64_t n_ops, const uint64_t* d_aln_off, uint32_t n_aln,
