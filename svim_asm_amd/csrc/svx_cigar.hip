@@ -1757,7 +1757,7 @@ void a3_fill(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, c
     o.scratch = svx_ws_take<char>(ctx, (size_t)q.n_reads * post_stride);
     o.scratch_off = nullptr;
     o.scratch_stride = post_stride;
-    // reads per workgroup of the rows + tree stage: two while the grid stays small (the shortest dependent sequence
+    // reads per workgroup of the rows + tree stage: one or two while the grid stays small (the shortest dependent sequence
     // per workgroup), up to 32 for a cohort's reads — about 100 segments and 100 chunks, six per sixteen-lane group,
     // and the 2 000 workgroups of a cohort of 256 samples are all resident at once (8 per CU).  Measured on that
     // cohort, k_finish_a3: 8 reads 67.7 us, 16: 55.3, 24: 56.4, 32: 53.5, 48: 57.1, 64: 59.1
@@ -1769,7 +1769,10 @@ void a3_fill(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, c
 #define SVX_A3_READS_MAX 32u
 #endif
     const uint32_t per = q.n_reads / SVX_A3_READS_DIV;
-    a->reads_per_block = per < 2u ? 2u : (per > SVX_A3_READS_MAX ? SVX_A3_READS_MAX : per);
+    // (one read per workgroup while that leaves at most a workgroup and a half per CU: one sample 13.1 -> 11.5 us per
+    //  step; the 533 reads of a diploid submission are better off with two: 25.9 vs 26.7 us)
+    const uint32_t least = q.n_reads < 384u ? 1u : 2u;
+    a->reads_per_block = per < least ? least : (per > SVX_A3_READS_MAX ? SVX_A3_READS_MAX : per);
 }
 
 // a3 != nullptr: the split-segment chain of the same submission goes out with the CIGAR path — inside the tile and
