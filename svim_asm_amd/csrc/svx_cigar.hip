@@ -678,15 +678,17 @@ __device__ __forceinline__ void fold_group_desc(const CigarArgs& p, uint4* s_agg
     if (lane == 0) s_agg[wave] = dsc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t f = 0, r = 0, d = 0, c = 0;
+        uint32_t f = 0, r = 0, d = 0, c = 0, dense = 0;
 #pragma unroll
         for (int k = 0; k < kWaves; ++k) {
             const uint4 v = s_agg[k];
             if (v.x >> 31) { f = 1; r = v.y; d = v.z; }
             else { r += v.y; d += v.z; }
             c += v.x & 0x3FFFFFFFu;
+            // .w: which of the four tiles k_cigar_finish_small has to walk again (beyond the slab, or a round beyond the queue)
+            if ((v.x & 0x3FFFFFFFu) > (uint32_t)kSlab || (v.x & kDescForceDense)) dense |= 1u << k;
         }
-        p.desc4[group] = make_uint4(c | (f << 31), r, d, 0u);
+        p.desc4[group] = make_uint4(c | (f << 31), r, d, dense);
     }
 }
 
@@ -1508,8 +1510,8 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
     }
     const uint32_t block = WITH_POST ? blockIdx.x - n_a3_blocks : blockIdx.x;
     __shared__ uint32_t s_cr[kWaves], s_cd[kWaves], s_ob[kWaves];  // exclusive prefix of this workgroup's groups
-    __shared__ uint4 s_dense[kFinTiles];
-    __shared__ uint32_t s_dense_alo[kFinTiles], s_n_dense;
+    __shared__ uint4 s_dense[kFinTiles];  // tile, and its group's exclusive prefix: carry_ref, carry_read, output base
+    __shared__ uint32_t s_n_dense;
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];
     __shared__ uint32_t s_f[4], s_r[4], s_d[4], s_c[4];
@@ -1548,6 +1550,7 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
     }
     SVX_SEG_SCAN()
     if (lane == 63) { s_f[wave] = f; s_r[wave] = sr; s_d[wave] = sd; s_c[wave] = sc; }
+    if (tid == 0) s_n_dense = 0;
     __syncthreads();
     uint32_t pr_ = 0, pd_ = 0, pc = 0, ar = 0, ad = 0, ac = 0;
     for (int w2 = 0; w2 < 4; ++w2) {
@@ -1570,6 +1573,28 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
         }
     }
     if (block == 0 && tid == 255) *n_out = (uint64_t)ac;
+    // ---- dense tiles (a round that overflowed the queue, a tile beyond the slab) are walked again with carry-in and
+    // output base known.  They come in stretches (an SV-dense contig), so they are dealt out round-robin over ALL
+    // finishing workgroups — tile t to workgroup t mod n — instead of staying with the workgroup that finishes
+    // their neighbours: every workgroup has scanned every group's prefix anyway.  (Until this change a workgroup
+    // walked its own sixteen tiles' dense ones, up to four per wave one after the other: 29 us for this kernel in
+    // the full-size run of the command line against 5 on sparse input.)
+    const uint32_t n_fin = WITH_POST ? gridDim.x - n_a3_blocks : gridDim.x;
+#pragma unroll
+    for (int i = 0; i < kSmallPer; ++i) {
+        uint32_t m = d[i].w & 0xFu;
+        const uint32_t g = (uint32_t)tid * kSmallPer + i;
+        while (m) {  // rare
+            const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            const uint32_t t = g * kWaves + k;
+            if (t % n_fin == block) {
+                const bool own = (lf >> i) & 1u;
+                const uint32_t at = atomicAdd(&s_n_dense, 1u);
+                s_dense[at] = make_uint4(t, own ? lr[i] : Tr + lr[i], own ? ld[i] : Td + ld[i], Tc + lc[i]);
+            }
+        }
+    }
     __syncthreads();
     // ---- inside the group (= this wave's four tiles, 16 lanes each): fold the tiles before mine
     uint32_t t_cr = s_cr[wave], t_cd = s_cd[wave], t_ob = s_ob[wave];
@@ -1616,24 +1641,23 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
             store_final(p, ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
         }
     }
-    // ---- dense tiles among this workgroup's sixteen (a round that overflowed the queue, a tile beyond the slab): listed
-    // in LDS and re-walked with carry-in and output base known, one wave each, the waves taking turns
-    if (tid == 0) s_n_dense = 0;
-    __syncthreads();
-    if (mine && dense && l == 0) {
-        const uint32_t at = atomicAdd(&s_n_dense, 1u);
-        s_dense[at] = make_uint4(tile, t_cr, t_cd, t_ob);
-        s_dense_alo[at] = dsc.w;
-    }
-    __syncthreads();
+    // ---- this workgroup's share of the dense tiles, one wave each, the waves taking turns: fold the tiles in front of
+    // it inside its group of four (scalar loads of their descriptors), then the walk
     const uint32_t n_dense = s_n_dense;
     for (uint32_t i = wave; i < n_dense; i += kWaves) {
         const uint4 e = s_dense[i];
         TileIn in;
-        in.a_lo = s_dense_alo[i];
         in.carry_r = e.y;
         in.carry_d = e.z;
         in.obase = e.w;
+        const uint32_t first = e.x & ~(uint32_t)(kWaves - 1);
+        for (uint32_t t = first; t < e.x; ++t) {  // wave-uniform
+            const uint4 v = p.desc[t];
+            if (v.x >> 31) { in.carry_r = v.y; in.carry_d = v.z; }
+            else { in.carry_r += v.y; in.carry_d += v.z; }
+            in.obase += v.x & 0x3FFFFFFFu;
+        }
+        in.a_lo = p.desc[e.x].w;
         (void)process_tile<MODE_DIRECT, SOA, kSmallTileOps, ALO_GIVEN>(p, e.x, lane, s_xpose[wave], s_head[wave],
                                                                               reinterpret_cast<uint4*>(s_head[wave]), nullptr, in);
     }
@@ -1862,7 +1886,13 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
             SVX_HIP(ctx, hipEventRecord(ctx->ev_dom, ctx->stream));
             ctx->ev_dom_recorded = true;
         }
-        const uint32_t fin_blocks = (n_tiles + kFinTiles - 1) / kFinTiles;
+        // (at least SVX_FIN_MIN_BLOCKS workgroups: the ones beyond the tiles' own have no records to copy and only take
+        //  their share of the dense tiles — a batch of a few hundred tiles that are ALL dense is a satellite array)
+#ifndef SVX_FIN_MIN_BLOCKS
+#define SVX_FIN_MIN_BLOCKS 128u  // (tools/dense_probe.py `satellite`, two-launch path: 48.4 -> 28.2 us; 256: 28.0)
+#endif
+        uint32_t fin_blocks = (n_tiles + kFinTiles - 1) / kFinTiles;
+        if (fin_blocks < SVX_FIN_MIN_BLOCKS) fin_blocks = SVX_FIN_MIN_BLOCKS;
         if (a3)
             hipLaunchKernelGGL((k_cigar_finish_small<SOA, true>), dim3(n_post_blocks + fin_blocks), dim3(256), 0, ctx->stream, a, d_n_out,
                                c, n_post_blocks);
