@@ -1091,6 +1091,8 @@ __device__ __forceinline__ AlnStats lane_alignment_stats(const uint32_t (&w)[kTi
 __device__ __forceinline__ AlnStats block_alignment_stats(const uint32_t* cigar, const uint64_t b, const uint64_t e, const int tid,
                                                           uint32_t* s_part) {
     const int lane = tid & 63, wave = tid >> 6;
+    // (the first 64 words, for the clip prefix below: requested now, so that the prefix costs no round trip of its own)
+    const uint32_t w_first = (b + (uint64_t)lane < e) ? cigar[b + lane] : 0u;
     uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
     for (uint64_t i0 = b; i0 < e; i0 += kStatLoads * 256) {
         uint32_t w[kStatLoads];
@@ -1124,7 +1126,7 @@ __device__ __forceinline__ AlnStats block_alignment_stats(const uint32_t* cigar,
         bool done = false;
         while (!done && i < e) {
             const uint64_t j = i + lane;
-            const uint32_t w = (j < e) ? cigar[j] : 0u;
+            const uint32_t w = i == b ? w_first : ((j < e) ? cigar[j] : 0u);
             const uint32_t op = w & 15u;
             const bool clip = (j < e) && (op == 4u || op == 5u);
             const uint64_t nb = __ballot(!clip);
@@ -1239,6 +1241,7 @@ constexpr int kChunksPerAln = kLongOps / kChunkOps;   // 16
 constexpr int kLongList = 60;
 struct A3Lds {
     uint32_t n_long, long_list[kLongList], part[16];
+    uint32_t long_b_lo[kLongList], long_b_hi[kLongList], long_e_lo[kLongList], long_e_hi[kLongList];  // their op ranges
     uint32_t n_chunks;
     uint32_t open[8];              // bit per slot: the whole first chunk was clips (the owner then walks the prefix itself)
     uint32_t cb_lo[256], cb_hi[256], n_ops[256];   // per slot = thread of the batch of 256 segments
@@ -1296,9 +1299,13 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
             const bool chunked = live && !tiny && !huge;
             uint32_t tw[kTinyOps];
             lane_alignment_load(p.cigar, cb, tiny ? (uint32_t)n : 0u, tw);
-            if (huge) {  // noted for the whole workgroup
+            if (huge) {  // noted for the whole workgroup, with its op range (two round trips less per alignment later)
                 const uint32_t at = atomicAdd(&lds->n_long, 1u);
-                if (at < (uint32_t)kLongList) lds->long_list[at] = j;
+                if (at < (uint32_t)kLongList) {
+                    lds->long_list[at] = j;
+                    lds->long_b_lo[at] = (uint32_t)cb; lds->long_b_hi[at] = (uint32_t)(cb >> 32);
+                    lds->long_e_lo[at] = (uint32_t)ce; lds->long_e_hi[at] = (uint32_t)(ce >> 32);
+                }
             }
             if (chunked) {
                 lds->cb_lo[tid] = (uint32_t)cb;
@@ -1413,8 +1420,9 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
         const uint32_t n_long_listed = n_long < (uint32_t)kLongList ? n_long : (uint32_t)kLongList;
         for (uint32_t k = 0; k < n_long_listed; ++k) {  // workgroup-uniform
             const uint32_t j = lds->long_list[k];
-            const uint32_t src = p.seg_src[j];
-            const AlnStats st = block_alignment_stats(p.cigar, p.aln_off[src], p.aln_off[src + 1], tid, s_part);
+            const uint64_t lb = ((uint64_t)lds->long_b_hi[k] << 32) | lds->long_b_lo[k];
+            const uint64_t le = ((uint64_t)lds->long_e_hi[k] << 32) | lds->long_e_lo[k];
+            const AlnStats st = block_alignment_stats(p.cigar, lb, le, tid, s_part);
             if (tid == 0) {
                 p.segs[j] = segment_row(p, j, st);
                 a.seg_rl[j] = (int32_t)st.rl;
