@@ -32,6 +32,7 @@
 //
 // VALU-bound integer work (≈ 50 VALU per 64 cells); no MFMA, HBM traffic is negligible.
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 
 #include "svx_internal.h"
@@ -168,7 +169,12 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         uint32_t raw_ahead = 0x100u, code_ahead = CAP;
         code_cur = shr1_in((uint32_t)__builtin_amdgcn_readlane((int)codechunk, 0), code_cur);
         uint64_t eq_cur = peq[code_cur * 64 + lane];
-        for (uint32_t t = 0; t < nsteps; ++t) {
+        // Two steps per trip: the symbol and the match vector of the next step change hands by name, not by moves.
+        // Steady steps — every block of the strip has started, none has finished: t in [last, n) — need no activity test:
+        // the mask is the loop-invariant `lane < nblk`.
+        const bool in_strip = lane < nblk;
+        auto one_step = [&](auto steady_c, const uint32_t t, const uint32_t code_cur, const uint64_t eq_cur, uint32_t& code_next,
+                            uint64_t& eq_next) {
 #if SVX_ED_PREFETCH
             if ((t & 63) == 0) raw_ahead = fetch_raw(t + 64);
             if ((t & 63) == 32) code_ahead = to_code(raw_ahead);
@@ -177,10 +183,10 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
             if ((t & 63) == 63) { raw_ahead = fetch_raw(t + 1); code_ahead = to_code(raw_ahead); codechunk = code_ahead; }
 #endif
             const uint32_t fresh_c = (uint32_t)__builtin_amdgcn_readlane((int)codechunk, (int)((t + 1) & 63));
-            const uint32_t code_next = shr1_in(fresh_c, code_cur);
-            const uint64_t eq_next = peq[code_next * 64 + lane];
+            code_next = shr1_in(fresh_c, code_cur);
+            eq_next = peq[code_next * 64 + lane];
             const uint32_t hin = shr1_in(1u, hout_prev);     // lane 0: the top row, +1
-            const bool active = (t - lane) < lim;            // (t < lane wraps to a huge value)
+            const bool active = decltype(steady_c)::value ? in_strip : (t - lane) < lim;  // (t < lane wraps to a huge value)
             const uint64_t hneg = hin >> 1, hpos = hin & 1u;
             uint64_t Eq = eq_cur;
             const uint64_t Xv = Eq | Mv;
@@ -197,8 +203,26 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
                 hout_prev = ho;
                 val += (ho & 1u) - (ho >> 1);
             }
-            code_cur = code_next;
-            eq_cur = eq_next;
+        };
+        {
+            uint32_t code_b = CAP;
+            uint64_t eq_b = 0;
+            uint32_t t = 0;
+            auto run = [&](const uint32_t t_end, auto steady_c) {
+                for (; t + 1 < t_end; t += 2) {
+                    one_step(steady_c, t, code_cur, eq_cur, code_b, eq_b);
+                    one_step(steady_c, t + 1, code_b, eq_b, code_cur, eq_cur);
+                }
+                if (t < t_end) {
+                    one_step(steady_c, t, code_cur, eq_cur, code_b, eq_b);
+                    code_cur = code_b; eq_cur = eq_b;
+                    ++t;
+                }
+            };
+            const uint32_t t_s0 = last < nsteps ? last : nsteps, t_s1 = n > t_s0 ? n : t_s0;
+            run(t_s0, std::false_type{});   // blocks joining
+            run(t_s1, std::true_type{});    // all of them at work
+            run(nsteps, std::false_type{}); // blocks leaving
         }
         const uint32_t result1 = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)last);
         if (lane == 0) p.dist[pi] = result1;
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         uint64_t Pv = ~0ull, Mv = 0;
         uint32_t val = base;        // running D' on the strip's last row (meaningful on lane `last`)
         uint32_t captured = base;   // value at cap_col (== c_lo - 1 unless seen later)
-        uint64_t acc = 0;           // packed outgoing deltas (lane `last`)
+        uint32_t acc_lo = 0, acc_hi = 0;  // packed outgoing deltas (lane `last`), 16 columns per half
         uint32_t hout_prev = 0, code_cur = CAP;
         uint32_t codechunk = CAP, hchunk = 1;
         uint64_t eq_cur = 0;
@@ -275,9 +299,14 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         //  strip above, the packed outgoing ones — only lane `last`'s are real; every lane shifts by lane `last`'s
         //  column, a scalar — and the score at the column where the next strip starts)
         const uint32_t lim = lane < nblk ? ncols : 0u;
+        const bool in_strip = lane < nblk;
         const uint32_t sh = lane == last ? outbit : 63u;
         const uint32_t t_cap = (cap_col != 0xFFFFFFFFu && cap_col >= c_lo) ? cap_col - c_lo + last : 0xFFFFFFFFu;
-        for (uint32_t t = 0; t < nsteps; ++t) {
+        // (the pattern's LAST strip hands nothing on: no outgoing stream, no captured score — a tenth of its step)
+        auto strip_steps = [&](auto hands_on_c) {
+        constexpr bool kHandsOn = decltype(hands_on_c)::value;
+        auto one_step = [&](auto steady_c, const uint32_t t, const uint32_t code_cur, const uint64_t eq_cur, uint32_t& code_next,
+                            uint64_t& eq_next) {
             const uint32_t tl = t & 63;
             const uint32_t fresh_h = (uint32_t)__builtin_amdgcn_readlane((int)hchunk, (int)tl);
             // next step's symbol and match vector (independent of this step's recurrence)
@@ -289,11 +318,11 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
             if (tl == 63) { fetch_raw(t + 1); decode_ahead(t + 1); codechunk = code_ahead; hchunk = h_ahead; }
 #endif
             const uint32_t fresh_c = (uint32_t)__builtin_amdgcn_readlane((int)codechunk, (int)((t + 1) & 63));
-            const uint32_t code_next = shr1_in(fresh_c, code_cur);
-            const uint64_t eq_next = peq[code_next * 64 + lane];
+            code_next = shr1_in(fresh_c, code_cur);
+            eq_next = peq[code_next * 64 + lane];
 
             const uint32_t hin = shr1_in(fresh_h, hout_prev);
-            const bool active = (t - lane) < lim;  // (t < lane wraps to a huge value)
+            const bool active = decltype(steady_c)::value ? in_strip : (t - lane) < lim;  // (t < lane wraps to a huge value)
             const uint64_t hneg = hin >> 1, hpos = hin & 1u;
             uint64_t Eq = eq_cur;
             const uint64_t Xv = Eq | Mv;
@@ -304,26 +333,48 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
             const uint32_t ho = (uint32_t)((Ph >> sh) & 1ull) | ((uint32_t)((Mh >> sh) & 1ull) << 1);
             Ph = (Ph << 1) | hpos;
             Mh = (Mh << 1) | hneg;
-            uint32_t ho_a = 0;
             if (active) {
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
                 hout_prev = ho;
                 val += (ho & 1u) - (ho >> 1);
-                ho_a = ho;
             }
-            captured = t == t_cap ? val : captured;
-            if (s_out && t >= last) {  // wave-uniform: lane `last` is at column col_last
-                const uint32_t col_last = c_lo + t - last;
-                acc |= (uint64_t)ho_a << (2 * ((col_last - 1) & 31));
-                if (((col_last - 1) & 31) == 31 || col_last == c_hi) {
-                    if (lane == last) s_out[(col_last - 1) >> 5] = acc;
-                    acc = 0;
+            if (kHandsOn) {
+                captured = t == t_cap ? val : captured;
+                if (t >= last) {  // wave-uniform: lane `last` is at column col_last — and active from here to the end, so
+                                  // its `ho` is the delta that leaves the strip; the other lanes' words are never stored
+                    const uint32_t col_last = c_lo + t - last;
+                    const uint32_t pos = (col_last - 1) & 31;  // scalar: one fused shift-or on the half it falls into
+                    if (pos < 16) acc_lo |= ho << (2 * pos);
+                    else acc_hi |= ho << (2 * pos - 32);
+                    if (pos == 31 || col_last == c_hi) {
+                        if (lane == last) s_out[(col_last - 1) >> 5] = ((uint64_t)acc_hi << 32) | acc_lo;
+                        acc_lo = acc_hi = 0;
+                    }
                 }
             }
-            code_cur = code_next;
-            eq_cur = eq_next;
-        }
+        };
+        uint32_t code_b = CAP;
+        uint64_t eq_b = 0;
+        uint32_t t = 0;
+        auto run = [&](const uint32_t t_end, auto steady_c) {
+            for (; t + 1 < t_end; t += 2) {
+                one_step(steady_c, t, code_cur, eq_cur, code_b, eq_b);
+                one_step(steady_c, t + 1, code_b, eq_b, code_cur, eq_cur);
+            }
+            if (t < t_end) {
+                one_step(steady_c, t, code_cur, eq_cur, code_b, eq_b);
+                code_cur = code_b; eq_cur = eq_b;
+                ++t;
+            }
+        };
+        const uint32_t t_s0 = last < nsteps ? last : nsteps, t_s1 = ncols > t_s0 ? ncols : t_s0;
+        run(t_s0, std::false_type{});   // blocks joining
+        run(t_s1, std::true_type{});    // all of them at work: no activity test (see the single-strip path)
+        run(nsteps, std::false_type{}); // blocks leaving
+        };
+        if (s_out && s + 1 < n_strips) strip_steps(std::true_type{});
+        else strip_steps(std::false_type{});
         carried = (uint32_t)__builtin_amdgcn_readlane((int)captured, (int)last);
         result = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)last);
         prev_c_hi = c_hi;
