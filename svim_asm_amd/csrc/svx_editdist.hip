@@ -69,6 +69,12 @@ __device__ __forceinline__ uint32_t shr1_in(uint32_t fresh, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)v, kDppWaveShr1, 0xF, 0xF, false);
 }
 
+__device__ __forceinline__ uint32_t shr1_zero(uint32_t v) {
+    // lane l receives v of lane l-1; lane 0 receives 0 (bound_ctrl) — no move in front of the DPP instruction, and an OR
+    // with it folds into one v_or_b32_dpp
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kDppWaveShr1, 0xF, 0xF, true);
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -157,7 +163,10 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         const uint32_t lim = lane < nblk ? n : 0u;          // steps this lane is active for, from step `lane` on
         const uint32_t sh = lane == last ? outbit : 63u;
         uint64_t Pv = ~0ull, Mv = 0;
-        uint32_t val = m, hout_prev = 0, code_cur = CAP, codechunk = CAP;
+        // the horizontal delta of a block's bottom row travels to the next lane as two separate bits (+1, -1): nothing to
+        // pack and unpack per step; lane 0's +1 (the matrix's top row) is a per-lane constant ORed into the shifted value
+        uint32_t val = m, hp_prev = 0, hm_prev = 0, code_cur = CAP, codechunk = CAP;
+        const uint32_t top_plus = lane == 0 ? 1u : 0u;
         // text symbols: 64 per register chunk; the chunk after the current one is requested a whole chunk ahead (its
         // bytes at step 0 of a chunk, their symbol codes at step 32) so that no step waits for memory
         auto fetch_raw = [&](uint32_t t0) -> uint32_t {
@@ -185,23 +194,23 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
             const uint32_t fresh_c = (uint32_t)__builtin_amdgcn_readlane((int)codechunk, (int)((t + 1) & 63));
             code_next = shr1_in(fresh_c, code_cur);
             eq_next = peq[code_next * 64 + lane];
-            const uint32_t hin = shr1_in(1u, hout_prev);     // lane 0: the top row, +1
             const bool active = decltype(steady_c)::value ? in_strip : (t - lane) < lim;  // (t < lane wraps to a huge value)
-            const uint64_t hneg = hin >> 1, hpos = hin & 1u;
+            const uint64_t hneg = shr1_zero(hm_prev), hpos = shr1_zero(hp_prev) | top_plus;
             uint64_t Eq = eq_cur;
             const uint64_t Xv = Eq | Mv;
             Eq |= hneg;
             const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             uint64_t Ph = Mv | ~(Xh | Pv);
             uint64_t Mh = Pv & Xh;
-            const uint32_t ho = (uint32_t)((Ph >> sh) & 1ull) | ((uint32_t)((Mh >> sh) & 1ull) << 1);
+            const uint32_t hop = (uint32_t)(Ph >> sh) & 1u, hom = (uint32_t)(Mh >> sh) & 1u;
             Ph = (Ph << 1) | hpos;
             Mh = (Mh << 1) | hneg;
             if (active) {
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
-                hout_prev = ho;
-                val += (ho & 1u) - (ho >> 1);
+                hp_prev = hop;
+                hm_prev = hom;
+                val += hop - hom;
             }
         };
         {
@@ -272,7 +281,8 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         uint32_t val = base;        // running D' on the strip's last row (meaningful on lane `last`)
         uint32_t captured = base;   // value at cap_col (== c_lo - 1 unless seen later)
         uint32_t acc_lo = 0, acc_hi = 0;  // packed outgoing deltas (lane `last`), 16 columns per half
-        uint32_t hout_prev = 0, code_cur = CAP;
+        uint32_t hp_prev = 0, hm_prev = 0, code_cur = CAP;
+        const uint32_t lane0 = lane == 0 ? 1u : 0u;
         uint32_t codechunk = CAP, hchunk = 1;
         uint64_t eq_cur = 0;
         // text symbols and incoming deltas: 64 per register chunk, the next chunk requested a whole chunk ahead
@@ -321,23 +331,26 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
             code_next = shr1_in(fresh_c, code_cur);
             eq_next = peq[code_next * 64 + lane];
 
-            const uint32_t hin = shr1_in(fresh_h, hout_prev);
             const bool active = decltype(steady_c)::value ? in_strip : (t - lane) < lim;  // (t < lane wraps to a huge value)
-            const uint64_t hneg = hin >> 1, hpos = hin & 1u;
+            // lane 0 takes the strip above's delta for this column (fresh_h: a scalar, two bits), the others their upper
+            // neighbour's, as two separate bits
+            const uint64_t hneg = shr1_zero(hm_prev) | (lane0 & (fresh_h >> 1)), hpos = shr1_zero(hp_prev) | (lane0 & fresh_h);
             uint64_t Eq = eq_cur;
             const uint64_t Xv = Eq | Mv;
             Eq |= hneg;
             const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             uint64_t Ph = Mv | ~(Xh | Pv);
             uint64_t Mh = Pv & Xh;
-            const uint32_t ho = (uint32_t)((Ph >> sh) & 1ull) | ((uint32_t)((Mh >> sh) & 1ull) << 1);
+            const uint32_t hop = (uint32_t)(Ph >> sh) & 1u, hom = (uint32_t)(Mh >> sh) & 1u;
+            const uint32_t ho = hop | (hom << 1);  // (only the hand-over strips use the packed form)
             Ph = (Ph << 1) | hpos;
             Mh = (Mh << 1) | hneg;
             if (active) {
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
-                hout_prev = ho;
-                val += (ho & 1u) - (ho >> 1);
+                hp_prev = hop;
+                hm_prev = hom;
+                val += hop - hom;
             }
             if (kHandsOn) {
                 captured = t == t_cap ? val : captured;
