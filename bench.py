@@ -425,11 +425,12 @@ def roofline_pair(local_rank):
                     "included; the kernel's own duration is in profiles/); latency-bound at this size, not byte-bound"}
 
 
-# VALU instructions per systolic step of k_edit_myers<16> (gfx950 ISA of the inner loops, `hipcc -S`: about 43 in the
-# steady two-step loops of single-strip patterns and of a pattern's last strip, about 50 in the strips that hand their
-# bottom row on — 42 / 50 with an activity test and copy moves in every step until the end of round 4, 75 until round 3):
-# a step updates 64 lanes x 64 rows of the DP matrix
-EDIT_VALU_PER_STEP = 45
+# VALU instructions per systolic step of k_edit_myers<16> (gfx950 ISA of the inner loops, `hipcc -S`: 38 in the steady
+# two-step loop of single-strip patterns — 32 for the recurrence, which the compiler fuses below its 36 with v_bfi /
+# v_or3, and 6 for the symbol, the match vector and the two delta bits —, about 40 in a pattern's last strip, about 46 in
+# the strips that hand their bottom row on; 42 / 50 until the end of round 4, 75 until round 3): a step updates 64 lanes
+# x 64 rows of the DP matrix
+EDIT_VALU_PER_STEP = 42
 # the recurrence alone (Myers 1999 / Hyyro 2003, one 64-row block and one column): 18 operations on 64-bit words,
 # two 32-bit VALU each — the floor any bit-vector formulation on this ISA pays per 64 x 64 lane-cells
 EDIT_ALGO_VALU_PER_STEP = 36
