@@ -25,10 +25,13 @@
 //   D  k_cigar_dense          dense tiles (> 128 signatures, e.g. adversarial all-indel CIGARs) are
 //                             re-walked with carry-in and output base known (process_tile<DIRECT>),
 //                             writing final SoA; an empty launch in the common case.
-// Batches of at most 2 M ops (one BAM of an assembly: what the svim-asm CLI launches) take a two-launch
+// Batches of at most 8 M ops (both haplotype BAMs of an assembly: what the svim-asm CLI launches) take a two-launch
 // variant of the same code: k_cigar_tiles with tiles of 1024 ops and the tile's start index from a wave
-// search, then k_cigar_finish_small, in which every workgroup scans all descriptors itself, finishes its
-// own 16 tiles and re-walks the dense ones (see the comment above that kernel).
+// search, then k_cigar_finish_small, in which every workgroup scans all (folded) descriptors itself, finishes its
+// own 16 tiles and re-walks its share of the dense ones, dealt out round-robin (see the comment above that kernel).
+// With chimeric reads in the submission (svx_collect_batch_dev) the split-segment chain of SVIM_inter.py:62-340 rides
+// inside these launches (a3_chain_block): rows + decision tree in the tile launch of the two-launch path
+// (k_tiles_a3) or in the finish launch of the streaming path (k_finish_a3), the post-passes in the last launch.
 // Output order = (alignment, op) order by construction (prefix sums, no atomically-ordered appends).
 #include "svx_internal.h"
 #include "svx_postpass_dev.h"
