@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses device 0")
     ap.add_argument("--init-timeout", type=int, default=180, help="seconds the process group may take to come up (rendezvous + "
                     "first collective) before a rank gives up with exit status 3")
+    ap.add_argument("--settle-ms", type=float, default=300.0, help="host idle time in front of the warm-up steps (lets the "
+                    "cgroup's CPU quota period roll over: see the comment at the timed region); 0 = none")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip latency_case / roofline_pair / roofline_editdist (N=1) and e2e / e2e_sharded (any N) — "
                          "rank 0 only, all outside the timed region of `value`")
@@ -79,6 +81,21 @@ def build_batch(args, rank):
             for i in range(distinct)]
     reps = [base[i % distinct] for i in range(args.samples)]
     return synth.concat_batches(reps)
+
+
+def _throttled_us():
+    """Microseconds the cgroup has throttled this process's group so far (cpu.stat), None where that is not exposed."""
+    for path, key, scale in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1.0),
+                             ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e-3)):
+        try:
+            with open(path) as fh:
+                for line in fh:
+                    parts = line.split()
+                    if len(parts) == 2 and parts[0] == key:
+                        return float(parts[1]) * scale
+        except OSError:
+            pass
+    return None
 
 
 def cpu_baseline(batch, args):
@@ -769,14 +786,24 @@ def main():
             junk.fill_(1)
             torch.cuda.synchronize(dev)
         del junk
+    # The box grants this process a CPU quota per 100-ms period (16 CPUs on the pool's boxes).  A process that has just
+    # burnt it — building and uploading the batch is multi-threaded numpy — is descheduled, every thread of it, until the
+    # period ends: once in a dozen runs that stall fell INTO the 7-ms timed region and doubled its figure (0.875 ms per
+    # step with a kernel of 0.259 ms and a sustained step of 0.328 ms, profiles/README.md).  So the host sits still for a
+    # moment before the warm-up steps, and the line says how long the cgroup throttled it inside the timed region.
+    if args.settle_ms > 0:
+        time.sleep(args.settle_ms / 1e3)
     for _ in range(args.warmup):
         step()
     barrier()
+    thr0 = _throttled_us()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    thr1 = _throttled_us()
+    host_throttled_ms = None if thr0 is None or thr1 is None else (thr1 - thr0) / 1e3
     # Sustained rate, reported beside `value` (never instead of it): the timed region above is `steps` steps after
     # `warmup` warm-up steps, as asked; with the driver's 5 + 20 steps that is 9 ms on a device that was idle while the
     # host prepared the batch, and its clocks are still on their way up (the same 20 steps after 50 warm-up steps take
@@ -915,6 +942,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "host_throttled_ms_in_timed_region": host_throttled_ms,  # (cgroup cpu.stat; rank 0's group; None: not exposed)
             "sustained": None if steady is None else dict(steady, value=total_ops * 200 / (steady["ms_per_step"] * 200 * 1e-3),
                                                           note="200 further steps behind the timed region, bracketed the same "
                                                                "way (barrier + synchronize, max over ranks): the rate of a device "
