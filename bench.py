@@ -791,6 +791,9 @@ def main():
     # period ends: once in a dozen runs that stall fell INTO the 7-ms timed region and doubled its figure (0.875 ms per
     # step with a kernel of 0.259 ms and a sustained step of 0.328 ms, profiles/README.md).  So the host sits still for a
     # moment before the warm-up steps, and the line says how long the cgroup throttled it inside the timed region.
+    import gc
+    gc.collect()
+    gc.disable()  # (no collector pause inside the 7 ms either; back on behind the sustained steps)
     if args.settle_ms > 0:
         time.sleep(args.settle_ms / 1e3)
     for _ in range(args.warmup):
@@ -821,6 +824,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             steady_elapsed = float(t.item())
         steady = {"steps": 200, "ms_per_step": steady_elapsed / 200 * 1e3}
+    gc.enable()
     if args.step_trace and rank == 0:
         time.sleep(2.0)
         trace = []
