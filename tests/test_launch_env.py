@@ -97,3 +97,17 @@ def test_the_launcher_reads_the_device_like_the_real_parser(argv, device, tmp_pa
                          capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     assert json.loads(out.stdout.strip().splitlines()[-1]) == device
+
+
+def test_bench_reads_the_cgroup_throttle_counter():
+    """bench.py reports how long the cgroup throttled the process inside the timed region: the reader returns a
+    number (microseconds so far) where cpu.stat is exposed and None elsewhere, never raises."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    v = bench._throttled_us()
+    assert v is None or (isinstance(v, float) and v >= 0.0)
+    w = bench._throttled_us()
+    assert (v is None) == (w is None) and (v is None or w >= v)
