@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--step", default="collect", choices=("collect", "split"),
                     help="collect (default): one step = svx_collect_batch_dev on the cohort, the product's own submission on one "
                          "stream; split: the round 1-3 step, a1+a2 beside a bare decision tree over random rows on a second stream")
+    ap.add_argument("--chain-deal", default="table", choices=("table", "equal"),
+                    help="how the chimeric reads of the step's submission go to the chain's workgroups: by the table of "
+                         "svx_chain_deal (equal op counts; what svx_collect_batch submits) or in equal read counts (A/B)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to smoke-test the "
                          "multi-rank logic on a box with fewer GPUs than ranks, together with --share-device)")
@@ -220,7 +223,7 @@ class ResidentCollect:
     """One submission of svx_collect_batch_dev with every input resident in HBM (svx_dev_malloc'ed buffers): what
     svx_collect_batch enqueues between its uploads and its read-backs."""
 
-    def __init__(self, ctx, b, case, min_len, cap=None):
+    def __init__(self, ctx, b, case, min_len, cap=None, use_deal=True):
         from svim_asm_amd import _lib
         self.ctx, self.b, self.case, self.min_len = ctx, b, case, min_len
         n_ops, n_aln = int(b["aln_off"][-1]), len(b["aln_off"]) - 1
@@ -238,6 +241,11 @@ class ResidentCollect:
         self.d_raw = ctx.dev_array(nbytes=32 * n_segs)
         self.d_post, self.d_cnt = ctx.dev_array(nbytes=32 * int(case["post_off"][-1])), ctx.dev_array(nbytes=4 * n_reads)
         self.prm = _lib.SegParams(min_len, 100000, 50, 50, 50, 50)
+        # part of the control block, as in svx_collect_batch: the chain's reads dealt to its workgroups by op count
+        deal = np.zeros(2 * (n_reads + 2), np.uint32)
+        self.n_deal = max(0, int(ctx.lib.svx_chain_deal(case["read_off"].ctypes.data, n_reads, case["seg_src"].ctypes.data,
+                                                         off_all.ctypes.data, deal.ctypes.data))) if use_deal else 0
+        self.d_deal = ctx.dev_array(deal[:2 * (self.n_deal + 1)]) if self.n_deal else None
         self.dv = _lib.CollectDev(
             d_cigar=d["cigar"].ptr, n_ops=n_ops, d_aln_off=d["off"].ptr, n_aln=n_aln, n_extra=case["n_extra"],
             d_ref_start=d["rs"].ptr, min_len=min_len, d_seg_src=d["src"].ptr, d_seg_tid=d["tid"].ptr, d_seg_pos=d["pos"].ptr,
@@ -245,7 +253,7 @@ class ResidentCollect:
             d_read_off=d["roff"].ptr, n_reads=n_reads, d_contig_rank=d["rank"].ptr, n_contigs=len(case["rank"]), params=self.prm,
             d_sig=_lib.SigSoa(*self.outs), sig_cap=cap, d_n_sig=self.o[5].ptr, d_segs=self.d_segs.ptr, d_read_len=self.d_rl.ptr,
             d_raw=self.d_raw.ptr, d_post=self.d_post.ptr, post_off=case["post_off"].ctypes.data, d_post_off=d["poff"].ptr,
-            d_post_cnt=self.d_cnt.ptr)
+            d_post_cnt=self.d_cnt.ptr, d_chain_deal=self.d_deal.ptr if self.n_deal else None, n_chain_blocks=self.n_deal)
 
     def step(self):
         import ctypes as C
@@ -295,7 +303,8 @@ class ResidentCollect:
         return bool(ok)
 
     def free(self):
-        for x in list(self.d.values()) + self.o + [self.d_segs, self.d_rl, self.d_raw, self.d_post, self.d_cnt]:
+        for x in list(self.d.values()) + self.o + [self.d_segs, self.d_rl, self.d_raw, self.d_post, self.d_cnt] + \
+                ([self.d_deal] if self.d_deal else []):
             x.free()
 
 
@@ -707,7 +716,7 @@ def main():
         # path) and the split-segment chain (rows -> decision tree -> post-passes, one launch) on ONE stream
         case = chimeric_case(batch, 77 + rank)
         n_reads, n_segs = case["n_reads"], case["n_segs"]
-        rcs = [ResidentCollect(c, batch, case, args.min_sv_size, cap) for c in ctxs]
+        rcs = [ResidentCollect(c, batch, case, args.min_sv_size, cap, use_deal=args.chain_deal == "table") for c in ctxs]
         rc0 = rcs[0]
         d_cig_ptr, d_off_ptr, d_rs_ptr, d_op_ptr = rc0.d["cigar"].ptr, rc0.d["off"].ptr, rc0.d["rs"].ptr, None
         outs, d_n_ptr = rc0.outs, rc0.o[5].ptr

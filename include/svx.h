@@ -440,9 +440,30 @@ typedef struct svx_collect_dev {
     const uint64_t* post_off;
     const uint64_t* d_post_off;
     uint32_t* d_post_cnt;
+    const uint32_t* d_chain_deal;   /* optional (NULL / 0): the table svx_chain_deal wrote, in HBM */
+    uint32_t n_chain_blocks;        /* its return value */
 } svx_collect_dev;
 
 int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d);
+
+/*
+ * Deals the chimeric reads of a submission to the workgroups of the split-segment chain by CIGAR OP COUNT.  The
+ * reference takes a read's rows from pysam properties that walk the record's CIGAR (reference_end,
+ * query_alignment_start / _end, infer_read_length: SVIM_inter.py:66-81); here a workgroup computes the rows of
+ * consecutive reads, and a primary can be anything between a few and 10^5 ops, so equal READ counts leave the launch
+ * waiting for the workgroup with the longest primaries.  The caller has every offset in hand when it builds the
+ * control block: this helper (host arithmetic, O(n_reads + n_segs)) cuts the reads into consecutive ranges of about
+ * equal cost — per segment its CIGAR rounded up to the chain's chunk size, plus a constant per read.
+ *   read_off[n_reads + 1], seg_src[n_segs]   as in svx_collect_in
+ *   aln_off      offsets of EVERY alignment seg_src can name (svx_collect_dev.d_aln_off's host copy)
+ *   deal         out: 2 * (n_reads + 2) words are always enough — {first read, first segment} per workgroup and a
+ *                closing {n_reads, n_segs} entry
+ * Returns the number of workgroups (entries - 1) — upload the table and pass both as d_chain_deal / n_chain_blocks —,
+ * 0 when the submission has too few reads for a table to matter (pass NULL / 0: reads are dealt out in equal
+ * counts), or SVX_E_INVALID.  Results never depend on the table; svx_collect_batch builds one itself.
+ */
+int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* seg_src, const uint64_t* aln_off,
+                   uint32_t* deal);
 
 /* ------------------------------------------------------------ f-1 on the device (prototype) ------ */
 /*

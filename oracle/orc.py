@@ -94,6 +94,31 @@ def cigar_stats(cigar, aln_off):
     return out
 
 
+def segment_rows(st, seg_src, seg_tid, seg_pos, seg_rev, seg_qend, read_off):
+    """The segment table of analyze_read_segments (SVIM_inter.py:66-81) from the CIGAR statistics `st` of
+    cigar_stats() (per ALIGNMENT; segment j is alignment seg_src[j]), one Python step per segment:
+      forward  q_start = query_alignment_start, q_end = query_alignment_end          (:75-76)
+      reverse  q_start = infer_read_length() - query_alignment_end, q_end = ... - query_alignment_start  (:68-73)
+      ref_end = reference_end = reference_start + sum{M,D,N,=,X}, 1 when that is 0 (htslib bam_endpos)
+    seg_qend[j] >= 0 stands for the query_alignment_end pysam takes from a stored sequence.  Returns (SEG_DTYPE
+    rows, infer_read_length() of every read's first segment: the `primary` of :120)."""
+    n = len(seg_src)
+    segs = np.zeros(n, SEG_DTYPE)
+    for j in range(n):
+        a = int(seg_src[j])
+        qs, qe, rl = int(st["q_start"][a]), int(st["q_end"][a]), int(st["read_len"][a])
+        if int(seg_qend[j]) >= 0:
+            qe = int(seg_qend[j])
+        ref_len = int(st["ref_len"][a])
+        row = ((rl - qe, rl - qs) if seg_rev[j] else (qs, qe)) + (
+            int(seg_tid[j]), int(seg_pos[j]), int(seg_pos[j]) + (ref_len if ref_len else 1), 1 if seg_rev[j] else 0)
+        for name, v in zip(("q_start", "q_end", "ref_id", "ref_start", "ref_end", "is_reverse"), row):
+            segs[j][name] = ((v + (1 << 31)) % (1 << 32)) - (1 << 31)  # int32 wrap-around, as the device's registers
+    read_len = np.array([int(st["read_len"][int(seg_src[int(read_off[r])])]) if read_off[r + 1] > read_off[r] else 0
+                         for r in range(len(read_off) - 1)], np.int64)
+    return segs, (((read_len + (1 << 31)) % (1 << 32)) - (1 << 31)).astype(np.int32)
+
+
 def segments_classify(segs, read_off, read_len, params):
     segs = np.ascontiguousarray(segs, SEG_DTYPE)
     read_off = np.ascontiguousarray(read_off, np.uint32)

@@ -87,7 +87,7 @@ class CollectDev(C.Structure):
                 ("d_contig_rank", C.c_void_p), ("n_contigs", C.c_uint32), ("params", SegParams), ("d_sig", SigSoa),
                 ("sig_cap", C.c_uint64), ("d_n_sig", C.c_void_p), ("d_segs", C.c_void_p), ("d_read_len", C.c_void_p),
                 ("d_raw", C.c_void_p), ("d_post", C.c_void_p), ("post_off", C.c_void_p), ("d_post_off", C.c_void_p),
-                ("d_post_cnt", C.c_void_p)]
+                ("d_post_cnt", C.c_void_p), ("d_chain_deal", C.c_void_p), ("n_chain_blocks", C.c_uint32)]
 
 
 class CollectOut(C.Structure):
@@ -148,6 +148,7 @@ SYMBOLS = {
     "svx_segments_rows_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]),
     "svx_collect_batch": (C.c_int, [_P, C.POINTER(CollectIn), C.POINTER(CollectOut)]),
     "svx_collect_batch_dev": (C.c_int, [_P, C.POINTER(CollectDev)]),
+    "svx_chain_deal": (C.c_int, [_P, C.c_uint32, _P, _P, _P]),
     "svx_linkage_cut_batch_dev": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_double, _P]),
     "svx_haplotype_distance_batch_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P]),
     "svx_pair_partition": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32)]),

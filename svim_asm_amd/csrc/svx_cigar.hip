@@ -251,6 +251,9 @@ struct WalkOut {
     uint32_t tail_r, tail_d;  // cursor sums since the last alignment start inside the lane (or lane start)
     uint32_t n_emit;          // emitting ops of this lane
     uint32_t n_queued;        // wave-uniform: signatures queued this round (WALK_QUEUE)
+#ifdef SVX_EXP_OPSET
+    uint32_t opset;
+#endif
 };
 
 // Everything WALK_DIRECT needs to finish a signature on the spot.  The alignment index is carried along the
@@ -290,6 +293,9 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
 #ifdef SVX_EXP_NOWALK  // perf experiment only: memory + scan floor without the per-op work
     { const uint4 v = myx[swz]; WalkOut o; o.tot_r = v.x; o.tot_d = v.y; o.tail_r = v.z; o.tail_d = v.w; o.n_emit = 0; o.n_queued = 0; return o; }
 #endif
+#ifdef SVX_EXP_OPSET
+    uint32_t opset = 0;
+#endif
     uint4 nxt = myx[swz];
 #pragma unroll 1
     for (int j = 0; j < kLU; ++j) {
@@ -302,6 +308,9 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
             uint32_t op, len;
             if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
             else { op = wv[t] & 15u; len = wv[t] >> 4; }
+#ifdef SVX_EXP_OPSET
+            if (WALK == WALK_QUEUE && !SOA) opset |= 1u << (wv[t] & 31u);
+#endif
             if (__builtin_expect(((hu4 >> t) & 1u) != 0u, 0)) {  // scalar test: some lane starts an alignment at this slot
                 asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch, not two selects per op
                 if ((hm4 >> t) & 1u) {
@@ -376,6 +385,9 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
     o.tail_d = rd - base_d;
     o.n_emit = n_emit;
     o.n_queued = qn;
+#ifdef SVX_EXP_OPSET
+    o.opset = opset;
+#endif
     return o;
 }
 
@@ -511,6 +523,9 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         obase = in.obase;
     }
 
+#ifdef SVX_EXP_OPSET
+    uint32_t exp_keep = 0;
+#endif
     for (int round = 0; round < kRounds; ++round) {
         const uint32_t ro = (uint32_t)round * kRoundOps;
         if (ro >= tile_len) break;  // wave-uniform
@@ -560,6 +575,13 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         const WalkOut wo = (!SOA && fast24) ? walk16<kWalk1, SOA, !SOA>(p, myx, swz, opw, hm, HU, lane, queue, dc)
                                             : walk16<kWalk1, SOA, false>(p, myx, swz, opw, hm, HU, lane, queue, dc);
 
+#ifdef SVX_EXP_OPSET
+        if (MODE == MODE_STAGE) {
+            const uint64_t odd = __builtin_amdgcn_ballot_w64((wo.opset & 0x00380038u) != 0u);
+            if (lane == round) exp_keep = (uint32_t)odd;
+            if (lane == round + 4) exp_keep = (uint32_t)(odd >> 32);
+        }
+#endif
         SVX_PROF_T(t_r2);
         SVX_PROF_ADD(2, t_r2 - t_r1);  // walk
         // ---- wave scans (DPP).  Plain inclusive sums of the lane totals, signature counts and
@@ -671,6 +693,10 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     }
     const uint4 dsc = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31), carry_r, carry_d, a_lo);
     if (MODE == MODE_STAGE && lane == 0) p.desc[tile] = dsc;
+#ifdef SVX_EXP_OPSET
+    // (experiment: the four rounds' masks go to the tile's last two slab records)
+    if (MODE == MODE_STAGE && lane < 8) __builtin_nontemporal_store(exp_keep, reinterpret_cast<uint32_t*>(p.slab + (uint64_t)tile * kSlab + kSlab - 2) + lane);
+#endif
     return dsc;  // wave-uniform
 }
 
@@ -1089,60 +1115,6 @@ __device__ __forceinline__ AlnStats lane_alignment_stats(const uint32_t (&w)[kTi
     return r;
 }
 
-// ... and for ONE long alignment by the whole workgroup (256 threads, kStatLoads loads in flight per thread): a
-// chimeric read's primary is a whole assembly contig — 10^4 to 10^6 ops.  s_part: 4 x 4 words of LDS.
-__device__ __forceinline__ AlnStats block_alignment_stats(const uint32_t* cigar, const uint64_t b, const uint64_t e, const int tid,
-                                                          uint32_t* s_part) {
-    const int lane = tid & 63, wave = tid >> 6;
-    // (the first 64 words, for the clip prefix below: requested now, so that the prefix costs no round trip of its own)
-    const uint32_t w_first = (b + (uint64_t)lane < e) ? cigar[b + lane] : 0u;
-    uint32_t ref = 0, qal = 0, rl = 0, hard = 0;
-    for (uint64_t i0 = b; i0 < e; i0 += kStatLoads * 256) {
-        uint32_t w[kStatLoads];
-#pragma unroll
-        for (int k = 0; k < kStatLoads; ++k) {
-            const uint64_t i = i0 + (uint64_t)k * 256 + tid;
-            w[k] = i < e ? cigar[i] : 0xFu;  // op 15: counts for nothing
-        }
-#pragma unroll
-        for (int k = 0; k < kStatLoads; ++k) {
-            const uint32_t op = w[k] & 15u, len = w[k] >> 4;
-            if ((0x18Du >> op) & 1u) ref += len;
-            if ((0x183u >> op) & 1u) qal += len;
-            if ((0x1B3u >> op) & 1u) rl += len;
-            if (op == 5u) hard += len;
-        }
-    }
-    ref = wave_sum(ref); qal = wave_sum(qal); rl = wave_sum(rl); hard = wave_sum(hard);
-    __syncthreads();  // s_part may still be read from the call before
-    if (lane == 0) { s_part[wave * 4 + 0] = ref; s_part[wave * 4 + 1] = qal; s_part[wave * 4 + 2] = rl; s_part[wave * 4 + 3] = hard; }
-    __syncthreads();
-    AlnStats r;
-    r.ref = s_part[0] + s_part[4] + s_part[8] + s_part[12];
-    r.qal = s_part[1] + s_part[5] + s_part[9] + s_part[13];
-    r.rl = s_part[2] + s_part[6] + s_part[10] + s_part[14];
-    r.hard = s_part[3] + s_part[7] + s_part[11] + s_part[15];
-    // leading soft clips: a prefix of the ops; every wave computes it redundantly (no further exchange)
-    uint32_t lead = 0;
-    {
-        uint64_t i = b;
-        bool done = false;
-        while (!done && i < e) {
-            const uint64_t j = i + lane;
-            const uint32_t w = i == b ? w_first : ((j < e) ? cigar[j] : 0u);
-            const uint32_t op = w & 15u;
-            const bool clip = (j < e) && (op == 4u || op == 5u);
-            const uint64_t nb = __ballot(!clip);
-            const int first = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
-            lead += wave_sum((lane < first && op == 4u && j < e) ? (w >> 4) : 0u);
-            done = first < 64;
-            i += 64;
-        }
-    }
-    r.lead = lead;
-    return r;
-}
-
 __global__ __launch_bounds__(256) void k_cigar_stats(StatsArgs p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t a = blockIdx.x * 4 + wave; a < p.n_aln; a += gridDim.x * 4) {
@@ -1224,32 +1196,37 @@ struct A3Args {
     svx_seg_dev::SegArgs tree;
     svx_post_dev::PostArgs post;
     uint32_t reads_per_block;
+    const uint32_t* deal;  // nullable: {first read, first segment} per workgroup of the rows + tree stage, n_deal + 1 entries
+    uint32_t n_deal;
 };
 
 enum { A3_ROWS_TREE = 1, A3_POST = 2 };
 
-// Rows of the alignments beyond kTinyOps: the workgroup cuts them into CHUNKS of kChunkOps ops (kStatLoads words per
-// lane of a 16-lane group), lists the chunks in LDS and deals the list out to its sixteen groups in contiguous,
-// equally long ranges — every group is busy for the same number of steps whatever the sizes are, and a long alignment
-// is shared by several groups.  A group keeps its sums in registers while consecutive chunks belong to one alignment
-// and adds them to the alignment's LDS accumulators when that changes.
-constexpr int kChunkOps = kStatLoads * 16;            // 128
-constexpr int kLongOps = 2048;                        // up to here: chunks; beyond: the whole workgroup, 2048 ops per round trip
-constexpr int kChunksPerAln = kLongOps / kChunkOps;   // 16
-// (The round's first version went by size classes — sixteen lanes per alignment up to 512 ops, four alignments side by
-// side per wave; a wave per alignment up to 8192, one after the other — and was bound by VALU issue at about 30 % lane
-// utilisation: four alignments side by side run for the longest of them, and a workgroup waits for the wave with the
-// most long ones.  k_finish_a3 on the cohort of 256 samples: 74.8 us by classes, 53.5 us by chunks;
-// profiles/r04_ab_chain_rows.txt.)
-constexpr int kLongList = 60;
+// Rows of the alignments beyond kTinyOps: the workgroup cuts them into CHUNKS of kChunkOps ops (kChunkX4 16-byte loads
+// per lane of a 16-lane group), numbers the chunks of its batch of 256 segments by an exclusive scan and deals the
+// numbers out to its sixteen groups in contiguous, equally long ranges — every group is busy for the same number of
+// steps whatever the sizes are, and a long alignment (of ANY length: there is no size class above this one) is shared
+// by several groups.  A group finds the segment of its first chunk by a binary search of the scan in LDS and walks on
+// from there; it keeps its sums in registers while consecutive chunks belong to one alignment and adds them to the
+// alignment's LDS accumulators when that changes.
+#ifndef SVX_CHUNK_X4
+#define SVX_CHUNK_X4 2
+#endif
+#ifndef SVX_A3_NT
+#define SVX_A3_NT 0
+#endif
+constexpr int kChunkX4 = SVX_CHUNK_X4;       // 16-byte loads per lane and step
+constexpr int kChunkOps = 64 * kChunkX4;     // 16 lanes x 4 words x kChunkX4 = 128
+// (Round 4: one word per load, 14 VALU per word, a materialised chunk list in LDS and alignments beyond 2048 ops walked
+// by the whole workgroup one at a time — 17.6 of the chain's 44.5 us on the cohort of 256 samples went to those 1.2 %
+// of the primaries, because reads were dealt 32 per workgroup whatever their sizes.  Before that, size classes:
+// k_finish_a3 74.8 us by classes, 53.5 us by chunks; profiles/r04_ab_chain_rows.txt.)
 struct A3Lds {
-    uint32_t n_long, long_list[kLongList], part[16];
-    uint32_t long_b_lo[kLongList], long_b_hi[kLongList], long_e_lo[kLongList], long_e_hi[kLongList];  // their op ranges
-    uint32_t n_chunks;
+    uint32_t wsum[4];
     uint32_t open[8];              // bit per slot: the whole first chunk was clips (the owner then walks the prefix itself)
     uint32_t cb_lo[256], cb_hi[256], n_ops[256];   // per slot = thread of the batch of 256 segments
-    uint32_t acc[5][256];          // lead, ref, qal, rl, hard
-    uint16_t chunk[256 * kChunksPerAln];           // slot | chunk number << 8
+    uint32_t cpre[257 + 3];        // exclusive scan of the slots' chunk counts; [256] = their number
+    uint32_t acc[4][256];          // lead, ref, qal, rl
 };
 
 // sum over an aligned row of 16 lanes, every lane gets it (four DPP adds)
@@ -1261,30 +1238,45 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += dpp0<kDppShr1, 0xF>(v); v += dpp0<kDppShr2, 0xF>(v); v += dpp0<kDppShr4, 0xF>(v); v += dpp0<kDppShr8, 0xF>(v);
+    v += dpp0<kDppBcast15, 0xA>(v); v += dpp0<kDppBcast31, 0xC>(v);
+    return v;
+}
+
+// four consecutive CIGAR words at any word address (a global 16-byte load only needs dword alignment)
+typedef uint32_t u32x4_dw __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int STAGES>
 __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t blk, A3Lds* lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_reads = a.rows.n_reads;
-    const uint32_t per = (STAGES & A3_ROWS_TREE) ? a.reads_per_block : 256u;  // the post-passes: one lane per read
-    const uint32_t r_lo = blk * per;
-    if (r_lo >= n_reads) return;
-    const uint32_t r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
+    uint32_t r_lo, r_hi, j_lo = 0, j_hi = 0;
+    const bool dealt = (STAGES & A3_ROWS_TREE) && a.deal != nullptr;
+    if (dealt) {  // the caller's table: {first read, first segment} of every workgroup, equal op counts (svx_chain_deal)
+        const uint2 d0 = *reinterpret_cast<const uint2*>(a.deal + 2 * (size_t)blk);
+        const uint2 d1 = *reinterpret_cast<const uint2*>(a.deal + 2 * (size_t)blk + 2);
+        r_lo = d0.x; j_lo = d0.y; r_hi = d1.x; j_hi = d1.y;
+        if (r_hi > n_reads) r_hi = n_reads;  // (a table is the caller's: nothing beyond the submission is indexed)
+        if (j_hi > a.rows.n_segs) j_hi = a.rows.n_segs;
+        if (r_lo >= r_hi || j_lo > j_hi) return;
+    } else {
+        const uint32_t per = (STAGES & A3_ROWS_TREE) ? a.reads_per_block : 256u;  // the post-passes: one lane per read
+        r_lo = blk * per;
+        if (r_lo >= n_reads) return;
+        r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
+    }
     if (STAGES & A3_ROWS_TREE) {
         // ---- rows.  One THREAD per segment fetches the segment's CIGAR range; tiny alignments (SA-derived: S M S)
-        // are finished by that lane, the others go through the chunk list (above), and alignments beyond kLongOps (a
-        // primary can be a whole assembly contig) are walked by the whole workgroup, one at a time.
-        uint32_t* s_part = lds->part;
+        // are finished by that lane, the others go through the chunks (above).
         const SegRowArgs& p = a.rows;
-        const uint32_t j_lo = p.read_off[r_lo], j_hi = p.read_off[r_hi];
-        if (tid == 0) lds->n_long = 0;
-        if (tid == 0) lds->n_chunks = 0;
+        if (!dealt) { j_lo = p.read_off[r_lo]; j_hi = p.read_off[r_hi]; }
         if (tid < 8) lds->open[tid] = 0;
         // the tree's own read_off words, requested now: one round trip less behind the rows
         const uint32_t r_tree = r_lo + (uint32_t)tid / svx_seg_dev::kGroup;
         uint32_t tree_b = 0, tree_e = 0;
         if (r_tree < r_hi) { tree_b = p.read_off[r_tree]; tree_e = p.read_off[r_tree + 1]; }
-        __syncthreads();
         const int gl = lane & 15;
         const int gid = __builtin_amdgcn_readfirstlane(wave) * 4 + (lane >> 4);  // group of sixteen lanes in the workgroup
         const int gshift = lane & ~15;
@@ -1298,28 +1290,20 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
                 ce = p.aln_off[src + 1];
             }
             const uint64_t n = ce - cb;
-            const bool tiny = live && n <= (uint64_t)kTinyOps, huge = live && n > (uint64_t)kLongOps;
-            const bool chunked = live && !tiny && !huge;
+            const bool tiny = live && n <= (uint64_t)kTinyOps;
+            const bool chunked = live && !tiny;
             uint32_t tw[kTinyOps];
             lane_alignment_load(p.cigar, cb, tiny ? (uint32_t)n : 0u, tw);
-            if (huge) {  // noted for the whole workgroup, with its op range (two round trips less per alignment later)
-                const uint32_t at = atomicAdd(&lds->n_long, 1u);
-                if (at < (uint32_t)kLongList) {
-                    lds->long_list[at] = j;
-                    lds->long_b_lo[at] = (uint32_t)cb; lds->long_b_hi[at] = (uint32_t)(cb >> 32);
-                    lds->long_e_lo[at] = (uint32_t)ce; lds->long_e_hi[at] = (uint32_t)(ce >> 32);
-                }
-            }
+            const uint32_t nch = chunked ? (uint32_t)((n + (uint64_t)kChunkOps - 1u) / (uint64_t)kChunkOps) : 0u;
             if (chunked) {
                 lds->cb_lo[tid] = (uint32_t)cb;
                 lds->cb_hi[tid] = (uint32_t)(cb >> 32);
                 lds->n_ops[tid] = (uint32_t)n;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) lds->acc[q][tid] = 0;
-                const uint32_t nch = ((uint32_t)n + (uint32_t)kChunkOps - 1u) / (uint32_t)kChunkOps;
-                const uint32_t at = atomicAdd(&lds->n_chunks, nch);
-                for (uint32_t c = 0; c < nch; ++c) lds->chunk[at + c] = (uint16_t)((uint32_t)tid | (c << 8));
+                for (int q = 0; q < 4; ++q) lds->acc[q][tid] = 0;
             }
+            const uint32_t incl = wave_incl_scan(nch);
+            if (lane == 63) lds->wsum[wave] = incl;
             if (tiny) {
                 const AlnStats st = lane_alignment_stats(tw, (uint32_t)n);
                 p.segs[j] = segment_row(p, j, st);
@@ -1327,71 +1311,126 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
             }
             __syncthreads();
             {
+                uint32_t pre = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) pre += w2 < wave ? lds->wsum[w2] : 0u;
+                lds->cpre[tid] = pre + incl - nch;
+                if (tid == 255) lds->cpre[256] = pre + incl;
+            }
+            __syncthreads();
+            {
 #ifdef SVX_EXP_A3_NOCHUNK  // timing ablation: wrong rows
                 const uint32_t total = 0;
 #else
-                const uint32_t total = lds->n_chunks;
+                const uint32_t total = lds->cpre[256];
 #endif
                 const uint32_t per_group = (total + 15u) / 16u;
-                const uint32_t c_lo = (uint32_t)gid * per_group;
+                const uint32_t c_lo = (uint32_t)gid * per_group < total ? (uint32_t)gid * per_group : total;
                 const uint32_t c_hi = c_lo + per_group < total ? c_lo + per_group : total;
-                uint32_t cur = ~0u;  // group-uniform: the slot the register sums belong to
-                uint32_t lead = 0, ref = 0, qal = 0, rl = 0, hard = 0;
-                uint64_t cbv = 0;
-                uint32_t nv = 0;
-                for (uint32_t c = c_lo;; ++c) {  // group-uniform; one step past the end: the last flush
-                    const bool more = c < c_hi;
-                    const uint32_t ent = more ? (uint32_t)lds->chunk[c] : 0u;
-                    const uint32_t slot = more ? (ent & 255u) : ~0u;
-                    if (slot != cur) {
-                        if (cur != ~0u) {
-                            lead = row16_sum(lead); ref = row16_sum(ref); qal = row16_sum(qal); rl = row16_sum(rl); hard = row16_sum(hard);
+                if (c_lo < c_hi) {  // group-uniform from here on
+                    // the slot of the group's first chunk: the smallest s with cpre[s + 1] > c_lo
+                    uint32_t slot = 0;
+                    {
+                        uint32_t lo = 0, hi = 255;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (lds->cpre[mid + 1] > c_lo) hi = mid; else lo = mid + 1u;
+                        }
+                        slot = lo;
+                    }
+                    uint32_t s_beg = lds->cpre[slot], s_end = lds->cpre[slot + 1];
+                    uint32_t nv = lds->n_ops[slot];
+                    const uint32_t* src = p.cigar + (((uint64_t)lds->cb_hi[slot] << 32) | lds->cb_lo[slot]);
+                    uint32_t lead = 0, ref = 0, qal = 0, rl = 0;
+                    for (uint32_t c = c_lo;; ++c) {
+                        const bool more = c < c_hi;
+                        if (!more || c >= s_end) {  // the sums leave for the slot's accumulators
+                            lead = row16_sum(lead); ref = row16_sum(ref); qal = row16_sum(qal); rl = row16_sum(rl);
                             if (gl == 0) {
-                                if (lead) atomicAdd(&lds->acc[0][cur], lead);
-                                atomicAdd(&lds->acc[1][cur], ref);
-                                atomicAdd(&lds->acc[2][cur], qal);
-                                atomicAdd(&lds->acc[3][cur], rl);
-                                if (hard) atomicAdd(&lds->acc[4][cur], hard);
+                                if (lead) atomicAdd(&lds->acc[0][slot], lead);
+                                atomicAdd(&lds->acc[1][slot], ref);
+                                atomicAdd(&lds->acc[2][slot], qal);
+                                atomicAdd(&lds->acc[3][slot], rl);
                             }
-                        }
-                        if (more) {
-                            cur = slot;
-                            lead = ref = qal = rl = hard = 0;
-                            cbv = ((uint64_t)lds->cb_hi[slot] << 32) | lds->cb_lo[slot];
+                            if (!more) break;
+                            do { ++slot; s_end = lds->cpre[slot + 1]; } while (c >= s_end);  // (slots without chunks are skipped)
+                            s_beg = lds->cpre[slot];
                             nv = lds->n_ops[slot];
+                            src = p.cigar + (((uint64_t)lds->cb_hi[slot] << 32) | lds->cb_lo[slot]);
+                            lead = ref = qal = rl = 0;
                         }
-                    }
-                    if (!more) break;
-                    const uint32_t ci = ent >> 8;
-                    const uint32_t rel0 = ci * (uint32_t)kChunkOps + (uint32_t)gl;
-                    const uint32_t* src = p.cigar + cbv + rel0;
-                    uint32_t w[kStatLoads];
+                        const uint32_t ci = c - s_beg;
+                        const uint32_t rel0 = ci * (uint32_t)kChunkOps + (uint32_t)gl * 4u;
+                        // position order inside a chunk: load k, lane, word — every load of the group is 256 contiguous bytes
+                        uint32_t w[kChunkX4][4];
 #pragma unroll
-                    for (int k = 0; k < kStatLoads; ++k) w[k] = rel0 + (uint32_t)(k * 16) < nv ? src[k * 16] : 0xFu;  // op 15: counts for nothing
-#pragma unroll
-                    for (int k = 0; k < kStatLoads; ++k) {
-                        // one bit of a 16-entry table per sum, as a mask (v_bfe_i32 takes its offset from the low five
-                        // bits: the table twice, the lowest length bit picks either copy)
-                        const uint32_t len = w[k] >> 4, sel = w[k] & 31u;
-                        ref += len & (uint32_t)__builtin_amdgcn_sbfe(0x018D018D, sel, 1);   // M D N = X
-                        qal += len & (uint32_t)__builtin_amdgcn_sbfe(0x01830183, sel, 1);   // M I = X
-                        rl += len & (uint32_t)__builtin_amdgcn_sbfe(0x01B301B3, sel, 1);    // M I S H = X
-                        hard += len & (uint32_t)__builtin_amdgcn_sbfe(0x00200020, sel, 1);  // H
-                    }
-                    if (ci == 0) {  // the prefix of clips: position order k, lane
-                        bool open = true;
-#pragma unroll
-                        for (int k = 0; k < kStatLoads; ++k) {
-                            if (open) {
-                                const uint32_t op = w[k] & 15u;
-                                const uint32_t nb = (uint32_t)(__ballot(!(op == 4u || op == 5u)) >> gshift) & 0xFFFFu;
-                                const int first = nb ? __ffs((int)nb) - 1 : 16;
-                                if (gl < first && op == 4u) lead += w[k] >> 4;
-                                open = nb == 0;
+                        for (int k = 0; k < kChunkX4; ++k) {
+                            const uint32_t rel = rel0 + (uint32_t)(k * 64);
+                            w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0xFu;  // op 15: counts for nothing, ends the clip prefix
+                            if (rel < nv) {
+                                const uint32_t rem = nv - rel;
+                                if (rem >= 4u) {
+#if SVX_A3_NT
+                                    const u32x4_dw v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_dw*>(src + rel));
+#else
+                                    const u32x4_dw v = *reinterpret_cast<const u32x4_dw*>(src + rel);
+#endif
+                                    w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
+                                } else {  // the alignment's last words (nothing behind them is read)
+                                    w[k][0] = src[rel];
+                                    if (rem > 1u) w[k][1] = src[rel + 1];
+                                    if (rem > 2u) w[k][2] = src[rel + 2];
+                                }
                             }
                         }
-                        // (words behind the end read as op 15 and close the prefix: still open = 128 clips and more ops)
-                        if (open && gl == 0) atomicOr(&lds->open[cur >> 5], 1u << (cur & 31u));
+                        // one bit of a 16-entry table per sum and word (v_bfe takes its offset from the word's low five
+                        // bits: the table twice, the lowest length bit picks either copy), one 24-bit multiply-add each
+                        uint32_t t_ref = 0, t_qal = 0, t_rl = 0, any = 0;
+#pragma unroll
+                        for (int k = 0; k < kChunkX4; ++k)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const uint32_t x = w[k][t], len = x >> 4;
+                                any |= x;
+                                t_ref += __umul24(len, __builtin_amdgcn_ubfe(0x018D018Du, x, 1));   // M D N = X
+                                t_qal += __umul24(len, __builtin_amdgcn_ubfe(0x01830183u, x, 1));   // M I = X
+                                t_rl += __umul24(len, __builtin_amdgcn_ubfe(0x01B301B3u, x, 1));    // M I S H = X
+                            }
+                        if (__builtin_expect(__ballot((any >> 28) != 0u) != 0ull, 0)) {  // a length of 2^24 or more: no multiply
+                            t_ref = t_qal = t_rl = 0;
+#pragma unroll
+                            for (int k = 0; k < kChunkX4; ++k)
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    const uint32_t x = w[k][t], len = x >> 4;
+                                    t_ref += len & (uint32_t)__builtin_amdgcn_sbfe(0x018D018D, x, 1);
+                                    t_qal += len & (uint32_t)__builtin_amdgcn_sbfe(0x01830183, x, 1);
+                                    t_rl += len & (uint32_t)__builtin_amdgcn_sbfe(0x01B301B3, x, 1);
+                                }
+                        }
+                        ref += t_ref; qal += t_qal; rl += t_rl;
+                        if (ci == 0) {  // the prefix of clips (S ops before the first op that is neither S nor H)
+                            bool open = true;
+#pragma unroll
+                            for (int k = 0; k < kChunkX4; ++k) {
+                                if (open) {
+                                    // inside the lane's four words: the clips in front, and the S lengths among them
+                                    uint32_t pfx = 1u, spre = 0;
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) {
+                                        const uint32_t x = w[k][t];
+                                        pfx &= __builtin_amdgcn_ubfe(0x00300030u, x, 1);                          // S H
+                                        spre += (x >> 4) & (0u - (pfx & __builtin_amdgcn_ubfe(0x00100010u, x, 1)));  // S
+                                    }
+                                    const uint32_t nb = (uint32_t)(__ballot(pfx == 0u) >> gshift) & 0xFFFFu;  // lanes whose four words end the prefix
+                                    const int first = nb ? __ffs((int)nb) - 1 : 16;
+                                    if (gl <= first) lead += spre;
+                                    open = nb == 0;
+                                }
+                            }
+                            // (words behind the end read as op 15 and close the prefix: still open = a whole chunk of clips)
+                            if (open && gl == 0) atomicOr(&lds->open[slot >> 5], 1u << (slot & 31u));
+                        }
                     }
                 }
             }
@@ -1399,13 +1438,14 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
             if (chunked) {
                 AlnStats st;
                 st.lead = lds->acc[0][tid]; st.ref = lds->acc[1][tid]; st.qal = lds->acc[2][tid]; st.rl = lds->acc[3][tid];
-                st.hard = lds->acc[4][tid];
+                st.hard = 0;
                 if ((lds->open[tid >> 5] >> (tid & 31)) & 1u) {  // S ops before the first op that is neither S nor H, by this lane
                     st.lead = 0;
-                    for (uint64_t i = cb; i < ce; ++i) {
-                        const uint32_t w = p.cigar[i], op = w & 15u;
+                    const uint64_t b2 = ((uint64_t)lds->cb_hi[tid] << 32) | lds->cb_lo[tid], e2 = b2 + lds->n_ops[tid];
+                    for (uint64_t i = b2; i < e2; ++i) {
+                        const uint32_t x = p.cigar[i], op = x & 15u;
                         if (op != 4u && op != 5u) break;
-                        if (op == 4u) st.lead += w >> 4;
+                        if (op == 4u) st.lead += x >> 4;
                     }
                 }
                 p.segs[j] = segment_row(p, j, st);
@@ -1413,37 +1453,7 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
             }
             if (j0 + 256 < j_hi) {  // workgroup-uniform: another batch of segments
                 __syncthreads();
-                if (tid == 0) lds->n_chunks = 0;
                 if (tid < 8) lds->open[tid] = 0;
-                __syncthreads();
-            }
-        }
-        __syncthreads();
-        const uint32_t n_long = lds->n_long;
-        const uint32_t n_long_listed = n_long < (uint32_t)kLongList ? n_long : (uint32_t)kLongList;
-        for (uint32_t k = 0; k < n_long_listed; ++k) {  // workgroup-uniform
-            const uint32_t j = lds->long_list[k];
-            const uint64_t lb = ((uint64_t)lds->long_b_hi[k] << 32) | lds->long_b_lo[k];
-            const uint64_t le = ((uint64_t)lds->long_e_hi[k] << 32) | lds->long_e_lo[k];
-            const AlnStats st = block_alignment_stats(p.cigar, lb, le, tid, s_part);
-            if (tid == 0) {
-                p.segs[j] = segment_row(p, j, st);
-                a.seg_rl[j] = (int32_t)st.rl;
-            }
-        }
-        if (n_long > (uint32_t)kLongList) {  // more than the list holds: the rest wave by wave
-            for (uint32_t j = j_lo + wave; j < j_hi; j += 4) {
-                const uint32_t src = p.seg_src[j];
-                const uint64_t cb = p.aln_off[src], ce = p.aln_off[src + 1];
-                if (ce - cb <= (uint64_t)kLongOps) continue;
-                bool listed = false;
-                for (int q = 0; q < kLongList; ++q) listed = listed || lds->long_list[q] == j;
-                if (listed) continue;
-                const AlnStats st = wave_alignment_stats(p.cigar, cb, ce, lane);
-                if (lane == 0) {
-                    p.segs[j] = segment_row(p, j, st);
-                    a.seg_rl[j] = (int32_t)st.rl;
-                }
             }
         }
         __syncthreads();
@@ -1808,6 +1818,8 @@ void a3_fill(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, c
     //  step; the 533 reads of a diploid submission are better off with two: 25.9 vs 26.7 us)
     const uint32_t least = q.n_reads < 384u ? 1u : 2u;
     a->reads_per_block = per < least ? least : (per > SVX_A3_READS_MAX ? SVX_A3_READS_MAX : per);
+    a->deal = q.n_deal_blocks ? q.d_deal : nullptr;
+    a->n_deal = q.n_deal_blocks;
 }
 
 // a3 != nullptr: the split-segment chain of the same submission goes out with the CIGAR path — inside the tile and
@@ -1874,7 +1886,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     uint32_t n_a3_blocks = 0, n_post_blocks = 0;
     if (a3) {
         a3_fill(ctx, d_cigar_or_len, d_aln_off, *a3, a3->post_stride, &c);
-        n_a3_blocks = (a3->n_reads + c.reads_per_block - 1) / c.reads_per_block;
+        n_a3_blocks = c.deal ? c.n_deal : (a3->n_reads + c.reads_per_block - 1) / c.reads_per_block;
         n_post_blocks = (a3->n_reads + 255u) / 256u;
     }
 

@@ -68,6 +68,8 @@ extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
         return SVX_E_INVALID;
     }
     if (d->read_off[d->n_reads] != d->n_segs) return SVX_E_INVALID;
+    if (d->n_chain_blocks && (!d->d_chain_deal || d->n_chain_blocks > d->n_reads || (reinterpret_cast<uintptr_t>(d->d_chain_deal) & 7u)))
+        return SVX_E_INVALID;
     uint64_t stride = 0;
     int rc = svx_postpass_plan(ctx, d->read_off, d->n_reads, d->post_off, &stride);
     if (rc != SVX_OK) return rc;
@@ -80,6 +82,7 @@ extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
         q.d_contig_rank = d->d_contig_rank; q.n_contigs = d->n_contigs; q.params = d->params; q.d_segs = d->d_segs;
         q.d_read_len = d->d_read_len; q.d_raw = d->d_raw; q.d_post = d->d_post; q.d_post_off = d->d_post_off;
         q.d_post_cnt = d->d_post_cnt; q.post_stride = stride;
+        q.d_deal = d->n_chain_blocks ? d->d_chain_deal : nullptr; q.n_deal_blocks = q.d_deal ? d->n_chain_blocks : 0;
         return svx_cigar_extract_chain_dev(ctx, d->d_cigar, d->n_ops, d->d_aln_off, d->n_aln, d->d_ref_start, d->min_len,
                                            d->d_sig, d->sig_cap, d->d_n_sig, &q);
     }
@@ -94,6 +97,51 @@ extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
     if (rc != SVX_OK) return rc;
     return svx_segments_postpass_dev(ctx, d->d_raw, d->read_off, d->d_read_off, d->n_reads, d->d_contig_rank, d->n_contigs,
                                      &d->params, d->d_post, d->post_off, d->d_post_off, d->d_post_cnt);
+}
+
+// Reads per workgroup of the chain's rows + tree stage for a submission of n_reads (0: no table — svx_cigar.hip deals
+// one or two reads per workgroup itself): as many as keep the grid at about 2 000 workgroups — eight per CU, all
+// resident at once —, at most 32.
+static uint32_t chain_reads_per_block(uint32_t n_reads) {
+    if (n_reads < 384u) return 0;
+    const uint32_t per = n_reads / 1024u;
+    return per < 2u ? 2u : (per > 32u ? 32u : per);
+}
+
+extern "C" int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* seg_src, const uint64_t* aln_off,
+                              uint32_t* deal) {
+    if (!deal || (n_reads && (!read_off || !seg_src || !aln_off))) return SVX_E_INVALID;
+    const uint32_t per = chain_reads_per_block(n_reads);
+    if (per == 0) return 0;
+    const uint32_t n_blocks = (n_reads + per - 1) / per;
+    // cost of a read in ops: the chunks of its segments' CIGARs (svx_cigar.hip: kChunkOps = 128; alignments of at most
+    // 8 ops are finished by one lane), and what the read costs whatever its size (its row stores, its share of the tree)
+    constexpr uint64_t kChunk = 128, kPerRead = 96, kPerTiny = 8;
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        if (read_off[r + 1] < read_off[r]) return SVX_E_INVALID;
+        total += kPerRead;
+        for (uint32_t j = read_off[r]; j < read_off[r + 1]; ++j) {
+            const uint64_t n = aln_off[(size_t)seg_src[j] + 1] - aln_off[seg_src[j]];
+            total += n <= 8 ? kPerTiny : (n + kChunk - 1) / kChunk * kChunk;
+        }
+    }
+    // read r goes to workgroup floor(prefix(r) * n_blocks / total): consecutive ranges; a read that costs more than a
+    // workgroup's share leaves the workgroups it skips empty
+    uint64_t prefix = 0;
+    uint32_t next = 0;  // first workgroup without a start yet
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        uint32_t b = (uint32_t)((unsigned __int128)prefix * n_blocks / total);
+        if (b >= n_blocks) b = n_blocks - 1;
+        for (; next <= b; ++next) { deal[2 * next] = r; deal[2 * next + 1] = read_off[r]; }
+        prefix += kPerRead;
+        for (uint32_t j = read_off[r]; j < read_off[r + 1]; ++j) {
+            const uint64_t n = aln_off[(size_t)seg_src[j] + 1] - aln_off[seg_src[j]];
+            prefix += n <= 8 ? kPerTiny : (n + kChunk - 1) / kChunk * kChunk;
+        }
+    }
+    for (; next <= n_blocks; ++next) { deal[2 * next] = n_reads; deal[2 * next + 1] = read_off[n_reads]; }
+    return (int)n_blocks;
 }
 
 extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_collect_out* out) {
@@ -174,6 +222,7 @@ extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_col
     const size_t o_pos = cb.take((size_t)n_segs * 4), o_qe = cb.take((size_t)n_segs * 4);
     const size_t o_roff = cb.take(((size_t)n_reads + 1) * 4), o_rank = cb.take((size_t)in->n_contigs * 4);
     const size_t o_rev = cb.take(n_segs);
+    const size_t o_deal = cb.take(chain_reads_per_block(n_reads) ? ((size_t)n_reads + 2) * 8 : 0);
     const size_t cb_bytes = cb.at;
     // ---- results block on the device; its head (counts) and its body are read back separately
     Pack rb;
@@ -209,6 +258,11 @@ extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_col
     }
     if (n_reads) memcpy(h + o_roff, in->read_off, ((size_t)n_reads + 1) * 4);
     if (in->n_contigs) memcpy(h + o_rank, in->contig_rank, (size_t)in->n_contigs * 4);
+    int n_deal = 0;
+    if (chain_reads_per_block(n_reads)) {
+        n_deal = svx_chain_deal(in->read_off, n_reads, in->seg_src, h_off, reinterpret_cast<uint32_t*>(h + o_deal));
+        if (n_deal < 0) return n_deal;
+    }
 
     // ---- uploads: the pools where they lie (page-locked reader memory: true DMA), extra CIGARs, control block
     uint64_t at = 0;
@@ -237,6 +291,7 @@ extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_col
     dv.d_segs = d_segs; dv.d_read_len = d_read_len; dv.d_raw = reinterpret_cast<svx_raw*>(d_rb + r_raw);
     dv.d_post = reinterpret_cast<svx_post*>(d_rb + r_post); dv.post_off = out->post_off;
     dv.d_post_off = reinterpret_cast<const uint64_t*>(d_cb + o_poff); dv.d_post_cnt = reinterpret_cast<uint32_t*>(d_rb + r_cnt);
+    if (n_deal > 0) { dv.d_chain_deal = reinterpret_cast<const uint32_t*>(d_cb + o_deal); dv.n_chain_blocks = (uint32_t)n_deal; }
     rc = svx_collect_batch_dev(ctx, &dv);
     if (rc != SVX_OK) return rc;
 

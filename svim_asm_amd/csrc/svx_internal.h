@@ -96,6 +96,8 @@ struct svx_a3_plan {
     const uint64_t* d_post_off;
     uint32_t* d_post_cnt;
     uint64_t post_stride;
+    const uint32_t* d_deal;    // svx_collect_dev.d_chain_deal (nullable)
+    uint32_t n_deal_blocks;
 };
 // Validates the host copies of read_off / out_off like svx_segments_postpass_dev and returns the uniform scratch
 // slice size of the post-passes (0: the reads are too uneven for one size — take the separate launches).

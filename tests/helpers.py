@@ -459,3 +459,52 @@ def oracle_backed_device(monkeypatch):
     ctx = OracleBackedContext()
     monkeypatch.setattr(_svxlib(), "default_context", lambda device=0: ctx)
     return ctx
+
+
+# ---- COLLECT of one submission by the checker alone (tests/test_gpu_collect.py)
+_POST_CODE = {1: "TANDEM", 2: "DUP_INT", 3: "INV"}
+_POST_WIDTH = {"TANDEM": 5, "DUP_INT": 6, "INV": 4}
+
+
+def post_records_as_tuples(post, first):
+    """The packed derived records of svx_segments_postpass / svx_collect_batch as the tuples of
+    oracle/svim_oracle.postpass_records, one list per read."""
+    out = []
+    for r in range(len(first) - 1):
+        recs = []
+        for rec in post[int(first[r]):int(first[r + 1])]:
+            kind = _POST_CODE[int(rec["kind"])]
+            vals = [int(rec[n]) for n in ("a0", "a1", "a2", "a3", "a4", "a5")][:_POST_WIDTH[kind]]
+            if kind == "TANDEM":
+                vals[4] = bool(vals[4])
+            if kind == "INV":
+                vals[3] = bool(vals[3])
+            recs.append((kind,) + tuple(vals))
+        out.append(recs)
+    return out
+
+
+def oracle_collect(cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src, seg_tid, seg_pos, seg_rev,
+                   seg_qend, read_off, contig_rank, params):
+    """What svx_collect_batch must return, from the oracle only: signatures (orc.cigar_extract, SVIM_intra.py:8-44),
+    segment rows from the oracle's CIGAR statistics (orc.segment_rows, SVIM_inter.py:66-81), the decision tree
+    (orc.segments_classify, :83-258) and the record-level post-passes (svim_oracle.postpass_records, :260-338).
+    Returns (sig, raw, post tuples per read)."""
+    from oracle import orc, svim_oracle
+    cigar = np.concatenate(cigar_parts) if len(cigar_parts) else np.zeros(0, np.uint32)
+    sig = orc.cigar_extract(cigar, aln_off, ref_start, min_len)
+    n_reads = len(read_off) - 1 if len(read_off) else 0
+    if n_reads <= 0 or len(seg_src) == 0:
+        return sig, np.zeros(0, dtype=orc.RAW_DTYPE), [[] for _ in range(max(n_reads, 0))]
+    n_ops = int(aln_off[-1])
+    off_all = np.concatenate((np.asarray(aln_off, np.uint64), n_ops + np.asarray(extra_off, np.uint64)[1:])).astype(np.uint64)
+    st = orc.cigar_stats(np.concatenate((cigar, np.asarray(extra_cigar, np.uint32))), off_all)
+    segs, read_len = orc.segment_rows(st, seg_src, seg_tid, seg_pos, seg_rev, seg_qend, read_off)
+    raw = orc.segments_classify(segs, read_off, read_len, [int(x) for x in params])
+    post = []
+    rank = [int(x) for x in contig_rank]
+    for r in range(n_reads):
+        rows = [tuple(int(raw[j][n]) for n in ("kind", "a0", "a1", "a2", "a3", "a4", "a5"))
+                for j in range(int(read_off[r]), int(read_off[r + 1]))]
+        post.append(svim_oracle.postpass_records(rows, rank, int(params[0]), int(params[1])))
+    return sig, raw, post

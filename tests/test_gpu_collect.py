@@ -88,6 +88,17 @@ def same(a, b):
     assert np.array_equal(ra, rb) and np.array_equal(pa, pb) and np.array_equal(fa, fb)
 
 
+def same_as_oracle(got, exp):
+    """One submission against the ORACLE alone — signatures, the adjacency records of every segment slot (rows from
+    the oracle's CIGAR statistics, the oracle's decision tree) and the derived records of every read (the record-level
+    post-passes of oracle/svim_oracle.py) — not against another composition of this library's kernels."""
+    (sig, raw, post, first), (o_sig, o_raw, o_post) = got, exp
+    for k in o_sig:
+        assert np.array_equal(sig[k], o_sig[k]), k
+    assert np.array_equal(raw.view(np.int32).reshape(-1, 8), o_raw.view(np.int32).reshape(-1, 8))
+    assert helpers.post_records_as_tuples(post, first) == o_post
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_one_submission_equals_the_single_purpose_calls(svx_ctx, seed):
     rng = np.random.default_rng(100 + seed)
@@ -97,11 +108,7 @@ def test_one_submission_equals_the_single_purpose_calls(svx_ctx, seed):
         got = call(svx_ctx.collect_batch, b, min_len, params)
         exp = call(svx_ctx.collect_batch_composed, b, min_len, params)
         same(got, exp)
-        # and the oracle directly for the signatures (the composed calls have their own oracle tests)
-        cigar = np.concatenate(b["parts"]) if len(b["parts"]) > 1 else b["parts"][0]
-        o = orc.cigar_extract(cigar, b["aln_off"], b["ref_start"], min_len)
-        for k in o:
-            assert np.array_equal(got[0][k], o[k]), k
+        same_as_oracle(got, call(helpers.oracle_collect, b, min_len, params))
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -113,7 +120,96 @@ def test_submission_with_long_primaries(svx_ctx, seed):
                      long_read=seed % 2 == 1, long_aln=0.5, long_max=int(rng.choice([600, 9000])))
     svx_ctx.set_small_batch_ops(0 if seed >= 2 else 1 << 23)
     try:
-        same(call(svx_ctx.collect_batch, b), call(svx_ctx.collect_batch_composed, b))
+        got = call(svx_ctx.collect_batch, b)
+        same(got, call(svx_ctx.collect_batch_composed, b))
+        same_as_oracle(got, call(helpers.oracle_collect, b))
+    finally:
+        svx_ctx.set_small_batch_ops(1 << 23)
+
+
+def tiling_batch(rng, n_reads, n_contigs=3):
+    """Chimeric reads whose segments tile the read (gaps / overlaps of a few bases around the tolerances) and land
+    close to each other on few contigs, both strands: most adjacent pairs are a tandem duplication, an inversion, a
+    deletion / insertion or a breakend, so the three post-passes (SVIM_inter.py:260-338) have work — merged tandem runs,
+    mirrored breakend pairs, overlapping inversion groups.  A segment's CIGAR is S M S in the record's orientation (the
+    primary is a pool record with an indel inside, the others SA-derived)."""
+    words, ref_start, extra, seg_src, seg_tid, seg_pos, seg_rev, counts = [], [], [], [], [], [], [], []
+    for r in range(n_reads):
+        k = int(rng.integers(2, 7))
+        style = int(rng.integers(0, 4))  # 0 tandem-like, 1 inversion-like, 2 mirrored breakends, 3 anything
+        if style == 0:  # copies of one unit, one after the other on the read, all at (nearly) one reference position
+            cuts = int(rng.integers(0, 500)) + np.arange(k + 1) * int(rng.integers(300, 3000))
+        else:
+            cuts = np.sort(rng.integers(200, 20000, size=k + 1))
+        total = int(cuts[-1]) + int(rng.integers(0, 300))
+        tid0, base = int(rng.integers(0, n_contigs)), int(rng.integers(10_000, 1_000_000))
+        px = base
+        for i in range(k):
+            jitter = 8 if style == 0 else 60
+            qs = int(cuts[i]) + int(rng.integers(-jitter, jitter + 1)) if i else int(cuts[0])
+            qe = int(cuts[i + 1])
+            qs = min(max(qs, 0), qe - 1)
+            rev = {0: 0, 1: i % 2, 2: 0, 3: int(rng.random() < 0.4)}[style]
+            tid = tid0 if style != 2 else (tid0 + (i % 2)) % n_contigs
+            if style == 0:
+                pos = base + int(rng.integers(-6, 7)) + (0 if rng.random() < 0.85 else 5000)
+            elif style == 2:  # A (here) B (elsewhere) C (where A ended): the two breakends of an interspersed duplication
+                pos = px + int(rng.integers(-8, 9)) if i % 2 == 0 else int(rng.integers(10_000, 1_000_000))
+                px += (qe - qs) if i % 2 == 0 else 0
+            else:
+                pos = base + int(rng.integers(-3000, 3000))
+            m = qe - qs
+            lead, tail = (total - qe, qs) if rev else (qs, total - qe)
+            cig = [(lead << 4) | 4] if lead else []
+            if i == 0 and m > 100:  # the primary: a pool record with an insertion inside
+                cig += [((m - 60) << 4) | 0, (50 << 4) | 1, (10 << 4) | 0]
+            else:
+                cig += [(m << 4) | 0]
+            cig += [(tail << 4) | 4] if tail else []
+            w = np.array(cig, np.uint32)
+            if i == 0:
+                seg_src.append(len(words)); words.append(w); ref_start.append(pos)
+            else:
+                seg_src.append(-1 - len(extra)); extra.append(w)
+            seg_tid.append(tid); seg_pos.append(pos); seg_rev.append(rev)
+        counts.append(k)
+    # unrelated records between the primaries
+    order = rng.permutation(len(words) + n_reads // 2)
+    pool, pool_rs, where = [], [], {}
+    for slot in order.tolist():
+        if slot < len(words):
+            where[slot] = len(pool); pool.append(words[slot]); pool_rs.append(ref_start[slot])
+        else:
+            t = helpers.random_cigar(rng, int(rng.integers(1, 40)))
+            pool.append(np.array([(l << 4) | o for o, l in t], np.uint32)); pool_rs.append(int(rng.integers(0, 1 << 27)))
+    n_aln = len(pool)
+    src = np.array([where[x] if x >= 0 else n_aln + (-1 - x) for x in seg_src], np.uint32)
+    aln_off = np.concatenate(([0], np.cumsum([len(w) for w in pool]))).astype(np.uint64)
+    extra_off = np.concatenate(([0], np.cumsum([len(w) for w in extra]))).astype(np.uint64)
+    rank = np.array(sorted(range(n_contigs), key=lambda i: "chr%d" % (i * 7 + 1)), np.int32)
+    return dict(parts=[np.concatenate(pool)], aln_off=aln_off, ref_start=np.array(pool_rs, np.int32),
+                extra_cigar=np.concatenate(extra), extra_off=extra_off, seg_src=src, seg_tid=np.array(seg_tid, np.int32),
+                seg_pos=np.array(seg_pos, np.int32), seg_rev=np.array(seg_rev, np.uint8),
+                seg_qend=np.full(len(src), -1, np.int32), read_off=np.concatenate(([0], np.cumsum(counts))).astype(np.uint32),
+                rank=np.argsort(rank).astype(np.int32))
+
+
+@pytest.mark.parametrize("seed,streaming", [(0, False), (1, False), (2, True)])
+def test_tiling_reads_against_the_oracle(svx_ctx, seed, streaming):
+    """The whole chain of one submission — rows, decision tree AND post-passes with plenty of derived records —
+    against the oracle alone (no second kernel composition involved)."""
+    rng = np.random.default_rng(900 + seed)
+    b = tiling_batch(rng, n_reads=[300, 50, 900][seed])
+    svx_ctx.set_small_batch_ops(0 if streaming else 1 << 23)
+    try:
+        for params in (PARAMS, (40, 2000, 50, 50, 50, 50)):
+            got = call(svx_ctx.collect_batch, b, 40, params)
+            o = call(helpers.oracle_collect, b, 40, params)
+            same_as_oracle(got, o)
+            kinds = {t[0] for recs in o[2] for t in recs}
+            assert {"TANDEM", "INV", "DUP_INT"} <= kinds, kinds
+            n_tandem_raw = int((o[1]["kind"] == 4).sum())
+            assert sum(t[0] == "TANDEM" for recs in o[2] for t in recs) < n_tandem_raw  # runs were merged
     finally:
         svx_ctx.set_small_batch_ops(1 << 23)
 
@@ -125,7 +221,9 @@ def test_streaming_path_and_capacity_retry(svx_ctx):
     b = random_batch(rng, n_aln=4000, n_parts=2, n_reads=100)
     svx_ctx.set_small_batch_ops(0)
     try:
-        same(call(svx_ctx.collect_batch, b, 1), call(svx_ctx.collect_batch_composed, b, 1))
+        got = call(svx_ctx.collect_batch, b, 1)
+        same(got, call(svx_ctx.collect_batch_composed, b, 1))
+        same_as_oracle(got, call(helpers.oracle_collect, b, 1))
     finally:
         svx_ctx.set_small_batch_ops(1 << 23)
 
@@ -280,12 +378,15 @@ def _sized_cigar(rng, n, lead):
     return np.array([(l << 4) | o for o, l in ops], dtype=np.uint32)
 
 
+@pytest.mark.parametrize("deal", ["equal_counts", "table"])
 @pytest.mark.parametrize("streaming", [False, True])
-def test_chain_rows_across_alignment_sizes(svx_ctx, streaming):
+def test_chain_rows_across_alignment_sizes(svx_ctx, streaming, deal):
     """The rows of the fused chain against the oracle's CIGAR statistics for alignments around every size boundary of
-    the kernel (a lane up to 8 ops, chunks of 128 ops up to 2048, the whole workgroup beyond), with clip prefixes that
-    end inside the first word, run through the whole first chunk (128, 129, 300 clips) or are the whole alignment, one
-    read with several hundred segments (more than one batch of 256 per workgroup)."""
+    the kernel (a lane up to 8 ops, chunks of 128 ops shared by the sixteen groups of a workgroup beyond), with clip
+    prefixes that end inside the first word, run through the whole first chunk (128, 129, 300 clips) or are the whole
+    alignment, lengths of 2^24 and more (no 24-bit multiply), one read with several hundred segments (more than one
+    batch of 256 per workgroup); reads dealt to the workgroups in equal counts and by a caller's table
+    (d_chain_deal: random cuts, empty workgroups among them)."""
     rng = np.random.default_rng(77)
     sizes = [1, 2, 8, 9, 15, 16, 17, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 2047, 2048, 2049, 4095, 4096, 4097,
              8192, 8193, 20000, 70000]
@@ -295,6 +396,11 @@ def test_chain_rows_across_alignment_sizes(svx_ctx, streaming):
             words.append(_sized_cigar(rng, n, lead))
     for lead, n in ((127, 400), (128, 400), (129, 400), (300, 1000), (200, 200), (128, 128), (2048, 2048), (1500, 2049), (9, 9)):
         words.append(_sized_cigar(rng, n, lead))
+    for n in (9, 130, 700):  # lengths beyond 24 bits (the sums wrap modulo 2^32 on either side)
+        w = _sized_cigar(rng, n, 1)
+        at = rng.integers(0, n, size=3)
+        w[at] = (rng.integers(1 << 24, 1 << 28, size=3).astype(np.uint32) << 4) | (w[at] & 15)
+        words.append(w)
     n_aln = len(words)
     aln_off = np.concatenate(([0], np.cumsum([len(w) for w in words]))).astype(np.uint64)
     n_ops = int(aln_off[-1])
@@ -328,8 +434,7 @@ def test_chain_rows_across_alignment_sizes(svx_ctx, streaming):
     post_off = np.concatenate(([0], np.cumsum(slots * (slots + 3) // 2))).astype(np.uint64)
     # expectation: the oracle's statistics -> rows (host formula of the binding)
     st_all = orc.cigar_stats(cigar, off)
-    st = {k: st_all[k].astype(np.int64)[seg_src.astype(np.int64)] for k in ("ref_len", "q_start", "q_end", "read_len")}
-    exp_segs, exp_rl = _lib.segment_rows(st, seg_tid, seg_pos, seg_rev, seg_qend, read_off)
+    exp_segs, exp_rl = orc.segment_rows(st_all, seg_src, seg_tid, seg_pos, seg_rev, seg_qend, read_off)
     exp_sig = orc.cigar_extract(cigar[:n_ops], aln_off, ref_start, 40)
     ctx = svx_ctx
     ctx.set_small_batch_ops(0 if streaming else 1 << 23)
@@ -349,6 +454,12 @@ def test_chain_rows_across_alignment_sizes(svx_ctx, streaming):
                                  n_contigs=len(rank), params=_lib.SegParams(*PARAMS), d_sig=_lib.SigSoa(*[x.ptr for x in o[:5]]),
                                  sig_cap=cap, d_n_sig=o[5].ptr, d_segs=d_segs.ptr, d_read_len=d_rl.ptr, d_raw=d_raw.ptr,
                                  d_post=d_post.ptr, post_off=post_off.ctypes.data, d_post_off=d["poff"].ptr, d_post_cnt=d_cnt.ptr)
+            if deal == "table":  # consecutive reads per workgroup, cut anywhere; some workgroups get nothing
+                cuts = np.sort(rng.integers(0, n_reads + 1, size=40))
+                first = np.concatenate(([0], cuts, [n_reads, n_reads])).astype(np.uint32)
+                table = np.stack((first, read_off[first]), axis=1).astype(np.uint32).ravel()
+                d_deal = ctx.dev_array(table)
+                dv.d_chain_deal, dv.n_chain_blocks = d_deal.ptr, len(first) - 1
             ctx._check(ctx.lib.svx_collect_batch_dev(ctx.h, C.byref(dv)))
             ctx.sync()
             got = d_segs.download(np.int32).reshape(-1, 6)
@@ -358,7 +469,7 @@ def test_chain_rows_across_alignment_sizes(svx_ctx, streaming):
             n = int(o[5].download(np.uint64)[0])
             assert n == len(exp_sig["aln"])
             assert np.array_equal(o[1].download(np.uint32, n), exp_sig["ref_pos"])
-            raw = ctx.segments_classify(exp_segs, read_off, exp_rl, PARAMS)
+            raw = orc.segments_classify(exp_segs, read_off, exp_rl, PARAMS)
             assert np.array_equal(d_raw.download(np.int32).reshape(-1, 8), raw.view(np.int32).reshape(-1, 8))
     finally:
         ctx.set_small_batch_ops(1 << 23)
