@@ -170,7 +170,8 @@ def run_samples(n_procs, bams, fasta, out, n_devices, check):
     for d in dirs:
         path = os.path.join(d, "wd", "variants.vcf")
         oks.append(check(masked(path)) if os.path.exists(path) else False)
-    leg = {"processes": n_procs, "devices": min(n_procs, max(1, n_devices)), "wall_s": wall, "samples_per_s": n_procs / wall,
+    leg = {"processes": n_procs, "devices": min(n_procs, max(1, n_devices)), "process_device": [k % max(1, n_devices) for k in range(n_procs)],
+           "wall_s": wall, "samples_per_s": n_procs / wall,
            "process_wall_s": walls, "rc": rcs, "cpu_seconds_all_processes": (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime),
            "cpu_quota_cpus": cpu_quota(), "own_copies_of_the_inputs": copied, "vcf_matches_real_reference_digest": oks}
     if any(rcs):
