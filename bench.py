@@ -56,6 +56,10 @@ def parse():
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to smoke-test the "
                          "multi-rank logic on a box with fewer GPUs than ranks, together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses device 0")
+    ap.add_argument("--group-at-1", action="store_true",
+                    help="testing only: bring the process group up (rendezvous, communicator, probe all-reduce, the reductions "
+                         "and the gather of the rank records) even with ONE rank — the only way to run the nccl = RCCL path of "
+                         "this script on a 1-GPU box, where RCCL refuses two ranks on one device")
     ap.add_argument("--init-timeout", type=int, default=180, help="seconds the process group may take to come up (rendezvous + "
                     "first collective) before a rank gives up with exit status 3")
     ap.add_argument("--settle-ms", type=float, default=300.0, help="host idle time in front of the warm-up steps (lets the "
@@ -100,9 +104,9 @@ def device_identity(torch, dev):
     return out
 
 
-def gather_rank_records(dist, world, record):
+def gather_rank_records(dist, world, record, grouped=None):
     """Every rank's record, in rank order, on every rank (one all_gather_object over the default group)."""
-    if world == 1:
+    if not (world > 1 if grouped is None else grouped):
         return [record]
     out = [None] * world
     dist.all_gather_object(out, record)
@@ -112,7 +116,7 @@ def gather_rank_records(dist, world, record):
 RANK_RECORD_KEYS = ("rank", "local_rank", "device_index", "ms_per_step", "sustained_ms", "ops_per_step", "host", "pid")
 
 
-def multi_rank_fields(records, backend, probe_sum, world):
+def multi_rank_fields(records, backend, probe_sum, world, grouped=None):
     """The part of the line that lets a reader verify a --gpus N run without trusting the launcher: which backend, that
     the probe all-reduce really summed over N ranks, and per rank where it ran and how long ITS steps took (`value` uses
     the maximum).  Raises when a record is missing or incomplete — a line is never printed with holes."""
@@ -124,7 +128,7 @@ def multi_rank_fields(records, backend, probe_sum, world):
             raise RuntimeError("rank record %d incomplete or out of order: missing %s, rank %r" % (i, missing, r.get("rank")))
     devices = [(r["host"], r.get("device_uuid") or (r.get("device_pci_domain_id"), r.get("device_pci_bus_id"), r.get("device_pci_device_id"), r["device_index"]))
                for r in records]
-    return {"backend": backend if world > 1 else None, "collective_world_verified": int(probe_sum),
+    return {"backend": backend if (world > 1 if grouped is None else grouped) else None, "collective_world_verified": int(probe_sum),
             "ranks": records, "distinct_devices": len(set(devices))}
 
 
@@ -700,7 +704,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the two scalars are reduced
     probe_sum = 1
-    if world > 1:
+    grouped = world > 1 or args.group_at_1
+    if args.group_at_1 and world == 1:
+        import socket as _s
+        sk = _s.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        sk.close()
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import datetime
@@ -828,7 +839,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -885,7 +896,7 @@ def main():
         barrier()
         steady_elapsed = time.perf_counter() - t1
         own_steady_elapsed = steady_elapsed
-        if world > 1:
+        if grouped:
             t = torch.tensor([steady_elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             steady_elapsed = float(t.item())
@@ -912,7 +923,7 @@ def main():
     if n_sig > cap:
         raise SystemExit("output capacity too small: %d > %d" % (n_sig, cap))
 
-    if world > 1:
+    if grouped:
         t = torch.tensor(repeats, dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         repeats = [float(x) for x in t.tolist()]
@@ -927,7 +938,7 @@ def main():
     rank_record = dict(device_identity(torch, dev), rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")),
                        ms_per_step=own_elapsed / args.steps * 1e3, sustained_ms=own_steady_ms, ops_per_step=n_ops,
                        host=socket.gethostname(), pid=os.getpid(), shares_device_0=bool(args.share_device))
-    rank_fields = multi_rank_fields(gather_rank_records(dist, world, rank_record), args.backend, probe_sum, world)
+    rank_fields = multi_rank_fields(gather_rank_records(dist, world, rank_record, grouped), args.backend, probe_sum, world, grouped)
 
     # ---- roofline of the dominant kernel: HIP events on its launch stream around every launch of the step's own
     # sequence (context 0; the event pair brackets the kernel itself).  The dominant kernel of the step is the streaming
@@ -1079,7 +1090,7 @@ def main():
     # ranks leave — their GPUs are then free for the rank processes of the BAM -> VCF legs
     for c in ctxs + ([ctx2] if ctx2 is not None else []):
         c.sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
         if rank != 0:

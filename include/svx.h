@@ -66,11 +66,12 @@ int svx_device_count(void);
  * the svim-asm CLI — one BAM of an assembly (~1.5 M ops) or both haplotype BAMs of a diploid sample
  * (~6 M ops) per call —, where five dependent launches cost more than the work.  Larger batches take the
  * streaming path (tiles of 4096 ops, five launches).  Default and upper limit 2^23 ops; 0 disables the
- * small-batch path.  Results are identical on both. */
+ * small-batch path; larger values are clamped to 2^23.  Results are identical on both. */
 int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
 /* svx_collect_batch* send the split-segment chain of a submission (segment rows -> decision tree -> post-passes,
- * SVIM_inter.py:62-340) out as ONE kernel: inside the first launch of the small-batch CIGAR path, or as one launch
- * behind the streaming path.  on != 0 restores the single-purpose launches (svx_segments_rows_dev,
+ * SVIM_inter.py:62-340) out INSIDE the launches of the CIGAR path: rows and decision tree among the workgroups of the
+ * tile launch (two-launch path) or of the finish launch (streaming path), the post-passes among the workgroups of
+ * the path's last launch.  on != 0 restores the single-purpose launches (svx_segments_rows_dev,
  * svx_segments_classify_dev, svx_segments_postpass_dev behind svx_cigar_extract_dev) — same results; kept for
  * comparison and for submissions whose reads are too uneven for one scratch slice size, which take it by
  * themselves.  Default off. */
@@ -473,12 +474,14 @@ int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* s
  *   d_in                 compressed payloads (the bytes between a member's header and its 8-byte trailer), anywhere
  *                        in one buffer: member m is d_in[d_in_off[m] .. + d_in_len[m]); the buffer must be readable 3 bytes
  *                        past the end of any member (input words are fetched whole)
- *   d_isize, d_crc       the trailer's ISIZE (<= 65536) and CRC32 of every member
+ *   d_isize, d_crc       the trailer's ISIZE and CRC32 of every member; a member whose ISIZE exceeds 65536 (no BGZF
+ *                        member can) is not decoded: status 2, nothing written
  *   d_out, d_out_off     member m's bytes are written to d_out[d_out_off[m] .. + d_isize[m]); the stretches must be
  *                        separated by at least 8 bytes (and d_out end 8 bytes behind the last one): match copies move
  *                        whole 8-byte words and may touch up to 7 bytes behind a member's end
  *   d_status             per member: 0 ok; 1 malformed stream; 2 length != ISIZE; 3 CRC32 mismatch; 4 input ended early.
- *                        Nothing outside a member's own input and output stretch is ever read or written.
+ *                        The two paddings above are the only bytes outside a member's own input and output stretch that
+ *                        are ever read (3 behind the input) or written (7 behind the output).
  * Asynchronous on the context's stream.
  */
 int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,

@@ -41,6 +41,11 @@ def main(argv=None):
         return 2
     mode, manifest, genome, rest = argv[0], argv[1], argv[2], argv[3:]
     n_bams = 2 if mode == "diploid" else 1
+    if shard.world()[1] > 1:
+        # one process = one cohort: under a launcher every rank would collect everything and write the same files
+        print("svim-asm-cohort runs as ONE process (WORLD_SIZE=%d): start one cohort per GPU with --device, or shard a "
+              "single sample with `svim-asm` under the launcher" % shard.world()[1], file=sys.stderr)
+        return 2
     samples = read_manifest(manifest, n_bams)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)-7.7s]  %(message)s")
     # one options object per sample through the reference's own parser (working dir and BAM paths differ)
@@ -64,6 +69,9 @@ def main(argv=None):
             candidates = shard.pair_sharded(mine[0], mine[1], reference, mine_files[0], o)
         else:
             candidates = mine[0]
+        # as cli._run_steps: a damaged BGZF member among the inserted-sequence bytes must fail the run before a VCF is
+        # written, also when nobody reads them (--symbolic_alleles)
+        _ = candidates.seqs, [t.seqs for t in mine]
         write_vcf_table(candidates, cli.__version__, mine_files[0].references, mine_files[0].lengths,
                         [entry.strip() for entry in o.types.split(",")], reference, o)
         logging.info("sample %d of %d: %s/variants.vcf", k + 1, len(samples), wd)

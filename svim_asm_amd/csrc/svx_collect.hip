@@ -74,7 +74,7 @@ extern "C" int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d) {
     int rc = svx_postpass_plan(ctx, d->read_off, d->n_reads, d->post_off, &stride);
     if (rc != SVX_OK) return rc;
     if (d->post_off[d->n_reads] && !d->d_post) return SVX_E_INVALID;
-    if (stride && !ctx->split_chain) {
+    if (stride && !ctx->split_chain && d->n_ops != 0) {  // (records without a single op: nothing for the chain to ride in)
         // the chain goes out with the CIGAR path, inside two of its launches (svx_cigar.hip, a3_chain_block)
         svx_a3_plan q;
         q.d_seg_src = d->d_seg_src; q.d_seg_tid = d->d_seg_tid; q.d_seg_pos = d->d_seg_pos; q.d_seg_rev = d->d_seg_rev;

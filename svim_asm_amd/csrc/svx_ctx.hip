@@ -132,7 +132,7 @@ int svx_stage_reserve(svx_ctx* ctx, size_t total) {
 
 extern "C" int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops) {
     if (!ctx) return SVX_E_INVALID;
-    ctx->small_batch_ops = max_ops;
+    ctx->small_batch_ops = max_ops > (1ull << 23) ? (1ull << 23) : max_ops;  // the limit include/svx.h states
     return SVX_OK;
 }
 

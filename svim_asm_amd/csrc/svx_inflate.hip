@@ -253,6 +253,10 @@ __global__ __launch_bounds__(kLanes) void k_bgzf_inflate(InfArgs a) {
     Bits b;
     bits_init(b, in, in_len);
     uint32_t produced = 0, st = ST_OK;
+    if (isize > 65536u) {  // no BGZF member is longer: a wrong trailer must not move the output limit
+        a.status[m] = ST_SIZE;
+        return;
+    }
     bool last = false;
     while (!last && st == ST_OK) {
         last = bits_get(b, 1) != 0;

@@ -73,6 +73,13 @@ def _rendezvous_path():
     return os.path.join(d, hashlib.sha256(job.encode()).hexdigest()[:24] + ".sock")
 
 
+def _job_token():
+    """What the ranks of ONE job share and another job of the same user (same MASTER_PORT, no run id: the same socket
+    path) does not: SVX_JOB_TOKEN if set, else the launcher's run id, else the parent process — a launcher starts all
+    ranks of a node from one agent.  Ranks started by hand from different shells set SVX_JOB_TOKEN."""
+    return (os.environ.get("SVX_JOB_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or "ppid-%d" % os.getppid()).encode()
+
+
 def _send_msg(sock, parts):
     """One message = 8-byte count of parts, then every part as 8-byte length + bytes."""
     import struct
@@ -157,19 +164,37 @@ class _SocketGroup(object):
             self.listener.listen(size)
             self.listener.settimeout(timeout)  # a rank that never shows up must not block rank 0 for ever
             self.peers = [None] * size
-            for _ in range(size - 1):
+            deadline = time.time() + timeout
+            strangers = 0
+            while any(p is None for p in self.peers[1:]):
+                left = deadline - time.time()
                 try:
+                    if left <= 0:
+                        raise OSError("timed out")
+                    self.listener.settimeout(left)
                     conn, _ = self.listener.accept()
                 except OSError as e:  # socket.timeout
                     self.close()
-                    raise RuntimeError("rank 0: only %d of %d ranks reached the exchange within %.0f s (%s)"
-                                       % (1 + sum(p is not None for p in self.peers), size, timeout, e))
-                self._check_peer(conn)
-                conn.settimeout(None)
-                r = int(_recv_msg(conn, 64)[0])
-                if not 0 < r < size or self.peers[r] is not None:
+                    raise RuntimeError("rank 0: only %d of %d ranks reached the exchange within %.0f s (%s; %d connection(s) "
+                                       "of other jobs turned away — ranks started from different shells share SVX_JOB_TOKEN)"
+                                       % (1 + sum(p is not None for p in self.peers), size, timeout, e, strangers))
+                try:
+                    self._check_peer(conn)
+                    # the announcement follows the connect at once: a peer that connects and says nothing is given five
+                    # seconds (never more than the rendezvous has left), then the next connection is looked at
+                    conn.settimeout(max(0.05, min(5.0, deadline - time.time())))
+                    hello = _recv_msg(conn, 256)
+                    r = int(hello[0])
+                    token = hello[1] if len(hello) > 1 else b""
+                except (OSError, ValueError, IndexError, RuntimeError):
                     conn.close()
-                    raise RuntimeError("rank 0: a peer announced itself as rank %d of %d" % (r, size))
+                    strangers += 1
+                    continue
+                if token != _job_token() or not 0 < r < size or self.peers[r] is not None:
+                    conn.close()  # a rank of ANOTHER job that found this listener (or a duplicate): turned away, not fatal
+                    strangers += 1
+                    continue
+                conn.settimeout(None)
                 self.peers[r] = conn
         else:
             deadline = time.time() + timeout
@@ -184,7 +209,7 @@ class _SocketGroup(object):
                         raise RuntimeError("rank %d: rank 0 did not open the exchange socket within %.0f s" % (rank, timeout))
                     time.sleep(0.005)
             self._check_peer(self.conn)
-            _send_msg(self.conn, [str(rank).encode()])
+            _send_msg(self.conn, [str(rank).encode(), _job_token()])
 
     @staticmethod
     def _check_peer(conn):

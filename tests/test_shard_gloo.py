@@ -117,3 +117,87 @@ def test_exchange_socket_lives_in_a_private_directory(tmp_path, monkeypatch):
         shard._rendezvous_path()
     os.chmod(d, 0o700)
     monkeypatch.setattr(tempfile, "tempdir", None)
+
+
+def test_rank_0_turns_strangers_away_and_still_meets_its_own_ranks(tmp_path, monkeypatch):
+    """Two jobs of one user with the same MASTER_PORT and no run id share the socket path.  A peer that connects and says
+    nothing, one that announces another job's token and one that claims a rank out of range are turned away — they
+    neither hang rank 0 (the announcement is read under the rendezvous deadline) nor make the job fail — and the
+    job's own rank is still met."""
+    import socket
+    import tempfile
+    import threading
+    import time
+    from svim_asm_amd import shard
+    monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setattr(tempfile, "tempdir", None)
+    monkeypatch.setenv("MASTER_PORT", "23456")
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    monkeypatch.setenv("SVX_JOB_TOKEN", "job-A")
+    path = shard._rendezvous_path()
+    out = {}
+
+    def rank0():
+        try:
+            out["g0"] = shard._SocketGroup(0, 2, timeout=20.0)
+        except Exception as e:  # noqa: BLE001
+            out["err"] = e
+    t0 = threading.Thread(target=rank0)
+    t0.start()
+    deadline = time.time() + 10
+    while not os.path.exists(path) and time.time() < deadline:
+        time.sleep(0.01)
+    silent = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    silent.connect(path)                      # says nothing (kept open: only the deadline can end it) ...
+    other = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    other.connect(path)
+    shard._send_msg(other, [b"1", b"job-B"])  # ... a rank 1 of ANOTHER job ...
+    wrong = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    wrong.connect(path)
+    shard._send_msg(wrong, [b"7", b"job-A"])  # ... and a rank that does not exist
+    silent.close()
+    g1 = shard._SocketGroup(1, 2, timeout=20.0)  # the job's own rank 1 (same token)
+    t0.join(30)
+    assert "err" not in out, out.get("err")
+    g0 = out["g0"]
+    assert g0.peers[1] is not None
+    for s in (other, wrong):
+        s.settimeout(5)
+        assert s.recv(1) == b""  # turned away: rank 0 closed them
+        s.close()
+    g0.close()
+    g1.close()
+
+
+def test_rank_0_gives_up_with_a_deadline_when_only_strangers_come(tmp_path, monkeypatch):
+    import socket
+    import tempfile
+    import threading
+    import time
+    from svim_asm_amd import shard
+    monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setattr(tempfile, "tempdir", None)
+    monkeypatch.setenv("MASTER_PORT", "23457")
+    monkeypatch.setenv("SVX_JOB_TOKEN", "job-A")
+    path = shard._rendezvous_path()
+    out = {}
+
+    def rank0():
+        t = time.time()
+        try:
+            shard._SocketGroup(0, 2, timeout=1.5)
+        except RuntimeError as e:
+            out["err"], out["s"] = str(e), time.time() - t
+    t0 = threading.Thread(target=rank0)
+    t0.start()
+    deadline = time.time() + 10
+    while not os.path.exists(path) and time.time() < deadline:
+        time.sleep(0.01)
+    silent = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    silent.connect(path)  # connects, never announces itself, never closes
+    t0.join(20)
+    silent.close()
+    assert "only 1 of 2 ranks" in out["err"] and out["s"] < 6.0
+    assert not os.path.exists(path)  # the listener is gone with the failed rendezvous
