@@ -690,6 +690,12 @@ def relaunch_if_needed(args):
 def main():
     args = parse()
     relaunch_if_needed(args)
+    # ONE JSON line on stdout: libraries under torch.distributed print to the C-level stdout (RCCL its version banner
+    # when the process ends — behind the line —, gloo its connection notes), so descriptor 1 is pointed at stderr for
+    # the whole run and the line is written to a duplicate of the real stdout
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -1132,7 +1138,8 @@ def main():
                         raise
                     for k in (name if isinstance(name, tuple) else (name,)):
                         res[k] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
 
 
 if __name__ == "__main__":

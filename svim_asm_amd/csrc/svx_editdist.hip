@@ -279,6 +279,9 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         const uint32_t last = nblk - 1;
         uint64_t Pv = ~0ull, Mv = 0;
         uint32_t val = base;        // running D' on the strip's last row (meaningful on lane `last`)
+        // ... and its minimum over the strip's columns, column 0 included when the strip reaches it (Ukkonen's cut-off
+        // test below; the cell left of a band-limited strip lies outside the band)
+        uint32_t row_min = c_lo == 1 ? base : 0xFFFFFFFFu;
         uint32_t captured = base;   // value at cap_col (== c_lo - 1 unless seen later)
         uint32_t acc_lo = 0, acc_hi = 0;  // packed outgoing deltas (lane `last`), 16 columns per half
         uint32_t hp_prev = 0, hm_prev = 0, code_cur = CAP;
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
                 hp_prev = hop;
                 hm_prev = hom;
                 val += hop - hom;
+                if (kHandsOn) row_min = val < row_min ? val : row_min;
             }
             if (kHandsOn) {
                 captured = t == t_cap ? val : captured;
@@ -390,6 +394,20 @@ __global__ __launch_bounds__(64) void k_edit_myers(EdArgs p) {
         else strip_steps(std::false_type{});
         carried = (uint32_t)__builtin_amdgcn_readlane((int)captured, (int)last);
         result = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)last);
+        // Ukkonen's cut-off at strip granularity: every alignment crosses this strip's last row, inside the band if it
+        // costs at most k (outside, |row - column| > k already), and a cell whose true value is <= k has D' = D (its
+        // best path never left the band).  So when EVERY value on the row exceeds k, so does the distance: the strips
+        // below need not be visited — a divergent pair (two unrelated alleles of a crowded partition, asked only
+        // "<= max_edit_distance?") ends after its first strip, a too narrow band of an exact request where it fails.
+        if (s + 1 < n_strips) {
+            const uint32_t rmin = (uint32_t)__builtin_amdgcn_readlane((int)row_min, (int)last);
+            if (rmin > k) {
+                // (an upper bound for the host's next band: from the strip's last visited cell straight down and right)
+                const uint64_t ub = (uint64_t)result + (m - row_hi) + (n > c_hi ? n - c_hi : 0u);
+                if (lane == 0) p.dist[pi] = (uint32_t)(ub < 0x7FFFFFFFu ? ub : 0x7FFFFFFFu) | kUnproven;
+                return;
+            }
+        }
         prev_c_hi = c_hi;
         if (s_out) {
             // the next strip reads what lane `last` just wrote (same wave): make it visible

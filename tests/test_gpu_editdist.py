@@ -143,6 +143,36 @@ def test_long_sequences_every_mode(svx_ctx, length):
     assert exp[0] == 0 and 0 < exp[1] <= 200 and exp[3] > 200
 
 
+def test_cut_off_between_strips(svx_ctx):
+    """Multi-strip patterns (5-6 strips of 4096 rows) whose distance exceeds the band early, late, or not at all: the
+    bit-vector kernel leaves a pair as soon as every value on a strip's last row exceeds the band (Ukkonen), which must
+    never change an answer — thresholds exactly at, one below and one above the distance, exact requests (the band is
+    widened from where the narrow one failed), edits piled up at the start, at the end, or spread evenly, a length
+    difference that alone nearly fills the band.  (With the wavefront pass switched off — the kernel alone — and on:
+    the module's fixture.)"""
+    rng = np.random.default_rng(4242)
+    L = 21000
+    base = _rand_dna(rng, L)
+    junk = lambda n: _rand_dna(rng, n)
+    pairs = [(junk(5000) + base[5000:], base),                  # unrelated first quarter, identical rest
+             (base[:18000] + junk(3000), base),                 # identical, then an unrelated tail
+             (base, _edited(rng, base, 600, 20, 30)),           # ~3 % spread evenly
+             (base[150:], _edited(rng, base, 12, 0, 1)),        # 150-base deletion at the very start + a few substitutions
+             (junk(190) + base, base),                          # 190-base insertion in front
+             (base, base[:9000] + base[9180:]),                 # 180-base deletion in the middle
+             (base, _edited(rng, base, 3, 1, 2)),               # a handful
+             (junk(3000) + base[3000:], base[:17000] + junk(4000))]   # bad at both ends
+    exp = np.array([orc.edit_distance_banded(a, b) for a, b in pairs], dtype=np.int64)
+    pool, ao, al, bo, bl = _pool(pairs)
+    assert np.array_equal(svx_ctx.edit_distance_batch(pool, ao, al, bo, bl).astype(np.int64), exp)
+    ks = sorted({0, 1, 150, 200, 256, 1000, 5000} | {int(d) + e for d in exp for e in (-1, 0, 1) if int(d) + e >= 0})
+    for k in ks:
+        thr = svx_ctx.edit_distance_batch(pool, ao, al, bo, bl, k_max=k).astype(np.int64)
+        le = exp <= k
+        assert np.array_equal(thr[le], exp[le]) and np.all(thr[~le] > k), k
+    assert exp[0] > 1000 and exp[1] > 1000 and 150 <= exp[3] <= 200 and exp[4] == 190 and exp[5] == 180
+
+
 def test_unrelated_long_pair_exact(svx_ctx):
     """3 x 10^4 unrelated bases on each side: every band falls short until the full matrix is visited."""
     rng = np.random.default_rng(77)
