@@ -632,6 +632,7 @@ def e2e_leg(scale, local_rank, n_devices=1):
             # indices and the FASTA right before the first run: it reads its inputs from storage (True = the kernel took
             # every request; the files were written by this process a minute earlier, pages still dirty then are synced first)
             "phases_s": {k: med[k] for k in ("open_index_s", "collect_s", "pair_s", "vcf_s")},
+            "pair_stages_s": med.get("pair_stages_s"), "vcf_stages_s": med.get("vcf_stages_s"),
             "collect_stages_s": med.get("collect_stages_s"),  # load_s: the record walks of both BAMs; sequences_wait_s: what PAIR still
             # waited for the inflate of the inserted alleles, which starts in COLLECT and runs beside PAIR's set-up
             "wall_s_prefix_only_no_crc": r.get("prefix_only_no_crc_total_s"),  # one more pass with svx_bam_set_verify(0)

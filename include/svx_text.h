@@ -109,6 +109,11 @@ typedef struct svx_vcf_in {
  * svx_vcf_free.  n_lines receives the number of record lines. */
 int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_bytes, uint64_t* n_lines);
 void svx_vcf_free(char* text);
+/* The same lines written to the file descriptor `fd` behind its current position (where the caller's header lines
+ * end; a regular file opened for writing, NOT in append mode): every formatting thread writes its own stretch with
+ * pwrite at its final place — no joined buffer, the copies into the page cache run side by side.  The position of
+ * `fd` is left behind the last line.  n_bytes receives the bytes written. */
+int svx_vcf_write(const svx_vcf_in* in, int fd, uint64_t* n_bytes, uint64_t* n_lines);
 
 #ifdef __cplusplus
 }

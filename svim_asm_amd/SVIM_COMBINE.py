@@ -26,7 +26,9 @@ lists of Candidate objects are converted to a table on the way in, `pair_candida
 """
 import ctypes as C
 import logging
+import os
 import re
+import stat
 import time
 
 import numpy as np
@@ -698,6 +700,23 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
         read_names=1 if options.query_names else 0)
     text, n_bytes, n_lines = C.c_void_p(), C.c_uint64(), C.c_uint64()
     tc = _clock("vcf_prepare_s", tc)
+    fd = None
+    if sink is not None:
+        try:
+            sink.flush()
+            fd = sink.fileno()
+            if not stat.S_ISREG(os.fstat(fd).st_mode):
+                fd = None
+        except (AttributeError, OSError, ValueError):  # not a real file: the buffer form below
+            fd = None
+    if fd is not None:
+        # straight from the formatting threads into the file, each stretch at its final place (svx_vcf_write)
+        rc = lib.svx_vcf_write(C.byref(arg), fd, C.byref(n_bytes), C.byref(n_lines))
+        if rc != 0:
+            raise _lib.SvxError(rc, "svx_vcf_write")
+        sink.seek(0, os.SEEK_END)
+        _clock("vcf_format_s", tc)
+        return None
     rc = lib.svx_vcf_format(C.byref(arg), C.byref(text), C.byref(n_bytes), C.byref(n_lines))
     if rc != 0:
         raise _lib.SvxError(rc, "svx_vcf_format")

@@ -181,6 +181,7 @@ SYMBOLS = {
     "svx_fasta_fetch_batch": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_int, _P, _P, C.c_int]),
     "svx_vcf_format": (C.c_int, [C.POINTER(VcfIn), C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "svx_vcf_free": (None, [_P]),
+    "svx_vcf_write": (C.c_int, [C.POINTER(VcfIn), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

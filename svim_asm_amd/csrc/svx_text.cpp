@@ -209,9 +209,28 @@ const int KIND_LABEL[9] = {0, 1, 2, 2, 3, 2, 4, 5, 5};
 
 }  // namespace
 
-extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_bytes, uint64_t* n_lines) {
-    if (!in || !text || !n_bytes) return SVX_E_INVALID;
-    *text = nullptr;
+namespace {
+
+// every byte of [p, p + n) at file offset `at` (pwrite may write less than asked)
+int pwrite_all(int fd, const char* p, size_t n, uint64_t at) {
+    while (n) {
+        const ssize_t k = pwrite(fd, p, n, (off_t)at);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return SVX_E_INVALID;
+        }
+        p += k; n -= (size_t)k; at += (uint64_t)k;
+    }
+    return SVX_OK;
+}
+
+// The record lines of write_final_vcf, formatted by a few threads over contiguous chunks of the sorted entries.
+// fd < 0: joined into one malloc'ed buffer (*text).  fd >= 0: every thread writes its own chunk at its place in the
+// file (pwrite at `file_at` + the sizes of the chunks in front of it) — no joined copy, and the copies into the page
+// cache run side by side.
+int vcf_format_impl(const svx_vcf_in* in, char** text, int fd, uint64_t file_at, uint64_t* n_bytes, uint64_t* n_lines) {
+    if (!in || !n_bytes || (fd < 0 && !text)) return SVX_E_INVALID;
+    if (text) *text = nullptr;
     *n_bytes = 0;
     if (n_lines) *n_lines = 0;
     const uint32_t ne = in->n_entries;
@@ -444,6 +463,26 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
         if (status.load() != SVX_OK) return status.load();
         size_t total = 0;
         for (const Out& part : parts) total += part.s.size();
+        if (fd >= 0) {
+            std::vector<size_t> at(n_thr);
+            size_t pos = 0;
+            for (unsigned t = 0; t < n_thr; ++t) { at[t] = pos; pos += parts[t].s.size(); }
+            auto put = [&](unsigned t) {
+                if (parts[t].s.size() && pwrite_all(fd, parts[t].s.data(), parts[t].s.size(), file_at + at[t]) != SVX_OK)
+                    status.store(SVX_E_INVALID);
+            };
+            if (n_thr == 1) {
+                put(0);
+            } else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(put, t);
+                for (std::thread& t : th) t.join();
+            }
+            if (status.load() != SVX_OK) return status.load();
+            *n_bytes = total;
+            if (n_lines) *n_lines = ne;
+            return SVX_OK;
+        }
         char* buf = (char*)malloc(total ? total : 1);
         if (!buf) return SVX_E_NOMEM;
         {
@@ -468,6 +507,24 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
     } catch (...) {
         return SVX_E_INVALID;
     }
+}
+
+}  // namespace
+
+extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_bytes, uint64_t* n_lines) {
+    if (!text) return SVX_E_INVALID;
+    return vcf_format_impl(in, text, -1, 0, n_bytes, n_lines);
+}
+
+extern "C" int svx_vcf_write(const svx_vcf_in* in, int fd, uint64_t* n_bytes, uint64_t* n_lines) {
+    if (fd < 0) return SVX_E_INVALID;
+    const off_t here = lseek(fd, 0, SEEK_CUR);  // behind what the caller has written (the header lines)
+    if (here < 0) return SVX_E_INVALID;
+    uint64_t n = 0;
+    const int rc = vcf_format_impl(in, nullptr, fd, (uint64_t)here, &n, n_lines);
+    if (n_bytes) *n_bytes = n;
+    if (rc != SVX_OK) return rc;
+    return lseek(fd, here + (off_t)n, SEEK_SET) < 0 ? SVX_E_INVALID : SVX_OK;
 }
 
 extern "C" void svx_vcf_free(char* text) { free(text); }

@@ -195,3 +195,14 @@ def test_native_vcf_lines_equal_the_object_formatters(seed):
     table = CandidateTable.from_objects(ordered, bam)
     got = SVIM_COMBINE.vcf_body(table, types, helpers.FakeFasta(seqs), o).decode().split("\n")
     assert got[-1] == "" and got[:-1] == exp
+    # ... and the form the command uses: the same lines written by the formatting threads straight into a file, each
+    # stretch at its final place behind the header the caller wrote (svx_vcf_write)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = d + "/out.vcf"
+        with open(path, "wb") as fh:
+            fh.write(b"##header line\n#CHROM\n")
+            assert SVIM_COMBINE.vcf_body(table, types, helpers.FakeFasta(seqs), o, sink=fh) is None
+            fh.write(b"trailer written by the caller\n")
+        text = open(path, "rb").read().decode().split("\n")
+    assert text[:2] == ["##header line", "#CHROM"] and text[2:-2] == exp and text[-2:] == ["trailer written by the caller", ""]
