@@ -207,7 +207,8 @@ class _Clusters(object):
         return part[o], np.concatenate(self.first)[o], np.concatenate(self.second)[o], np.concatenate(self.size)[o]
 
 
-def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig, win_base, win_lo, L_part, reference):
+def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig, win_base, win_lo, L_part, reference,
+                      seq_split=None):
     """svx_hap_piece recipes (3 per haplotype, 6 per job) of the strings compute_distance aligns
     (SVIM_COMBINE.py:43-100) for jobs (candidate rows a, b of partition job_part).  Returns (pieces [J, 2, 3],
     extra pool parts appended behind the windows: interspersed-duplication source intervals, inserted sequences)."""
@@ -252,11 +253,29 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
         extra_at += len(pool)
     ins = typ == T_INS
     want_seqs = bool(ins.any())
+    seq_ranges = []  # the stretches of the sequence pool that are appended behind the windows
     if want_seqs:
         # INS: the inserted sequence as it is — the reference does not fold its case (:74-75).  Only the OFFSETS are
-        # needed here; the bytes (possibly still being decoded) are appended to the pool at the very end
+        # needed here; the bytes (possibly still being decoded) are appended to the pool at the very end — the stretch
+        # of the sequence pool these jobs' alleles lie in (a chunk of PAIR's jobs is a range of partitions, i.e. of
+        # contigs: its alleles are a stretch of each haplotype's part of the pool), not the whole pool
+        used = np.concatenate((job_a[ins], job_b[ins]))
+        used = used[T.q_len[used] > 0]
+        # the two haplotype tables' sequences lie one behind the other in the pool: one stretch of each
+        split = int(seq_split) if seq_split is not None else 0
+        shift = np.zeros(2, np.int64)  # what to subtract from a pool offset below / at or above `split`
+        at = extra_at
+        for side in (0, 1):
+            u = used[(T.q_off[used] >= split) == bool(side)] if seq_split is not None else (used if side == 0 else used[:0])
+            if len(u):
+                q_lo, q_hi = int(T.q_off[u].min()), int((T.q_off[u] + T.q_len[u]).max())
+                seq_ranges.append((q_lo, q_hi))
+                shift[side] = q_lo - at
+                at += q_hi - q_lo
         for h in (0, 1):
-            mid_off[:, h] = np.where(ins, extra_at + T.q_off[rows[h]], mid_off[:, h])
+            off_h = T.q_off[rows[h]]
+            side_h = (off_h >= split).astype(np.int64) if seq_split is not None else np.zeros(J, np.int64)
+            mid_off[:, h] = np.where(ins, off_h - shift[side_h], mid_off[:, h])
             mid_len[:, h] = np.where(ins, T.q_len[rows[h]], mid_len[:, h])
     tan = typ == T_DUP_TAN
     if bool(tan.any()):
@@ -276,12 +295,15 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
         m_rep = np.where(tan, T.copies[rows[h]] + 1, one)
         m_flg = np.where(typ == T_INV, up | _lib.PIECE_REVCOMP, np.where(tan | (typ == T_DUP_INT), up, 0))
         put(h, 1, m_off, m_len, m_rep, m_flg)
-    if want_seqs:
-        extra_parts.append(np.asarray(T.seqs, dtype=np.uint8))
+    if seq_ranges:
+        seqs = np.asarray(T.seqs, dtype=np.uint8)
+        extra_parts.extend(seqs[q_lo:q_hi] for q_lo, q_hi in seq_ranges)
     return pieces, extra_parts
 
 
 LAST_TIMING = {}  # seconds per stage of the latest pair_tables / vcf_body call (tools/, bench legs)
+_PAIR_CHUNK_MIN_JOBS = 30000  # PAIR's distance jobs are pipelined in chunks from this many on (a human sample: ~20 k) ...
+_PAIR_CHUNKS = max(1, int(os.environ.get("SVX_PAIR_CHUNKS", "4")))  # ... this many chunks (measured: profiles/README.md)
 
 
 _cpu_mark = [0.0]
@@ -367,43 +389,78 @@ def pair_tables(t1, t2, reference, bam, options, ctx=None):
     tc = _clock("pair_enumerate_s", tc)
     if classes and sum(len(a) for a in job_a):
         job_a, job_b, job_p, job_two = (np.concatenate(x) for x in (job_a, job_b, job_p, job_two))
-        # one reference window per partition with jobs: [min start - 100, max end + 100) of ALL its members (:45-46,...)
         s_sorted, e_sorted = kstart[order], kend[order]
-        wp = np.unique(job_p)
-        first_row = order[p_start[wp]]
-        p_contig = np.full(n_parts, -1, np.int64)
-        p_contig[wp] = T.key_contig()[first_row]
-        L_names = _reference_lengths(reference, T.contigs, p_contig[wp])
-        L_part = np.zeros(n_parts, np.int64)
-        L_part[wp] = L_names[p_contig[wp]]
-        seg_lo = np.minimum.reduceat(s_sorted, p_start)[wp]
-        seg_hi = np.maximum.reduceat(e_sorted, p_start)[wp]
-        wlo = np.maximum(0, seg_lo - 100)
-        whi = np.minimum(L_part[wp], seg_hi + 100)
-        tc = _clock("pair_windows_plan_s", tc)
-        pool_w, off_w = _fetch_windows(reference, T.contigs, p_contig[wp], wlo, np.maximum(whi, wlo), False)
-        tc = _clock("pair_windows_fetch_s", tc)
-        if not np.array_equal(off_w[1:] - off_w[:-1], np.maximum(whi - wlo, 0)):
-            raise ValueError("reference windows shorter than the index says")
-        win_base = np.zeros(n_parts + 1, np.int64)
-        win_base[wp] = off_w[:-1]
-        win_base[-1] = off_w[-1]
-        win_lo = np.zeros(n_parts, np.int64)
-        win_lo[wp] = wlo
-        pieces, extra = _haplotype_pieces(T, kstart, kend, job_a, job_b, job_p, p_type, p_contig, win_base, win_lo, L_part, reference)
-        pool = np.concatenate([pool_w] + extra) if extra else pool_w
-        tc = _clock("pair_recipes_s", tc)
+        seg_lo_all = np.minimum.reduceat(s_sorted, p_start)
+        seg_hi_all = np.maximum.reduceat(e_sorted, p_start)
         # two-member partitions only need "<= threshold?"; larger ones get exact values so that the dendrogram
         # above the cut (hence scipy's cluster label order) is the reference's.  Any threshold the reference
         # accepts: a negative one pairs nothing, one beyond 32 bits everything
         k_max = max(min(max(int(threshold), -1), 0xFFFFFFFE), 0)
-        # one call for both kinds of pairs (per-pair threshold; 0xFFFFFFFF = exact): one upload of the windows and
-        # alleles, one assembly of the haplotype strings, one wavefront pass and one bit-vector pass
-        per_pair = np.where(job_two, np.uint32(k_max), np.uint32(0xFFFFFFFF)).astype(np.uint32)
-        dist = ctx.haplotype_distance_batch_mixed(pool, pieces.reshape(-1), per_pair).astype(np.float64)
+
+        def prepare(sel):
+            """Pool (one reference window per partition with jobs + the alleles behind them), recipes and thresholds of
+            the jobs `sel` (None: all)."""
+            ja, jb, jp, jtwo = (job_a, job_b, job_p, job_two) if sel is None else (job_a[sel], job_b[sel], job_p[sel], job_two[sel])
+            t0 = _clock_start()
+            # one reference window per partition with jobs: [min start - 100, max end + 100) of ALL its members (:45-46,...)
+            wp = np.unique(jp)
+            first_row = order[p_start[wp]]
+            p_contig = np.full(n_parts, -1, np.int64)
+            p_contig[wp] = T.key_contig()[first_row]
+            L_names = _reference_lengths(reference, T.contigs, p_contig[wp])
+            L_part = np.zeros(n_parts, np.int64)
+            L_part[wp] = L_names[p_contig[wp]]
+            wlo = np.maximum(0, seg_lo_all[wp] - 100)
+            whi = np.minimum(L_part[wp], seg_hi_all[wp] + 100)
+            t0 = _clock("pair_windows_plan_s", t0)
+            pool_w, off_w = _fetch_windows(reference, T.contigs, p_contig[wp], wlo, np.maximum(whi, wlo), False)
+            t0 = _clock("pair_windows_fetch_s", t0)
+            if not np.array_equal(off_w[1:] - off_w[:-1], np.maximum(whi - wlo, 0)):
+                raise ValueError("reference windows shorter than the index says")
+            win_base = np.zeros(n_parts + 1, np.int64)
+            win_base[wp] = off_w[:-1]
+            win_base[-1] = off_w[-1]
+            win_lo = np.zeros(n_parts, np.int64)
+            win_lo[wp] = wlo
+            pieces, extra = _haplotype_pieces(T, kstart, kend, ja, jb, jp, p_type, p_contig, win_base, win_lo, L_part, reference,
+                                              seq_split=t1.seqs_nbytes)
+            pool = np.concatenate([pool_w] + extra) if extra else pool_w
+            # one call for both kinds of pairs (per-pair threshold; 0xFFFFFFFF = exact): one upload of the windows and
+            # alleles, one assembly of the haplotype strings, one wavefront pass and one bit-vector pass
+            per_pair = np.where(jtwo, np.uint32(k_max), np.uint32(0xFFFFFFFF)).astype(np.uint32)
+            _clock("pair_recipes_s", t0)
+            return pool, pieces.reshape(-1), per_pair
+
+        J = len(job_a)
+        n_chunks = 1 if J < _PAIR_CHUNK_MIN_JOBS else _PAIR_CHUNKS
+        if n_chunks == 1:
+            pool, pieces, per_pair = prepare(None)
+            tc = _clock_start()
+            dist = ctx.haplotype_distance_batch_mixed(pool, pieces, per_pair).astype(np.float64)
+            tc = _clock("pair_distances_s", tc)
+        else:
+            # a crowded sample (config 5: ~10^5 pairs): the jobs are cut into chunks of whole partitions and the device
+            # computes the distances of chunk i (one worker thread holds the context meanwhile; the call sleeps on a
+            # blocking event) while this thread fetches the windows and builds the recipes of chunk i + 1
+            from concurrent.futures import ThreadPoolExecutor
+            per_part = np.bincount(job_p, minlength=n_parts)
+            cuts = np.searchsorted(np.cumsum(per_part), J * np.arange(1, n_chunks) / n_chunks, side="left")
+            chunk_of = np.searchsorted(cuts, job_p, side="left")
+            dist = np.zeros(J, np.float64)
+            with ThreadPoolExecutor(max_workers=1) as worker:
+                pending = []
+                for c in range(n_chunks):
+                    sel = np.flatnonzero(chunk_of == c)
+                    if not len(sel):
+                        continue
+                    pending.append((sel, worker.submit(ctx.haplotype_distance_batch_mixed, *prepare(sel))))
+                tc = _clock_start()
+                for sel, fut in pending:
+                    dist[sel] = fut.result().astype(np.float64)
+                tc = _clock("pair_distances_wait_s", tc)
         over = job_two & (dist == float(0xFFFFFFFF))
         dist[over] = k_max + 1  # "more than the threshold" is all that is known, and all that matters
-        tc = _clock("pair_distances_s", tc)
+        tc = _clock_start()
     # condensed distance vectors per size class (row-major pairs (i < j), :131-133), then the clusters
     at = 0
     for c in classes:

@@ -36,8 +36,13 @@ def test_collect_matches_oracle(seed):
     assert got == svim_oracle.collect(recs, NAMES, LENGTHS, o)
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
 @pytest.mark.parametrize("seed", range(3))
-def test_pair_candidates_matches_oracle(seed):
+def test_pair_candidates_matches_oracle(seed, chunks, monkeypatch):
+    # (chunks = 3: the distance jobs pipelined in chunks of whole partitions, as PAIR does for crowded samples — windows
+    #  and recipes of chunk i + 1 built while a worker thread holds the device for chunk i)
+    monkeypatch.setattr(SVIM_COMBINE, "_PAIR_CHUNK_MIN_JOBS", 1 if chunks > 1 else 10 ** 9)
+    monkeypatch.setattr(SVIM_COMBINE, "_PAIR_CHUNKS", chunks)
     rng = np.random.default_rng(300 + seed)
     seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=30000)) for n in NAMES}
     lengths = [30000] * len(NAMES)
