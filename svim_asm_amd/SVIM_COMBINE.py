@@ -303,7 +303,8 @@ def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig,
 
 LAST_TIMING = {}  # seconds per stage of the latest pair_tables / vcf_body call (tools/, bench legs)
 _PAIR_CHUNK_MIN_JOBS = 30000  # PAIR's distance jobs are pipelined in chunks from this many on (a human sample: ~20 k) ...
-_PAIR_CHUNKS = max(1, int(os.environ.get("SVX_PAIR_CHUNKS", "4")))  # ... this many chunks (measured: profiles/README.md)
+_PAIR_CHUNKS = max(1, int(os.environ.get("SVX_PAIR_CHUNKS", "2")))  # ... this many chunks (config 5, medians of three interleaved
+#                               runs of five: 1 chunk 0.185 s, 2 chunks 0.167 s, 4 chunks 0.171 s, 8 slower; profiles/README.md)
 
 
 _cpu_mark = [0.0]

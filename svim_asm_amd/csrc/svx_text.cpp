@@ -435,7 +435,9 @@ int vcf_format_impl(const svx_vcf_in* in, char** text, int fd, uint64_t file_at,
         }
         return SVX_OK;
         };
-        unsigned n_thr = std::min<unsigned>(8u, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+        // (8 threads; 16 for the ~10^5 records of a crowded sample.  SVX_VCF_THREADS overrides — measurements)
+        unsigned n_thr = std::min<unsigned>(ne >= 65536 ? 16u : 8u, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+        if (const char* v = getenv("SVX_VCF_THREADS")) n_thr = (unsigned)std::max(1, std::min(64, atoi(v)));
         if (ne < 4096) n_thr = 1;
         std::vector<Out> parts(n_thr);
         auto run = [&](unsigned t) {

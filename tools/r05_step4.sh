@@ -4,8 +4,8 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r05_s4; mkdir -p $out
 timeout 1200 python3 tools/e2e_bench.py --config5 --keep $out/c5data --repeat 1 --ranks "" > /dev/null 2> $out/gen.err
-for i in 1 2; do
-for k in 1 2 4 8; do
+for i in 1 2 3; do
+for k in 1 2 4; do
   SVX_PAIR_CHUNKS=$k timeout 600 python3 tools/e2e_bench.py --config5 --dataset $out/c5data --repeat 5 --ranks "" > $out/c5_chunks${k}_$i.json 2> $out/c5_chunks${k}_$i.err
   python3 -c "
 import json; r=json.loads(open('$out/c5_chunks${k}_$i.json').read().strip().splitlines()[-1]); m=r.get('median_run', r)
@@ -15,10 +15,4 @@ print('   vcf stages', {k2[4:-2]: round(v*1e3,1) for k2,v in m.get('vcf_stages_s
 done
 done
 rm -rf $out/c5data
-timeout 900 python3 -m pytest tests/test_config5_golden.py -x -q -m gpu > $out/pytest_c5.txt 2>&1; tail -2 $out/pytest_c5.txt
-timeout 1500 python3 tools/e2e_bench.py --scale 1.0 --repeat 5 --ranks "" > $out/full.json 2> $out/full.err
-python3 -c "
-import json; r=json.loads(open('$out/full.json').read().strip().splitlines()[-1]); m=r.get('median_run', r)
-print('full: total %.4f all %s collect %.4f pair %.4f vcf %.4f ok %s optout %s' % (m['product_total_s'], [round(x,3) for x in r.get('all_runs_total_s',[])], m['collect_s'], m['pair_s'], m['vcf_s'], r.get('vcf_matches_real_reference_digest'), r.get('prefix_only_no_crc_total_s')))
-print('   vcf stages', {k2[4:-2]: round(v*1e3,1) for k2,v in m.get('vcf_stages_s',{}).items() if not k2.endswith('cpu_s')})
-print('   pair stages', {k2[5:-2]: round(v*1e3,1) for k2,v in m.get('pair_stages_s',{}).items() if not k2.endswith('cpu_s')})"
+timeout 900 python3 -m pytest tests/test_config5_golden.py tests/test_medium_golden.py -x -q -m gpu > $out/pytest_c5.txt 2>&1; tail -2 $out/pytest_c5.txt
