@@ -728,7 +728,9 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
         b_off[w], b_len[w] = off[:-1][:len(w)], ln[:len(w)]
         b2_off[w2], b2_len[w2] = off[:-1][len(w):], ln[len(w):]
     if seq:
+        tc = _clock("vcf_prepare_s", tc)
         reference.close()  # (:466-467)
+        tc = _clock("vcf_reference_close_s", tc)
     if ne == 0:
         return b"" if sink is None else None
     natural = _natural_ranks(set(t.contigs))

@@ -114,8 +114,12 @@ class FastaFile(object):
     def close(self):
         if getattr(self, "_native", None) is not None:
             lib, h = self._native
-            lib.svx_fasta_close(h)
             self._native = None
+            # unmapping a genome-sized file takes tens of milliseconds of page-table work (49 ms for the 3.1 GB of
+            # the full-size sample, in the middle of write_final_vcf where the reference closes its FastaFile,
+            # SVIM_COMBINE.py:466-467): the object is closed NOW, the mapping goes away beside whatever comes next
+            import threading
+            threading.Thread(target=lib.svx_fasta_close, args=(h,), daemon=True).start()
         if getattr(self, "_map", None) is not None:
             self._map.close()
             self._map = None

@@ -211,12 +211,19 @@ def fuzz_haplotypes(ctx, rng):
 
 
 def fuzz_collect(ctx, rng):
-    """svx_collect_batch (one submission) against the composition of the single-purpose entry points."""
+    """svx_collect_batch (one submission) against the composition of the single-purpose entry points AND against the
+    oracle alone (signatures, raw records from oracle-derived rows, derived records from the record-level post-passes);
+    random batches and reads whose segments tile the read (plenty of derived records); from 384 reads on the chain's
+    reads are dealt by the op-count table."""
     import test_gpu_collect as tcol
-    b = tcol.random_batch(rng, n_aln=int(rng.choice([1, 2, 50, 800, 6000])), n_parts=int(rng.choice([1, 2, 3, 5])),
-                          n_reads=int(rng.choice([0, 1, 7, 300, 2000])), max_supp=int(rng.choice([1, 3, 7, 12])),
-                          long_read=bool(rng.random() < 0.3), long_aln=float(rng.choice([0.0, 0.0, 0.2, 0.8])),
-                          long_max=int(rng.choice([300, 3000, 12000])))
+    import helpers
+    if rng.random() < 0.3:
+        b = tcol.tiling_batch(rng, n_reads=int(rng.choice([1, 20, 383, 384, 1500])), n_contigs=int(rng.choice([1, 3, 4])))
+    else:
+        b = tcol.random_batch(rng, n_aln=int(rng.choice([1, 2, 50, 800, 6000])), n_parts=int(rng.choice([1, 2, 3, 5])),
+                              n_reads=int(rng.choice([0, 1, 7, 300, 384, 2000])), max_supp=int(rng.choice([1, 3, 7, 12])),
+                              long_read=bool(rng.random() < 0.3), long_aln=float(rng.choice([0.0, 0.0, 0.2, 0.8])),
+                              long_max=int(rng.choice([300, 3000, 12000, 40000])))
     min_len = int(rng.choice([1, 30, 40, 500]))
     prm = (int(rng.choice([1, 40, 50, 1000])), int(rng.choice([20, 1000, 100000, 1 << 30])),
            int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])), int(rng.choice([0, 50, 500])))
@@ -229,6 +236,7 @@ def fuzz_collect(ctx, rng):
         ctx.set_small_batch_ops(1 << 23)
     try:
         tcol.same(got, exp)
+        tcol.same_as_oracle(got, tcol.call(helpers.oracle_collect, b, min_len, prm))
         ok = True
     except AssertionError:
         ok = False
