@@ -797,6 +797,8 @@ def write_vcf_table(table, version, contig_names, contig_lengths, types_to_outpu
         header = "".join(line + "\n" for line in _header_lines(version, contig_names, contig_lengths, types_to_output, options))
         vcf_output.write(header.encode("utf-8", "surrogateescape"))
         vcf_body(table, types_to_output, reference, options, sink=vcf_output)
+    from svim_asm_amd import fasta
+    fasta.release_deferred()  # the reference genome's mapping, closed inside vcf_body (:466-467), goes away behind the file
 
 
 def write_final_vcf(int_duplication_candidates, inversion_candidates, tandem_duplication_candidates,

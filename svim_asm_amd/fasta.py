@@ -35,6 +35,8 @@ class FastaFile(object):
         self._native = None  # svx_fasta handle (libsvx.so), opened by the first batch fetch
 
     def _handle(self):
+        if getattr(self, "_closed", False):
+            raise ValueError("I/O operation on closed file")
         if self._native is None:
             import ctypes as C
             from svim_asm_amd import _lib
@@ -90,6 +92,8 @@ class FastaFile(object):
 
     def fetch_bytes(self, reference, start=None, end=None):
         """fetch() without the str round trip (the GPU path uploads reference windows as bytes)."""
+        if getattr(self, "_closed", False):
+            raise ValueError("I/O operation on closed file")
         length, offset, line_bases, line_width = self._idx[reference]
         start = 0 if start is None else start
         end = length if end is None else end
@@ -112,20 +116,48 @@ class FastaFile(object):
         return raw
 
     def close(self):
+        """The object is closed at once (fetches fail from here on); its mappings are released by release_deferred().
+        Unmapping a genome-sized file whose pages were touched all over is tens of milliseconds of page-table work
+        under the process's mapping lock (57 ms for the 3.1 GB of the full-size sample) — in the middle of
+        write_final_vcf, where the reference closes its FastaFile (SVIM_COMBINE.py:466-467), it would stall the threads
+        that format the record lines; a command that exits right after the VCF never needs it at all."""
+        self._closed = True
         if getattr(self, "_native", None) is not None:
-            lib, h = self._native
+            _DEFERRED.append(("native",) + tuple(self._native))
             self._native = None
-            # unmapping a genome-sized file takes tens of milliseconds of page-table work (49 ms for the 3.1 GB of
-            # the full-size sample, in the middle of write_final_vcf where the reference closes its FastaFile,
-            # SVIM_COMBINE.py:466-467): the object is closed NOW, the mapping goes away beside whatever comes next
-            import threading
-            threading.Thread(target=lib.svx_fasta_close, args=(h,), daemon=True).start()
         if getattr(self, "_map", None) is not None:
-            self._map.close()
+            _DEFERRED.append(("map", self._map))
             self._map = None
         if self._fh:
-            self._fh.close()
+            _DEFERRED.append(("file", self._fh))
             self._fh = None
+
+
+_DEFERRED = []  # mappings and descriptors of closed FastaFile objects, not yet given back
+
+
+def release_deferred(background=True):
+    """Give back what closed FastaFile objects held (write_vcf_table calls this behind its last write; a long-lived
+    caller may call it any time).  `background`: on a daemon thread, beside whatever the caller does next."""
+    todo = _DEFERRED[:]
+    del _DEFERRED[:len(todo)]
+    if not todo:
+        return
+
+    def work():
+        for item in todo:
+            try:
+                if item[0] == "native":
+                    item[1].svx_fasta_close(item[2])
+                else:
+                    item[1].close()
+            except Exception:  # noqa: BLE001 — nothing left to report to
+                pass
+    if background:
+        import threading
+        threading.Thread(target=work, daemon=True).start()
+    else:
+        work()
 
 
 def write_fasta(path, names, seqs, line=60):

@@ -130,7 +130,8 @@ def test_rank_0_turns_strangers_away_and_still_meets_its_own_ranks(tmp_path, mon
     import time
     from svim_asm_amd import shard
     monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
-    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    short = tempfile.mkdtemp(prefix="svx", dir="/tmp")  # (a unix socket path holds 107 bytes: pytest's tmp_path can be longer)
+    monkeypatch.setenv("TMPDIR", short)
     monkeypatch.setattr(tempfile, "tempdir", None)
     monkeypatch.setenv("MASTER_PORT", "23456")
     monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
@@ -177,7 +178,8 @@ def test_rank_0_gives_up_with_a_deadline_when_only_strangers_come(tmp_path, monk
     import time
     from svim_asm_amd import shard
     monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
-    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    short = tempfile.mkdtemp(prefix="svx", dir="/tmp")
+    monkeypatch.setenv("TMPDIR", short)
     monkeypatch.setattr(tempfile, "tempdir", None)
     monkeypatch.setenv("MASTER_PORT", "23457")
     monkeypatch.setenv("SVX_JOB_TOKEN", "job-A")
