@@ -59,7 +59,7 @@ def _rendezvous_path():
     base = os.environ.get("XDG_RUNTIME_DIR")
     if not (base and os.path.isdir(base) and os.stat(base).st_uid == uid):
         base = tempfile.gettempdir()
-    if len(os.fsencode(base)) > 60 and os.path.isdir("/tmp"):
+    if len(os.fsencode(base)) + len("/svx-%d/" % uid) + 24 + len(".sock") > 107 and os.path.isdir("/tmp"):
         base = "/tmp"  # a unix socket path holds 107 bytes: a deep TMPDIR would not leave room for the name
     d = os.path.join(base, "svx-%d" % uid)
     try:
