@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 5: the bench line of the final tree (all legs), and the driver's own command twice
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/r05b; mkdir -p $out
+timeout 1800 python3 bench.py > $out/bench.json 2> $out/bench.err; tail -c 300 $out/bench.json; echo
+for i in 1 2; do timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras > $out/bench_driver_cmd_$i.json 2>> $out/bench.err; python3 -c "
+import json; r=json.loads(open('$out/bench_driver_cmd_$i.json').read().strip().splitlines()[-1]); rf=r['roofline']
+print('driver cmd $i: value %.4g ms/step %.4f median5 %.4g kernel_ms %.4f frac %.3f path_frac %.3f step_frac %.3f throttled %s' % (r['value'], r['ms_per_step'], r['value_median_of_5'], rf['kernel_ms'], rf['frac'], rf['path_frac'], rf['step_frac'], r['host_throttled_ms_in_timed_region']))"; done
