@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -244,6 +245,9 @@ int vcf_format_impl(const svx_vcf_in* in, char** text, int fd, uint64_t file_at,
                                        (in->seqs_bytes && !in->seqs)))
         return SVX_E_INVALID;
     try {
+        const bool dbg = getenv("SVX_VCF_DEBUG") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_begin = now();
         // ---- sort keys: ((contig, start, end)) per entry, SVIM_COMBINE.py:431-464; natural contig order :369-376
         std::vector<Entry> ent(ne);
         for (uint32_t e = 0; e < ne; ++e) {
@@ -282,11 +286,43 @@ int vcf_format_impl(const svx_vcf_in* in, char** text, int fd, uint64_t file_at,
             }
             ent[e] = Entry{in->contig_rank[contig], a, b, e};
         }
-        std::stable_sort(ent.begin(), ent.end(), [](const Entry& x, const Entry& y) {
-            if (x.rank != y.rank) return x.rank < y.rank;
-            if (x.start != y.start) return x.start < y.start;
-            return x.end < y.end;
-        });
+        const double t_keys = now();
+        auto by_pos = [](const Entry& x, const Entry& y) { return x.start != y.start ? x.start < y.start : x.end < y.end; };
+        uint32_t split_from = 32768;  // (SVX_VCF_SORT_SPLIT: tests run small tables through the split form)
+        if (const char* v = getenv("SVX_VCF_SORT_SPLIT")) split_from = (uint32_t)std::max(0, atoi(v));
+        if (ne < split_from) {
+            std::stable_sort(ent.begin(), ent.end(), [&](const Entry& x, const Entry& y) {
+                return x.rank != y.rank ? x.rank < y.rank : by_pos(x, y);
+            });
+        } else {
+            // many entries: one stable counting pass by contig rank, then the contigs' stretches sorted side by side
+            int32_t max_rank = 0;
+            for (const Entry& e : ent) {
+                if (e.rank < 0) return SVX_E_INVALID;
+                max_rank = std::max(max_rank, e.rank);
+            }
+            if ((uint64_t)max_rank > 4u * (uint64_t)in->n_contigs + 16u) return SVX_E_INVALID;  // (ranks are ranks of the contigs)
+            std::vector<uint32_t> first((size_t)max_rank + 2, 0);
+            for (const Entry& e : ent) ++first[(size_t)e.rank + 1];
+            for (size_t r = 1; r < first.size(); ++r) first[r] += first[r - 1];
+            std::vector<Entry> byrank(ne);
+            {
+                std::vector<uint32_t> at(first.begin(), first.end() - 1);
+                for (const Entry& e : ent) byrank[at[(size_t)e.rank]++] = e;
+            }
+            ent.swap(byrank);
+            std::atomic<size_t> next(0);
+            auto work = [&] {
+                for (size_t r = next.fetch_add(1); r + 1 < first.size(); r = next.fetch_add(1))
+                    std::stable_sort(ent.begin() + first[r], ent.begin() + first[r + 1], by_pos);
+            };
+            const unsigned n_sort = std::min<unsigned>(8u, std::max<unsigned>(1u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < n_sort; ++t) th.emplace_back(work);
+            work();
+            for (std::thread& t : th) t.join();
+        }
+        const double t_sort = now();
         // ---- IDs numbered per label in sorted order (:470-475): serial, one counter per label
         std::vector<int64_t> id_no(ne);
         {
@@ -463,6 +499,9 @@ int vcf_format_impl(const svx_vcf_in* in, char** text, int fd, uint64_t file_at,
             for (std::thread& t : th) t.join();
         }
         if (status.load() != SVX_OK) return status.load();
+        const double t_fmt = now();
+        if (dbg) fprintf(stderr, "svx_vcf: %u entries, %u threads: keys %.1f ms, sort %.1f ms, format %.1f ms\n", ne, n_thr,
+                         (t_keys - t_begin) * 1e3, (t_sort - t_keys) * 1e3, (t_fmt - t_sort) * 1e3);
         size_t total = 0;
         for (const Out& part : parts) total += part.s.size();
         if (fd >= 0) {

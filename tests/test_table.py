@@ -151,8 +151,11 @@ def test_constructor_assertion_and_unknown_contig_are_raised():
         _apply_constructors(t)
 
 
-@pytest.mark.parametrize("seed", range(5))
-def test_native_vcf_lines_equal_the_object_formatters(seed):
+@pytest.mark.parametrize("seed", list(range(5)) + [14])
+def test_native_vcf_lines_equal_the_object_formatters(seed, monkeypatch):
+    if seed >= 10:  # the sort of a crowded sample's entries — by contig, the contigs' stretches side by side — on a small table
+        monkeypatch.setenv("SVX_VCF_SORT_SPLIT", "0")
+        seed -= 10
     rng = np.random.default_rng(200 + seed)
     seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=l)) for n, l in zip(NAMES, LENGTHS)}
     # (seed 4: more than 4096 entries — the formatter then works on chunks in several threads)
