@@ -1183,10 +1183,11 @@ __global__ __launch_bounds__(256) void k_segment_rows(SegRowArgs p) {
 }
 
 // ---- the split-segment chain of one submission (SVIM_inter.py:62-340) inside the launches of the CIGAR path: a
-// workgroup owns `reads_per_block` consecutive chimeric reads.  Stage A (in the tile launch of the two-launch path,
-// in the finish launch of the streaming path): the segment rows (CIGAR statistics -> svx_seg, :66-81: a lane per
-// tiny alignment, the workgroup's chunk list for the others, the whole workgroup beyond kLongOps), a workgroup
-// barrier, the adjacent-pair decision tree (eight lanes per read, :83-258).  Stage B (in the last launch of the
+// workgroup owns consecutive chimeric reads — the range the caller's table gives it (`deal`: equal CIGAR op counts,
+// svx_chain_deal), else `reads_per_block` of them.  Stage A (in the tile launch of the two-launch path, in the finish
+// launch of the streaming path): the segment rows (CIGAR statistics -> svx_seg, :66-81: a lane per tiny alignment,
+// chunks of 128 ops dealt to the workgroup's sixteen 16-lane groups for all others), a workgroup barrier, the
+// adjacent-pair decision tree (eight lanes per read, :83-258).  Stage B (in the last launch of the
 // path): the three post-passes (one lane per read, :260-338).  The rows travel through HBM
 // and are read back by the workgroup that wrote them, i.e. from the same CU's cache, behind the barrier; the raw
 // records are an output anyway.  Round 3 ran the chain as three launches of 4-7 us each behind the CIGAR path.
@@ -1802,11 +1803,11 @@ void a3_fill(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t* d_aln_off, c
     o.scratch = svx_ws_take<char>(ctx, (size_t)q.n_reads * post_stride);
     o.scratch_off = nullptr;
     o.scratch_stride = post_stride;
-    // reads per workgroup of the rows + tree stage: one or two while the grid stays small (the shortest dependent sequence
-    // per workgroup), up to 32 for a cohort's reads — about 100 segments and 100 chunks, six per sixteen-lane group,
-    // and the 2 000 workgroups of a cohort of 256 samples are all resident at once (8 per CU).  Measured on that
-    // cohort, k_finish_a3: 8 reads 67.7 us, 16: 55.3, 24: 56.4, 32: 53.5, 48: 57.1, 64: 59.1
-    // (profiles/r04_ab_chain_rows.txt)
+    // reads per workgroup of the rows + tree stage when the caller hands over no table: one or two while the grid stays
+    // small (the shortest dependent sequence per workgroup), up to 32 for a cohort's reads, so that its ~2 000
+    // workgroups are all resident at once (8 per CU).  Measured on the cohort of 256 samples with the round-4 rows loop,
+    // k_finish_a3: 8 reads 67.7 us, 16: 55.3, 24: 56.4, 32: 53.5, 48: 57.1, 64: 59.1 (profiles/r04_ab_chain_rows.txt);
+    // svx_chain_deal (svx_collect.hip) uses the same count of workgroups for its table
 #ifndef SVX_A3_READS_DIV
 #define SVX_A3_READS_DIV 1024u
 #endif
