@@ -235,6 +235,7 @@ struct Cursor {
     bool prefix_mode = false;   // inflate members only as far as the bytes asked for (svx_bam_seq_slices)
     bool whole = false;         // the member in `buf` has been inflated to its end and its CRC32 checked
     uint64_t n_hopped = 0;      // members passed (inflated or not)
+    std::vector<uint64_t>* verified = nullptr;  // (walks) file offsets of the members inflated whole with their CRC32 checked
     std::vector<uint8_t> buf;
 
     Cursor(const File* file, Inflater* i) : f(file), inf(i) {}
@@ -273,6 +274,7 @@ struct Cursor {
         if (!inf->extend(buf.data(), buf_valid, want, blk.isize, blk.crc, &valid)) { bad = true; buf_coff = ~0ull; return false; }
         buf_coff = coff;
         buf_valid = valid;
+        if (want == blk.isize && !whole && verified) verified->push_back(coff);
         whole = want == blk.isize;
         return true;
     }
@@ -315,6 +317,7 @@ struct Chunk {
     std::vector<char> names;
     std::vector<uint8_t> aux;
     uint64_t blocks_spanned = 0;
+    std::vector<uint64_t> verified;  // members this walk inflated whole and CRC-checked (verifying ingest)
     std::string err;
 };
 
@@ -356,6 +359,7 @@ bool walk_records(const File* f, VPos start, bool have_stop, VPos stop, Inflater
     // a record's head, name and CIGAR are followed by its SEQ bytes — the expensive kind to inflate (svx_inflate.h) —
     // which the walk hops over: stopping right behind the CIGAR is a third of the CPU time of inflating the member
     c.prefix_mode = !whole_members;
+    if (whole_members) c.verified = &out->verified;
     char msg[256];
     if (!c.seek(start)) { out->err = "malformed BGZF member at a walk start"; return false; }
     std::vector<uint8_t> body;
@@ -691,6 +695,9 @@ struct svx_bam {
     std::vector<char> names;
     std::vector<uint8_t> aux;
     uint64_t blocks_inflated = 0, blocks_spanned = 0;
+    std::vector<uint64_t> verified_members;  // sorted: members a record walk has inflated whole and CRC-checked — a sequence
+                                             // slice that lands in one of them (a third do: the first member of a record's
+                                             // SEQ bytes holds its head and CIGAR) needs only its prefix, not a second check
     int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
     bool verify = true;   // inflate whole members and check their CRC32 (svx_bam_set_verify); the default
     Pool pool;
@@ -1048,6 +1055,16 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     }
     // ---- concatenate
     uint64_t n = 0, n_cig = 0, n_name = 0, n_aux = 0, spanned = 0;
+    {
+        size_t add = 0;
+        for (const Chunk& ch : chunks) add += ch.verified.size();
+        if (add) {
+            b->verified_members.reserve(b->verified_members.size() + add);
+            for (const Chunk& ch : chunks) b->verified_members.insert(b->verified_members.end(), ch.verified.begin(), ch.verified.end());
+            std::sort(b->verified_members.begin(), b->verified_members.end());
+            b->verified_members.erase(std::unique(b->verified_members.begin(), b->verified_members.end()), b->verified_members.end());
+        }
+    }
     for (const Chunk& ch : chunks) {
         spanned += ch.blocks_spanned;
         for (size_t i = 0; i < ch.tid.size(); ++i) {
@@ -1204,7 +1221,9 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 in[k] = b->file.map + jb.coff + jb.blk.payload_off;
                 in_len[k] = jb.blk.payload_len;
                 isize[k] = jb.blk.isize;
-                want[k] = verify_all ? jb.blk.isize : jb.upto;
+                // (a member a record walk has already inflated whole and checked is not checked a second time)
+                want[k] = (verify_all && !std::binary_search(b->verified_members.begin(), b->verified_members.end(), jb.coff))
+                              ? jb.blk.isize : jb.upto;
                 crc[k] = jb.blk.crc;
             }
             if (!Inflater::run_two(st.inf, in, in_len, st.buf, isize, want, crc, nj)) { failed.store(true); return; }
