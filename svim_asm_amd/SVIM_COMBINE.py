@@ -791,14 +791,17 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
         _clock("vcf_write_s", tc)
 
 
-def write_vcf_table(table, version, contig_names, contig_lengths, types_to_output, reference, options):
-    """write_final_vcf for a CandidateTable (rows of each type in the order the reference's per-type lists have)."""
+def write_vcf_table(table, version, contig_names, contig_lengths, types_to_output, reference, options, release_reference=True):
+    """write_final_vcf for a CandidateTable (rows of each type in the order the reference's per-type lists have).
+    release_reference=False: the mappings of the reference genome, closed inside (:466-467), are left to the end of the
+    process — what the command does, which exits right behind the VCF."""
     with open(options.working_dir + "/variants.vcf", "wb") as vcf_output:
         header = "".join(line + "\n" for line in _header_lines(version, contig_names, contig_lengths, types_to_output, options))
         vcf_output.write(header.encode("utf-8", "surrogateescape"))
         vcf_body(table, types_to_output, reference, options, sink=vcf_output)
-    from svim_asm_amd import fasta
-    fasta.release_deferred()  # the reference genome's mapping, closed inside vcf_body (:466-467), goes away behind the file
+    if release_reference:
+        from svim_asm_amd import fasta
+        fasta.release_deferred()  # the genome's mapping, closed inside vcf_body (:466-467), goes away behind the file, on a thread
 
 
 def write_final_vcf(int_duplication_candidates, inversion_candidates, tandem_duplication_candidates,

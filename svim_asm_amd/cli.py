@@ -225,7 +225,7 @@ def _run_steps(options):
     logging.info("Write SV candidates..")
     types_to_output = [entry.strip() for entry in options.types.split(",")]
     write_vcf_table(sv_candidates, __version__, aln_file1.references, aln_file1.lengths, types_to_output, reference,
-                    options)
+                    options, release_reference=False)  # (the process ends here: the kernel takes the mappings back)
     logging.info("Done.")
 
 

@@ -62,8 +62,8 @@ def main(argv=None):
     logging.info("****************** STEP 1: COLLECT (%d samples, %d BAM files, one submission) ******************",
                  len(samples), len(files))
     tables = SVIM_COLLECT.collect_tables(files, opts[0])
-    reference = FastaFile(genome)
     for k, (o, (wd, bams)) in enumerate(zip(opts, samples)):
+        reference = FastaFile(genome)  # (write_final_vcf closes its FastaFile, SVIM_COMBINE.py:466-467: one per sample)
         mine, mine_files = tables[k * n_bams:(k + 1) * n_bams], files[k * n_bams:(k + 1) * n_bams]
         if mode == "diploid":
             candidates = shard.pair_sharded(mine[0], mine[1], reference, mine_files[0], o)

@@ -1156,7 +1156,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
     // CRC32 (htslib's behaviour) instead of stopping at the last byte needed (a member inflated in part cannot be checked)
     const bool verify_all = b->verify;
     std::atomic<bool> failed(false);
-    std::atomic<uint64_t> inflated(0);
+    std::atomic<uint64_t> inflated(0), n_jobs(0), n_known(0);
     // A run of slices in three steps: (1) locate — walk the member headers (nothing is inflated) from each record's
     // SEQ start to the bytes of its slices: which members, and how far into each; (2) inflate those members two at a
     // time (Inflater::run_two: the decoder's rounds are latency-bound, two streams side by side cost 1.3x one);
@@ -1222,8 +1222,10 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 in_len[k] = jb.blk.payload_len;
                 isize[k] = jb.blk.isize;
                 // (a member a record walk has already inflated whole and checked is not checked a second time)
-                want[k] = (verify_all && !std::binary_search(b->verified_members.begin(), b->verified_members.end(), jb.coff))
-                              ? jb.blk.isize : jb.upto;
+                const bool known = verify_all && std::binary_search(b->verified_members.begin(), b->verified_members.end(), jb.coff);
+                want[k] = (verify_all && !known) ? jb.blk.isize : jb.upto;
+                n_jobs.fetch_add(1, std::memory_order_relaxed);
+                if (known) n_known.fetch_add(1, std::memory_order_relaxed);
                 crc[k] = jb.blk.crc;
             }
             if (!Inflater::run_two(st.inf, in, in_len, st.buf, isize, want, crc, nj)) { failed.store(true); return; }
@@ -1293,6 +1295,10 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                     start_max.load() / 1e3, wall_max.load() / 1e3, cpu_max.load() / 1e3, cpu_sum.load() / 1e3);
     }
     b->blocks_inflated += inflated.load();
+    if (getenv("SVX_BAM_DEBUG"))
+        fprintf(stderr, "svx_bam_seq_slices: %llu member inflations, %llu of them of members a record walk had verified (prefix only); "
+                "%zu members verified by walks\n", (unsigned long long)n_jobs.load(), (unsigned long long)n_known.load(),
+                b->verified_members.size());
     if (failed.load()) return fail(b, SVX_E_INVALID, "svx_bam_seq_slices: bad slice bounds or malformed BGZF data");
     return SVX_OK;
 }

@@ -217,3 +217,19 @@ def test_submission_groups_respect_the_op_limit():
     assert SVIM_COLLECT._submission_groups(samples, False) == [[s] for s in samples]  # headers differ: one per file
     big = [S((1 << 31) + 5, []), S((1 << 31) + 5, []), S(7, [])]
     assert [len(g) for g in SVIM_COLLECT._submission_groups(big, True)] == [1, 2]
+
+
+def test_cohort_command_writes_every_samples_vcf(tmp_path, monkeypatch):
+    """svim-asm-cohort (host logic; the device answered by the oracle): three diploid samples in one process — every
+    sample's VCF is the one the real reference wrote for it alone.  (write_final_vcf closes its FastaFile,
+    SVIM_COMBINE.py:466-467: the cohort opens the genome once per sample.)"""
+    from svim_asm_amd import cli, cohort
+    monkeypatch.setattr(cli, "_warm_device", lambda device: None)
+    g = os.path.join(GOLD, "config1")
+    rows = [("s1", "hap1.bam", "hap2.bam"), ("s2", "hap1.bam", "hap2.bam"), ("s3", "hap1.bam", "hap2.bam")]
+    manifest = tmp_path / "cohort.tsv"
+    manifest.write_text("".join("%s %s %s\n" % (tmp_path / wd, os.path.join(g, a), os.path.join(g, b)) for wd, a, b in rows))
+    assert cohort.main(["diploid", str(manifest), os.path.join(g, "ref.fa")]) == 0
+    for wd, _, _ in rows:
+        got = "".join(l for l in open(tmp_path / wd / "variants.vcf") if not l.startswith("##fileDate="))
+        assert got == open(os.path.join(g, "diploid_default.vcf")).read()

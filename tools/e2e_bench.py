@@ -275,7 +275,8 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             from svim_asm_amd import SVIM_COMBINE
             r["pair_stages_s"] = {k: v for k, v in SVIM_COMBINE.LAST_TIMING.items() if k.startswith("pair_")}
             t = time.perf_counter()
-            write_vcf_table(paired, "1.0.3", f1.references, f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts)
+            write_vcf_table(paired, "1.0.3", f1.references, f1.lengths, [x.strip() for x in opts.types.split(",")], ref, opts,
+                            release_reference=False)  # as cli._run_steps: the command exits behind the VCF
             r["vcf_s"] = time.perf_counter() - t
             cpu.append(time.process_time())
             # what the run costs in CPU seconds: on a node that grants a process a CPU quota (cgroup cpu.max) the sum,
@@ -295,6 +296,8 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
                           "cigar_ops": [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]}
             del t1, t2, paired
             f1.close(), f2.close()
+            from svim_asm_amd import fasta as _fasta
+            _fasta.release_deferred(background=False)  # (the genome's mapping of this repeat, outside every clock)
             gc.enable()
             if prof is not None:
                 import pstats
