@@ -102,13 +102,14 @@ def test_exchange_socket_lives_in_a_private_directory(tmp_path, monkeypatch):
     import stat
     from svim_asm_amd import shard
     monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
-    monkeypatch.setenv("TMPDIR", str(tmp_path))
     import tempfile
+    short = tempfile.mkdtemp(prefix="svx", dir="/tmp")  # (a deep TMPDIR makes the product fall back to /tmp: 107-byte socket paths)
+    monkeypatch.setenv("TMPDIR", short)
     monkeypatch.setattr(tempfile, "tempdir", None)
     monkeypatch.setenv("MASTER_PORT", "12345")
     path = shard._rendezvous_path()
     d = os.path.dirname(path)
-    assert d == str(tmp_path / ("svx-%d" % os.getuid())) and path.endswith(".sock")
+    assert d == os.path.join(short, "svx-%d" % os.getuid()) and path.endswith(".sock")
     assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700
     monkeypatch.setenv("MASTER_PORT", "12346")
     assert shard._rendezvous_path() != path  # another job, another socket
