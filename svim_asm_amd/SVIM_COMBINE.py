@@ -765,7 +765,9 @@ def vcf_body(table, types_to_output, reference, options, sink=None):
         try:
             sink.flush()
             fd = sink.fileno()
-            if not stat.S_ISREG(os.fstat(fd).st_mode):
+            import fcntl
+            # (pwrite ignores its offset on a descriptor opened for appending; anything but a regular file has no offsets)
+            if not stat.S_ISREG(os.fstat(fd).st_mode) or (fcntl.fcntl(fd, fcntl.F_GETFL) & os.O_APPEND):
                 fd = None
         except (AttributeError, OSError, ValueError):  # not a real file: the buffer form below
             fd = None

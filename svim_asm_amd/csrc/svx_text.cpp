@@ -559,6 +559,8 @@ extern "C" int svx_vcf_format(const svx_vcf_in* in, char** text, uint64_t* n_byt
 
 extern "C" int svx_vcf_write(const svx_vcf_in* in, int fd, uint64_t* n_bytes, uint64_t* n_lines) {
     if (fd < 0) return SVX_E_INVALID;
+    const int fl = fcntl(fd, F_GETFL);
+    if (fl < 0 || (fl & O_APPEND)) return SVX_E_INVALID;  // (pwrite on an append-mode descriptor ignores its offset)
     const off_t here = lseek(fd, 0, SEEK_CUR);  // behind what the caller has written (the header lines)
     if (here < 0) return SVX_E_INVALID;
     uint64_t n = 0;

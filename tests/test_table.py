@@ -209,3 +209,14 @@ def test_native_vcf_lines_equal_the_object_formatters(seed, monkeypatch):
             fh.write(b"trailer written by the caller\n")
         text = open(path, "rb").read().decode().split("\n")
     assert text[:2] == ["##header line", "#CHROM"] and text[2:-2] == exp and text[-2:] == ["trailer written by the caller", ""]
+    if seed == 0:  # a sink opened for appending (pwrite would ignore its offsets) or without a descriptor: the buffer form
+        import io
+        with tempfile.TemporaryDirectory() as d:
+            with open(d + "/a.vcf", "wb") as fh:
+                fh.write(b"earlier content\n")
+            with open(d + "/a.vcf", "ab") as fh:
+                SVIM_COMBINE.vcf_body(table, types, helpers.FakeFasta(seqs), o, sink=fh)
+            assert open(d + "/a.vcf", "rb").read().decode().split("\n") == ["earlier content"] + exp + [""]
+        mem = io.BytesIO()
+        SVIM_COMBINE.vcf_body(table, types, helpers.FakeFasta(seqs), o, sink=mem)
+        assert mem.getvalue().decode().split("\n") == exp + [""]
