@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, step 4: config 5 end to end with the PAIR distance jobs in 1 / 2 / 4 / 8 chunks; the config-5 golden; the
+# config 5 end to end with the PAIR distance jobs in 1 / 2 / 4 / 8 chunks; the config-5 golden; the
 # full-size sample in process (VCF written by the formatting threads)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r05_s4; mkdir -p $out
