@@ -1,6 +1,6 @@
 // text_sanitize.cpp — the native text side (svim_asm_amd/csrc/svx_text.cpp, the C-ABI of include/svx_text.h) under
 // AddressSanitizer / UBSan / ThreadSanitizer on the CPU: svx_fasta_fetch_batch on a wrapped FASTA with valid, clipped and
-// invalid intervals, and svx_vcf_format on random candidate columns — well-formed ones (every kind, every option) and
+// invalid intervals, and svx_vcf_format / svx_vcf_write on random candidate columns — well-formed ones (every kind, every option) and
 // ones whose indices, offsets or lengths were damaged.  A damaged input may be refused or formatted as what it now says;
 // the library must not touch memory it does not own.  Test infrastructure (tests/test_text_sanitizers.py builds and runs
 // it); not part of the product.
@@ -177,6 +177,30 @@ int main(int argc, char** argv) {
             uint64_t nl = 0;
             for (uint64_t i = 0; i < n_bytes; ++i) { g_sum += (uint8_t)text[i]; nl += text[i] == '\n'; }
             if (nl != ne) return 9;
+            // the same lines through svx_vcf_write (every formatting thread writes its stretch with pwrite behind what the
+            // caller wrote) and, every other round, with the entries sorted contig by contig (SVX_VCF_SORT_SPLIT=0)
+            {
+                if (round & 1) setenv("SVX_VCF_SORT_SPLIT", "0", 1); else unsetenv("SVX_VCF_SORT_SPLIT");
+                const std::string vpath = dir + "/out.vcf";
+                FILE* vf = fopen(vpath.c_str(), "wb");
+                if (!vf) return 12;
+                fputs("#header\n", vf);
+                fflush(vf);
+                uint64_t wb = 0, wl = 0;
+                const int wrc = svx_vcf_write(&in, fileno(vf), &wb, &wl);
+                fclose(vf);
+                unsetenv("SVX_VCF_SORT_SPLIT");
+                if (wrc != 0 || wb != n_bytes || wl != n_lines) return 13;
+                vf = fopen(vpath.c_str(), "rb");
+                if (!vf) return 12;
+                std::vector<char> back(n_bytes + 8);
+                const size_t got = fread(back.data(), 1, back.size(), vf);
+                const bool at_end = fgetc(vf) == EOF;
+                fclose(vf);
+                if (got != n_bytes + 8 || !at_end || memcmp(back.data(), "#header\n", 8) != 0 ||
+                    (n_bytes && memcmp(back.data() + 8, text, n_bytes) != 0))
+                    return 14;
+            }
             svx_vcf_free(text);
             ++formatted;
         } else {
