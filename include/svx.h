@@ -408,6 +408,9 @@ int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_collect_out* o
  *   read_off, post_off   HOST copies (sizes of the per-read scratch and output regions; validated by
  *                svx_collect_batch, here a precondition), d_read_off / d_post_off the same in HBM
  *   d_segs, d_read_len   n_segs rows / n_reads lengths of scratch the chain writes and reads
+ *   d_chain_deal, n_chain_blocks   optional: the table svx_chain_deal (below) wrote, uploaded by the caller — which
+ *                workgroup computes which reads' rows (8-byte aligned, entries within the submission's reads and
+ *                segments: a precondition; the kernel clamps what it indexes with).  Results never depend on it.
  * Outputs as svx_collect_batch, in HBM: d_sig (exactly min(count, sig_cap) signatures), d_n_sig (one uint64),
  * d_raw[n_segs], d_post / d_post_cnt.
  */
