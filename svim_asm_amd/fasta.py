@@ -131,6 +131,14 @@ class FastaFile(object):
         if self._fh:
             _DEFERRED.append(("file", self._fh))
             self._fh = None
+        if len(_DEFERRED) > 12:  # a caller that opens and closes many genomes and never writes a VCF: bounded
+            release_deferred()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 — interpreter shutdown
+            pass
 
 
 _DEFERRED = []  # mappings and descriptors of closed FastaFile objects, not yet given back
