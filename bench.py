@@ -1025,6 +1025,11 @@ def main():
             try:
                 entry = json.load(open(tpath)).get(wl_key, {})
                 traffic = entry.get("hbm_bytes_per_launch")
+                # the committed counters belong to ONE workload: the bytes this run's launch counts must be the ones the
+                # counter passes' launch counted (same ops, alignments, signatures, tiles), else no figure at all
+                counted = entry.get("counted_bytes_per_launch")
+                if traffic is not None and counted is not None and abs(kernel_bytes - counted) > 0.002 * counted:
+                    traffic = None
                 if traffic is not None:
                     # not a property of THIS run: PMC counters need their own rocprofv3 passes (separate --pmc runs,
                     # MI355X_MICROARCH.md); the figure is the committed one of the same workload and kernel
