@@ -566,6 +566,45 @@ typedef struct svx_hap_piece {
 
 int svx_haplotype_distance_batch(svx_ctx* ctx, const uint8_t* pool, uint64_t pool_bytes,
                                  const svx_hap_piece* pieces, uint32_t n_pairs, uint32_t k_max, uint32_t* dist);
+
+/*
+ * The recipes of a PAIR step's jobs from the candidate columns — host arithmetic (threads), the counterpart of the
+ * six `reference.fetch` calls and the string concatenations of compute_distance (SVIM_COMBINE.py:43-100) per pair:
+ * job j compares rows job_a[j] and job_b[j] (different haplotypes) of partition job_part[j].  Per partition: its SV
+ * type (0 DEL, 1 INV, 2 INS, 3 DUP_TAN, 4 DUP_INT), the length of its contig, and ONE reference window in the pool —
+ * [win_lo, ...) starting at pool byte win_base — that covers [min start - 100, max end + 100) of all its members.  The
+ * pool continues behind the windows at `extra_at` with (in this order) the DUP_INT source intervals the caller fetched
+ * (their places per job and haplotype in mid_off / mid_len, n_jobs x 2; NULL without DUP_INT jobs) and the stretches of
+ * the inserted-sequence pool the INS jobs' alleles lie in: returned in seq_range as {lo, hi} of the first haplotype
+ * table's part and {lo, hi} of the second's (offsets >= seq_split; seq_split < 0: one table) — the caller appends
+ * seqs[lo:hi] of both.  pieces receives 6 per job (3 of haplotype a, 3 of b).  worst_copies: the largest `copies` of a
+ * tandem job (SVX_E_TOO_LARGE when a piece would repeat more than 65 535 times).
+ */
+typedef struct svx_recipe_in {
+    uint32_t n_rows;
+    const uint8_t* type;
+    const int64_t* ss;
+    const int64_t* se;
+    const int64_t* ds;
+    const int64_t* q_off;
+    const int64_t* q_len;
+    const int64_t* copies;
+    uint64_t n_jobs;
+    const int64_t* job_a;
+    const int64_t* job_b;
+    const int64_t* job_part;
+    uint32_t n_parts;
+    const int64_t* part_type;
+    const int64_t* part_len;
+    const int64_t* win_base;
+    const int64_t* win_lo;
+    uint64_t extra_at;
+    int64_t seq_split;
+    const int64_t* mid_off;
+    const int64_t* mid_len;
+} svx_recipe_in;
+
+int svx_pair_recipes(const svx_recipe_in* in, svx_hap_piece* pieces, int64_t* seq_range, int64_t* worst_copies);
 /* The same with the byte pool already in HBM (d_pool: e.g. one upload of the reference windows serving the
  * thresholded and the exact batch of a PAIR step).  pieces and dist stay host arrays and the call synchronises:
  * the stages of the distance computation are planned from read-backs (which pairs the wavefront pass resolved). */

@@ -209,6 +209,60 @@ class _Clusters(object):
 
 def _haplotype_pieces(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig, win_base, win_lo, L_part, reference,
                       seq_split=None):
+    """The recipes of the jobs: svx_pair_recipes (include/svx.h; host arithmetic in libsvx.so) for everything but the
+    fetch of the interspersed duplications' source intervals.  _haplotype_pieces_numpy below is the same arithmetic as
+    array expressions (the form it had until round 5; tests/test_host_logic.py holds the two against each other)."""
+    J = len(job_a)
+    lib = _lib.load()
+    typ = p_type[job_part]
+    windows_bytes = int(win_base[-1]) if len(win_base) else 0
+    extra_parts, extra_at = [], windows_bytes
+    mid_off = mid_len = None
+    dint = np.flatnonzero(typ == T_DUP_INT)
+    if len(dint):
+        rows = (job_a, job_b)
+        mid_off, mid_len = np.zeros((J, 2), np.int64), np.zeros((J, 2), np.int64)
+        cand = np.unique(np.concatenate((job_a[dint], job_b[dint])))
+        Ls = _reference_lengths(reference, T.contigs, T.sc[cand])[T.sc[cand]]
+        n_src = np.maximum(0, np.minimum(T.se[cand], Ls) - T.ss[cand])
+        pool, off = _fetch_windows(reference, T.contigs, T.sc[cand], T.ss[cand], T.se[cand], False)
+        if not np.array_equal(off[1:] - off[:-1], n_src):
+            raise ValueError("reference windows shorter than the index says")
+        extra_parts.append(pool)
+        for h in (0, 1):
+            where = np.searchsorted(cand, rows[h][dint])
+            mid_off[dint, h] = extra_at + off[:-1][where]
+            mid_len[dint, h] = n_src[where]
+        extra_at += len(pool)
+    keep = []
+
+    def ptr(a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        keep.append(a)
+        return a.ctypes.data if a.size else None
+    pieces = np.zeros((J, 2, 3), dtype=_lib.HAP_PIECE_DTYPE)
+    seq_range, worst = np.zeros(4, np.int64), np.zeros(1, np.int64)
+    arg = _lib.RecipeIn(
+        n_rows=len(T), type=ptr(T.type, np.uint8), ss=ptr(T.ss, np.int64), se=ptr(T.se, np.int64), ds=ptr(T.ds, np.int64),
+        q_off=ptr(T.q_off, np.int64), q_len=ptr(T.q_len, np.int64), copies=ptr(T.copies, np.int64), n_jobs=J,
+        job_a=ptr(job_a, np.int64), job_b=ptr(job_b, np.int64), job_part=ptr(job_part, np.int64), n_parts=len(p_type),
+        part_type=ptr(p_type, np.int64), part_len=ptr(L_part, np.int64), win_base=ptr(win_base, np.int64),
+        win_lo=ptr(win_lo, np.int64), extra_at=extra_at, seq_split=-1 if seq_split is None else int(seq_split),
+        mid_off=ptr(mid_off, np.int64) if mid_off is not None else None,
+        mid_len=ptr(mid_len, np.int64) if mid_len is not None else None)
+    rc = lib.svx_pair_recipes(C.byref(arg), pieces.ctypes.data if J else None, seq_range.ctypes.data, worst.ctypes.data)
+    if rc == _lib.SVX_E_TOO_LARGE:
+        raise ValueError("tandem duplication with %d copies" % int(worst[0]))
+    if rc != 0:
+        raise _lib.SvxError(rc, "svx_pair_recipes")
+    if int(seq_range[1]) > int(seq_range[0]) or int(seq_range[3]) > int(seq_range[2]):
+        seqs = np.asarray(T.seqs, dtype=np.uint8)
+        extra_parts.extend(seqs[int(lo_):int(hi_)] for lo_, hi_ in ((seq_range[0], seq_range[1]), (seq_range[2], seq_range[3])) if hi_ > lo_)
+    return pieces, extra_parts
+
+
+def _haplotype_pieces_numpy(T, kstart, kend, job_a, job_b, job_part, p_type, p_contig, win_base, win_lo, L_part, reference,
+                            seq_split=None):
     """svx_hap_piece recipes (3 per haplotype, 6 per job) of the strings compute_distance aligns
     (SVIM_COMBINE.py:43-100) for jobs (candidate rows a, b of partition job_part).  Returns (pieces [J, 2, 3],
     extra pool parts appended behind the windows: interspersed-duplication source intervals, inserted sequences)."""

@@ -90,6 +90,15 @@ class CollectDev(C.Structure):
                 ("d_post_cnt", C.c_void_p), ("d_chain_deal", C.c_void_p), ("n_chain_blocks", C.c_uint32)]
 
 
+class RecipeIn(C.Structure):
+    """svx_recipe_in (include/svx.h)."""
+    _fields_ = [("n_rows", C.c_uint32), ("type", C.c_void_p), ("ss", C.c_void_p), ("se", C.c_void_p), ("ds", C.c_void_p),
+                ("q_off", C.c_void_p), ("q_len", C.c_void_p), ("copies", C.c_void_p), ("n_jobs", C.c_uint64),
+                ("job_a", C.c_void_p), ("job_b", C.c_void_p), ("job_part", C.c_void_p), ("n_parts", C.c_uint32),
+                ("part_type", C.c_void_p), ("part_len", C.c_void_p), ("win_base", C.c_void_p), ("win_lo", C.c_void_p),
+                ("extra_at", C.c_uint64), ("seq_split", C.c_int64), ("mid_off", C.c_void_p), ("mid_len", C.c_void_p)]
+
+
 class CollectOut(C.Structure):
     """svx_collect_out (include/svx.h)."""
     _fields_ = [("sig", SigSoa), ("sig_cap", C.c_uint64), ("n_sig", C.c_uint64), ("raw", C.c_void_p),
@@ -158,6 +167,7 @@ SYMBOLS = {
                                           _P]),
     "svx_haplotype_distance_batch": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P]),
     "svx_haplotype_distance_batch_mixed": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, _P]),
+    "svx_pair_recipes": (C.c_int, [C.POINTER(RecipeIn), _P, _P, _P]),
     "svx_linkage_cut_batch": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_double, _P]),
     # native BAM ingest (include/svx_bam.h)
     "svx_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P), C.c_char_p, C.c_size_t]),

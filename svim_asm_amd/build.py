@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsvx.so")
-SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip", "svx_linkage.hip", "svx_postpass.hip", "svx_collect.hip", "svx_inflate.hip", "svx_bam.cpp", "svx_text.cpp"]
+SOURCES = ["svx_ctx.hip", "svx_cigar.hip", "svx_segments.hip", "svx_pair.hip", "svx_editdist.hip", "svx_linkage.hip", "svx_postpass.hip", "svx_collect.hip", "svx_inflate.hip", "svx_bam.cpp", "svx_text.cpp", "svx_pairhost.cpp"]
 
 
 def _hipcc():

@@ -216,3 +216,63 @@ def test_cli_rejects_unsorted_bam_without_touching_the_gpu(tmp_path, caplog):
         cli.main(["haploid", str(wd), os.path.join(GOLD, "chimeric_read.bam"), os.path.join(GOLD, "config1", "ref.fa")])
     assert "needs to be coordinate-sorted" in caplog.text
     assert not (wd / "variants.vcf").exists()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_native_recipes_equal_the_array_form(seed):
+    """svx_pair_recipes (libsvx.so, host arithmetic) against _haplotype_pieces_numpy — the recipes of compute_distance
+    (SVIM_COMBINE.py:43-100) as array expressions — on random candidate columns of every type: windows clipped at both
+    contig ends, empty and absent alleles, tandem copies, interspersed duplications whose source intervals are fetched,
+    one and two haplotype tables' sequence pools, more than 8192 jobs (the threaded form)."""
+    from svim_asm_amd.table import CandidateTable, T_DEL, T_DUP_INT, T_DUP_TAN, T_INS, T_INV
+    rng = np.random.default_rng(7000 + seed)
+    names = ["c%d" % i for i in range(4)]
+    lens = [int(x) for x in rng.integers(3000, 9000, size=4)]
+    seqs = {n: "".join(rng.choice(list("ACGTacgtN"), size=l)) for n, l in zip(names, lens)}
+    ref = helpers.FakeFasta(seqs)
+    n = 600
+    pool_bytes = 50_000
+    T = CandidateTable(names, lens, n, seqs=rng.integers(65, 91, size=pool_bytes).astype(np.uint8))
+    T.type[:] = rng.choice([T_DEL, T_INV, T_INS, T_DUP_TAN, T_DUP_INT], size=n)
+    T.sc[:] = rng.integers(0, 4, size=n)
+    T.dc[:] = T.sc
+    L_row = np.array(lens)[T.sc]
+    T.ss[:] = rng.integers(0, L_row)
+    T.se[:] = np.minimum(T.ss + rng.integers(0, 400, size=n), L_row + rng.integers(0, 3, size=n))  # some ends behind the contig
+    T.ds[:] = rng.integers(0, L_row)
+    T.de[:] = T.ds
+    split = 30_000 if seed % 2 == 0 else None
+    hap2 = rng.random(n) < 0.5
+    T.q_len[:] = np.where(T.type == T_INS, rng.integers(0, 300, size=n), 0)
+    T.q_off[:] = np.where(hap2 & (split is not None), rng.integers(30_000, 49_000, size=n), rng.integers(0, 29_000, size=n))
+    T.copies[:] = np.where(T.type == T_DUP_TAN, rng.integers(0, 5, size=n), 0)
+    src_like = (T.type == T_DEL) | (T.type == T_INV) | (T.type == T_DUP_TAN)
+    kstart, kend = np.where(src_like, T.ss, T.ds), np.where(src_like, T.se, T.ds)
+    # partitions: rows of one type on one contig; a job = two rows of a partition
+    J = [50, 700, 9000, 0][seed]
+    n_parts = 40
+    p_type = rng.choice([T_DEL, T_INV, T_INS, T_DUP_TAN, T_DUP_INT], size=n_parts).astype(np.int64)
+    p_contig = rng.integers(0, 4, size=n_parts).astype(np.int64)
+    members = [np.flatnonzero((T.type == p_type[p]) & (T.sc == p_contig[p])) for p in range(n_parts)]
+    ok_parts = [p for p in range(n_parts) if len(members[p]) >= 2]
+    job_part = rng.choice(ok_parts, size=J).astype(np.int64) if J else np.zeros(0, np.int64)
+    job_a = np.array([rng.choice(members[p]) for p in job_part], np.int64)
+    job_b = np.array([rng.choice(members[p]) for p in job_part], np.int64)
+    L_part = np.array(lens, np.int64)[p_contig]
+    seg_lo = np.array([kstart[m].min() if len(m) else 0 for m in members])
+    seg_hi = np.array([kend[m].max() if len(m) else 0 for m in members])
+    wlo = np.maximum(0, seg_lo - 100)
+    whi = np.minimum(L_part, seg_hi + 100)
+    win_base = np.concatenate(([0], np.cumsum(np.maximum(whi - wlo, 0)))).astype(np.int64)
+    args = (T, kstart, kend, job_a, job_b, job_part, p_type, p_contig, win_base, wlo.astype(np.int64), L_part, ref)
+    got, got_extra = SVIM_COMBINE._haplotype_pieces(*args, seq_split=split)
+    exp, exp_extra = SVIM_COMBINE._haplotype_pieces_numpy(*args, seq_split=split)
+    assert got.shape == exp.shape
+    for f in ("off", "len", "repeat", "flags"):
+        assert np.array_equal(got[f], exp[f]), f
+    assert len(got_extra) == len(exp_extra) and all(np.array_equal(a, b) for a, b in zip(got_extra, exp_extra))
+    if J:
+        T.copies[job_a[0]] = 70000
+        p_type[job_part[0]] = T_DUP_TAN
+        with pytest.raises(ValueError):
+            SVIM_COMBINE._haplotype_pieces(*args, seq_split=split)
