@@ -342,6 +342,9 @@ def _submit(samples, options, ctx):
         g_at += ng
 
 
+_TABLES_SIDE_BY_SIDE_FROM = 200000  # signatures of a submission from which its samples' tables are built on threads
+
+
 def _python_slice(a, b, n):
     """[lo, hi) that s[a:b] selects from a sequence of length n (negative indices wrap, as in the reference's
     primary.query_sequence[...] slices, SVIM_inter.py:117,120)."""
@@ -625,8 +628,15 @@ def collect_tables(bams, options, ctx=None):
     for group in groups:
         _submit(group, options, ctx)
     t2 = time.perf_counter()
-    for s in samples:   # starts every sample's sequence decoding (the readers' threads) before waiting for any
-        _table_of(s, options)
+    # (every sample's table starts its sequence decoding — the readers' threads — before anybody waits for any; the
+    #  tables of a crowded pair of haplotypes are ~10 ms of array arithmetic each: side by side)
+    if len(samples) > 1 and sum(len(s.sig_aln) for s in samples) > _TABLES_SIDE_BY_SIDE_FROM:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(4, len(samples))) as ex:
+            list(ex.map(lambda s: _table_of(s, options), samples))
+    else:
+        for s in samples:
+            _table_of(s, options)
     t3, c3 = time.perf_counter(), time.process_time()
     # (…_cpu_s: CPU seconds of all threads of the process — what a run costs under a CPU quota)
     LAST_TIMING.update(load_s=t0 - tl, prepare_s=t1 - t0, submit_s=t2 - t1, tables_s=t3 - t2, sequences_wait_s=0.0,

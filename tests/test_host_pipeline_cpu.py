@@ -233,3 +233,14 @@ def test_cohort_command_writes_every_samples_vcf(tmp_path, monkeypatch):
     for wd, _, _ in rows:
         got = "".join(l for l in open(tmp_path / wd / "variants.vcf") if not l.startswith("##fileDate="))
         assert got == open(os.path.join(g, "diploid_default.vcf")).read()
+
+
+def test_tables_built_side_by_side_give_the_same_vcf(tmp_path, monkeypatch):
+    """The tables of a crowded sample's two haplotypes are built on threads (SVIM_COLLECT.collect_tables): forced
+    here on the config-1 BAMs — the VCF is the real reference's."""
+    from svim_asm_amd import cli
+    monkeypatch.setattr(SVIM_COLLECT, "_TABLES_SIDE_BY_SIDE_FROM", 0)
+    g = os.path.join(GOLD, "config1")
+    cli.main(["diploid", str(tmp_path), os.path.join(g, "hap1.bam"), os.path.join(g, "hap2.bam"), os.path.join(g, "ref.fa")])
+    got = "".join(l for l in open(tmp_path / "variants.vcf") if not l.startswith("##fileDate="))
+    assert got == open(os.path.join(g, "diploid_default.vcf")).read()
