@@ -369,17 +369,32 @@ def collect_leg(args, local_rank, torch, batches, what, seed):
         t = torch.from_numpy(x["cigar"].view(np.int32)).pin_memory()
         pools.append((t, t.numpy().view(np.uint32)))
 
-    def host_call():
+    def host_call(part_dev=None):
         return ctx.collect_batch([p[1] for p in pools], b["aln_off"], b["ref_start"], args.min_sv_size, case["extra_cigar"],
                                  case["extra_off"], case["seg_src"], case["seg_tid"], case["seg_pos"], case["seg_rev"],
-                                 case["seg_qend"], case["read_off"], case["rank"], (args.min_sv_size, 100000, 50, 50, 50, 50))
+                                 case["seg_qend"], case["read_off"], case["rank"], (args.min_sv_size, 100000, 50, 50, 50, 50),
+                                 part_dev=part_dev)
     sig, raw, post, first = host_call()
-    host_t = []
-    for _ in range(20):
-        t0 = time.perf_counter()
-        host_call()
-        host_t.append(time.perf_counter() - t0)
-    host_ms = float(np.median(host_t)) * 1e3  # (median: a single call that meets a page fault storm is 10x the others)
+
+    def median_ms(call):
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3  # (median: a single call that meets a page fault storm is 10x the others)
+    host_ms = median_ms(host_call)
+    # the same call when the reader has put its pools into HBM during the walk (svx_bam_device_pool → part_dev): what is
+    # left of the submission is the control block's upload, a device-to-device move per pool, kernels and read-backs
+    in_hbm = [p[0].cuda(local_rank) for p in pools]
+    torch.cuda.synchronize()
+    where = [(t.data_ptr(), None) for t in in_hbm]
+    again = host_call(where)
+    if not (np.array_equal(again[0]["aln"], sig["aln"]) and np.array_equal(again[0]["ref_pos"], sig["ref_pos"])
+            and np.array_equal(again[1], raw) and np.array_equal(again[2], post)):
+        raise SystemExit("%s: the submission over pools in HBM differs from the one that uploads them" % what)
+    host_hbm_ms = median_ms(lambda: host_call(where))
+    del in_hbm
     # ---- the same kernel sequence with everything resident: one stream, no host round trip inside a step
     rc = ResidentCollect(ctx, b, case, args.min_sv_size)
     for _ in range(20):
@@ -421,6 +436,10 @@ def collect_leg(args, local_rank, torch, batches, what, seed):
             "host_call_ms": host_ms, "host_call_note": "svx_collect_batch from page-locked host memory: uploads (%.1f MB), kernels, "
                                                        "two read-backs, two synchronisations — the PCIe-inclusive figure, never `value`"
                                                        % ((4 * n_ops + 8 * n_aln) / 1e6),
+            "host_call_pools_in_hbm_ms": host_hbm_ms,
+            "host_call_pools_in_hbm_note": "the same call with the CIGAR pools already in HBM (the BAM reader uploads its pool "
+                                           "while it assembles it: svx_bam_device_pool, svx_collect_in.part_dev) — what the "
+                                           "command line's submission costs between the walk and the results",
             "bit_exact_vs_oracle": True}
 
 

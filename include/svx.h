@@ -358,6 +358,12 @@ int svx_segments_rows_dev(svx_ctx* ctx, const uint32_t* d_cigar, const uint64_t*
  *                 svx_segments_rows_dev
  *   read_off      n_reads + 1 offsets into the segment rows
  *   contig_rank, params   as for svx_segments_postpass
+ *   part_dev / part_ready   optional (NULL: every part is uploaded from cigar_parts): part_dev[k] != NULL says part k's
+ *                 part_ops[k] words are in HBM already, on the context's device (svx_bam_device_pool: the reader
+ *                 uploads its pool while it assembles it) — cigar_parts[k] is not read; part_ready[k], when
+ *                 part_ready != NULL and the entry is not NULL, is a hipEvent_t the part's producer recorded behind its
+ *                 last write: the context's stream waits for it, then moves the words into place device-to-device.
+ *                 The submission no longer carries 4 bytes per op over the host link between the walk and the kernels.
  * Output (host arrays):
  *   sig, sig_cap, n_sig    as svx_cigar_extract (SVX_E_CAPACITY with n_sig set when sig_cap is too small)
  *   raw[n_segs]            as svx_segments_classify
@@ -385,6 +391,8 @@ typedef struct svx_collect_in {
     const int32_t* contig_rank;
     uint32_t n_contigs;
     svx_seg_params params;
+    const uint32_t* const* part_dev;
+    void* const* part_ready;
 } svx_collect_in;
 
 typedef struct svx_collect_out {

@@ -79,6 +79,19 @@ int svx_bam_set_verify(svx_bam* bam, int on);
  * (the one the svx_ctx that will consume it lives on); device < 0 (default): pageable memory. */
 int svx_bam_set_pinned_device(svx_bam* bam, int device);
 
+/* The CIGAR pool's copy in HBM.  With a pinned device set, svx_bam_load also uploads the pool to that device, part by
+ * part on a stream of its own WHILE it assembles the pool from the walkers' chunks (the last part leaves within
+ * microseconds of the walk's end), so that svx_collect_batch can take it where it lies (svx_collect_in.part_dev /
+ * part_ready in svx.h) instead of uploading 4 bytes per op between the walk and the kernels.
+ *   *d_cigar  device address of the n_ops words of svx_bam_columns.cigar, NULL when there is no copy (no pinned device,
+ *             an empty pool, SVX_BAM_DEVICE_POOL=0 in the environment, or no memory: the caller uploads as before)
+ *   *ready    a hipEvent_t recorded behind the last part: a consumer on another stream waits for it
+ *             (hipStreamWaitEvent) before it reads *d_cigar
+ * Both stay valid until the next svx_bam_load on the handle or svx_bam_close.
+ * svx_bam_device_pool_wait blocks until the copy is complete; *waited_us = how long that took (0 without a copy). */
+int svx_bam_device_pool(svx_bam* bam, const uint32_t** d_cigar, uint64_t* n_ops, void** ready);
+int svx_bam_device_pool_wait(svx_bam* bam, double* waited_us);
+
 /* Index the records of contigs tids[0..n_tids) (NULL: every record of the file, unplaced ones
  * included), in file order. */
 int svx_bam_load(svx_bam* bam, const int32_t* tids, int32_t n_tids);

@@ -293,11 +293,15 @@ def _prepare(bam, options):
 def _submit(samples, options, ctx):
     """ONE device submission for all `samples` (their headers agree): fills s.sig / s.raw / s.post / s.post_first
     with each sample's share of the results (record and segment indices local to the sample)."""
-    parts, aln_base, ops_base, at_aln, at_ops = [], [], [], 0, 0
+    parts, part_dev, aln_base, ops_base, at_aln, at_ops = [], [], [], [], 0, 0
     for s in samples:
         aln_base.append(at_aln)
         ops_base.append(at_ops)
         parts.append(s.rec.cigar)
+        # the reader's own upload of its pool (svx_bam_device_pool): under way since the walk, not part of the submission
+        base = getattr(s.rec, "base", None)
+        pool = base.device_pool() if base is not None and hasattr(base, "device_pool") and s.rec.cigar is base._cigar else None
+        part_dev.append(pool)
         at_aln += len(s.rec.tid)
         at_ops += int(s.rec.cig_off[-1])
     n_aln = at_aln
@@ -321,10 +325,14 @@ def _submit(samples, options, ctx):
     read_off = np.zeros(len(seg_count) + 1, np.uint32)
     np.cumsum(seg_count, out=read_off[1:])
     cat = lambda k, dt: np.concatenate([getattr(s, k) for s in samples]).astype(dt, copy=False)
+    t_call = time.perf_counter()
     sig, raw, post, post_first = ctx.collect_batch(
         parts, aln_off, ref_start, options.min_sv_size, extra_cigar, extra_off, seg_src, cat("seg_tid", np.int32),
         cat("seg_pos", np.int32), cat("seg_rev", np.uint8), cat("seg_qend", np.int32), read_off,
-        SVIM_inter.contig_ranks(getattr(samples[0].bam, "_bam", samples[0].bam)), SVIM_inter.seg_params(options))
+        SVIM_inter.contig_ranks(getattr(samples[0].bam, "_bam", samples[0].bam)), SVIM_inter.seg_params(options),
+        part_dev=part_dev)
+    # (seconds inside svx_collect_batch: uploads — none for pools the reader put into HBM —, kernels, read-backs)
+    LAST_TIMING["collect_call_s"] = LAST_TIMING.get("collect_call_s", 0.0) + time.perf_counter() - t_call
     # split the results by sample
     sig_aln = sig["aln"].astype(np.int64)
     cut = np.searchsorted(sig_aln, aln_base + [n_aln], side="left")
@@ -620,6 +628,7 @@ def collect_tables(bams, options, ctx=None):
     agree, several where one would exceed the 2^32-op limit of svx_collect_batch."""
     ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
     tl, cl = time.perf_counter(), time.process_time()
+    LAST_TIMING.pop("collect_call_s", None)
     _load_together(bams)
     t0, c0 = time.perf_counter(), time.process_time()
     samples = [_prepare(bam, options) for bam in bams]

@@ -75,7 +75,8 @@ class CollectIn(C.Structure):
                 ("extra_cigar", C.c_void_p), ("extra_off", C.c_void_p), ("n_extra", C.c_uint32),
                 ("seg_src", C.c_void_p), ("seg_tid", C.c_void_p), ("seg_pos", C.c_void_p), ("seg_rev", C.c_void_p),
                 ("seg_qend", C.c_void_p), ("n_segs", C.c_uint32), ("read_off", C.c_void_p), ("n_reads", C.c_uint32),
-                ("contig_rank", C.c_void_p), ("n_contigs", C.c_uint32), ("params", SegParams)]
+                ("contig_rank", C.c_void_p), ("n_contigs", C.c_uint32), ("params", SegParams),
+                ("part_dev", C.POINTER(C.c_void_p)), ("part_ready", C.POINTER(C.c_void_p))]
 
 
 class CollectDev(C.Structure):
@@ -179,6 +180,8 @@ SYMBOLS = {
     "svx_bam_contig_spans": (C.c_int, [_P, _P]),
     "svx_bam_set_pinned_device": (C.c_int, [_P, C.c_int]),
     "svx_bam_set_verify": (C.c_int, [_P, C.c_int]),
+    "svx_bam_device_pool": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(_P)]),
+    "svx_bam_device_pool_wait": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "svx_bam_load": (C.c_int, [_P, _P, C.c_int32]),
     "svx_bam_get_columns": (C.c_int, [_P, _P]),
     "svx_bam_seq_slices": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P]),
@@ -446,9 +449,11 @@ class Context:
 
     # ---------------------------------------------------------------- COLLECT of a sample in one go
     def collect_batch(self, cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src, seg_tid,
-                      seg_pos, seg_rev, seg_qend, read_off, contig_rank, params):
+                      seg_pos, seg_rev, seg_qend, read_off, contig_rank, params, part_dev=None):
         """a1 + a2 + a3 of one sample (or of both haplotypes of one): see collect_batch_composed for the
-        contract.  One submission on the context's stream (svx_collect_batch)."""
+        contract.  One submission on the context's stream (svx_collect_batch).  `part_dev`: per part None or
+        (device address, hipEvent_t or None) of a copy of the part that is in HBM already
+        (BamFile.device_pool(): svx_collect_in.part_dev / part_ready) — that part is not uploaded again."""
         parts = [np.ascontiguousarray(p, dtype=np.uint32) for p in cigar_parts]
         aln_off = _as(aln_off, np.uint64)
         ref_start = _as(ref_start, np.int32)
@@ -479,6 +484,12 @@ class Context:
                         seg_tid=_ptr(seg_tid), seg_pos=_ptr(seg_pos), seg_rev=_ptr(seg_rev), seg_qend=_ptr(seg_qend),
                         n_segs=n_segs if n_reads else 0, read_off=_ptr(read_off), n_reads=n_reads,
                         contig_rank=_ptr(contig_rank), n_contigs=len(contig_rank), params=prm)
+        if part_dev is not None and any(d is not None and d[0] for d in part_dev):
+            if len(part_dev) != len(parts):
+                raise ValueError("part_dev: one entry per CIGAR part")
+            dev = [d if d is not None and d[0] else (None, None) for d in part_dev]
+            arg.part_dev = (C.c_void_p * len(parts))(*[d[0] for d in dev])
+            arg.part_ready = (C.c_void_p * len(parts))(*[d[1] for d in dev])
         while True:
             sig = {"aln": np.empty(cap, np.uint32), "ref_pos": np.empty(cap, np.uint32), "read_pos": np.empty(cap, np.uint32),
                    "len": np.empty(cap, np.uint32), "type": np.empty(cap, np.uint8)}
@@ -504,8 +515,9 @@ class Context:
         return sig, raw, packed, first
 
     def collect_batch_composed(self, cigar_parts, aln_off, ref_start, min_len, extra_cigar, extra_off, seg_src,
-                               seg_tid, seg_pos, seg_rev, seg_qend, read_off, contig_rank, params):
-        """The arithmetic of analyze_alignment_file_coordsorted (SVIM_COLLECT.py:61-83) for a whole batch,
+                               seg_tid, seg_pos, seg_rev, seg_qend, read_off, contig_rank, params, part_dev=None):
+        """(`part_dev` is accepted for collect_batch's signature and not used: the single-purpose calls upload.)
+        The arithmetic of analyze_alignment_file_coordsorted (SVIM_COLLECT.py:61-83) for a whole batch,
         composed from the single-purpose entry points (one call each):
           cigar_parts   BAM-native CIGAR pools, logically back to back; aln_off[n_aln + 1] / ref_start[n_aln]
                         describe EVERY record of the pools (records the filters drop are masked by the caller)

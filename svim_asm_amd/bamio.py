@@ -593,6 +593,24 @@ class AlignmentFile(object):
         """HIP device whose context page-locks the CIGAR pool of later loads (None: pageable)."""
         self._pin_device = device
 
+    def device_pool(self, wait=False):
+        """(device address, hipEvent_t) of the loaded CIGAR pool's copy in HBM, or None when there is none
+        (svx_bam_device_pool: the reader uploads the page-locked pool while it assembles it).  With `wait`, blocks
+        until the copy is complete and returns (address, None, microseconds waited)."""
+        if self._h is None or self._loaded is None:
+            return None
+        d, n, ev = C.c_void_p(), C.c_uint64(), C.c_void_p()
+        if self._lib.svx_bam_device_pool(self._h, C.byref(d), C.byref(n), C.byref(ev)) != 0 or not d.value:
+            return None
+        if int(n.value) != len(self._c_cigar):
+            return None
+        if wait:
+            us = C.c_double()
+            if self._lib.svx_bam_device_pool_wait(self._h, C.byref(us)) != 0:
+                raise ValueError("%s: %s" % (self.filename, self._lib.svx_bam_last_error(self._h).decode(errors="replace")))
+            return d.value, None, float(us.value)
+        return d.value, ev.value
+
     def load(self, contigs=None):
         """Index the records of `contigs` (names or tids; None = the whole file)."""
         if contigs is None:

@@ -672,6 +672,46 @@ class Pool {
     bool stop_ = false;
 };
 
+// The copy stream of the pools' uploads: ONE per device for the whole process, created and warmed on first use.  A
+// stream's creation plus its first host-to-device copy cost 10-25 ms on gfx950 (rocprofv3 --hip-trace of the command:
+// the first hipMemcpyAsync of a fresh stream returns after 12-15 ms) — per reader handle that was paid in every load;
+// here it is paid once, and svx_bam_load starts it on a thread BEFORE the record walk, so that it hides behind the walk.
+struct UploadLane {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    bool tried = false;
+    std::atomic<bool> up{false};  // tried, and the result is in `stream`
+};
+constexpr int kMaxLanes = 64;
+static UploadLane g_lanes[kMaxLanes];
+
+static hipStream_t upload_stream(int device) {
+    if (device < 0 || device >= kMaxLanes) return nullptr;
+    UploadLane& L = g_lanes[device];
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (L.tried) return L.stream;
+    L.tried = true;
+    hipStream_t st = nullptr;
+    void *h = nullptr, *d = nullptr;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    // the first copy of the stream sets up its DMA path: a 4 KiB one now instead of the pool's first part later
+    ok = ok && hipHostMalloc(&h, 4096, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, 4096) == hipSuccess;
+    if (ok) {
+        memset(h, 0, 4096);
+        ok = hipMemcpyAsync(d, h, 4096, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    if (!ok) {
+        (void)hipGetLastError();
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+    }
+    L.stream = st;
+    L.up.store(true);
+    return st;
+}
+
 struct svx_bam {
     int fd = -1;
     File file;
@@ -702,12 +742,58 @@ struct svx_bam {
     bool verify = true;   // inflate whole members and check their CRC32 (svx_bam_set_verify); the default
     Pool pool;
 
+    // copy of the page-locked pool in the pinned device's HBM, uploaded while svx_bam_load assembles the pool
+    // (svx_bam_device_pool); the buffer lives as long as the handle, the stream is the process's (upload_stream)
+    uint32_t* d_cigar = nullptr;
+    uint64_t d_cap = 0, d_ops = 0;   // words allocated / words of the current pool
+    hipStream_t up_stream = nullptr; // not owned
+    hipEvent_t up_done = nullptr;    // recorded behind the pool's last part
+    bool d_valid = false;
+    int d_device = -1;
+
     void free_cigar() {
+        if (d_valid) {  // the upload reads the page-locked pool: it must have ended before the pool goes
+            (void)hipEventSynchronize(up_done);
+            d_valid = false;
+        }
         if (!cigar) return;
         if (cigar_pinned) (void)hipHostFree(cigar);
         else free(cigar);
         cigar = nullptr;
         cigar_pinned = false;
+    }
+    void free_device() {
+        d_valid = false;
+        if (d_cigar) (void)hipFree(d_cigar);
+        if (up_done) (void)hipEventDestroy(up_done);
+        d_cigar = nullptr; up_done = nullptr; up_stream = nullptr;
+        d_cap = 0; d_ops = 0; d_device = -1;
+    }
+    static bool device_pool_off() {
+        static const bool off = [] { const char* e = getenv("SVX_BAM_DEVICE_POOL"); return e && e[0] == '0'; }();
+        return off;
+    }
+    // room for n_words of the pool on pin_device, the copy stream and an event; false: no device copy this time
+    bool prepare_device(uint64_t n_words) {
+        if (device_pool_off() || pin_device < 0) return false;
+        if (d_device != pin_device) free_device();
+        d_device = pin_device;
+        up_stream = upload_stream(pin_device);
+        bool ok = up_stream != nullptr;
+        if (ok && !up_done) ok = hipEventCreateWithFlags(&up_done, hipEventDisableTiming) == hipSuccess;
+        if (ok && d_cap < n_words) {
+            if (d_cigar) (void)hipFree(d_cigar);
+            d_cigar = nullptr; d_cap = 0;
+            const uint64_t want = (n_words + (n_words >> 3) + 0x3FFFFu) & ~0x3FFFFull;  // 1 MiB steps, an eighth of slack
+            void* p = nullptr;
+            ok = hipMalloc(&p, want * 4) == hipSuccess;
+            if (ok) { d_cigar = static_cast<uint32_t*>(p); d_cap = want; }
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            free_device();
+        }
+        return ok;
     }
 };
 
@@ -868,6 +954,7 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out, char
 extern "C" void svx_bam_close(svx_bam* b) {
     if (!b) return;
     b->free_cigar();
+    b->free_device();
     if (b->file.map) munmap(const_cast<uint8_t*>(b->file.map), b->file.fsize);
     if (b->fd >= 0) close(b->fd);
     delete b;
@@ -947,6 +1034,13 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
             want[tids[i]] = 1;
         }
     }
+    // the upload stream of the pool's device copy comes up (first load of the process only) beside the walk
+    std::thread lane_up;
+    if (b->pin_device >= 0 && b->pin_device < kMaxLanes && !g_lanes[b->pin_device].up.load() && !svx_bam::device_pool_off()) lane_up = std::thread([dev = b->pin_device] { (void)upload_stream(dev); });
+    struct Joiner {
+        std::thread& t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } lane_joiner{lane_up};
     // ---- cut the requested ranges into pieces
     std::vector<Piece> pieces;
     bool filter_after = false;
@@ -1022,6 +1116,19 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     std::atomic<size_t> next(0);
     std::atomic<bool> failed(false);
     std::atomic<uint64_t> inflated(0);
+    const int nt = (int)std::min<size_t>((size_t)b->n_threads, pieces.size());
+    // The page-locked pool (3-5 ms of page pinning for a genome's 12 MB) and the room for its device copy are made
+    // BESIDE the walk's last pieces: the first worker that finds no piece left — every piece is handed out, all but at
+    // most nt - 1 are done — extrapolates the pool's size from the finished pieces (equal compressed spans) plus an
+    // eighth, and allocates; a pool that turns out larger is allocated again behind the walk, as before.
+    struct Early {
+        void* pinned = nullptr;
+        uint64_t words = 0;
+        ~Early() { if (pinned) (void)hipHostFree(pinned); }
+    } early;
+    std::atomic<uint64_t> cig_done(0), pieces_done(0);
+    std::atomic<bool> early_claimed(false);
+    const bool early_ok = b->pin_device >= 0 && nt > 1 && !filter_after && !getenv("SVX_BAM_LATE_POOL");
     auto worker = [&]() {
         Inflater inf;
         for (;;) {
@@ -1029,10 +1136,26 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
             if (i >= pieces.size() || failed.load()) break;
             if (!walk_records(&b->file, pieces[i].start, pieces[i].have_stop, pieces[i].stop, &inf, &chunks[i], b->verify))
                 failed.store(true);
+            cig_done.fetch_add(chunks[i].cigar.size());
+            pieces_done.fetch_add(1);
         }
         inflated.fetch_add(inf.n_blocks);
+        if (early_ok && !failed.load() && !early_claimed.exchange(true)) {
+            const uint64_t done = pieces_done.load(), words = cig_done.load();
+            if (done * 4 >= pieces.size() * 3 && words) {
+                const uint64_t est = words * pieces.size() / done;
+                const uint64_t want = est + (est >> 3) + (64u << 10);
+                if (hipSetDevice(b->pin_device) == hipSuccess && hipHostMalloc(&early.pinned, want * 4, hipHostMallocDefault) == hipSuccess) {
+                    early.words = want;
+                    if (b->d_valid) (void)hipEventSynchronize(b->up_done);  // (the previous pool's upload, long over)
+                    (void)b->prepare_device(want);
+                } else {
+                    (void)hipGetLastError();
+                    early.pinned = nullptr;
+                }
+            }
+        }
     };
-    const int nt = (int)std::min<size_t>((size_t)b->n_threads, pieces.size());
     if (getenv("SVX_BAM_DEBUG")) fprintf(stderr, "svx_bam_load: %zu pieces, %d threads\n", pieces.size(), nt);
     if (nt <= 1) {
         worker();
@@ -1078,7 +1201,11 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     b->free_cigar();
     const size_t cig_bytes = std::max<uint64_t>(4, n_cig * 4);
     void* pinned = nullptr;
-    if (b->pin_device >= 0 && hipSetDevice(b->pin_device) == hipSuccess &&
+    if (early.pinned && early.words >= std::max<uint64_t>(1, n_cig)) {  // allocated beside the walk
+        b->cigar = static_cast<uint32_t*>(early.pinned);
+        b->cigar_pinned = true;
+        early.pinned = nullptr;
+    } else if (b->pin_device >= 0 && hipSetDevice(b->pin_device) == hipSuccess &&
         hipHostMalloc(&pinned, cig_bytes, hipHostMallocDefault) == hipSuccess) {
         b->cigar = static_cast<uint32_t*>(pinned);
         b->cigar_pinned = true;
@@ -1096,9 +1223,25 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     b->mapq.reserve(n); b->voffset.reserve(n); b->seq_coff.reserve(n); b->seq_uoff.reserve(n);
     b->sa_len.reserve(n); b->sa_off.reserve(n); b->cigar_off.reserve(n + 1); b->name_off.reserve(n + 1);
     b->aux_off.reserve(n + 1); b->names.reserve(n_name); b->aux.reserve(n_aux);
+    // The pool's device copy travels while the pool is assembled: every kUploadWords of finished pool are handed to
+    // the copy stream (DMA out of the page-locked pool, beside this thread's memcpy of the next chunk), so the last
+    // part is on its way when the loop ends — svx_collect_batch finds the pool in HBM (svx_collect_in.part_dev)
+    // instead of uploading it between the walk and the kernels.
+    constexpr uint64_t kUploadWords = 128u << 10;  // 512 KiB: ~10 us of DMA behind the last chunk
+    bool up = b->cigar_pinned && n_cig && b->prepare_device(n_cig);
+    uint64_t up_at = 0;
+    auto upload_to = [&](uint64_t end) {
+        if (up && end > up_at &&
+            hipMemcpyAsync(b->d_cigar + up_at, b->cigar + up_at, (end - up_at) * 4, hipMemcpyHostToDevice, b->up_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            up = false;
+        }
+        up_at = end;
+    };
     uint64_t cw = 0;
     for (const Chunk& ch : chunks) {
         size_t co = 0, no = 0, ao = 0;
+        if (cw - up_at >= kUploadWords) upload_to(cw);
         for (size_t i = 0; i < ch.tid.size(); ++i) {
             const bool keep = !(filter_after && (ch.tid[i] < 0 || !want[ch.tid[i]]));
             if (keep) {
@@ -1122,7 +1265,37 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
             ao += ch.aux_len[i];
         }
     }
+    upload_to(cw);
+    if (up && hipEventRecord(b->up_done, b->up_stream) == hipSuccess) {
+        b->d_valid = true;
+        b->d_ops = n_cig;
+    } else if (b->up_stream) {  // a part failed: nothing of the copy is handed out (and none of it is still reading the pool)
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(b->up_stream);
+    }
     b->blocks_spanned = spanned;
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_device_pool(svx_bam* b, const uint32_t** d_cigar, uint64_t* n_ops, void** ready) {
+    if (!b) return SVX_E_INVALID;
+    if (d_cigar) *d_cigar = b->d_valid ? b->d_cigar : nullptr;
+    if (n_ops) *n_ops = b->d_valid ? b->d_ops : 0;
+    if (ready) *ready = b->d_valid ? static_cast<void*>(b->up_done) : nullptr;
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_device_pool_wait(svx_bam* b, double* waited_us) {
+    if (!b) return SVX_E_INVALID;
+    if (waited_us) *waited_us = 0.0;
+    if (!b->d_valid) return SVX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipEventSynchronize(b->up_done) != hipSuccess) {
+        (void)hipGetLastError();
+        b->d_valid = false;
+        return fail(b, SVX_E_HIP, "the CIGAR pool's upload failed");
+    }
+    if (waited_us) *waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return SVX_OK;
 }
 

@@ -236,11 +236,25 @@ constexpr int kStage = SVX_STAGE;  // finished records staged in LDS per wave be
 #ifndef SVX_QUEUE
 #define SVX_QUEUE 64  // (32 until round 3: a fifth of the 1024-op rounds of an SV-dense contig overflowed it)
 #endif
-constexpr int kQueue = SVX_QUEUE;  // signatures one round may queue in LDS (one flush lane each, so at most 64)
-static_assert(kQueue <= 64, "one flush lane per queued signature");
+#ifndef SVX_QUEUE_SMALL
+#define SVX_QUEUE_SMALL 96
+#endif
+// Signatures one round may queue in LDS (flushed 64 at a time, one lane each); a round with more marks its tile for
+// the dense re-walk.  The one-round tiles of the two-launch path take 96: there the re-walk sits on the critical path of
+// a 25 us submission (a diploid sample's rounds with 65..96 signatures cost its finish launch 12.1 instead of 4.9 us);
+// the streaming kernel stays at 64 — its dense tiles are a launch of their own beside 250 us, and the larger queue
+// cost it 1-2 us on the dense probes (profiles/r05_ab_queue96.txt).
+template <int TILE_OPS>
+constexpr int queue_cap() { return TILE_OPS == kRoundOps ? SVX_QUEUE_SMALL : SVX_QUEUE; }
+constexpr int kQueue = SVX_QUEUE;
+static_assert(SVX_QUEUE <= 128 && SVX_QUEUE % 32 == 0 && SVX_QUEUE_SMALL <= 128 && SVX_QUEUE_SMALL % 32 == 0,
+              "the flush takes the queue in at most two passes of 64 lanes");
 // LDS words per wave for the start mask, which the queue re-uses once the mask has moved to registers
-constexpr int kHeadWords = (kTileOps / 32) > kQueue * 4 ? (kTileOps / 32) : kQueue * 4;
-static_assert(kStage >= kQueue, "one round's records must fit the stage buffer");
+template <int TILE_OPS>
+constexpr int head_words() { return (TILE_OPS / 32) > queue_cap<TILE_OPS>() * 4 ? (TILE_OPS / 32) : queue_cap<TILE_OPS>() * 4; }
+constexpr int kHeadWords = head_words<kTileOps>();
+// a round's records beyond the stage buffer's room (only a round with more than kStage of them) go straight to the slab
+static_assert(kStage == 64, "drain() moves the stage buffer with one lane per record");
 constexpr uint32_t kDescForceDense = 1u << 30;  // descriptor flag: a round overflowed the queue
 
 enum { WALK_TOTALS = 0, WALK_QUEUE = 1, WALK_DIRECT = 2 };
@@ -279,7 +293,7 @@ struct DirectCtx {
 // 9-bit op tables are replicated at bit 16 (offset op or op + 16, whatever the length's lowest bit
 // is); the masked add becomes one 24-bit multiply-add per cursor, and "I or D and long enough"
 // one compare of (word & -isID(op)) against (min_len << 4, at least 1).  8 VALU per op, not 11.
-template <int WALK, bool SOA, bool FAST24>
+template <int WALK, bool SOA, bool FAST24, int QCAP = kQueue>
 __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, int swz, const uint32_t (&opw)[kLU],
                                           uint32_t hm, uint32_t HU, int lane, uint4* queue,
                                           const DirectCtx& dc) {
@@ -339,7 +353,7 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
                         // rank among the lanes emitting at this slot: mbcnt over the scalar mask
                         const uint32_t qi = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(eb >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)eb, 0u));
-                        if (qi < (uint32_t)kQueue) {
+                        if (qi < (uint32_t)QCAP) {
                             // meta: lane | slot << 6 | (start at/before op i inside this lane) << 11 |
                             //       index among the lane's signatures << 12 | op << 18 (SoA only)
                             const uint32_t meta = (uint32_t)lane | (i << 6) | (hs << 11) | (n_emit << 12) |
@@ -478,10 +492,11 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     }
     wave_lds_sync();
     // this lane's start bits of all rounds move to two registers; the mask's LDS then serves as the
-    // per-round signature queue (kQueue * 16 B == the mask's 512 B) — 5.25 KiB of LDS per wave keeps
-    // six 4-wave workgroups on a CU
+    // per-round signature queue (1 KiB at 64 entries, 1.5 KiB at the one-round tiles' 96) — six 4-wave workgroups
+    // stay on a CU either way
     static_assert(kLaneOps == 16 && kRounds <= 4, "the queue aliases the start mask: 16 ops per lane, at most 4 rounds");
-    static_assert(kQueue * sizeof(uint4) <= kHeadWords * sizeof(uint32_t), "queue must fit the start mask's LDS");
+    constexpr int kQ = queue_cap<TILE_OPS>();
+    static_assert(kQ * sizeof(uint4) <= head_words<TILE_OPS>() * sizeof(uint32_t), "queue must fit the start mask's LDS");
     uint32_t hm01 = 0, hm23 = 0;
     if (kLaneOps == 16 && kRounds <= 4) {
         const uint32_t sh = ((uint32_t)lane & 1u) * 16u, wi = (uint32_t)lane >> 1;
@@ -572,8 +587,8 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
         dc.aln0 = 0; dc.rs0 = 0; dc.dup = dup;
         constexpr int kWalk1 = (MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS;
-        const WalkOut wo = (!SOA && fast24) ? walk16<kWalk1, SOA, !SOA>(p, myx, swz, opw, hm, HU, lane, queue, dc)
-                                            : walk16<kWalk1, SOA, false>(p, myx, swz, opw, hm, HU, lane, queue, dc);
+        const WalkOut wo = (!SOA && fast24) ? walk16<kWalk1, SOA, !SOA, kQ>(p, myx, swz, opw, hm, HU, lane, queue, dc)
+                                            : walk16<kWalk1, SOA, false, kQ>(p, myx, swz, opw, hm, HU, lane, queue, dc);
 
 #ifdef SVX_EXP_OPSET
         if (MODE == MODE_STAGE) {
@@ -620,9 +635,10 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
                 //     | "still lacks the tile's carry-in" << 31;   .w: this lane's start mask
                 lcarry[lane] = make_uint4(in_r, in_d, xc | ((xch >> 16) << 12) | ((!seen && !xf) ? 0x80000000u : 0u), hm);
                 wave_lds_sync();
-                const uint32_t n_here = wo.n_queued < (uint32_t)kQueue ? wo.n_queued : (uint32_t)kQueue;
-                if ((uint32_t)lane < n_here) {
-                    const uint4 e = queue[lane];
+                const uint32_t n_here = wo.n_queued < (uint32_t)kQ ? wo.n_queued : (uint32_t)kQ;
+                for (uint32_t qb = 0; qb < n_here; qb += 64u)  // (a second pass only for a round with more than 64)
+                if (qb + (uint32_t)lane < n_here) {
+                    const uint4 e = queue[qb + lane];
                     const uint32_t L = e.w & 63u, slot = (e.w >> 6) & 31u, own = (e.w >> 11) & 1u,
                                    li = (e.w >> 12) & 63u;
                     const uint4 cin = lcarry[L];
@@ -634,15 +650,16 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
                     else { op = e.z & 15u; len = e.z >> 4; }
                     const uint32_t type = (op == 2u) ? SVX_SIG_DEL : SVX_SIG_INS;
                     const uint32_t rank = tile_cnt + (cin.z & 0xFFFu) + li;
-                    if (rank - stage_base < (uint32_t)kStage) {  // (a round with more than kStage signatures overflowed)
-                        // alignment index: a_lo - 1 + (alignment starts at or before the op inside the tile)
-                        const uint32_t m = heads_before + ((cin.z >> 12) & 0xFFFu) + __popc(cin.w & ((slot == 31u) ? 0xFFFFFFFFu : ((2u << slot) - 1u)));
-                        uint32_t aln = a_lo + m - 1u;
-                        if (dup) aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + round * kRoundOps + L * kLaneOps + slot);
-                        stage[rank - stage_base] = make_uint4(aln, ref, rdp, len | (type << 28) | (prec << 29));
-                    }
+                    // alignment index: a_lo - 1 + (alignment starts at or before the op inside the tile)
+                    const uint32_t m = heads_before + ((cin.z >> 12) & 0xFFFu) + __popc(cin.w & ((slot == 31u) ? 0xFFFFFFFFu : ((2u << slot) - 1u)));
+                    uint32_t aln = a_lo + m - 1u;
+                    if (dup) aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + round * kRoundOps + L * kLaneOps + slot);
+                    const uint4 rec = make_uint4(aln, ref, rdp, len | (type << 28) | (prec << 29));
+                    if (rank - stage_base < (uint32_t)kStage) stage[rank - stage_base] = rec;
+                    else if (kQ > kStage && rank < (uint32_t)kSlab)  // the round's records past the stage buffer
+                        p.slab[(uint64_t)tile * kSlab + rank] = rec;
                 }
-                if (wo.n_queued > (uint32_t)kQueue) overflow = true;
+                if (wo.n_queued > (uint32_t)kQ) overflow = true;
             }
         } else {
             if (C) {  // dense tile: second walk finishes each signature on the spot
@@ -740,7 +757,7 @@ __global__ __launch_bounds__(256) void k_tile_alo(const uint64_t* __restrict__ a
 template <bool SOA, int TILE_OPS, int ALO>
 __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles(CigarArgs p) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];  // start mask, then the queue
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][head_words<TILE_OPS>()];  // start mask, then the queue
     __shared__ uint4 s_stage[kWaves][kStage];
     // the wave index is wave-uniform: tell the compiler so that tile indices, loop bounds and
     // carries live in SGPRs and the tile/round loops are scalar branches
@@ -1696,7 +1713,7 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(Ci
     // a workgroup is either a chain workgroup or a tile workgroup: one LDS block, two layouts
     struct TileLds {
         uint4 xpose[kWaves][kXposeU4];
-        __attribute__((aligned(16))) uint32_t head[kWaves][kHeadWords];
+        __attribute__((aligned(16))) uint32_t head[kWaves][head_words<TILE_OPS>()];
         uint4 stage[kWaves][kStage];
     };
     constexpr size_t kLdsBytes = sizeof(TileLds) > sizeof(A3Lds) ? sizeof(TileLds) : sizeof(A3Lds);

@@ -158,7 +158,7 @@ extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_col
     // ---- validate what the kernels will index with (host copies; nothing is trusted on the device)
     uint64_t n_ops = 0;
     for (uint32_t k = 0; k < in->n_parts; ++k) {
-        if (in->part_ops[k] && !in->cigar_parts[k]) return SVX_E_INVALID;
+        if (in->part_ops[k] && !in->cigar_parts[k] && !(in->part_dev && in->part_dev[k])) return SVX_E_INVALID;
         n_ops += in->part_ops[k];
     }
     if (n_aln) {
@@ -267,8 +267,13 @@ extern "C" int svx_collect_batch(svx_ctx* ctx, const svx_collect_in* in, svx_col
     // ---- uploads: the pools where they lie (page-locked reader memory: true DMA), extra CIGARs, control block
     uint64_t at = 0;
     for (uint32_t k = 0; k < in->n_parts; ++k) {
-        if (in->part_ops[k])
+        if (in->part_ops[k] && in->part_dev && in->part_dev[k]) {  // the reader's copy in HBM (svx_bam_device_pool)
+            if (in->part_ready && in->part_ready[k])
+                SVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, static_cast<hipEvent_t>(in->part_ready[k]), 0));
+            SVX_HIP(ctx, hipMemcpyAsync(d_cigar + at, in->part_dev[k], (size_t)in->part_ops[k] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        } else if (in->part_ops[k]) {
             SVX_HIP(ctx, hipMemcpyAsync(d_cigar + at, in->cigar_parts[k], (size_t)in->part_ops[k] * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
         at += in->part_ops[k];
     }
     if (n_xops) SVX_HIP(ctx, hipMemcpyAsync(d_cigar + n_ops, in->extra_cigar, (size_t)n_xops * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -1,0 +1,137 @@
+"""The reader's own upload of its CIGAR pool (svx_bam_device_pool, include/svx_bam.h) and svx_collect_batch taking a
+part where it lies in HBM (svx_collect_in.part_dev / part_ready, include/svx.h): same words on the device as in the
+page-locked pool, same results as the submission that uploads the pool itself, across reloads of the handle."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from svim_asm_amd import SVIM_COLLECT, SVIM_inter, bamio, synth_bam
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("devpool"))
+    # short match runs: 184 k CIGAR ops per haplotype — more than one part of the reader's upload (128 k words each)
+    contigs = (("chrA", 900000), ("chrB", 600000), ("chrC", 400000))
+    fa, bams = synth_bam.write_dataset(d, seed=23, contigs=contigs, n_shared=14, n_private=4, median_aln=120000, mean_m=12)
+    return fa, bams
+
+
+def device_words(address, n):
+    """n uint32 words at a device address, copied back with the HIP runtime itself."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.empty(n, np.uint32)
+    assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(address), n * 4, 2) == 0  # hipMemcpyDeviceToHost
+    return out
+
+
+def test_pool_is_in_hbm_when_the_load_returns(svx_ctx, dataset):
+    fa, bams = dataset
+    f = bamio.AlignmentFile(bams[0], device=0)
+    f.load(None)
+    assert f.cigar_pinned and len(f._cigar) > 100000
+    pool = f.device_pool()
+    assert pool is not None and pool[0] and pool[1]
+    address, _none, waited_us = f.device_pool(wait=True)
+    assert address == pool[0] and waited_us < 5000.0
+    assert np.array_equal(device_words(address, len(f._cigar)), f._cigar)
+    # a reload of other contigs: the pool changes, the device copy follows it
+    f.load(["chrB"])
+    again = f.device_pool(wait=True)
+    assert again is not None and len(f._cigar) > 0
+    assert np.array_equal(device_words(again[0], len(f._cigar)), f._cigar)
+    # pageable pool (no device): no copy, the submission uploads
+    g = bamio.AlignmentFile(bams[0])
+    g.load(None)
+    assert not g.cigar_pinned and g.device_pool() is None
+
+
+def collect_of(svx_ctx, files, part_dev):
+    """svx_collect_batch over the pools of `files` (every record, no segments)."""
+    parts = [f._cigar for f in files]
+    base = np.cumsum([0] + [len(p) for p in parts])
+    aln_off = np.concatenate([f._cig_off[:-1] + b for f, b in zip(files, base)] + [[base[-1]]]).astype(np.uint64)
+    ref_start = np.concatenate([f._cols["pos"] for f in files]).astype(np.int32)
+    z32, z64 = np.zeros(0, np.uint32), np.zeros(1, np.uint64)
+    return svx_ctx.collect_batch(parts, aln_off, ref_start, 40, z32, z64, z32, np.zeros(0, np.int32), np.zeros(0, np.int32),
+                                 np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32),
+                                 np.zeros(3, np.int32), seg_params(), part_dev=part_dev)
+
+
+def seg_params():
+    return SVIM_inter.seg_params(helpers.options())
+
+
+@pytest.mark.parametrize("which", ["both", "first", "second", "no events"])
+def test_submission_takes_parts_where_they_lie(svx_ctx, dataset, which):
+    fa, bams = dataset
+    files = [bamio.AlignmentFile(b, device=0) for b in bams[:2]]
+    for f in files:
+        f.load(None)
+    exp = collect_of(svx_ctx, files, None)
+    assert len(exp[0]["aln"]) > 50
+    pools = [f.device_pool() for f in files]
+    assert all(p is not None for p in pools)
+    if which == "first":
+        pools[1] = None
+    elif which == "second":
+        pools[0] = None
+    elif which == "no events":
+        pools = [(f.device_pool(wait=True)[0], None) for f in files]
+    got = collect_of(svx_ctx, files, pools)
+    for k in exp[0]:
+        assert np.array_equal(got[0][k], exp[0][k]), k
+    # the host pointer of a part that is in HBM is not read: hand the call a poisoned copy of it
+    if which == "both":
+        real = [f._c_cigar for f in files]
+        try:
+            for f in files:
+                f._c_cigar = np.full(len(f._c_cigar), 0xFFFFFFFF, np.uint32)
+            got = collect_of(svx_ctx, files, pools)
+        finally:
+            for f, r in zip(files, real):
+                f._c_cigar = r
+        for k in exp[0]:
+            assert np.array_equal(got[0][k], exp[0][k]), k
+
+
+def test_collect_of_the_product_goes_through_the_device_pool(svx_ctx, dataset, monkeypatch):
+    """analyze_alignment_file_coordsorted hands the reader's device copy to the submission, and finds what the
+    submission that uploads finds."""
+    fa, bams = dataset
+    seen = []
+    real = type(svx_ctx).collect_batch
+
+    def spy(self, *a, **kw):
+        seen.append(kw.get("part_dev"))
+        return real(self, *a, **kw)
+    monkeypatch.setattr(type(svx_ctx), "collect_batch", spy)
+    o = helpers.options()
+    got = [helpers.candidate_tuple(c) for c in
+           SVIM_COLLECT.analyze_alignment_file_coordsorted(bamio.AlignmentFile(bams[0], device=0), o)]
+    assert seen and seen[0] and seen[0][0] is not None and seen[0][0][0]
+    del seen[:]
+    exp = [helpers.candidate_tuple(c) for c in
+           SVIM_COLLECT.analyze_alignment_file_coordsorted(bamio.AlignmentFile(bams[0]), o)]
+    assert seen and (seen[0] is None or seen[0][0] is None)
+    assert got == exp and len(got) > 10
+
+
+def test_switch_in_the_environment(dataset):
+    fa, bams = dataset
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from svim_asm_amd import bamio\n"
+            "f = bamio.AlignmentFile(%r, device=0); f.load(None)\n"
+            "print('POOL', f.cigar_pinned, f.device_pool() is None)\n" % (ROOT, bams[0]))
+    env = dict(os.environ, SVX_BAM_DEVICE_POOL="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "POOL True True" in out.stdout, out.stdout + out.stderr
