@@ -92,6 +92,16 @@ int svx_bam_set_pinned_device(svx_bam* bam, int device);
 int svx_bam_device_pool(svx_bam* bam, const uint32_t** d_cigar, uint64_t* n_ops, void** ready);
 int svx_bam_device_pool_wait(svx_bam* bam, double* waited_us);
 
+/* A share of svx_bam_seq_slices on the device.  percent > 0 (with a pinned device set, verification on — the default —
+ * and a call of at least 2048 slices): the BGZF members under the first `percent` % of a call's slices are inflated and
+ * checked (CRC32, ISIZE: the same judgement as the host decoder's, svx_bgzf_inflate_dev's kernel) on the pinned device
+ * while the handle's threads decode the members of the other slices; the slices' packed bases come back, nothing else.
+ * DEFLATE on the device is one lane per member — 55-60 ms for any number of members up to the 16 k the chip holds at
+ * once — so the share is what the threads would need that long for; results never depend on it.  0 (default): host only.
+ * svx_bam_device_members: members the device has inflated for this handle so far. */
+int svx_bam_set_device_inflate(svx_bam* bam, int percent);
+uint64_t svx_bam_device_members(const svx_bam* bam);
+
 /* Index the records of contigs tids[0..n_tids) (NULL: every record of the file, unplaced ones
  * included), in file order. */
 int svx_bam_load(svx_bam* bam, const int32_t* tids, int32_t n_tids);

@@ -180,6 +180,8 @@ SYMBOLS = {
     "svx_bam_contig_spans": (C.c_int, [_P, _P]),
     "svx_bam_set_pinned_device": (C.c_int, [_P, C.c_int]),
     "svx_bam_set_verify": (C.c_int, [_P, C.c_int]),
+    "svx_bam_set_device_inflate": (C.c_int, [_P, C.c_int]),
+    "svx_bam_device_members": (C.c_uint64, [_P]),
     "svx_bam_device_pool": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(_P)]),
     "svx_bam_device_pool_wait": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "svx_bam_load": (C.c_int, [_P, _P, C.c_int32]),

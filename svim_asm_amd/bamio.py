@@ -488,6 +488,37 @@ def ingest_threads(n_files=1):
     return int(max(1, min(64, max(8, hw // (4 * max(1, n_files))), hw)))
 
 
+def host_cpus():
+    """CPUs' worth of time this process gets: the hardware threads, or the cgroup's quota when that is smaller
+    (cpu.max: 16 of a 256-thread host on the GPU pool)."""
+    hw = float(os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            hw = min(hw, float(quota) / float(period))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if quota > 0:
+                hw = min(hw, quota / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
+        except (OSError, ValueError):
+            pass
+    return hw
+
+
+def default_device_inflate_percent():
+    """Share of a sequence-slice call the device inflates (svx_bam_set_device_inflate) unless SVX_BAM_DEVICE_INFLATE says
+    otherwise.  The device decodes any number of members up to 16 k in 55-60 ms (one lane per member) plus ~10 ms of
+    staging — a full-size sample's call takes the host's threads 45 ms when every thread has a core, but 1.4 CPU-seconds
+    of a run whose wall-clock IS its CPU-seconds over the CPUs it may use when those are few (the pool's 16-CPU quota:
+    3.6 CPU-s, 0.22-0.26 s).  So: half the call with at most 24 CPUs' worth of time (0.26 → 0.18-0.20 s end to end,
+    profiles/r05_device_leg.txt), none above."""
+    env = os.environ.get("SVX_BAM_DEVICE_INFLATE")
+    if env not in (None, ""):
+        return max(0, min(100, int(env)))
+    return 50 if host_cpus() <= 24 else 0
+
+
 class _BamColumns(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("l_seq", C.c_void_p),
                 ("ref_len", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p), ("cigar_off", C.c_void_p),
@@ -589,6 +620,14 @@ class AlignmentFile(object):
             return None
         return span.astype(np.int64)
 
+    # share of a sequence-slice call's members that the pinned device inflates and verifies beside the reader's threads
+    # (svx_bam_set_device_inflate; default_device_inflate_percent above)
+    device_inflate_percent = default_device_inflate_percent()
+
+    @property
+    def device_members(self):
+        return int(self._lib.svx_bam_device_members(self._h)) if self._h is not None else 0
+
     def set_device(self, device):
         """HIP device whose context page-locks the CIGAR pool of later loads (None: pageable)."""
         self._pin_device = device
@@ -623,6 +662,7 @@ class AlignmentFile(object):
             return self
         if self._h is not None:
             self._lib.svx_bam_set_pinned_device(self._h, -1 if self._pin_device is None else int(self._pin_device))
+            self._lib.svx_bam_set_device_inflate(self._h, 0 if self._pin_device is None else self.device_inflate_percent)
             if tids is None:
                 rc = self._lib.svx_bam_load(self._h, None, 0)
             else:

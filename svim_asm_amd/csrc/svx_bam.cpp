@@ -672,29 +672,53 @@ class Pool {
     bool stop_ = false;
 };
 
-// The copy stream of the pools' uploads: ONE per device for the whole process, created and warmed on first use.  A
-// stream's creation plus its first host-to-device copy cost 10-25 ms on gfx950 (rocprofv3 --hip-trace of the command:
-// the first hipMemcpyAsync of a fresh stream returns after 12-15 ms) — per reader handle that was paid in every load;
-// here it is paid once, and svx_bam_load starts it on a thread BEFORE the record walk, so that it hides behind the walk.
-struct UploadLane {
-    std::mutex mu;
+// Device lanes: the streams (and page-locked staging rings) the reader uses on a device, ONE set per device for the
+// whole process, brought up by a background thread that svx_bam_load starts before its record walk.  A stream's
+// creation plus its first host-to-device copy cost 10-25 ms on gfx950 (rocprofv3 --hip-trace of the command: the first
+// hipMemcpyAsync of a fresh stream returns after 12-15 ms) — per reader handle that was paid in every load; here it is
+// paid once and hides behind the walk.
+//   upload    the copy stream of the CIGAR pools' device copies (svx_bam_device_pool)
+//   inflate   kInflateLanes streams, each with a ring of page-locked staging slots, for svx_bam_seq_slices' device leg
+//             (svx_bam_set_device_inflate): one per call in flight — both haplotype BAMs decode at the same time
+typedef int (*svx_inflate_launch_fn)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint32_t*,
+                                     uint32_t, uint8_t*, const uint64_t*, uint32_t*);
+typedef int (*svx_gather_launch_fn)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, uint8_t*);
+static svx_inflate_launch_fn g_inflate_launch = nullptr;  // svx_inflate.hip registers its launches when the library loads
+static svx_gather_launch_fn g_gather_launch = nullptr;    // (a build of this file alone — the sanitizer tests — has none)
+extern "C" void svx_bam_register_device_kernels(svx_inflate_launch_fn inflate, svx_gather_launch_fn gather) {
+    g_inflate_launch = inflate;
+    g_gather_launch = gather;
+}
+
+constexpr int kInflateLanes = 2;
+constexpr int kRingSlots = 8;
+constexpr size_t kSlotBytes = 2u << 20;
+struct InflateLane {
     hipStream_t stream = nullptr;
-    bool tried = false;
-    std::atomic<bool> up{false};  // tried, and the result is in `stream`
+    uint8_t* ring = nullptr;          // kRingSlots * kSlotBytes, page-locked
+    hipEvent_t slot_done[kRingSlots] = {};
+    hipEvent_t done = nullptr;
+    std::mutex busy;                  // held by the call that uses the lane
+};
+struct DeviceLanes {
+    std::once_flag once;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool upload_tried = false;
+    hipStream_t upload = nullptr;
+    std::atomic<bool> upload_up{false};
+    InflateLane inflate[kInflateLanes];
+    std::atomic<bool> inflate_up{false};  // all inflate lanes are usable
+    bool inflate_tried = false;
 };
 constexpr int kMaxLanes = 64;
-static UploadLane g_lanes[kMaxLanes];
+static DeviceLanes g_lanes[kMaxLanes];
 
-static hipStream_t upload_stream(int device) {
-    if (device < 0 || device >= kMaxLanes) return nullptr;
-    UploadLane& L = g_lanes[device];
-    std::lock_guard<std::mutex> lock(L.mu);
-    if (L.tried) return L.stream;
-    L.tried = true;
+static bool warm_stream(hipStream_t* out) {
     hipStream_t st = nullptr;
     void *h = nullptr, *d = nullptr;
-    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-    // the first copy of the stream sets up its DMA path: a 4 KiB one now instead of the pool's first part later
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    // the first copy of a stream sets up its DMA path: a 4 KiB one now instead of the first real one later
     ok = ok && hipHostMalloc(&h, 4096, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, 4096) == hipSuccess;
     if (ok) {
         memset(h, 0, 4096);
@@ -707,9 +731,61 @@ static hipStream_t upload_stream(int device) {
         if (st) (void)hipStreamDestroy(st);
         st = nullptr;
     }
-    L.stream = st;
-    L.up.store(true);
-    return st;
+    *out = st;
+    return ok;
+}
+
+static void lanes_bring_up(int device) {
+    DeviceLanes& L = g_lanes[device];
+    // the inflate lanes on threads of their own: stream creations run side by side (each 10-25 ms), and a fresh
+    // process's first sequence-slice call comes only tens of milliseconds after its first load
+    std::vector<std::thread> th;
+    std::atomic<int> good(0);
+    const bool want_inflate = g_inflate_launch && !getenv("SVX_BAM_NO_INFLATE_LANES");
+    for (int k = 0; want_inflate && k < kInflateLanes; ++k)
+        th.emplace_back([&L, &good, device, k] {
+            InflateLane& I = L.inflate[k];
+            bool ok = hipSetDevice(device) == hipSuccess && warm_stream(&I.stream);
+            void* ring = nullptr;
+            ok = ok && hipHostMalloc(&ring, kRingSlots * kSlotBytes, hipHostMallocDefault) == hipSuccess;
+            I.ring = static_cast<uint8_t*>(ring);
+            for (int q = 0; q < kRingSlots && ok; ++q) ok = hipEventCreateWithFlags(&I.slot_done[q], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&I.done, hipEventDisableTiming) == hipSuccess;
+            if (ok) good.fetch_add(1);
+            else (void)hipGetLastError();
+        });
+    hipStream_t up = nullptr;
+    if (hipSetDevice(device) == hipSuccess) (void)warm_stream(&up);
+    else (void)hipGetLastError();
+    {
+        std::lock_guard<std::mutex> lock(L.mu);
+        L.upload = up;
+        L.upload_tried = true;
+        L.upload_up.store(true);
+    }
+    L.cv.notify_all();
+    for (std::thread& t : th) t.join();
+    {
+        std::lock_guard<std::mutex> lock(L.mu);
+        L.inflate_up.store(want_inflate && good.load() == kInflateLanes);
+        L.inflate_tried = true;
+    }
+    L.cv.notify_all();
+}
+
+// starts the lanes of `device` once per process (returns at once)
+static void lanes_start(int device) {
+    if (device < 0 || device >= kMaxLanes) return;
+    std::call_once(g_lanes[device].once, [device] { std::thread(lanes_bring_up, device).detach(); });
+}
+
+static hipStream_t upload_stream(int device) {
+    if (device < 0 || device >= kMaxLanes) return nullptr;
+    lanes_start(device);
+    DeviceLanes& L = g_lanes[device];
+    std::unique_lock<std::mutex> lock(L.mu);
+    L.cv.wait(lock, [&] { return L.upload_tried; });
+    return L.upload;
 }
 
 struct svx_bam {
@@ -739,6 +815,10 @@ struct svx_bam {
                                              // slice that lands in one of them (a third do: the first member of a record's
                                              // SEQ bytes holds its head and CIGAR) needs only its prefix, not a second check
     int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
+    int inflate_pct = 0;  // share of a sequence-slice call whose members the device inflates (svx_bam_set_device_inflate)
+    uint8_t* d_inflate = nullptr;  // the device leg's buffer, kept between calls
+    size_t d_inflate_cap = 0;
+    uint64_t device_members = 0;   // members the device has inflated and verified for this handle
     bool verify = true;   // inflate whole members and check their CRC32 (svx_bam_set_verify); the default
     Pool pool;
 
@@ -764,6 +844,8 @@ struct svx_bam {
     }
     void free_device() {
         d_valid = false;
+        if (d_inflate) (void)hipFree(d_inflate);
+        d_inflate = nullptr; d_inflate_cap = 0;
         if (d_cigar) (void)hipFree(d_cigar);
         if (up_done) (void)hipEventDestroy(up_done);
         d_cigar = nullptr; up_done = nullptr; up_stream = nullptr;
@@ -985,6 +1067,14 @@ extern "C" int svx_bam_set_verify(svx_bam* b, int on) {
     return SVX_OK;
 }
 
+extern "C" int svx_bam_set_device_inflate(svx_bam* b, int percent) {
+    if (!b || percent < 0 || percent > 100) return SVX_E_INVALID;
+    b->inflate_pct = percent;
+    return SVX_OK;
+}
+
+extern "C" uint64_t svx_bam_device_members(const svx_bam* b) { return b ? b->device_members : 0; }
+
 extern "C" int svx_bam_set_pinned_device(svx_bam* b, int device) {
     if (!b) return SVX_E_INVALID;
     b->pin_device = device;
@@ -1034,13 +1124,8 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
             want[tids[i]] = 1;
         }
     }
-    // the upload stream of the pool's device copy comes up (first load of the process only) beside the walk
-    std::thread lane_up;
-    if (b->pin_device >= 0 && b->pin_device < kMaxLanes && !g_lanes[b->pin_device].up.load() && !svx_bam::device_pool_off()) lane_up = std::thread([dev = b->pin_device] { (void)upload_stream(dev); });
-    struct Joiner {
-        std::thread& t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } lane_joiner{lane_up};
+    // the device lanes (the pool's upload stream first) come up beside the walk: first load of the process only
+    if (b->pin_device >= 0 && !svx_bam::device_pool_off()) lanes_start(b->pin_device);
     // ---- cut the requested ranges into pieces
     std::vector<Piece> pieces;
     bool filter_after = false;
@@ -1351,37 +1436,53 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
         uint32_t cur_rec = ~0u;
         uint64_t cur_byte = 0;  // bytes of the record's SEQ field already passed by the cursor
     };
-    auto work_on = [&](Cursor& c, State& st, uint32_t lo, uint32_t hi) {
+    // the 4-bit codes of piece p (packed bytes at `packed`) → the ASCII bases of its slice
+    auto unpack_piece = [&](const Piece& p, const uint8_t* packed) {
+        const uint32_t i = p.slice;
+        const uint32_t L = (uint32_t)b->l_seq[rec[i]];
+        const uint32_t a = std::min(begin[i], L), e = std::max(a, std::min(end[i], L));
+        const uint64_t k0 = std::max<uint64_t>(a, 2 * p.first), k1 = std::min<uint64_t>(e, 2 * (p.first + p.n));
+        uint8_t* dst = out + out_off[i] + (k0 - a);
+        for (uint64_t k = k0; k < k1; ++k) {
+            const uint8_t by = packed[(k >> 1) - p.first];
+            *dst++ = (uint8_t)kLut[(k & 1) ? (by & 15) : (by >> 4)];
+        }
+    };
+    auto locate = [&](Cursor& c, State& st, uint32_t lo, uint32_t hi) -> bool {
         st.jobs.clear();
         st.pieces.clear();
         for (uint32_t i = lo; i < hi; ++i) {
             const uint32_t r = rec[i];
             const uint32_t L = (uint32_t)b->l_seq[r];
             const uint32_t a = std::min(begin[i], L), e = std::max(a, std::min(end[i], L));
-            if (out_off[i + 1] - out_off[i] != (uint64_t)(e - a)) { failed.store(true); return; }
+            if (out_off[i + 1] - out_off[i] != (uint64_t)(e - a)) { failed.store(true); return false; }
             if (e == a) continue;
             const uint64_t b0 = a >> 1, b1 = ((uint64_t)e + 1) >> 1;
             if (r != st.cur_rec || b0 < st.cur_byte) {
                 VPos p;
                 p.coff = b->seq_coff[r];
                 p.uoff = b->seq_uoff[r];
-                if (!c.seek(p)) { failed.store(true); return; }
+                if (!c.seek(p)) { failed.store(true); return false; }
                 st.cur_rec = r;
                 st.cur_byte = 0;
             }
-            if (!c.skip(b0 - st.cur_byte)) { failed.store(true); return; }
+            if (!c.skip(b0 - st.cur_byte)) { failed.store(true); return false; }
             for (uint64_t at = b0; at < b1;) {
-                if (c.eof || c.bad) { failed.store(true); return; }
+                if (c.eof || c.bad) { failed.store(true); return false; }
                 const uint32_t take = (uint32_t)std::min<uint64_t>(b1 - at, c.blk.isize - c.uoff);
                 if (st.jobs.empty() || st.jobs.back().coff != c.coff) st.jobs.push_back(Job{c.coff, c.blk, 0});
                 Job& j = st.jobs.back();
                 j.upto = std::max(j.upto, c.uoff + take);
                 st.pieces.push_back(Piece{i, (uint32_t)(st.jobs.size() - 1), c.uoff, take, at});
                 at += take;
-                if (!c.skip(take)) { failed.store(true); return; }
+                if (!c.skip(take)) { failed.store(true); return false; }
             }
             st.cur_byte = b1;
         }
+        return true;
+    };
+    auto work_on = [&](Cursor& c, State& st, uint32_t lo, uint32_t hi) {
+        if (!locate(c, st, lo, hi)) return;
         size_t pc = 0;
         for (size_t j = 0; j < st.jobs.size() && !failed.load(); j += 2) {
             const size_t nj = std::min<size_t>(2, st.jobs.size() - j);
@@ -1404,16 +1505,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             if (!Inflater::run_two(st.inf, in, in_len, st.buf, isize, want, crc, nj)) { failed.store(true); return; }
             for (; pc < st.pieces.size() && st.pieces[pc].job < j + nj; ++pc) {
                 const Piece& p = st.pieces[pc];
-                const uint8_t* packed = st.buf[p.job - j].data() + p.uoff;
-                const uint32_t i = p.slice;
-                const uint32_t L = (uint32_t)b->l_seq[rec[i]];
-                const uint32_t a = std::min(begin[i], L), e = std::max(a, std::min(end[i], L));
-                const uint64_t k0 = std::max<uint64_t>(a, 2 * p.first), k1 = std::min<uint64_t>(e, 2 * (p.first + p.n));
-                uint8_t* dst = out + out_off[i] + (k0 - a);
-                for (uint64_t k = k0; k < k1; ++k) {
-                    const uint8_t by = packed[(k >> 1) - p.first];
-                    *dst++ = (uint8_t)kLut[(k & 1) ? (by & 15) : (by >> 4)];
-                }
+                unpack_piece(p, st.buf[p.job - j].data() + p.uoff);
             }
         }
     };
@@ -1435,6 +1527,189 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
         const bool debug = getenv("SVX_BAM_DEBUG") != nullptr;
         std::atomic<int64_t> cpu_sum(0), cpu_max(0), wall_max(0), start_max(0);
         const auto t_call = std::chrono::steady_clock::now();
+        auto since_call_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+
+        // ---- the device leg (svx_bam_set_device_inflate): the members of the first n_g slices are inflated and verified
+        // by svx_inflate.hip's kernel while the handle's threads take the other slices.  DEFLATE on the device is one
+        // lane per member — 55-60 ms for ANY number of members up to the 16 k the chip holds at once — so the leg is
+        // worth what the threads get done in that time: it takes its share in one launch and is collected when the
+        // threads are through.  In order: (1) the threads locate the leg's runs (member headers only), (2) the payloads
+        // travel through a ring of page-locked slots (the threads fill, the lane's stream copies), (3) inflate kernel,
+        // a gather of the slices' packed bytes, (4) the threads' own share, (5) read-back, statuses, unpacking.
+        struct RunPlan {
+            std::vector<Job> jobs;
+            std::vector<Piece> pieces;
+        };
+        uint32_t n_g = 0;
+        InflateLane* lane = nullptr;
+        std::unique_lock<std::mutex> lane_lock;
+        const bool leg_wanted = verify_all && b->inflate_pct > 0 && b->pin_device >= 0 && b->pin_device < kMaxLanes && n >= 2048 &&
+                                g_inflate_launch && g_gather_launch;
+        if (leg_wanted && !g_lanes[b->pin_device].inflate_up.load()) {
+            // a fresh process: the lanes were started beside the first load and may be a few milliseconds away — worth a
+            // short wait (the leg takes ~40 % of the call's CPU seconds), not a long one
+            DeviceLanes& L = g_lanes[b->pin_device];
+            lanes_start(b->pin_device);
+            std::unique_lock<std::mutex> lock(L.mu);
+            L.cv.wait_for(lock, std::chrono::milliseconds(30), [&] { return L.inflate_tried; });
+        }
+        if (leg_wanted && g_lanes[b->pin_device].inflate_up.load()) {
+            for (int k = 0; k < kInflateLanes && !lane; ++k) {
+                std::unique_lock<std::mutex> l(g_lanes[b->pin_device].inflate[k].busy, std::try_to_lock);
+                if (l.owns_lock()) {
+                    lane = &g_lanes[b->pin_device].inflate[k];
+                    lane_lock = std::move(l);
+                }
+            }
+            if (lane) n_g = (uint32_t)((uint64_t)n * (uint64_t)b->inflate_pct / 100 / kRun * kRun);
+        }
+        std::vector<RunPlan> plans(n_g / kRun);
+        std::vector<uint64_t> g_src_off, g_dst_off;   // per piece of the leg: where its packed bytes lie in d_out / in the read-back
+        std::vector<uint32_t> g_len;
+        std::vector<uint32_t> g_status;
+        std::vector<uint8_t> g_packed;
+        uint32_t g_members = 0;
+        bool leg_running = false;
+        uint64_t leg_o_status = 0, leg_o_packed = 0;  // where the leg's statuses and packed bytes lie in d_inflate
+        double t_located = 0, t_staged = 0, t_launched = 0;
+        if (n_g) {
+            bool ok = hipSetDevice(b->pin_device) == hipSuccess;
+            // (1) locate
+            std::atomic<uint32_t> next_run(0);
+            auto locate_runs = [&]() {
+                Inflater none;
+                Cursor c(&b->file, &none);
+                State st;
+                for (;;) {
+                    const uint32_t r = next_run.fetch_add(1);
+                    if (r >= plans.size() || failed.load()) break;
+                    if (!locate(c, st, r * kRun, (r + 1) * kRun)) break;
+                    plans[r].jobs = st.jobs;
+                    plans[r].pieces = st.pieces;
+                }
+            };
+            b->pool.run((int)nt, locate_runs);
+            t_located = since_call_ms();
+            ok = ok && !failed.load();
+            // member and piece tables; device memory
+            std::vector<uint64_t> in_off, out_off_m;
+            std::vector<uint32_t> in_len, isz, crc;
+            std::vector<const uint8_t*> src;
+            uint64_t in_bytes = 0, out_bytes = 0, packed_bytes = 0;
+            for (const RunPlan& pl : plans) {
+                const uint32_t base = (uint32_t)in_off.size();
+                for (const Job& jb : pl.jobs) {
+                    in_off.push_back(in_bytes);
+                    in_len.push_back(jb.blk.payload_len);
+                    isz.push_back(jb.blk.isize);
+                    crc.push_back(jb.blk.crc);
+                    out_off_m.push_back(out_bytes);
+                    src.push_back(b->file.map + jb.coff + jb.blk.payload_off);
+                    in_bytes += ((uint64_t)jb.blk.payload_len + 3) & ~3ull;
+                    out_bytes += ((uint64_t)jb.blk.isize + 8 + 15) & ~15ull;
+                }
+                for (const Piece& pc : pl.pieces) {
+                    g_src_off.push_back(out_off_m[base + pc.job] + pc.uoff);
+                    g_len.push_back(pc.n);
+                    g_dst_off.push_back(packed_bytes);
+                    packed_bytes += pc.n;
+                }
+            }
+            g_members = (uint32_t)in_off.size();
+            const uint32_t n_pc = (uint32_t)g_len.size();
+            auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
+            const uint64_t o_in = 0, o_out = up256(in_bytes + 8), o_tab = o_out + up256(out_bytes + 16);
+            const uint64_t tab_bytes = (uint64_t)g_members * 28 + (uint64_t)n_pc * 20 + 256;
+            const uint64_t o_status = o_tab + up256(tab_bytes), o_packed = o_status + up256((uint64_t)g_members * 4);
+            const uint64_t need = o_packed + up256(packed_bytes + 8);
+            if (ok && g_members && n_pc) {
+                if (b->d_inflate_cap < need) {
+                    if (b->d_inflate) (void)hipFree(b->d_inflate);
+                    b->d_inflate = nullptr;
+                    b->d_inflate_cap = 0;
+                    void* pdev = nullptr;
+                    ok = hipMalloc(&pdev, need + (need >> 3)) == hipSuccess;
+                    if (ok) { b->d_inflate = static_cast<uint8_t*>(pdev); b->d_inflate_cap = need + (need >> 3); }
+                }
+            } else {
+                ok = false;
+            }
+            // the tables as one blob: in_off | out_off | src_off | dst_off (u64) | in_len | isize | crc | len (u32)
+            std::vector<uint8_t> blob;
+            uint64_t t_in_off = 0, t_out_off = 0, t_src_off = 0, t_dst_off = 0, t_in_len = 0, t_isz = 0, t_crc = 0, t_len = 0;
+            if (ok) {
+                auto put = [&](const void* ptr, size_t bytes) { const uint64_t at = blob.size(); blob.insert(blob.end(), (const uint8_t*)ptr, (const uint8_t*)ptr + bytes); return at; };
+                t_in_off = put(in_off.data(), (size_t)g_members * 8);
+                t_out_off = put(out_off_m.data(), (size_t)g_members * 8);
+                t_src_off = put(g_src_off.data(), (size_t)n_pc * 8);
+                t_dst_off = put(g_dst_off.data(), (size_t)n_pc * 8);
+                t_in_len = put(in_len.data(), (size_t)g_members * 4);
+                t_isz = put(isz.data(), (size_t)g_members * 4);
+                t_crc = put(crc.data(), (size_t)g_members * 4);
+                t_len = put(g_len.data(), (size_t)n_pc * 4);
+                ok = blob.size() <= tab_bytes &&
+                     hipMemcpyAsync(b->d_inflate + o_tab, blob.data(), blob.size(), hipMemcpyHostToDevice, lane->stream) == hipSuccess;
+            }
+            // (2) payloads through the ring: batch i = members [cut[i], cut[i + 1]) in slot i % kRingSlots
+            std::vector<uint32_t> cut(1, 0);
+            for (uint32_t m = 0; ok && m < g_members; ++m) {
+                const uint64_t end_m = (m + 1 < g_members ? in_off[m + 1] : in_bytes);
+                if (end_m - in_off[cut.back()] > kSlotBytes) cut.push_back(m);
+            }
+            cut.push_back(g_members);
+            std::atomic<uint32_t> next_batch(0), slot_gen[kRingSlots];
+            for (int q = 0; q < kRingSlots; ++q) slot_gen[q].store(0);
+            std::atomic<bool> stage_failed(false);
+            auto stage = [&]() {
+                if (hipSetDevice(b->pin_device) != hipSuccess) { stage_failed.store(true); return; }
+                for (;;) {
+                    const uint32_t i = next_batch.fetch_add(1);
+                    if (i + 1 >= cut.size()) break;
+                    const uint32_t q = i % kRingSlots, gen = i / kRingSlots;
+                    while (slot_gen[q].load(std::memory_order_acquire) != gen) std::this_thread::yield();  // batch i - kRingSlots has enqueued its copy
+                    if (stage_failed.load()) { slot_gen[q].store(gen + 1, std::memory_order_release); continue; }
+                    bool good = gen == 0 || hipEventSynchronize(lane->slot_done[q]) == hipSuccess;  // ... and the copy has read the slot
+                    uint8_t* slot = lane->ring + (size_t)q * kSlotBytes;
+                    const uint64_t b0 = in_off[cut[i]];
+                    const uint64_t b1 = cut[i + 1] < g_members ? in_off[cut[i + 1]] : in_bytes;
+                    for (uint32_t m = cut[i]; good && m < cut[i + 1]; ++m) memcpy(slot + (in_off[m] - b0), src[m], in_len[m]);
+                    good = good && hipMemcpyAsync(b->d_inflate + o_in + b0, slot, b1 - b0, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
+                           hipEventRecord(lane->slot_done[q], lane->stream) == hipSuccess;
+                    if (!good) stage_failed.store(true);
+                    slot_gen[q].store(gen + 1, std::memory_order_release);
+                }
+            };
+            if (ok) {
+                b->pool.run((int)std::min<uint32_t>(nt, (uint32_t)cut.size()), stage);
+                ok = !stage_failed.load();
+            }
+            t_staged = since_call_ms();
+            // (3) kernels, and the event behind them
+            if (ok) {
+                uint8_t* d = b->d_inflate;
+                const uint8_t* tab = d + o_tab;
+                ok = g_inflate_launch(lane->stream, d + o_in, (const uint64_t*)(tab + t_in_off), (const uint32_t*)(tab + t_in_len),
+                                      (const uint32_t*)(tab + t_isz), (const uint32_t*)(tab + t_crc), g_members, d + o_out,
+                                      (const uint64_t*)(tab + t_out_off), (uint32_t*)(d + o_status)) == 0 &&
+                     g_gather_launch(lane->stream, d + o_out, (const uint64_t*)(tab + t_src_off), (const uint32_t*)(tab + t_len),
+                                     (const uint64_t*)(tab + t_dst_off), n_pc, d + o_packed) == 0 &&
+                     hipEventRecord(lane->done, lane->stream) == hipSuccess;
+            }
+            t_launched = since_call_ms();
+            if (ok) {
+                leg_running = true;
+                g_status.resize(g_members);
+                g_packed.resize(packed_bytes + 8);
+                next.store(n_g);  // the threads take the slices behind the leg's
+            } else {
+                (void)hipGetLastError();
+                if (lane) (void)hipStreamSynchronize(lane->stream);  // nothing of a failed leg is still reading the ring
+                n_g = 0;      // the threads take everything
+                g_members = 0;
+            }
+            leg_o_status = o_status;
+            leg_o_packed = o_packed;
+        }
         auto pull = [&]() {
             timespec c0;
             clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
@@ -1461,6 +1736,41 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             }
         };
         b->pool.run((int)nt, pull);
+        // (5) the leg's results
+        if (leg_running) {
+            const double t_cpu_done = since_call_ms();
+            bool ok = hipEventSynchronize(lane->done) == hipSuccess;
+            const double t_dev_done = since_call_ms();
+            ok = ok && hipMemcpy(g_status.data(), b->d_inflate + leg_o_status, (size_t)g_members * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(g_packed.data(), b->d_inflate + leg_o_packed, g_packed.size() - 8, hipMemcpyDeviceToHost) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                return fail(b, SVX_E_HIP, "svx_bam_seq_slices: the device leg failed");
+            }
+            for (uint32_t m = 0; m < g_members; ++m)
+                if (g_status[m] != 0) failed.store(true);  // malformed stream, wrong length or CRC32: as the host decoder judges
+            if (!failed.load()) {
+                // unpack: piece k of the leg (plans in order) lies at g_dst_off[k] of the read-back
+                std::vector<uint32_t> first_piece(plans.size() + 1, 0);
+                for (size_t r = 0; r < plans.size(); ++r) first_piece[r + 1] = first_piece[r] + (uint32_t)plans[r].pieces.size();
+                std::atomic<uint32_t> next_plan(0);
+                auto unpack = [&]() {
+                    for (;;) {
+                        const uint32_t r = next_plan.fetch_add(1);
+                        if (r >= plans.size()) break;
+                        for (size_t k = 0; k < plans[r].pieces.size(); ++k)
+                            unpack_piece(plans[r].pieces[k], g_packed.data() + g_dst_off[first_piece[r] + k]);
+                    }
+                };
+                b->pool.run((int)std::min<uint32_t>(nt, (uint32_t)plans.size()), unpack);
+            }
+            inflated.fetch_add(g_members);
+            b->device_members += g_members;
+            if (debug)
+                fprintf(stderr, "svx_bam_seq_slices: device leg: %u of %u slices, %u members, %.1f MB packed; located +%.1f ms, staged +%.1f, "
+                        "launched +%.1f, threads done +%.1f, device done +%.1f, all +%.1f\n", n_g, n, g_members, g_packed.size() / 1e6,
+                        t_located, t_staged, t_launched, t_cpu_done, t_dev_done, since_call_ms());
+        }
         if (debug)
             fprintf(stderr, "svx_bam_seq_slices: %u slices, %u threads: call %.1f ms; per thread: last start +%.1f ms, longest wall %.1f ms, "
                     "longest cpu %.1f ms, cpu sum %.1f ms\n", n, nt,

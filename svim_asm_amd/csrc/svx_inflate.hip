@@ -23,9 +23,21 @@ namespace {
 
 constexpr int kLL = 288, kDist = 30, kMaxBits = 15;
 #ifndef SVX_INFL_LANES
-#define SVX_INFL_LANES 32
+#define SVX_INFL_LANES 16
 #endif
-constexpr int kLanes = SVX_INFL_LANES;  // members per workgroup (part of a wave: the LDS tables of 64 members would not fit)
+constexpr int kLanes = SVX_INFL_LANES;  // members per workgroup (their LDS tables: 2.2 KB each)
+#ifndef SVX_INFL_ACTIVE
+#define SVX_INFL_ACTIVE 4
+#endif
+// Lanes of a wave that hold a member.  The lanes of a wave are at different points of their streams, and every distinct
+// path is issued for the whole wave: the fewer members share a wave, the shorter each one's decode — and the more waves
+// the same number of members in flight needs (110 VGPRs: 16 waves per CU).  7 261 SEQ members, kernel time
+// (profiles/r05_inflate_geometry.txt): 32 per wave 58 ms (16 k members in flight on the chip), 4 per wave 49 (16 k),
+// 2 per wave 34.5 (8 k), 1 per wave 23 ms up to the 4 096 it holds at once, 48 beyond.  Four per wave keeps the chip's
+// capacity of 64 members per CU (4 workgroups of 16 members: 39 KB of LDS each) — a sample's two readers bring 13-14 k.
+constexpr int kActive = SVX_INFL_ACTIVE;
+static_assert(kActive >= 1 && kActive <= 64 && kLanes % kActive == 0, "a workgroup is kLanes / kActive whole waves");
+constexpr int kThreads = kLanes / kActive * 64;
 constexpr int kLLBits = 9;    // literal/length codes up to this many bits are resolved by ONE table look-up
 constexpr int kDBits = 7;     // ... distance codes
 
@@ -226,18 +238,19 @@ __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 
 enum { ST_OK = 0, ST_BAD_STREAM = 1, ST_SIZE = 2, ST_CRC = 3, ST_INPUT_END = 4 };
 
-__global__ __launch_bounds__(kLanes) void k_bgzf_inflate(InfArgs a) {
+__global__ __launch_bounds__(kThreads) void k_bgzf_inflate(InfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds& s = *reinterpret_cast<Lds*>(lds_raw);
-    const int lane = threadIdx.x;
-    // CRC-32 (IEEE 802.3, reflected 0xEDB88320) table, 4 entries per lane
-    for (int i = lane; i < 256; i += kLanes) {
+    const int lane = (int)(threadIdx.x >> 6) * kActive + (int)(threadIdx.x & 63u);  // this thread's member slot, if it has one
+    const bool holds_member = (threadIdx.x & 63u) < (uint32_t)kActive;
+    // CRC-32 (IEEE 802.3, reflected 0xEDB88320) table
+    for (int i = threadIdx.x; i < 256; i += kThreads) {
         uint32_t c = (uint32_t)i;
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
         s.crc_table4[0][i] = c;
     }
     __syncthreads();
-    for (int i = lane; i < 256; i += kLanes) {
+    for (int i = threadIdx.x; i < 256; i += kThreads) {
         uint32_t c = s.crc_table4[0][i];
         for (int t = 1; t < 4; ++t) {
             c = s.crc_table4[0][c & 0xFFu] ^ (c >> 8);
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(kLanes) void k_bgzf_inflate(InfArgs a) {
     }
     __syncthreads();
     const uint32_t m = blockIdx.x * kLanes + lane;
-    if (m >= a.n) return;
+    if (!holds_member || m >= a.n) return;
     const uint8_t* in = a.in + a.in_off[m];
     const uint32_t in_len = a.in_len[m], isize = a.isize[m];
     uint8_t* out = a.out + a.out_off[m];
@@ -407,7 +420,51 @@ __global__ __launch_bounds__(kLanes) void k_bgzf_inflate(InfArgs a) {
     a.status[m] = st;
 }
 
+// pieces of the inflated members → one compact buffer: piece p = src[src_off[p] .. + len[p]) → dst[dst_off[p] ..]; one
+// wave per piece (the packed SEQ bytes of one sequence slice inside one member: tens to thousands of bytes)
+__global__ __launch_bounds__(256) void k_gather_ranges(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
+                                                       const uint32_t* __restrict__ len, const uint64_t* __restrict__ dst_off,
+                                                       uint32_t n, uint8_t* __restrict__ dst) {
+    const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const uint8_t* s = src + src_off[p];
+    uint8_t* d = dst + dst_off[p];
+    const uint32_t l = len[p];
+    for (uint32_t i = threadIdx.x & 63u; i < l; i += 64u) d[i] = s[i];
+}
+
 }  // namespace
+
+// The two launches the BAM reader's device leg needs (svx_bam_seq_slices with svx_bam_set_device_inflate), on a stream of
+// the caller's: hipError_t as int.
+int svx_bgzf_inflate_on_stream(void* stream, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                               const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
+                               const uint64_t* d_out_off, uint32_t* d_status) {
+    if (n_members == 0) return 0;
+    InfArgs a{d_in, d_in_off, d_in_len, d_isize, d_crc, d_out, d_out_off, d_status, n_members};
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(Lds));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_members + kLanes - 1) / kLanes), dim3(kThreads), sizeof(Lds),
+                       static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int svx_gather_ranges_on_stream(void* stream, const uint8_t* d_src, const uint64_t* d_src_off, const uint32_t* d_len,
+                                const uint64_t* d_dst_off, uint32_t n, uint8_t* d_dst) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_gather_ranges, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), d_src, d_src_off, d_len,
+                       d_dst_off, n, d_dst);
+    return (int)hipGetLastError();
+}
+
+// svx_bam.cpp reaches the two launches through pointers (it also builds alone, without this file, for the CPU sanitizer tests)
+extern "C" void svx_bam_register_device_kernels(
+    int (*)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint8_t*,
+            const uint64_t*, uint32_t*),
+    int (*)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, uint8_t*));
+static const int svx_device_kernels_registered =
+    (svx_bam_register_device_kernels(&svx_bgzf_inflate_on_stream, &svx_gather_ranges_on_stream), 0);
 
 extern "C" int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                     const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
@@ -416,15 +473,12 @@ extern "C" int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uin
     if (n_members == 0) return SVX_OK;
     if (!d_in || !d_in_off || !d_in_len || !d_isize || !d_crc || !d_out || !d_out_off || !d_status) return SVX_E_INVALID;
     SVX_HIP(ctx, hipSetDevice(ctx->device));
-    InfArgs a{d_in, d_in_off, d_in_len, d_isize, d_crc, d_out, d_out_off, d_status, n_members};
     int rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-    SVX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(Lds)));
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_members + kLanes - 1) / kLanes), dim3(kLanes), sizeof(Lds), ctx->stream, a);
-    SVX_HIP(ctx, hipGetLastError());
+    SVX_HIP(ctx, (hipError_t)svx_bgzf_inflate_on_stream(ctx->stream, d_in, d_in_off, d_in_len, d_isize, d_crc, n_members, d_out, d_out_off,
+                                                        d_status));
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     return svx_timing_end(ctx);

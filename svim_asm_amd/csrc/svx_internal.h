@@ -125,6 +125,12 @@ static inline size_t svx_take_bytes(size_t count, size_t elem) {
 // Wait for everything enqueued on the context's stream WITHOUT spinning: an event created with hipEventBlockingSync
 // puts the thread to sleep until the device signals (hipStreamSynchronize burns a CPU for the whole wait: under a
 // CPU quota, milliseconds of kernel time then cost the host's other threads their share).
+// svx_inflate.hip, for the BAM reader's device leg (svx_bam.cpp): hipError_t as int
+int svx_bgzf_inflate_on_stream(void* stream, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                               const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
+                               const uint64_t* d_out_off, uint32_t* d_status);
+int svx_gather_ranges_on_stream(void* stream, const uint8_t* d_src, const uint64_t* d_src_off, const uint32_t* d_len,
+                                const uint64_t* d_dst_off, uint32_t n, uint8_t* d_dst);
 int svx_wait_blocking(svx_ctx* ctx);
 int svx_timing_begin(svx_ctx* ctx);           // records ev[0]
 int svx_timing_mark(svx_ctx* ctx, int which); // records ev[which] (1: dominant start, 2: dominant end)

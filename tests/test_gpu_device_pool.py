@@ -135,3 +135,82 @@ def test_switch_in_the_environment(dataset):
     env = dict(os.environ, SVX_BAM_DEVICE_POOL="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "POOL True True" in out.stdout, out.stdout + out.stderr
+
+
+def random_slices(f, rng, n):
+    """n slices sorted by (record, first base), as COLLECT asks for them."""
+    l_seq = f._cols["l_seq"]
+    rec = np.sort(rng.integers(0, len(l_seq), n))
+    a = (rng.random(n) * l_seq[rec]).astype(np.int64)
+    b = np.minimum(a + rng.integers(1, 3000, n), l_seq[rec])
+    order = np.lexsort((a, rec))
+    return rec[order].astype(np.uint32), a[order], b[order]
+
+
+@pytest.mark.parametrize("percent", [25, 60, 100])
+def test_device_leg_of_the_sequence_slices(svx_ctx, dataset, percent):
+    """svx_bam_set_device_inflate: the members under the first share of a call's slices are inflated and verified by
+    the device while the reader's threads take the rest — the same bases as the host alone decodes."""
+    fa, bams = dataset
+    host = bamio.AlignmentFile(bams[0], device=0)
+    host.device_inflate_percent = 0
+    host.load(None)
+    rec, a, b = random_slices(host, np.random.default_rng(percent), 6000)
+    exp, exp_off = host.sequence_slices_raw(rec, a, b)
+    assert host.device_members == 0 and len(exp) > 1_000_000
+    dev = bamio.AlignmentFile(bams[0], device=0)
+    dev.device_inflate_percent = percent
+    dev.load(None)
+    import time
+    for attempt in range(200):  # (the lanes come up beside the first load of the process: tens of milliseconds)
+        got, got_off = dev.sequence_slices_raw(rec, a, b)
+        assert np.array_equal(got_off, exp_off) and np.array_equal(got, exp)
+        if dev.device_members:
+            break
+        time.sleep(0.05)
+    assert dev.device_members > 0
+    # a second call reuses the lane and the device buffer
+    before = dev.device_members
+    got, got_off = dev.sequence_slices_raw(rec[:4000], a[:4000], b[:4000])
+    exp2, exp2_off = host.sequence_slices_raw(rec[:4000], a[:4000], b[:4000])
+    assert np.array_equal(got, exp2) and dev.device_members > before
+
+
+def test_device_leg_flags_a_damaged_member(svx_ctx, dataset, tmp_path):
+    """A member whose payload is damaged (CRC32 no longer fits) under a slice of the device's share: the call fails as it
+    does on the host."""
+    import shutil
+    fa, bams = dataset
+    bad = str(tmp_path / "bad.bam")
+    shutil.copy(bams[0], bad)
+    shutil.copy(bams[0] + ".bai", bad + ".bai")
+    probe = bamio.AlignmentFile(bad, device=0)
+    probe.load(None)
+    rec, a, b = random_slices(probe, np.random.default_rng(5), 6000)
+    # flip one byte inside a SEQ member's payload that no record walk reads (the load still succeeds)
+    clean = open(bad, "rb").read()
+    spans = [sp for sp in bamio._bgzf_block_spans(clean) if sp[2] and sp[1] >= 8192]
+    for st, ln, *_ in spans[len(spans) // 3:]:
+        raw = bytearray(clean)
+        raw[st + ln // 2] ^= 0x55
+        open(bad, "wb").write(bytes(raw))
+        try:
+            bamio.AlignmentFile(bad, device=0).load(None)
+            break
+        except ValueError:
+            continue
+    else:
+        pytest.skip("every SEQ member of this file holds a record head")
+    import time
+    results = []
+    for percent in (0, 100):
+        f = bamio.AlignmentFile(bad, device=0)
+        f.device_inflate_percent = percent
+        f.load(None)
+        time.sleep(0.5)  # (the lanes of a first load in this process)
+        try:
+            f.sequence_slices_raw(rec, a, b)
+            results.append("ok")
+        except ValueError:
+            results.append("error")
+    assert results == ["error", "error"]

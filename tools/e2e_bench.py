@@ -293,7 +293,11 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             r["facts"] = {"index_state": f1.index_state(), "bgzf_members_inflated": [f1.blocks_inflated, f2.blocks_inflated],
                           "bgzf_members_walked": [f1.blocks_spanned, f2.blocks_spanned],
                           "candidates": [len(t1), len(t2), len(paired)],
-                          "cigar_ops": [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())]}
+                          "cigar_ops": [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())],
+                          # the device leg of the sequence slices (svx_bam_set_device_inflate): its share of each call and
+                          # the members the device inflated + verified for the two readers
+                          "device_inflate_percent": f1.device_inflate_percent,
+                          "bgzf_members_inflated_on_device": [f1.device_members, f2.device_members]}
             del t1, t2, paired
             f1.close(), f2.close()
             from svim_asm_amd import fasta as _fasta
@@ -316,7 +320,9 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
             res["best_run"] = min(runs, key=lambda x: x["product_total_s"])
             res["median_run"] = sorted(runs, key=lambda x: x["product_total_s"])[len(runs) // 2]
             res["all_runs_total_s"] = [r["product_total_s"] for r in runs]
-        res.update(res.pop("facts"))
+        facts = dict(runs[-1].get("facts") or res.get("facts"))  # (of the last default run: the device lanes of a fresh process
+        res.pop("facts", None)                                   #  come up during the first one)
+        res.update(facts)
         for r in runs:
             r.pop("facts", None)
         res["ingest_threads"] = threads or bamio.ingest_threads(2)
