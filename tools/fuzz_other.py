@@ -244,6 +244,62 @@ def fuzz_collect(ctx, rng):
         len(b["aln_off"]) - 1, len(b["parts"]), len(b["read_off"]) - 1, min_len, prm, streaming)
 
 
+def fuzz_inflate(ctx, rng):
+    """svx_bgzf_inflate_dev (the kernel of the sequence slices' device leg) against zlib: members of random kinds of
+    data at random levels / strategies / memLevels, a share of them damaged (flipped bit, cut short, wrong CRC32, wrong
+    ISIZE): status 0 exactly where zlib and the trailer agree, bytes equal there."""
+    import zlib
+
+    def deflate(data, level, strategy, mem):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
+        return c.compress(data) + c.flush()
+    n = int(rng.choice([1, 3, 17, 64, 200]))
+    payloads, isize, crc, want_ok, expect = [], [], [], [], []
+    for _ in range(n):
+        kind = int(rng.integers(0, 7))
+        size = int(rng.choice([0, 1, 2, 300, 5000, 65000, 65536]))
+        if kind == 0:
+            d = rng.choice(np.frombuffer(bytes([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88, 0xFF]), np.uint8), size=size).tobytes()
+        elif kind == 1:
+            d = bytes(size)
+        elif kind == 2:
+            d = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+        elif kind == 3:
+            d = (b"chr1\t12345\tsvim_asm.DEL.7\tACGTNNNN\t<DEL>\t.\tPASS\tSVTYPE=DEL;END=12400\n" * 1200)[:size]
+        elif kind == 4:
+            d = b"".join(bytes([int(x)]) * int(k) for x, k in zip(rng.integers(0, 256, 300), rng.integers(1, 400, 300)))[:size]
+        elif kind == 5:
+            d = rng.integers(0, 4, size, dtype=np.uint8).tobytes()  # tiny alphabet: long codes for the rare symbols
+        else:
+            base = rng.integers(0, 256, max(1, size // 7), dtype=np.uint8).tobytes()
+            d = (base * 8)[:size]                                     # long-distance repeats
+        p = deflate(d, int(rng.choice([0, 1, 2, 4, 6, 9])),
+                    int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])),
+                    int(rng.choice([1, 5, 9])))
+        g_isize, g_crc, ok = len(d), zlib.crc32(d) & 0xFFFFFFFF, True
+        damage = int(rng.integers(0, 8))
+        bad = bytearray(p)
+        if damage == 0 and len(bad):
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        elif damage == 1 and len(bad) > 1:
+            bad = bad[:int(rng.integers(1, len(bad)))]
+        elif damage == 2:
+            g_crc ^= 1 << int(rng.integers(0, 32))
+        elif damage == 3:
+            g_isize = max(0, min(65536, g_isize + int(rng.choice([-1, 1, -100, 7]))))
+        if damage < 4:
+            try:
+                o = zlib.decompress(bytes(bad), -15)
+                ok = o == d and len(o) == g_isize and (zlib.crc32(o) & 0xFFFFFFFF) == g_crc
+            except zlib.error:
+                ok = False
+        payloads.append(bytes(bad)); isize.append(g_isize); crc.append(g_crc); want_ok.append(ok); expect.append(d)
+    status, outs, _ = ctx.bgzf_inflate(payloads, isize, crc)
+    good = all((st == 0) == ok for st, ok in zip(status.tolist(), want_ok)) and \
+        all(o == e for o, e, ok in zip(outs, expect, want_ok) if ok)
+    return good, "inflate n %d" % n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -251,7 +307,7 @@ def main():
     ap.add_argument("--only", default="", help="one of the fuzz_* functions, e.g. pair")
     a = ap.parse_args()
     ctx = _lib.default_context(0)
-    fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats, fuzz_linkage, fuzz_postpass, fuzz_haplotypes, fuzz_collect]
+    fns = [fuzz_segments, fuzz_pair, fuzz_edit, fuzz_stats, fuzz_linkage, fuzz_postpass, fuzz_haplotypes, fuzz_collect, fuzz_inflate]
     if a.only:
         fns = [f for f in fns if f.__name__ == "fuzz_" + a.only]
     counts = {f.__name__: 0 for f in fns}
