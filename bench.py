@@ -656,6 +656,8 @@ def e2e_leg(scale, local_rank, n_devices=1):
             # waited for the inflate of the inserted alleles, which starts in COLLECT and runs beside PAIR's set-up
             "wall_s_prefix_only_no_crc": r.get("prefix_only_no_crc_total_s"),  # one more pass with svx_bam_set_verify(0)
             # (`--no_bgzf_crc`): members inflated only as far as needed, no CRC32 unless a member is inflated to its end
+            "wall_s_host_inflate_only": r.get("host_inflate_only_total_s"),  # median of three more runs with the device leg off
+            "all_runs_wall_s_host_inflate_only": r.get("host_inflate_only_runs_total_s"),  # (what a one-shot command runs: cli.py)
             "device_inflate_percent": r.get("device_inflate_percent"),  # the device leg of the sequence slices: share of
             "bgzf_members_inflated_on_device": r.get("bgzf_members_inflated_on_device"),  # each call, members per reader
             "cpu_seconds": med.get("cpu_seconds"),  # CPU seconds of all threads per phase, and beside them

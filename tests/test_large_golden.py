@@ -45,6 +45,29 @@ def test_cli_reproduces_reference_vcf_large(svx_ctx, large_dataset, tmp_path):
     _check(tmp_path / "variants.vcf")
 
 
+def test_cli_with_the_device_leg_reproduces_reference_vcf_large(svx_ctx, large_dataset, tmp_path, monkeypatch):
+    """The same command with 60 % of every sequence-slice call's BGZF members inflated and verified on the device
+    (svx_bam_set_device_inflate; a one-shot command runs without that share unless SVX_BAM_DEVICE_INFLATE asks for it)."""
+    import time
+    from svim_asm_amd import bamio, cli
+    fasta, bams = large_dataset
+    warm = bamio.AlignmentFile(bams[0], device=0)
+    warm.load(["chr21"])   # the device lanes come up beside the first load of a process
+    time.sleep(0.5)
+    monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "60")
+    seen = []
+    real = bamio.AlignmentFile._slices_native
+
+    def spy(self, rec, a, b):
+        out = real(self, rec, a, b)
+        seen.append((len(rec), self.device_members))
+        return out
+    monkeypatch.setattr(bamio.AlignmentFile, "_slices_native", spy)
+    cli.main(["diploid", str(tmp_path), bams[0], bams[1], fasta])
+    _check(tmp_path / "variants.vcf")
+    assert seen and max(n for n, _ in seen) >= 2048 and max(m for _, m in seen) > 1000, seen
+
+
 @pytest.mark.spawns_gpu_children
 def test_four_rank_cli_reproduces_reference_vcf_large(large_dataset, tmp_path):
     """BASELINE config 4: four ranks (fresh processes, product kernels, all on device 0 of the one-GPU box)."""
