@@ -749,8 +749,11 @@ static void lanes_bring_up(int device) {
             void* ring = nullptr;
             ok = ok && hipHostMalloc(&ring, kRingSlots * kSlotBytes, hipHostMallocDefault) == hipSuccess;
             I.ring = static_cast<uint8_t*>(ring);
-            for (int q = 0; q < kRingSlots && ok; ++q) ok = hipEventCreateWithFlags(&I.slot_done[q], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&I.done, hipEventDisableTiming) == hipSuccess;
+            // (blocking events: a thread that waits for a slot or for the leg sleeps — under a CPU quota a spinning wait
+            //  spends the very seconds the leg is there to save)
+            for (int q = 0; q < kRingSlots && ok; ++q)
+                ok = hipEventCreateWithFlags(&I.slot_done[q], hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&I.done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
             if (ok) good.fetch_add(1);
             else (void)hipGetLastError();
         });
@@ -1666,7 +1669,8 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                     const uint32_t i = next_batch.fetch_add(1);
                     if (i + 1 >= cut.size()) break;
                     const uint32_t q = i % kRingSlots, gen = i / kRingSlots;
-                    while (slot_gen[q].load(std::memory_order_acquire) != gen) std::this_thread::yield();  // batch i - kRingSlots has enqueued its copy
+                    while (slot_gen[q].load(std::memory_order_acquire) != gen)  // batch i - kRingSlots has enqueued its copy
+                        std::this_thread::sleep_for(std::chrono::microseconds(20));
                     if (stage_failed.load()) { slot_gen[q].store(gen + 1, std::memory_order_release); continue; }
                     bool good = gen == 0 || hipEventSynchronize(lane->slot_done[q]) == hipSuccess;  // ... and the copy has read the slot
                     uint8_t* slot = lane->ring + (size_t)q * kSlotBytes;
@@ -1680,7 +1684,9 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 }
             };
             if (ok) {
-                b->pool.run((int)std::min<uint32_t>(nt, (uint32_t)cut.size()), stage);
+                // as many threads as the ring has slots: each batch finds its slot free or about to be — more threads would
+                // only wait for their turn (spinning through the CPU quota: measured, 3.4 instead of 2.9 CPU-seconds per run)
+                b->pool.run((int)std::min<uint32_t>(std::min<uint32_t>(nt, (uint32_t)kRingSlots), (uint32_t)cut.size() - 1), stage);
                 ok = !stage_failed.load();
             }
             t_staged = since_call_ms();

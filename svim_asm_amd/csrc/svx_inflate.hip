@@ -238,7 +238,12 @@ __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 
 enum { ST_OK = 0, ST_BAD_STREAM = 1, ST_SIZE = 2, ST_CRC = 3, ST_INPUT_END = 4 };
 
-__global__ __launch_bounds__(kThreads) void k_bgzf_inflate(InfArgs a) {
+#ifdef SVX_INFL_WAVES  // waves per SIMD the register allocator must leave room for (experiments: tools/r05_infl_geom.sh)
+#define SVX_INFL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SVX_INFL_WAVES, SVX_INFL_WAVES)))
+#else
+#define SVX_INFL_OCCUPANCY
+#endif
+__global__ __launch_bounds__(kThreads) SVX_INFL_OCCUPANCY void k_bgzf_inflate(InfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds& s = *reinterpret_cast<Lds*>(lds_raw);
     const int lane = (int)(threadIdx.x >> 6) * kActive + (int)(threadIdx.x & 63u);  // this thread's member slot, if it has one
