@@ -701,7 +701,7 @@ struct InflateLane {
     std::mutex busy;                  // held by the call that uses the lane
 };
 struct DeviceLanes {
-    std::once_flag once;
+    std::once_flag once, inflate_once;
     std::mutex mu;
     std::condition_variable cv;
     bool upload_tried = false;
@@ -714,18 +714,21 @@ struct DeviceLanes {
 constexpr int kMaxLanes = 64;
 static DeviceLanes g_lanes[kMaxLanes];
 
-static bool warm_stream(hipStream_t* out) {
+// A new stream and one host-to-device copy of `bytes` through it (page-locked source `src`, or a buffer of its own): the
+// first copy of a stream sets up its DMA path, and the first copy of this SIZE class does so once more (the command's
+// trace: 6-9 ms for the first 512 KiB part of a pool on a stream that had only moved 4 KiB) — done here, beside the walk.
+static bool warm_stream(hipStream_t* out, size_t bytes, void* src = nullptr) {
     hipStream_t st = nullptr;
-    void *h = nullptr, *d = nullptr;
+    void *h = src, *d = nullptr;
     bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-    // the first copy of a stream sets up its DMA path: a 4 KiB one now instead of the first real one later
-    ok = ok && hipHostMalloc(&h, 4096, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, 4096) == hipSuccess;
-    if (ok) {
-        memset(h, 0, 4096);
-        ok = hipMemcpyAsync(d, h, 4096, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (ok && !h) {
+        ok = hipHostMalloc(&h, bytes, hipHostMallocDefault) == hipSuccess;
+        if (ok) memset(h, 0, bytes);
     }
+    ok = ok && hipMalloc(&d, bytes) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     if (d) (void)hipFree(d);
-    if (h) (void)hipHostFree(h);
+    if (h && !src) (void)hipHostFree(h);
     if (!ok) {
         (void)hipGetLastError();
         if (st) (void)hipStreamDestroy(st);
@@ -735,30 +738,10 @@ static bool warm_stream(hipStream_t* out) {
     return ok;
 }
 
-static void lanes_bring_up(int device) {
+static void upload_lane_bring_up(int device) {
     DeviceLanes& L = g_lanes[device];
-    // the inflate lanes on threads of their own: stream creations run side by side (each 10-25 ms), and a fresh
-    // process's first sequence-slice call comes only tens of milliseconds after its first load
-    std::vector<std::thread> th;
-    std::atomic<int> good(0);
-    const bool want_inflate = g_inflate_launch && !getenv("SVX_BAM_NO_INFLATE_LANES");
-    for (int k = 0; want_inflate && k < kInflateLanes; ++k)
-        th.emplace_back([&L, &good, device, k] {
-            InflateLane& I = L.inflate[k];
-            bool ok = hipSetDevice(device) == hipSuccess && warm_stream(&I.stream);
-            void* ring = nullptr;
-            ok = ok && hipHostMalloc(&ring, kRingSlots * kSlotBytes, hipHostMallocDefault) == hipSuccess;
-            I.ring = static_cast<uint8_t*>(ring);
-            // (blocking events: a thread that waits for a slot or for the leg sleeps — under a CPU quota a spinning wait
-            //  spends the very seconds the leg is there to save)
-            for (int q = 0; q < kRingSlots && ok; ++q)
-                ok = hipEventCreateWithFlags(&I.slot_done[q], hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&I.done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
-            if (ok) good.fetch_add(1);
-            else (void)hipGetLastError();
-        });
     hipStream_t up = nullptr;
-    if (hipSetDevice(device) == hipSuccess) (void)warm_stream(&up);
+    if (hipSetDevice(device) == hipSuccess) (void)warm_stream(&up, 1u << 20);
     else (void)hipGetLastError();
     {
         std::lock_guard<std::mutex> lock(L.mu);
@@ -767,6 +750,31 @@ static void lanes_bring_up(int device) {
         L.upload_up.store(true);
     }
     L.cv.notify_all();
+}
+
+// the inflate lanes, each on a thread of its own: stream creations run side by side (each 10-25 ms), and a fresh
+// process's first sequence-slice call comes only tens of milliseconds after its first load
+static void inflate_lanes_bring_up(int device) {
+    DeviceLanes& L = g_lanes[device];
+    std::vector<std::thread> th;
+    std::atomic<int> good(0);
+    const bool want_inflate = g_inflate_launch && !getenv("SVX_BAM_NO_INFLATE_LANES");
+    for (int k = 0; want_inflate && k < kInflateLanes; ++k)
+        th.emplace_back([&L, &good, device, k] {
+            InflateLane& I = L.inflate[k];
+            void* ring = nullptr;
+            bool ok = hipSetDevice(device) == hipSuccess && hipHostMalloc(&ring, kRingSlots * kSlotBytes, hipHostMallocDefault) == hipSuccess;
+            if (ok) memset(ring, 0, kSlotBytes);
+            I.ring = static_cast<uint8_t*>(ring);
+            ok = ok && warm_stream(&I.stream, kSlotBytes, ring);
+            // (blocking events: a thread that waits for a slot or for the leg sleeps — under a CPU quota a spinning wait
+            //  spends the very seconds the leg is there to save)
+            for (int q = 0; q < kRingSlots && ok; ++q)
+                ok = hipEventCreateWithFlags(&I.slot_done[q], hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&I.done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
+            if (ok) good.fetch_add(1);
+            else (void)hipGetLastError();
+        });
     for (std::thread& t : th) t.join();
     {
         std::lock_guard<std::mutex> lock(L.mu);
@@ -776,15 +784,17 @@ static void lanes_bring_up(int device) {
     L.cv.notify_all();
 }
 
-// starts the lanes of `device` once per process (returns at once)
-static void lanes_start(int device) {
+// start the lanes of `device` once per process (returns at once); the inflate lanes only for a reader that has a device
+// share (svx_bam_set_device_inflate): a one-shot command without one does not pay for two more streams and 32 MB of ring
+static void lanes_start(int device, bool with_inflate) {
     if (device < 0 || device >= kMaxLanes) return;
-    std::call_once(g_lanes[device].once, [device] { std::thread(lanes_bring_up, device).detach(); });
+    std::call_once(g_lanes[device].once, [device] { std::thread(upload_lane_bring_up, device).detach(); });
+    if (with_inflate) std::call_once(g_lanes[device].inflate_once, [device] { std::thread(inflate_lanes_bring_up, device).detach(); });
 }
 
 static hipStream_t upload_stream(int device) {
     if (device < 0 || device >= kMaxLanes) return nullptr;
-    lanes_start(device);
+    lanes_start(device, false);
     DeviceLanes& L = g_lanes[device];
     std::unique_lock<std::mutex> lock(L.mu);
     L.cv.wait(lock, [&] { return L.upload_tried; });
@@ -1128,7 +1138,8 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
         }
     }
     // the device lanes (the pool's upload stream first) come up beside the walk: first load of the process only
-    if (b->pin_device >= 0 && !svx_bam::device_pool_off()) lanes_start(b->pin_device);
+    if (b->pin_device >= 0 && !svx_bam::device_pool_off()) lanes_start(b->pin_device, b->inflate_pct > 0);
+    else if (b->pin_device >= 0 && b->inflate_pct > 0) lanes_start(b->pin_device, true);
     // ---- cut the requested ranges into pieces
     std::vector<Piece> pieces;
     bool filter_after = false;
@@ -1552,7 +1563,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             // a fresh process: the lanes were started beside the first load and may be a few milliseconds away — worth a
             // short wait (the leg takes ~40 % of the call's CPU seconds), not a long one
             DeviceLanes& L = g_lanes[b->pin_device];
-            lanes_start(b->pin_device);
+            lanes_start(b->pin_device, true);
             std::unique_lock<std::mutex> lock(L.mu);
             L.cv.wait_for(lock, std::chrono::milliseconds(30), [&] { return L.inflate_tried; });
         }
