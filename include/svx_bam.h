@@ -100,6 +100,9 @@ int svx_bam_device_pool_wait(svx_bam* bam, double* waited_us);
  * once — so the share is what the threads would need that long for; results never depend on it.  0 (default): host only.
  * svx_bam_device_members: members the device has inflated for this handle so far. */
 int svx_bam_set_device_inflate(svx_bam* bam, int percent);
+/* The share goes to the device only when it holds at least `members` BGZF members (default 3000: the leg's latency is one
+ * member's decode time on the device, 45-55 ms, whatever their number — below that the threads are through sooner). */
+int svx_bam_set_device_inflate_min(svx_bam* bam, uint32_t members);
 uint64_t svx_bam_device_members(const svx_bam* bam);
 
 /* Index the records of contigs tids[0..n_tids) (NULL: every record of the file, unplaced ones

@@ -623,6 +623,7 @@ class AlignmentFile(object):
     # share of a sequence-slice call's members that the pinned device inflates and verifies beside the reader's threads
     # (svx_bam_set_device_inflate; default_device_inflate_percent above)
     device_inflate_percent = default_device_inflate_percent()
+    device_inflate_min_members = 3000  # the share goes to the device only when it holds that many members (svx_bam.h)
 
     @property
     def device_members(self):
@@ -663,6 +664,7 @@ class AlignmentFile(object):
         if self._h is not None:
             self._lib.svx_bam_set_pinned_device(self._h, -1 if self._pin_device is None else int(self._pin_device))
             self._lib.svx_bam_set_device_inflate(self._h, 0 if self._pin_device is None else self.device_inflate_percent)
+            self._lib.svx_bam_set_device_inflate_min(self._h, int(self.device_inflate_min_members))
             if tids is None:
                 rc = self._lib.svx_bam_load(self._h, None, 0)
             else:

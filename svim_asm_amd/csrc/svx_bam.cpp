@@ -829,6 +829,7 @@ struct svx_bam {
                                              // SEQ bytes holds its head and CIGAR) needs only its prefix, not a second check
     int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
     int inflate_pct = 0;  // share of a sequence-slice call whose members the device inflates (svx_bam_set_device_inflate)
+    uint32_t inflate_min_members = 3000;  // ... when that share holds at least this many members
     uint8_t* d_inflate = nullptr;  // the device leg's buffer, kept between calls
     size_t d_inflate_cap = 0;
     uint64_t device_members = 0;   // members the device has inflated and verified for this handle
@@ -1083,6 +1084,12 @@ extern "C" int svx_bam_set_verify(svx_bam* b, int on) {
 extern "C" int svx_bam_set_device_inflate(svx_bam* b, int percent) {
     if (!b || percent < 0 || percent > 100) return SVX_E_INVALID;
     b->inflate_pct = percent;
+    return SVX_OK;
+}
+
+extern "C" int svx_bam_set_device_inflate_min(svx_bam* b, uint32_t members) {
+    if (!b) return SVX_E_INVALID;
+    b->inflate_min_members = members;
     return SVX_OK;
 }
 
@@ -1630,6 +1637,11 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 }
             }
             g_members = (uint32_t)in_off.size();
+            // The leg's latency is that of ONE member on the device (45-55 ms) whatever their number: it pays when the
+            // members it takes would keep the threads busy about that long — 3 000 members are 0.2 CPU-seconds, 25 ms of
+            // eight cores (two readers share the pool's sixteen).  A small sample's call (config 5: 1 200 members, 6 ms on
+            // the host) stays on the host.
+            if (g_members < b->inflate_min_members) ok = false;
             const uint32_t n_pc = (uint32_t)g_len.size();
             auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
             const uint64_t o_in = 0, o_out = up256(in_bytes + 8), o_tab = o_out + up256(out_bytes + 16);

@@ -160,6 +160,7 @@ def test_device_leg_of_the_sequence_slices(svx_ctx, dataset, percent):
     assert host.device_members == 0 and len(exp) > 1_000_000
     dev = bamio.AlignmentFile(bams[0], device=0)
     dev.device_inflate_percent = percent
+    dev.device_inflate_min_members = 0
     dev.load(None)
     import time
     for attempt in range(200):  # (the lanes come up beside the first load of the process: tens of milliseconds)
@@ -206,6 +207,7 @@ def test_device_leg_flags_a_damaged_member(svx_ctx, dataset, tmp_path):
     for percent in (0, 100):
         f = bamio.AlignmentFile(bad, device=0)
         f.device_inflate_percent = percent
+        f.device_inflate_min_members = 0
         f.load(None)
         time.sleep(0.5)  # (the lanes of a first load in this process)
         try:

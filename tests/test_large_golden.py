@@ -55,6 +55,7 @@ def test_cli_with_the_device_leg_reproduces_reference_vcf_large(svx_ctx, large_d
     warm.load(["chr21"])   # the device lanes come up beside the first load of a process
     time.sleep(0.5)
     monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "60")
+    monkeypatch.setattr(bamio.AlignmentFile, "device_inflate_min_members", 0)  # (a quarter-size sample: 2 k members in the share)
     seen = []
     real = bamio.AlignmentFile._slices_native
 
