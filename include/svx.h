@@ -477,7 +477,7 @@ int svx_collect_batch_dev(svx_ctx* ctx, const svx_collect_dev* d);
 int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* seg_src, const uint64_t* aln_off,
                    uint32_t* deal);
 
-/* ------------------------------------------------------------ f-1 on the device (prototype) ------ */
+/* ------------------------------------------------------------ f-1 on the device ------------------- */
 /*
  * BGZF members inflated and checked on the device: what htslib's bgzf_read_block does under every record the
  * reference reads (pysam bam.fetch, SVIM_COLLECT.py:65-68) — inflate the member's raw DEFLATE payload, compare

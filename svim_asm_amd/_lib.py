@@ -308,7 +308,7 @@ class Context:
         self._check(self.lib.svx_ctx_set_timing(self.h, 1 if on else 0))
 
     def bgzf_inflate(self, payloads, isize, crc, keep_output=True):
-        """Inflate + CRC-check BGZF member payloads on the device (svx_bgzf_inflate_dev; prototype).  payloads: list of
+        """Inflate + CRC-check BGZF member payloads on the device (svx_bgzf_inflate_dev: the kernel of the reader's device leg).  payloads: list of
         bytes-like raw DEFLATE streams; isize / crc: the members' trailers.  Returns (status u32[n], outputs or None,
         kernel milliseconds)."""
         n = len(payloads)

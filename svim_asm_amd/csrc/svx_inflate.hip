@@ -1,10 +1,11 @@
-// svx_inflate.hip — BGZF members inflated and CRC32-checked on gfx950 (prototype; SURVEY.md §8 row f-1, "later
-// parallel/GPU inflate").  What it stands in for: htslib's bgzf_read_block under every record the reference reads
+// svx_inflate.hip — BGZF members inflated and CRC32-checked on gfx950 ("later parallel/GPU
+// inflate").  What it stands in for: htslib's bgzf_read_block under every record the reference reads
 // (pysam bam.fetch, SVIM_COLLECT.py:65-68; the inserted sequences of SVIM_intra.py:42) — inflate a member, check
-// its CRC32 and ISIZE.
+// its CRC32 and ISIZE.  In the product path it is the kernel of the BAM reader's device leg (svx_bam.cpp,
+// svx_bam_set_device_inflate): a share of the members under a call's sequence slices, beside the reader's threads.
 //
 // DEFLATE (RFC 1951) is a serial bit stream per member, so the parallelism is ACROSS members: one LANE per member,
-// 64 members per wave, all of a sample's touched members (tens of thousands) in one launch.  Per lane:
+// kActive members per wave (4: below), all members of a call (thousands) in one launch.  Per lane:
 //   * bit buffer of 64 bits, refilled 32 bits at a time from the member's compressed bytes in HBM; the next word
 //     is requested one refill ahead, so a refill never waits for memory;
 //   * canonical Huffman decoding by code length (count / first / index walk, one bit per step — the scheme of

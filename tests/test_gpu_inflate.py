@@ -1,4 +1,4 @@
-"""svx_bgzf_inflate_dev (prototype): BGZF member payloads inflated and CRC32-checked on the
+"""svx_bgzf_inflate_dev (the kernel of the reader's device leg, svx_bam_set_device_inflate): BGZF member payloads inflated and CRC32-checked on the
 device, one lane per member, against zlib — what htslib's bgzf_read_block does under every record the reference
 reads (SVIM_COLLECT.py:65-68).  Bytes identical for every zlib level / strategy over several kinds of data, stored
 and fixed-code members, members of the config-1 golden BAMs; damaged members are flagged, never read past."""

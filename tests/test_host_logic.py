@@ -276,3 +276,40 @@ def test_native_recipes_equal_the_array_form(seed):
         p_type[job_part[0]] = T_DUP_TAN
         with pytest.raises(ValueError):
             SVIM_COMBINE._haplotype_pieces(*args, seq_split=split)
+
+
+def test_device_inflate_share_policy(monkeypatch):
+    """bamio.default_device_inflate_percent: the environment wins; otherwise half a call with at most 24 CPUs' worth of
+    time (hardware threads or cgroup quota), none above; the one-shot command runs without a share unless asked."""
+    from svim_asm_amd import bamio
+    monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "35")
+    assert bamio.default_device_inflate_percent() == 35
+    monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "250")
+    assert bamio.default_device_inflate_percent() == 100
+    monkeypatch.delenv("SVX_BAM_DEVICE_INFLATE")
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 16.0)
+    assert bamio.default_device_inflate_percent() == 50
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 64.0)
+    assert bamio.default_device_inflate_percent() == 0
+
+
+def test_host_cpus_is_the_smaller_of_threads_and_quota():
+    import os
+    from svim_asm_amd import bamio
+    n = bamio.host_cpus()
+    assert 0 < n <= (os.cpu_count() or 1)
+
+
+def test_command_opens_its_bams_without_a_device_share(monkeypatch, tmp_path):
+    """cli._open_file: share 0 unless SVX_BAM_DEVICE_INFLATE asks (a one-shot command's wall-clock is start-up)."""
+    import types
+    from svim_asm_amd import bamio, cli, synth_bam
+    fa, bams = synth_bam.write_dataset(str(tmp_path), seed=3, contigs=(("chrA", 80000), ("chrB", 60000)), n_shared=3, n_private=1,
+                                       median_aln=20000)
+    opts = types.SimpleNamespace(device=0, sub="diploid", no_bgzf_crc=False)
+    monkeypatch.setattr(bamio.AlignmentFile, "device_inflate_percent", 50)
+    monkeypatch.delenv("SVX_BAM_DEVICE_INFLATE", raising=False)
+    assert cli._open_file(bams[0], opts).device_inflate_percent == 0
+    monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "40")
+    assert cli._open_file(bams[0], opts).device_inflate_percent == 40
+    assert bamio.AlignmentFile(bams[0], device=0).device_inflate_percent == 50  # (the library's readers keep their default)
