@@ -22,6 +22,14 @@ static int walk(const char* path, int threads, bool per_contig) {
     if (svx_bam_open(path, threads, &b, err, sizeof err) != 0 || !b) return 1;  // refused: fine
     static unsigned turn = 0;
     (void)svx_bam_set_verify(b, (int)(++turn & 1));  // whole members + CRC32 and inflate-what-is-needed in turn
+    // every third handle asks for a page-locked pool, its device copy and a device share of the sequence slices: there is
+    // no device here, so every HIP call fails — the walkers' early-pool claim, the lanes' bring-up threads and the
+    // fall-backs to pageable memory and to the host's decoder run under the sanitizers
+    if (turn % 3 == 0) {
+        (void)svx_bam_set_pinned_device(b, 0);
+        (void)svx_bam_set_device_inflate(b, 50);
+        (void)svx_bam_set_device_inflate_min(b, 0);
+    }
     const char* text = nullptr;
     uint64_t l_text = 0;
     int32_t n_ref = 0;
