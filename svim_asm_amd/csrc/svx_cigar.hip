@@ -64,7 +64,7 @@ constexpr int kWaves = SVX_WAVES;              // waves (= tiles) per workgroup
 constexpr int kXposeU4 = 64 * kLU;             // transpose buffer: kLU uint4 per lane, XOR-swizzled
 constexpr int kScanBlock = 1024;               // tile descriptors per scan workgroup
 
-enum { MODE_STAGE = 0, MODE_DIRECT = 1 };
+enum { MODE_STAGE = 0, MODE_DIRECT = 1, MODE_SP = 2 };
 
 struct CigarArgs {
     const uint32_t* cigar;  // packed words, or len[] in SoA mode
@@ -86,6 +86,15 @@ struct CigarArgs {
     uint32_t* n_dense;   // [0] dense-tile counter, [1] scan ticket (both left at 0 by the scan), [2] published count
     uint4* blk_agg;      // per scan block: {has_start, ref_tail, read_tail, count}
     uint4* blk_prefix;   // exclusive scan of blk_agg
+    // single-pass streaming path (k_tiles_sp): the scanner workgroup's per-tile exclusive prefix {output base, carry_ref,
+    // carry_read, epoch}; the word both it and the tile descriptors carry in .w once they are valid for THIS call
+    // (k_tile_alo zeroes both arrays first); the number of tile waves (= the stride of a wave's tiles)
+    uint4* pfx;
+    uint32_t epoch;
+    uint32_t sp_waves;
+    uint32_t sp_skip;    // workgroups whose index is a multiple of this leave at once (0: none): they would share the scanner's CU
+    uint4* sp_stat;      // per tile wave: {tiles placed by the wave itself, tiles left to the finish launch, HW_ID, XCC_ID}; behind them
+                         // the scanner's {steps, polls that found a descriptor missing, its run in 100 MHz ticks, 0} (svx_ctx_cigar_single_pass_stats)
     svx_sig_soa out;
     uint64_t cap;
 };
@@ -265,9 +274,6 @@ struct WalkOut {
     uint32_t tail_r, tail_d;  // cursor sums since the last alignment start inside the lane (or lane start)
     uint32_t n_emit;          // emitting ops of this lane
     uint32_t n_queued;        // wave-uniform: signatures queued this round (WALK_QUEUE)
-#ifdef SVX_EXP_OPSET
-    uint32_t opset;
-#endif
 };
 
 // Everything WALK_DIRECT needs to finish a signature on the spot.  The alignment index is carried along the
@@ -307,9 +313,6 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
 #ifdef SVX_EXP_NOWALK  // perf experiment only: memory + scan floor without the per-op work
     { const uint4 v = myx[swz]; WalkOut o; o.tot_r = v.x; o.tot_d = v.y; o.tail_r = v.z; o.tail_d = v.w; o.n_emit = 0; o.n_queued = 0; return o; }
 #endif
-#ifdef SVX_EXP_OPSET
-    uint32_t opset = 0;
-#endif
     uint4 nxt = myx[swz];
 #pragma unroll 1
     for (int j = 0; j < kLU; ++j) {
@@ -322,9 +325,6 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
             uint32_t op, len;
             if (SOA) { op = (opw[j] >> (t * 8)) & 0xFFu; len = wv[t]; }
             else { op = wv[t] & 15u; len = wv[t] >> 4; }
-#ifdef SVX_EXP_OPSET
-            if (WALK == WALK_QUEUE && !SOA) opset |= 1u << (wv[t] & 31u);
-#endif
             if (__builtin_expect(((hu4 >> t) & 1u) != 0u, 0)) {  // scalar test: some lane starts an alignment at this slot
                 asm volatile("" ::: "memory");  // keep this a real (rarely taken) branch, not two selects per op
                 if ((hm4 >> t) & 1u) {
@@ -364,10 +364,6 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
                         const uint32_t ref = rr - base_r + (hs ? 0u : dc.in_r);
                         const uint32_t rdp = rd - base_d + (hs ? 0u : dc.in_d);
                         const uint64_t slot = dc.out0 + n_emit;
-#ifdef SVX_EXP_DENSE_FIND  // ablation (profiles/README.md): round 3's per-signature search + ref_start gather
-                        aln_cur = find_aln(p.aln_off, p.n_aln, dc.a_lo, dc.g_lane0 + i);
-                        rs_cur = p.ref_start ? (uint32_t)p.ref_start[aln_cur] : 0u;
-#endif
                         if (slot < p.cap) {
                             p.out.aln[slot] = aln_cur;
                             p.out.ref_pos[slot] = ref + rs_cur;
@@ -399,9 +395,6 @@ __device__ __forceinline__ WalkOut walk16(const CigarArgs& p, const uint4* myx, 
     o.tail_d = rd - base_d;
     o.n_emit = n_emit;
     o.n_queued = qn;
-#ifdef SVX_EXP_OPSET
-    o.opset = opset;
-#endif
     return o;
 }
 
@@ -422,6 +415,61 @@ __device__ uint32_t g_prof[kProfTiles * 8];  // 5 phase sums (shader clocks), li
 #define SVX_PROF_ADD(i, d)
 #endif
 
+// ---- single-pass streaming path: what a tile wave keeps across its tiles.  The records of a finished tile stay in
+// the wave's LDS ring while the wave walks its NEXT tile (one tile time for the scanner workgroup to publish the
+// tile's exclusive prefix); then they go straight to the final SoA — or, if the prefix is not there yet, to the
+// tile's slab like on the five-launch path, for the finish launch to place.  Nobody but the scanner ever waits.
+#ifndef SVX_SP_RING
+#define SVX_SP_RING 96
+#endif
+constexpr uint32_t kRing = SVX_SP_RING;  // records per wave (64 .. kSlab): six workgroups per CU still fit (26 KiB each)
+static_assert(kRing >= (uint32_t)SVX_QUEUE && kRing <= (uint32_t)SVX_SLAB, "the ring takes a round's queue; a tile beyond the slab is dense anyway");
+constexpr uint32_t kNoTile = 0xFFFFFFFFu;
+struct SpWave {
+    uint32_t p_tile;  // the pending tile (kNoTile: none), its record count and the ring position of its first record
+    uint32_t p_cnt;
+    uint32_t p_lo;
+    uint32_t w_lo;    // ring position where the next tile's records start
+    uint32_t n_direct, n_left;  // tiles this wave placed itself / left to the finish launch
+};
+
+__device__ __forceinline__ u32x4 sp_load_pfx(const CigarArgs& p, const uint32_t tile) {
+    // sc0 sc1: served from memory, never from a line this XCD's L2 may still hold (the scanner stores write-through)
+    return __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.pfx, p.n_tiles * 16u), (int)(tile * 16u), 0, 17);
+}
+
+// The pending tile leaves the ring: to the final SoA when its prefix P is valid (and its descriptor is rewritten with
+// count 0: nothing left for the finish launch), to its slab otherwise.
+__device__ __forceinline__ void sp_retire(const CigarArgs& p, const int lane, const uint4* ring, SpWave& sp, const u32x4 P) {
+    const uint32_t t = sp.p_tile, n = sp.p_cnt, lo = sp.p_lo;
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)P.w) == p.epoch) {  // wave-uniform
+        const uint32_t ob = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.x), cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.y),
+                       cd = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.z);
+        for (uint32_t r = (uint32_t)lane; r < n; r += 64u) {
+            uint32_t pos = lo + r;
+            if (pos >= kRing) pos -= kRing;
+            const uint4 rec = ring[pos];
+            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+            store_final(p, (uint64_t)ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
+        }
+        if (lane == 0) {
+            u32x4 w; w.x = 0u; w.y = 0u; w.z = 0u; w.w = p.epoch;
+            __builtin_amdgcn_raw_buffer_store_b128(w, make_rsrc(p.desc, p.n_tiles * 16u), (int)(t * 16u), 0, 17);
+        }
+        ++sp.n_direct;
+    } else {
+        for (uint32_t r = (uint32_t)lane; r < n; r += 64u) {
+            uint32_t pos = lo + r;
+            if (pos >= kRing) pos -= kRing;
+            const uint4 v = ring[pos];
+            u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+            __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p.slab + (uint64_t)t * kSlab + r));
+        }
+        ++sp.n_left;
+    }
+    sp.p_tile = kNoTile;
+}
+
 // What a tile needs from outside.  MODE_STAGE: where a_lo (alignments that start before the tile)
 // comes from; MODE_DIRECT: a_lo, the carry-in and the output base, all known to the caller.
 enum { ALO_TABLE = 0, ALO_SEARCH = 1, ALO_GIVEN = 2 };
@@ -433,7 +481,8 @@ struct TileIn {
 // with tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
 template <int MODE, bool SOA, int TILE_OPS, int ALO>
 __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t tile, const int lane, uint4* xp,
-                                             uint32_t* hmask, uint4* queue, uint4* stage, const TileIn& in) {
+                                             uint32_t* hmask, uint4* queue, uint4* stage, const TileIn& in,
+                                             SpWave* sp = nullptr) {
     static_assert(TILE_OPS % kRoundOps == 0 && TILE_OPS <= kTileOps, "a tile is 1..kRounds whole rounds");
     uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
     const uint64_t g0 = (uint64_t)tile * TILE_OPS;
@@ -519,10 +568,24 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     // tile's slab in one contiguous burst — at the end of the tile for all but the densest ones.
     // Four small scattered 16-byte stores per round cost 10-15 % of the kernel (every one opens
     // another DRAM row in the middle of the read stream).
+    // MODE_SP: `stage` is the wave's ring of kRing records, which may still hold the previous tile's; this tile's
+    // records start at ring_lo.  A tile that outgrows the ring spills to its slab (and is then the finish launch's).
+    constexpr uint32_t kCap = MODE == MODE_SP ? kRing : (uint32_t)kStage;
     uint32_t stage_base = 0;
+    const uint32_t ring_lo = MODE == MODE_SP ? sp->w_lo : 0u;
+    bool spilled = false;
     auto drain = [&](uint32_t upto) {  // slab ranks [stage_base, upto) leave LDS
         const uint32_t n = upto - stage_base;
-        if ((uint32_t)lane < n && stage_base + (uint32_t)lane < (uint32_t)kSlab) {
+        if (MODE == MODE_SP) {
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64u)
+                if (stage_base + i < (uint32_t)kSlab) {
+                    uint32_t pos = ring_lo + i;
+                    if (pos >= kRing) pos -= kRing;
+                    const uint4 v = stage[pos];
+                    u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+                    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p.slab + (uint64_t)tile * kSlab + stage_base + i));
+                }
+        } else if ((uint32_t)lane < n && stage_base + (uint32_t)lane < (uint32_t)kSlab) {
             // streaming store: the slab is written once and read once by k_cigar_finish
             const uint4 v = stage[lane];
             u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
@@ -530,6 +593,9 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         }
         stage_base = upto;
     };
+    u32x4 sp_P;  // the pending tile's prefix, requested at the top of this tile's last round
+    sp_P.x = sp_P.y = sp_P.z = sp_P.w = 0u;
+    bool sp_P_valid = false;
     uint32_t obase = 0;
     if (MODE == MODE_DIRECT) {
         carry_r = in.carry_r;
@@ -538,12 +604,13 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         obase = in.obase;
     }
 
-#ifdef SVX_EXP_OPSET
-    uint32_t exp_keep = 0;
-#endif
     for (int round = 0; round < kRounds; ++round) {
         const uint32_t ro = (uint32_t)round * kRoundOps;
         if (ro >= tile_len) break;  // wave-uniform
+        if (MODE == MODE_SP && round == kRounds - 1 && sp->p_tile != kNoTile) {
+            sp_P = sp_load_pfx(p, sp->p_tile);  // in flight during the round's walk
+            sp_P_valid = true;
+        }
 
         SVX_PROF_T(t_r0);
         // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
@@ -586,17 +653,10 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         DirectCtx dc;
         dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
         dc.aln0 = 0; dc.rs0 = 0; dc.dup = dup;
-        constexpr int kWalk1 = (MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS;
+        constexpr int kWalk1 = (MODE == MODE_STAGE || MODE == MODE_SP) ? WALK_QUEUE : WALK_TOTALS;
         const WalkOut wo = (!SOA && fast24) ? walk16<kWalk1, SOA, !SOA, kQ>(p, myx, swz, opw, hm, HU, lane, queue, dc)
                                             : walk16<kWalk1, SOA, false, kQ>(p, myx, swz, opw, hm, HU, lane, queue, dc);
 
-#ifdef SVX_EXP_OPSET
-        if (MODE == MODE_STAGE) {
-            const uint64_t odd = __builtin_amdgcn_ballot_w64((wo.opset & 0x00380038u) != 0u);
-            if (lane == round) exp_keep = (uint32_t)odd;
-            if (lane == round + 4) exp_keep = (uint32_t)(odd >> 32);
-        }
-#endif
         SVX_PROF_T(t_r2);
         SVX_PROF_ADD(2, t_r2 - t_r1);  // walk
         // ---- wave scans (DPP).  Plain inclusive sums of the lane totals, signature counts and
@@ -625,9 +685,20 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         const uint32_t in_r = xr + (xf ? gq_r : carry_r);   // lane carry-in
         const uint32_t in_d = xd + (xf ? gq_d : carry_d);
 
-        if (MODE == MODE_STAGE) {
+        if (MODE == MODE_STAGE || MODE == MODE_SP) {
             if (C) {  // wave-uniform
-                if (tile_cnt + C - stage_base > (uint32_t)kStage) {  // no room for this round's records
+                if (MODE == MODE_SP) {
+                    const uint32_t need = tile_cnt - stage_base + C;  // this tile's records in the ring after the round
+                    if (sp->p_tile != kNoTile && sp->p_cnt + need > kRing) {  // the previous tile has to leave now
+                        sp_retire(p, lane, stage, *sp, sp_load_pfx(p, sp->p_tile));
+                        wave_lds_sync();
+                    }
+                    if (need > kRing) {  // more than a ring by itself: to the slab
+                        drain(tile_cnt);
+                        spilled = true;
+                        wave_lds_sync();
+                    }
+                } else if (tile_cnt + C - stage_base > (uint32_t)kStage) {  // no room for this round's records
                     drain(tile_cnt);
                     wave_lds_sync();
                 }
@@ -655,7 +726,13 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
                     uint32_t aln = a_lo + m - 1u;
                     if (dup) aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + round * kRoundOps + L * kLaneOps + slot);
                     const uint4 rec = make_uint4(aln, ref, rdp, len | (type << 28) | (prec << 29));
-                    if (rank - stage_base < (uint32_t)kStage) stage[rank - stage_base] = rec;
+                    if (MODE == MODE_SP) {
+                        if (rank - stage_base < kCap) {
+                            uint32_t pos = ring_lo + (rank - stage_base);
+                            if (pos >= kRing) pos -= kRing;
+                            stage[pos] = rec;
+                        }
+                    } else if (rank - stage_base < (uint32_t)kStage) stage[rank - stage_base] = rec;
                     else if (kQ > kStage && rank < (uint32_t)kSlab)  // the round's records past the stage buffer
                         p.slab[(uint64_t)tile * kSlab + rank] = rec;
                 }
@@ -710,10 +787,28 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     }
     const uint4 dsc = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31), carry_r, carry_d, a_lo);
     if (MODE == MODE_STAGE && lane == 0) p.desc[tile] = dsc;
-#ifdef SVX_EXP_OPSET
-    // (experiment: the four rounds' masks go to the tile's last two slab records)
-    if (MODE == MODE_STAGE && lane < 8) __builtin_nontemporal_store(exp_keep, reinterpret_cast<uint32_t*>(p.slab + (uint64_t)tile * kSlab + kSlab - 2) + lane);
-#endif
+    if (MODE == MODE_SP) {
+        const bool dense = tile_cnt > (uint32_t)kSlab || overflow;
+        if (spilled && !dense) {  // the rest of a tile that outgrew the ring
+            drain(tile_cnt - stage_base < kRing ? tile_cnt : stage_base + kRing);
+            ++sp->n_left;
+        }
+        if (lane == 0) {  // published write-through, the epoch in .w: the scanner workgroup polls for it
+            u32x4 w; w.x = dsc.x; w.y = dsc.y; w.z = dsc.z; w.w = p.epoch;
+            __builtin_amdgcn_raw_buffer_store_b128(w, make_rsrc(p.desc, p.n_tiles * 16u), (int)(tile * 16u), 0, 17);
+        }
+        if (sp->p_tile != kNoTile) {  // the previous tile: its prefix has had this tile's time to arrive
+            wave_lds_sync();
+            sp_retire(p, lane, stage, *sp, sp_P_valid ? sp_P : sp_load_pfx(p, sp->p_tile));
+        }
+        if (!spilled && !dense && tile_cnt) {  // this tile's records wait in the ring
+            sp->p_tile = tile;
+            sp->p_cnt = tile_cnt;
+            sp->p_lo = ring_lo;
+            const uint32_t w = ring_lo + tile_cnt;
+            sp->w_lo = w >= kRing ? w - kRing : w;
+        }
+    }
     return dsc;  // wave-uniform
 }
 
@@ -742,9 +837,17 @@ __device__ __forceinline__ void fold_group_desc(const CigarArgs& p, uint4* s_agg
 // first op in aln_off).  One thread per alignment: alignment a is the last one starting before
 // tile t exactly when aln_off[a] < t*kTileOps <= aln_off[a+1], so every tile t >= 1 has exactly one
 // writer and the streaming kernel's prologue needs no search (four dependent loads per tile). ----
+// (Single-pass path: the same threads clear the tile descriptors and the scanner's prefixes of the call — their .w
+// words are the hand-off flags of the next launch — write-through, like every later store to those lines.)
 __global__ __launch_bounds__(256) void k_tile_alo(const uint64_t* __restrict__ aln_off, uint32_t n_aln,
-                                                  uint32_t n_tiles, uint32_t* __restrict__ tile_alo) {
+                                                  uint32_t n_tiles, uint32_t* __restrict__ tile_alo,
+                                                  uint4* __restrict__ sp_desc, uint4* __restrict__ sp_pfx) {
     const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+    if (sp_desc && a < n_tiles) {
+        u32x4 z; z.x = z.y = z.z = z.w = 0u;
+        __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_desc, n_tiles * 16u), (int)(a * 16u), 0, 17);
+        __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_pfx, n_tiles * 16u), (int)(a * 16u), 0, 17);
+    }
     if (a >= n_aln) return;
     if (a == 0) tile_alo[0] = 0;
     const uint64_t lo = aln_off[a], hi = aln_off[a + 1];
@@ -776,6 +879,161 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
     for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves)
         (void)process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
                                                                   reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
+}
+
+// ---- single-pass streaming path: k_tiles_sp = the tile waves of A + the scan of B + (for most tiles) the placement
+// of C in ONE launch.  A persistent grid — as many workgroups as the device holds at once, the host asks the runtime —;
+// workgroup 0 is the SCANNER, every wave of the others walks the tiles w, w + W, w + 2W, ... (W tile waves: static
+// striding, so a tile's predecessors are being walked at the same time or have been).  A tile wave publishes its
+// descriptor {count | flags, ref_tail, read_tail, epoch} write-through, keeps the tile's records in its LDS ring and
+// walks its next tile; the scanner polls the descriptors in tile order (2048 per step, never across a generation of W
+// tiles), runs the segmented exclusive scan of k_desc_scan on them and publishes per tile {output base, carry_ref,
+// carry_read, epoch}, write-through as well, plus the list of dense tiles and the batch's signature count.  One tile
+// time later the wave looks at its previous tile's prefix ONCE: there → records straight from the ring to the final
+// SoA (no slab round trip, nothing for the finish launch); not there → to the slab, as on the five-launch path, and
+// the finish launch places them with the scanner's prefix.  The scanner is the only one that ever waits, and only for
+// waves that never wait: no residency or dispatch-order assumption is needed for correctness — a grid that does not
+// fit, a scanner that starts late only move tiles from the first kind to the second.
+constexpr int kSpPer = 8;                          // descriptors per scanner lane and step
+constexpr uint32_t kSpWaveStep = 64u * kSpPer;     // ... per scanner wave: 512 consecutive tiles, lane-interleaved (coalesced 1 KiB loads)
+constexpr uint32_t kSpStep = kWaves * kSpWaveStep; // 2048 tiles per step
+#ifndef SVX_SP_FINAL_POLLS
+#define SVX_SP_FINAL_POLLS 8
+#endif
+#ifndef SVX_SP_LOAD_AUX
+#define SVX_SP_LOAD_AUX 17
+#endif
+
+__device__ __forceinline__ void sp_scanner(const CigarArgs& p, uint64_t* __restrict__ n_out, uint32_t* s_u32) {
+    uint32_t* s_f = s_u32, *s_r = s_u32 + 4, *s_d = s_u32 + 8, *s_c = s_u32 + 12, *s_nd = s_u32 + 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(p.desc, p.n_tiles * 16u), rs_p = make_rsrc(p.pfx, p.n_tiles * 16u);
+    uint32_t run_r = 0, run_d = 0, run_c = 0, run_dense = 0;
+    uint32_t n_steps = 0, n_missed = 0;
+    uint32_t ph_poll = 0, ph_scan = 0, ph_store = 0;  // phase sums in 100 MHz ticks
+    const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_setprio(3);
+    for (uint32_t gen = 0; gen < p.n_tiles; gen += p.sp_waves) {
+        const uint32_t gen_end = gen + p.sp_waves < p.n_tiles ? gen + p.sp_waves : p.n_tiles;
+        for (uint32_t base = gen; base < gen_end; base += kSpStep) {
+            // this wave's 512 tiles of the step, item i of lane l = tile t0 + 64 i + l
+            const uint32_t t0 = base + (uint32_t)wave * kSpWaveStep + (uint32_t)lane;
+            uint4 d[kSpPer];
+            if (tid == 0) *s_nd = 0;
+            const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
+            for (;;) {  // until all of them carry the call's epoch
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < kSpPer; ++i) {
+                    d[i] = make_uint4(0, 0, 0, 0);
+                    if (t0 + 64u * i < gen_end) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)((t0 + 64u * i) * 16u), 0, SVX_SP_LOAD_AUX);
+                        d[i] = make_uint4(v.x, v.y, v.z, v.w);
+                        ok = ok && v.w == p.epoch;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;  // the wave stays together
+                ++n_missed;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            ++n_steps;
+            const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
+            ph_poll += (uint32_t)(t_b - t_a);
+            // segmented exclusive scan in tile order: eight wave scans, the fold of the items before carried along (scalars)
+            uint32_t ef = 0, er[kSpPer], ed[kSpPer], ec[kSpPer], dx[kSpPer];
+            uint32_t wf = 0, wr = 0, wd = 0, wc = 0;
+#pragma unroll
+            for (int i = 0; i < kSpPer; ++i) {
+                dx[i] = d[i].x;
+                uint32_t f = d[i].x >> 31, sr = d[i].y, sd = d[i].z, sc = d[i].x & 0x3FFFFFFFu;
+                SVX_SEG_SCAN()
+                const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
+                               xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
+                ef |= (xf | wf) << i;
+                er[i] = xf ? xr : wr + xr;
+                ed[i] = xf ? xd : wd + xd;
+                ec[i] = wc + xc;
+                const uint32_t F = __builtin_amdgcn_readlane(f, 63), R = __builtin_amdgcn_readlane(sr, 63),
+                               D = __builtin_amdgcn_readlane(sd, 63), Cn = __builtin_amdgcn_readlane(sc, 63);
+                if (F) { wf = 1; wr = R; wd = D; }
+                else { wr += R; wd += D; }
+                wc += Cn;
+            }
+            if (lane == 0) { s_f[wave] = wf; s_r[wave] = wr; s_d[wave] = wd; s_c[wave] = wc; }
+            __syncthreads();
+            uint32_t pr_ = 0, pd_ = 0, pc = 0, ar = run_r, ad = run_d, ac = run_c;
+            for (int w2 = 0; w2 < kWaves; ++w2) {
+                if (w2 == wave) { pr_ = ar; pd_ = ad; pc = ac; }
+                if (s_f[w2]) { ar = s_r[w2]; ad = s_d[w2]; }
+                else { ar += s_r[w2]; ad += s_d[w2]; }
+                ac += s_c[w2];
+            }
+            const uint64_t t_c = __builtin_amdgcn_s_memrealtime();
+            ph_scan += (uint32_t)(t_c - t_b);
+#pragma unroll
+            for (int i = 0; i < kSpPer; ++i) {
+                const uint32_t t = t0 + 64u * i;
+                if (t < gen_end) {
+                    const bool own = (ef >> i) & 1u;  // an alignment start among this wave's earlier tiles of the step
+                    u32x4 w; w.x = pc + ec[i]; w.y = own ? er[i] : pr_ + er[i]; w.z = own ? ed[i] : pd_ + ed[i]; w.w = p.epoch;
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rs_p, (int)(t * 16u), 0, 17);
+                    if ((dx[i] & 0x3FFFFFFFu) > (uint32_t)kSlab || (dx[i] & kDescForceDense)) p.dense_list[run_dense + atomicAdd(s_nd, 1u)] = t;
+                }
+            }
+#ifdef SVX_SP_EXP_STOREWAIT
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            __syncthreads();
+            run_r = ar; run_d = ad; run_c = ac;
+            run_dense += *s_nd;
+            __syncthreads();
+            ph_store += (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_c);
+        }
+    }
+    if (tid == 0) {
+        *n_out = (uint64_t)run_c;
+        p.n_dense[2] = run_dense;
+        p.sp_stat[p.sp_waves] = make_uint4(n_steps, n_missed, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin),
+                                          __builtin_amdgcn_s_getreg((31 << 11) | 4));
+        p.sp_stat[p.sp_waves + 1] = make_uint4(ph_poll, ph_scan, ph_store, 0);
+    }
+}
+
+template <bool SOA>
+__global__ __launch_bounds__(64 * kWaves, 6) void k_tiles_sp(CigarArgs p, uint64_t* __restrict__ n_out) {
+    __shared__ uint4 s_xpose[kWaves][kXposeU4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];  // start mask, then the queue
+    __shared__ uint4 s_ring[kWaves][kRing];
+    if (blockIdx.x == 0) {  // workgroup-uniform
+        sp_scanner(p, n_out, s_head[0]);
+        return;
+    }
+    // The scanner's CU stays otherwise empty (its polls and write-through stores then do not queue behind a CU's worth
+    // of streaming loads: 11 us per step of 2048 tiles beside five tile workgroups): workgroups b, b + n_cu, b + 2 n_cu,
+    // ... have been observed to share a CU (block b on XCD b % 8, CUs of an XCD in turn), so the multiples of
+    // p.sp_skip leave at once.  A device that places differently only has a slower scanner — see above.
+    if (p.sp_skip && blockIdx.x % p.sp_skip == 0) return;
+    const uint32_t wg = blockIdx.x - 1u - (p.sp_skip ? blockIdx.x / p.sp_skip : 0u);  // dense index of this tile workgroup
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    SpWave sp;
+    sp.p_tile = kNoTile; sp.p_cnt = 0; sp.p_lo = 0; sp.w_lo = 0; sp.n_direct = 0; sp.n_left = 0;
+    for (uint32_t tile = wg * kWaves + wave; tile < p.n_tiles; tile += p.sp_waves)
+        (void)process_tile<MODE_SP, SOA, kTileOps, ALO_TABLE>(p, tile, lane, s_xpose[wave], s_head[wave],
+                                                               reinterpret_cast<uint4*>(s_head[wave]), s_ring[wave], TileIn(), &sp);
+    if (sp.p_tile != kNoTile) {  // the wave's last tile: nothing left to walk meanwhile — a few polls, then the slab
+        u32x4 P = sp_load_pfx(p, sp.p_tile);
+        for (int i = 0; i < SVX_SP_FINAL_POLLS && (uint32_t)__builtin_amdgcn_readfirstlane((int)P.w) != p.epoch; ++i) {
+            __builtin_amdgcn_s_sleep(32);
+            P = sp_load_pfx(p, sp.p_tile);
+        }
+        wave_lds_sync();
+        sp_retire(p, lane, s_ring[wave], sp, P);
+    }
+    if (lane == 0 && wg * kWaves + (uint32_t)wave < p.sp_waves)
+        p.sp_stat[wg * kWaves + wave] = make_uint4(sp.n_direct, sp.n_left, __builtin_amdgcn_s_getreg((31 << 11) | 4),
+                                                                  __builtin_amdgcn_s_getreg((31 << 11) | 20));
 }
 
 // ---- B: segmented exclusive scan over tile descriptors ----
@@ -888,10 +1146,25 @@ constexpr int kFinLanes = 16;
 #define SVX_FINSPEC 3
 #endif
 constexpr int kFinSpec = SVX_FINSPEC;  // records per lane requested together with the descriptor (48 per tile)
+// Single-pass path (SP): only the tiles whose prefix had not arrived in time are left (their descriptors still carry a
+// count); the descriptor is looked at first, the records are requested behind it, the prefix is the scanner's.
+template <bool SP>
 __device__ __forceinline__ void cigar_finish_block(const CigarArgs& p, const uint32_t block) {
     const uint32_t tile = block * (256u / kFinLanes) + threadIdx.x / kFinLanes;
     const uint32_t l = threadIdx.x % kFinLanes;
     if (tile >= p.n_tiles) return;
+    if (SP) {
+        const uint4 dsc = p.desc[tile];
+        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
+        if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) return;
+        const uint4 P = p.pfx[tile];
+        for (uint32_t r = l; r < cnt; r += kFinLanes) {
+            const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
+            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+            store_final(p, (uint64_t)P.x + r, rec.x, rec.y + (prec ? P.y : 0u), rec.z + (prec ? P.z : 0u), len, type);
+        }
+        return;
+    }
     // speculative: slots past the tile's count hold stale bytes and are never used
     uint4 spec[kFinSpec];
 #pragma unroll
@@ -931,7 +1204,8 @@ __device__ __forceinline__ void cigar_finish_block(const CigarArgs& p, const uin
     }
 }
 
-__global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) { cigar_finish_block(p, blockIdx.x); }
+template <bool SP>
+__global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) { cigar_finish_block<SP>(p, blockIdx.x); }
 
 // ---- D: dense tiles (more than kSlab signatures, or a round that overflowed the queue: SV-dense stretches of
 // an assembly, satellite arrays, a tiny min_len) are re-walked with carry-in and output base known.  Always
@@ -1493,7 +1767,7 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
 
 // The dense-tile launch of the streaming path (dense_tile_wg above); with WITH_POST its first n_a3_blocks workgroups
 // run the post-passes of the split-segment chain instead — the launch is empty in the common case anyway.
-template <bool SOA, bool WITH_POST>
+template <bool SOA, bool WITH_POST, bool SP>
 __global__ __launch_bounds__(64 * kWaves) void k_cigar_dense(CigarArgs p, A3Args a3, uint32_t n_a3_blocks) {
     if (WITH_POST && blockIdx.x < n_a3_blocks) {  // workgroup-uniform
         a3_chain_block<A3_POST>(a3, blockIdx.x, nullptr);
@@ -1509,14 +1783,21 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_dense(CigarArgs p, A3Args
     const uint32_t first = WITH_POST ? n_a3_blocks : 0u;
     for (uint32_t work = blockIdx.x - first; work < n_dense; work += gridDim.x - first) {
         const uint32_t tile = p.dense_list[work];
-        const uint4 bp = p.blk_prefix[tile / kScanBlock];
-        const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
-        const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
         TileIn in;
         in.a_lo = p.tile_alo[tile];
-        in.carry_r = local_head ? lr : lr + bp.y;
-        in.carry_d = local_head ? ld : ld + bp.z;
-        in.obase = (lb & 0x7FFFFFFFu) + bp.w;
+        if (SP) {  // the scanner's prefix
+            const uint4 P = p.pfx[tile];
+            in.carry_r = P.y;
+            in.carry_d = P.z;
+            in.obase = P.x;
+        } else {
+            const uint4 bp = p.blk_prefix[tile / kScanBlock];
+            const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
+            const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
+            in.carry_r = local_head ? lr : lr + bp.y;
+            in.carry_d = local_head ? ld : ld + bp.z;
+            in.obase = (lb & 0x7FFFFFFFu) + bp.w;
+        }
         dense_tile_wg<SOA>(p, tile, wave, lane, s_xpose[wave], s_mask, &s_dup, s_round, in);
     }
 }
@@ -1708,8 +1989,7 @@ __global__ __launch_bounds__(256) void k_cigar_finish_small(CigarArgs p, uint64_
 // a1+a2 and a3 of a sample overlap without a second stream and its cross-stream events, and the register-hungry
 // post-pass code (float64 linkage) stays out of the kernel whose occupancy matters.
 template <bool SOA, int TILE_OPS, int ALO>
-__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks,
-                                                                              uint32_t a3_stride) {
+__global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks) {
     // a workgroup is either a chain workgroup or a tile workgroup: one LDS block, two layouts
     struct TileLds {
         uint4 xpose[kWaves][kXposeU4];
@@ -1719,26 +1999,12 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(Ci
     constexpr size_t kLdsBytes = sizeof(TileLds) > sizeof(A3Lds) ? sizeof(TileLds) : sizeof(A3Lds);
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLdsBytes];
     TileLds& tl = *reinterpret_cast<TileLds*>(s_raw);
-    // which workgroups carry the chain: the first n_a3_blocks (a3_stride == 0: small batches, the chain is the
-    // longer dependent sequence) or every a3_stride-th one (streaming path: the latency-bound chain spreads over
-    // the run of the bandwidth-bound tile workgroups)
-    uint32_t tile_block, a3_block;
-    bool is_a3;
-    if (a3_stride == 0) {
-        is_a3 = blockIdx.x < n_a3_blocks;
-        a3_block = blockIdx.x;
-        tile_block = blockIdx.x - n_a3_blocks;
-    } else {
-        const uint32_t q = blockIdx.x / a3_stride, rem = blockIdx.x % a3_stride;
-        is_a3 = rem == 0 && q < n_a3_blocks;
-        a3_block = q;
-        const uint32_t before = q + (rem ? 1u : 0u);  // chain workgroups in front of this one
-        tile_block = blockIdx.x - (before < n_a3_blocks ? before : n_a3_blocks);
-    }
-    if (is_a3) {  // workgroup-uniform
-        a3_chain_block<A3_ROWS_TREE>(a, a3_block, reinterpret_cast<A3Lds*>(s_raw));
+    // the first n_a3_blocks workgroups carry the chain: it is the longer dependent sequence
+    if (blockIdx.x < n_a3_blocks) {  // workgroup-uniform
+        a3_chain_block<A3_ROWS_TREE>(a, blockIdx.x, reinterpret_cast<A3Lds*>(s_raw));
         return;
     }
+    const uint32_t tile_block = blockIdx.x - n_a3_blocks;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t tile = tile_block * kWaves + wave;
@@ -1754,46 +2020,24 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(Ci
 
 // Streaming path: the chain's stage A rides inside the FINISH launch (the chain's workgroups first: they are the longer
 // dependent sequences), its stage B inside the dense-tile launch; the bandwidth-bound streaming launch stays pure.
-// (-DSVX_A3_IN_FINISH=0 puts stage A among the tile workgroups of the streaming launch instead, k_tiles_a3<4096>:
-// the chain workgroups then hold slots of the tile workgroups; interleaved A/B, n = 4: step 0.3936 vs 0.3877 ms,
-// profiles/r04_ab_chain_placement.txt.  Inside this launch the chain's workgroups first is the best order: dealt
-// out between the finishing workgroups 62 us instead of 54, behind them 63.)
+// (Measured and not kept, profiles/r04_ab_chain_placement.txt: stage A among the tile workgroups of the streaming launch
+// — the chain workgroups then hold slots of the tile workgroups, step 0.3936 vs 0.3877 ms —; the chain's workgroups
+// dealt out between the finishing ones, 62 us instead of 54, or behind them, 63.)
 #ifndef SVX_FIN_A3_WAVES
 #define SVX_FIN_A3_WAVES 8
 #endif
+template <bool SP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SVX_FIN_A3_WAVES, 8)))
-void k_finish_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks, uint32_t a3_stride) {
-    // every a3_stride-th workgroup carries the chain (both kinds are sequences of round trips: side by side from the
-    // first moment of the launch they hide each other's waits; a3_stride == 1: the chain's workgroups first)
-    uint32_t fin_block, a3_block;
-    bool is_a3;
-    if (a3_stride <= 1) {
-#ifdef SVX_FIN_A3_LAST
-        const uint32_t n_fin = gridDim.x - n_a3_blocks;
-        is_a3 = blockIdx.x >= n_fin;
-        a3_block = blockIdx.x - n_fin;
-        fin_block = blockIdx.x;
-#else
-        is_a3 = blockIdx.x < n_a3_blocks;
-        a3_block = blockIdx.x;
-        fin_block = blockIdx.x - n_a3_blocks;
-#endif
-    } else {
-        const uint32_t q = blockIdx.x / a3_stride, rem = blockIdx.x % a3_stride;
-        is_a3 = rem == 0 && q < n_a3_blocks;
-        a3_block = q;
-        const uint32_t before = q + (rem ? 1u : 0u);  // chain workgroups in front of this one
-        fin_block = blockIdx.x - (before < n_a3_blocks ? before : n_a3_blocks);
-    }
-    if (is_a3) {  // workgroup-uniform
+void k_finish_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks) {
+    if (blockIdx.x < n_a3_blocks) {  // workgroup-uniform
 #ifndef SVX_EXP_FIN_ONLY
         __shared__ A3Lds lds;
-        a3_chain_block<A3_ROWS_TREE>(a, a3_block, &lds);
+        a3_chain_block<A3_ROWS_TREE>(a, blockIdx.x, &lds);
 #endif
         return;
     }
 #ifndef SVX_EXP_A3_ONLY
-    cigar_finish_block(p, fin_block);
+    cigar_finish_block<SP>(p, blockIdx.x - n_a3_blocks);
 #endif
 }
 
@@ -1897,6 +2141,11 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t n_scan_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
     a.blk_agg = svx_ws_take<uint4>(ctx, n_scan_blocks);
     a.blk_prefix = svx_ws_take<uint4>(ctx, n_scan_blocks);
+    a.pfx = svx_ws_take<uint4>(ctx, n_tiles);
+    a.epoch = 0;
+    a.sp_waves = 0;
+    a.sp_skip = 0;
+    a.sp_stat = svx_ws_take<uint4>(ctx, (size_t)ctx->n_cu * 8u * kWaves + 2u);
     a.out = d_out;
     a.cap = cap;
     A3Args c;
@@ -1916,7 +2165,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
         const uint32_t tile_blocks = (n_tiles + kWaves - 1) / kWaves;
         if (a3)
             hipLaunchKernelGGL((k_tiles_a3<SOA, kSmallTileOps, ALO_SEARCH>), dim3(n_a3_blocks + tile_blocks), dim3(64 * kWaves), 0,
-                               ctx->stream, a, c, n_a3_blocks, 0u);
+                               ctx->stream, a, c, n_a3_blocks);
         else
             hipLaunchKernelGGL((k_cigar_tiles<SOA, kSmallTileOps, ALO_SEARCH>), dim3(tile_blocks), dim3(64 * kWaves), 0,
                                ctx->stream, a);
@@ -1944,23 +2193,63 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     }
     const uint32_t blocks_all = (n_tiles + kWaves - 1) / kWaves;
     const uint32_t blocks_cap = (uint32_t)ctx->n_cu * 8u;
+    const uint32_t finish_blocks = (n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes);
+    const uint32_t dense_blocks = n_tiles < blocks_cap ? n_tiles : blocks_cap;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
+    if (ctx->single_pass) {
+        // ---- single-pass path: k_tile_alo (+ the hand-off words cleared), k_tiles_sp (tiles + scan + placement), the
+        // finish launch for the tiles whose prefix came too late (+ the chain's stage A), the dense-tile launch (+ stage B)
+        if (!ctx->sp_wg_per_cu) {  // how many of its workgroups the device holds at once: asked once per context
+            int per_cu = 0;
+            SVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tiles_sp<SOA>, 64 * kWaves, 0));
+            // (the runtime's answer can be one too many where the SGPR count decides, MI355X_MICROARCH.md: a workgroup
+            //  that has to queue costs time here, never the result — see the comment above k_tiles_sp)
+            ctx->sp_wg_per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
+        }
+        // one workgroup is the scanner, the others that would land on its CU stay empty (k_tiles_sp)
+        uint32_t grid = (uint32_t)ctx->n_cu * (uint32_t)ctx->sp_wg_per_cu;
+        a.sp_skip = ctx->sp_wg_per_cu > 1 ? (uint32_t)ctx->n_cu : 0u;
+        uint32_t tile_wgs = grid - 1u - (a.sp_skip ? (grid - 1u) / a.sp_skip : 0u);
+        if (tile_wgs > blocks_all) {  // a batch of fewer tiles than the device holds
+            tile_wgs = blocks_all;
+            grid = tile_wgs + 1u;
+            grid += a.sp_skip ? (grid - 1u) / (a.sp_skip - 1u) : 0u;  // room for the ones that leave
+        }
+        a.sp_waves = tile_wgs * kWaves;
+        ctx->sp_last_waves = a.sp_waves;
+        ctx->sp_last_stat = a.sp_stat;
+        if (++ctx->sp_epoch == 0) ctx->sp_epoch = 1;
+        a.epoch = ctx->sp_epoch;
+        const uint32_t alo_threads = n_aln > n_tiles ? n_aln : n_tiles;
+        hipLaunchKernelGGL(k_tile_alo, dim3((alo_threads + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
+                           a.tile_alo, a.desc, a.pfx);
+        rc = svx_timing_mark(ctx, 1);
+        if (rc != SVX_OK) return rc;
+        hipLaunchKernelGGL((k_tiles_sp<SOA>), dim3(grid), dim3(64 * kWaves), 0, ctx->stream, a, d_n_out);
+        rc = svx_timing_mark(ctx, 2);
+        if (rc != SVX_OK) return rc;
+        if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)
+            if (!ctx->ev_dom) SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dom, hipEventDisableTiming));
+            SVX_HIP(ctx, hipEventRecord(ctx->ev_dom, ctx->stream));
+            ctx->ev_dom_recorded = true;
+        }
+        if (a3) {
+            hipLaunchKernelGGL(k_finish_a3<true>, dim3(n_a3_blocks + finish_blocks), dim3(256), 0, ctx->stream, a, c, n_a3_blocks);
+            hipLaunchKernelGGL((k_cigar_dense<SOA, true, true>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream,
+                               a, c, n_post_blocks);
+        } else {
+            hipLaunchKernelGGL(k_cigar_finish<true>, dim3(finish_blocks), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL((k_cigar_dense<SOA, false, true>), dim3(dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c, 0u);
+        }
+        SVX_HIP(ctx, hipGetLastError());
+        return svx_timing_end(ctx);
+    }
     hipLaunchKernelGGL(k_tile_alo, dim3((n_aln + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
-                       a.tile_alo);
+                       a.tile_alo, (uint4*)nullptr, (uint4*)nullptr);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-#ifndef SVX_A3_IN_FINISH
-#define SVX_A3_IN_FINISH 1  // 0: among the tile workgroups of the streaming launch (k_tiles_a3<4096>): 1.5 % slower per step
-#endif
-    if (a3 && !SVX_A3_IN_FINISH) {  // the chain's rows and decision tree ride inside the streaming launch, every stride-th workgroup
-        const uint32_t total = blocks_all + n_a3_blocks;
-        const uint32_t stride = total / n_a3_blocks ? total / n_a3_blocks : 1u;
-        hipLaunchKernelGGL((k_tiles_a3<SOA, kTileOps, ALO_TABLE>), dim3(total), dim3(64 * kWaves), 0, ctx->stream, a, c, n_a3_blocks,
-                           stride);
-    } else {
-        hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
-    }
+    hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)
@@ -1971,23 +2260,14 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     hipLaunchKernelGGL(k_desc_scan, dim3(n_scan_blocks), dim3(kScanBlock), 0, ctx->stream, a.desc, n_tiles,
                        a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
                        a.blk_prefix, a.n_dense + 1, d_n_out);
-    const uint32_t finish_blocks = (n_tiles + 256 / kFinLanes - 1) / (256 / kFinLanes);
-    if (a3 && SVX_A3_IN_FINISH)
-    {
-#ifndef SVX_FIN_A3_INTERLEAVE
-#define SVX_FIN_A3_INTERLEAVE 0
-#endif
-        const uint32_t stride = SVX_FIN_A3_INTERLEAVE && n_a3_blocks ? (n_a3_blocks + finish_blocks) / n_a3_blocks : 1u;
-        hipLaunchKernelGGL(k_finish_a3, dim3(n_a3_blocks + finish_blocks), dim3(256), 0, ctx->stream, a, c, n_a3_blocks, stride);
-    }
-    else
-        hipLaunchKernelGGL(k_cigar_finish, dim3(finish_blocks), dim3(256), 0, ctx->stream, a);
-    const uint32_t dense_blocks = n_tiles < blocks_cap ? n_tiles : blocks_cap;
-    if (a3)  // ... and its post-passes inside the dense-tile launch
-        hipLaunchKernelGGL((k_cigar_dense<SOA, true>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c,
+    if (a3) {  // the chain's rows and decision tree inside the finish launch, its post-passes inside the dense-tile launch
+        hipLaunchKernelGGL(k_finish_a3<false>, dim3(n_a3_blocks + finish_blocks), dim3(256), 0, ctx->stream, a, c, n_a3_blocks);
+        hipLaunchKernelGGL((k_cigar_dense<SOA, true, false>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c,
                            n_post_blocks);
-    else
-        hipLaunchKernelGGL((k_cigar_dense<SOA, false>), dim3(dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c, 0u);
+    } else {
+        hipLaunchKernelGGL(k_cigar_finish<false>, dim3(finish_blocks), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_cigar_dense<SOA, false, false>), dim3(dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c, 0u);
+    }
     SVX_HIP(ctx, hipGetLastError());
     return svx_timing_end(ctx);
 }
@@ -2068,6 +2348,32 @@ int cigar_extract_host_impl(svx_ctx* ctx, const uint32_t* cigar_or_len, const ui
 }
 
 }  // namespace
+
+extern "C" int svx_ctx_cigar_single_pass_stats(svx_ctx* ctx, uint32_t* out8) {
+    if (!ctx || !out8) return SVX_E_INVALID;
+    memset(out8, 0, 8 * sizeof(uint32_t));
+    out8[0] = (uint32_t)ctx->sp_wg_per_cu;
+    out8[1] = ctx->sp_last_waves;
+    if (!ctx->sp_last_stat || !ctx->sp_last_waves) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint4> h((size_t)ctx->sp_last_waves + 2);
+    SVX_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sp_last_stat, h.size() * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 2 < h.size(); ++i) { out8[2] += h[i].x; out8[3] += h[i].y; }
+    const uint4 sc = h[h.size() - 2], ph = h.back();
+    out8[4] = sc.x; out8[5] = sc.y; out8[6] = sc.z / 100u;  // s_memrealtime: 100 MHz
+    out8[7] = ph.x / 100u;  // of which waiting for descriptors
+    return SVX_OK;
+}
+
+// (tools only: the raw per-wave records of the latest single-pass launch, 4 words per tile wave + the scanner's)
+extern "C" int svx_debug_sp_raw(svx_ctx* ctx, uint32_t* out, uint32_t n_words) {
+    if (!ctx || !out || !ctx->sp_last_stat) return -1;
+    const size_t have = ((size_t)ctx->sp_last_waves + 2) * 4;
+    const size_t n = n_words < have ? n_words : have;
+    if (hipMemcpy(out, ctx->sp_last_stat, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
+}
 
 extern "C" int svx_cigar_extract_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint64_t n_ops,
                                      const uint64_t* d_aln_off, uint32_t n_aln,
@@ -2161,7 +2467,8 @@ size_t svx_cigar_extract_ws_need(const svx_ctx* ctx, uint64_t n_ops) {
     const bool small = n_ops <= (uint64_t)kSmallMaxTiles * kSmallTileOps && n_ops <= ctx->small_batch_ops;
     const uint32_t n_tiles = small ? (uint32_t)((n_ops + kSmallTileOps - 1) / kSmallTileOps)
                                    : (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
-    return svx_take_bytes(n_tiles, sizeof(uint4)) + svx_take_bytes((n_tiles + kWaves - 1) / kWaves, sizeof(uint4)) +
+    return 2 * svx_take_bytes(n_tiles, sizeof(uint4)) + svx_take_bytes((n_tiles + kWaves - 1) / kWaves, sizeof(uint4)) +
+           svx_take_bytes((size_t)ctx->n_cu * 8u * kWaves + 2u, sizeof(uint4)) +
            svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
            5 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
            2 * svx_take_bytes((n_tiles + kScanBlock - 1) / kScanBlock, sizeof(uint4));
