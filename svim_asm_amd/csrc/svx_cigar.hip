@@ -64,7 +64,7 @@ constexpr int kWaves = SVX_WAVES;              // waves (= tiles) per workgroup
 constexpr int kXposeU4 = 64 * kLU;             // transpose buffer: kLU uint4 per lane, XOR-swizzled
 constexpr int kScanBlock = 1024;               // tile descriptors per scan workgroup
 
-enum { MODE_STAGE = 0, MODE_DIRECT = 1, MODE_SP = 2 };
+enum { MODE_STAGE = 0, MODE_DIRECT = 1 };
 
 struct CigarArgs {
     const uint32_t* cigar;  // packed words, or len[] in SoA mode
@@ -86,9 +86,10 @@ struct CigarArgs {
     uint32_t* n_dense;   // [0] dense-tile counter, [1] scan ticket (both left at 0 by the scan), [2] published count
     uint4* blk_agg;      // per scan block: {has_start, ref_tail, read_tail, count}
     uint4* blk_prefix;   // exclusive scan of blk_agg
-    // single-pass streaming path (k_tiles_sp): the scanner workgroup's per-tile exclusive prefix {output base, carry_ref,
-    // carry_read, epoch}; the word both it and the tile descriptors carry in .w once they are valid for THIS call
-    // (k_tile_alo zeroes both arrays first); the number of tile waves (= the stride of a wave's tiles)
+    // single-pass streaming path (k_tiles_sp): the scanner workgroup's exclusive prefix per GROUP of four tiles {output
+    // base, carry_ref, carry_read, epoch}; the word it, the tile descriptors and the group descriptors (desc4) carry in
+    // .w once they are valid for THIS call (k_tile_alo zeroes the three arrays first); the number of tile waves (= the
+    // stride of a wave's tiles)
     uint4* pfx;
     uint32_t epoch;
     uint32_t sp_waves;
@@ -415,60 +416,11 @@ __device__ uint32_t g_prof[kProfTiles * 8];  // 5 phase sums (shader clocks), li
 #define SVX_PROF_ADD(i, d)
 #endif
 
-// ---- single-pass streaming path: what a tile wave keeps across its tiles.  The records of a finished tile stay in
-// the wave's LDS ring while the wave walks its NEXT tile (one tile time for the scanner workgroup to publish the
-// tile's exclusive prefix); then they go straight to the final SoA — or, if the prefix is not there yet, to the
-// tile's slab like on the five-launch path, for the finish launch to place.  Nobody but the scanner ever waits.
-#ifndef SVX_SP_RING
-#define SVX_SP_RING 96
-#endif
-constexpr uint32_t kRing = SVX_SP_RING;  // records per wave (64 .. kSlab): six workgroups per CU still fit (26 KiB each)
-static_assert(kRing >= (uint32_t)SVX_QUEUE && kRing <= (uint32_t)SVX_SLAB, "the ring takes a round's queue; a tile beyond the slab is dense anyway");
-constexpr uint32_t kNoTile = 0xFFFFFFFFu;
-struct SpWave {
-    uint32_t p_tile;  // the pending tile (kNoTile: none), its record count and the ring position of its first record
-    uint32_t p_cnt;
-    uint32_t p_lo;
-    uint32_t w_lo;    // ring position where the next tile's records start
-    uint32_t n_direct, n_left;  // tiles this wave placed itself / left to the finish launch
+// Called by process_tile at the top of a tile's last round (wave-uniform): the single-pass path requests the prefix of
+// the tile it will place behind this one there, so that the answer travels during the round's walk.
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
 };
-
-__device__ __forceinline__ u32x4 sp_load_pfx(const CigarArgs& p, const uint32_t tile) {
-    // sc0 sc1: served from memory, never from a line this XCD's L2 may still hold (the scanner stores write-through)
-    return __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.pfx, p.n_tiles * 16u), (int)(tile * 16u), 0, 17);
-}
-
-// The pending tile leaves the ring: to the final SoA when its prefix P is valid (and its descriptor is rewritten with
-// count 0: nothing left for the finish launch), to its slab otherwise.
-__device__ __forceinline__ void sp_retire(const CigarArgs& p, const int lane, const uint4* ring, SpWave& sp, const u32x4 P) {
-    const uint32_t t = sp.p_tile, n = sp.p_cnt, lo = sp.p_lo;
-    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)P.w) == p.epoch) {  // wave-uniform
-        const uint32_t ob = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.x), cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.y),
-                       cd = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.z);
-        for (uint32_t r = (uint32_t)lane; r < n; r += 64u) {
-            uint32_t pos = lo + r;
-            if (pos >= kRing) pos -= kRing;
-            const uint4 rec = ring[pos];
-            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
-            store_final(p, (uint64_t)ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
-        }
-        if (lane == 0) {
-            u32x4 w; w.x = 0u; w.y = 0u; w.z = 0u; w.w = p.epoch;
-            __builtin_amdgcn_raw_buffer_store_b128(w, make_rsrc(p.desc, p.n_tiles * 16u), (int)(t * 16u), 0, 17);
-        }
-        ++sp.n_direct;
-    } else {
-        for (uint32_t r = (uint32_t)lane; r < n; r += 64u) {
-            uint32_t pos = lo + r;
-            if (pos >= kRing) pos -= kRing;
-            const uint4 v = ring[pos];
-            u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-            __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p.slab + (uint64_t)t * kSlab + r));
-        }
-        ++sp.n_left;
-    }
-    sp.p_tile = kNoTile;
-}
 
 // What a tile needs from outside.  MODE_STAGE: where a_lo (alignments that start before the tile)
 // comes from; MODE_DIRECT: a_lo, the carry-in and the output base, all known to the caller.
@@ -479,10 +431,10 @@ struct TileIn {
 
 // One tile (TILE_OPS <= 4096 ops) processed by one wave.  MODE_STAGE: signatures go to the tile's slab
 // with tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
-template <int MODE, bool SOA, int TILE_OPS, int ALO>
+template <int MODE, bool SOA, int TILE_OPS, int ALO, class Hook = NoHook>
 __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t tile, const int lane, uint4* xp,
                                              uint32_t* hmask, uint4* queue, uint4* stage, const TileIn& in,
-                                             SpWave* sp = nullptr) {
+                                             const Hook& last_round_hook = Hook()) {
     static_assert(TILE_OPS % kRoundOps == 0 && TILE_OPS <= kTileOps, "a tile is 1..kRounds whole rounds");
     uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
     const uint64_t g0 = (uint64_t)tile * TILE_OPS;
@@ -568,24 +520,10 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     // tile's slab in one contiguous burst — at the end of the tile for all but the densest ones.
     // Four small scattered 16-byte stores per round cost 10-15 % of the kernel (every one opens
     // another DRAM row in the middle of the read stream).
-    // MODE_SP: `stage` is the wave's ring of kRing records, which may still hold the previous tile's; this tile's
-    // records start at ring_lo.  A tile that outgrows the ring spills to its slab (and is then the finish launch's).
-    constexpr uint32_t kCap = MODE == MODE_SP ? kRing : (uint32_t)kStage;
     uint32_t stage_base = 0;
-    const uint32_t ring_lo = MODE == MODE_SP ? sp->w_lo : 0u;
-    bool spilled = false;
     auto drain = [&](uint32_t upto) {  // slab ranks [stage_base, upto) leave LDS
         const uint32_t n = upto - stage_base;
-        if (MODE == MODE_SP) {
-            for (uint32_t i = (uint32_t)lane; i < n; i += 64u)
-                if (stage_base + i < (uint32_t)kSlab) {
-                    uint32_t pos = ring_lo + i;
-                    if (pos >= kRing) pos -= kRing;
-                    const uint4 v = stage[pos];
-                    u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-                    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p.slab + (uint64_t)tile * kSlab + stage_base + i));
-                }
-        } else if ((uint32_t)lane < n && stage_base + (uint32_t)lane < (uint32_t)kSlab) {
+        if ((uint32_t)lane < n && stage_base + (uint32_t)lane < (uint32_t)kSlab) {
             // streaming store: the slab is written once and read once by k_cigar_finish
             const uint4 v = stage[lane];
             u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
@@ -593,9 +531,6 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         }
         stage_base = upto;
     };
-    u32x4 sp_P;  // the pending tile's prefix, requested at the top of this tile's last round
-    sp_P.x = sp_P.y = sp_P.z = sp_P.w = 0u;
-    bool sp_P_valid = false;
     uint32_t obase = 0;
     if (MODE == MODE_DIRECT) {
         carry_r = in.carry_r;
@@ -607,10 +542,7 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     for (int round = 0; round < kRounds; ++round) {
         const uint32_t ro = (uint32_t)round * kRoundOps;
         if (ro >= tile_len) break;  // wave-uniform
-        if (MODE == MODE_SP && round == kRounds - 1 && sp->p_tile != kNoTile) {
-            sp_P = sp_load_pfx(p, sp->p_tile);  // in flight during the round's walk
-            sp_P_valid = true;
-        }
+        if (round == kRounds - 1) last_round_hook();
 
         SVX_PROF_T(t_r0);
         // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
@@ -653,7 +585,7 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         DirectCtx dc;
         dc.in_r = 0; dc.in_d = 0; dc.out0 = 0; dc.a_lo = a_lo; dc.g_lane0 = g0 + lbase;
         dc.aln0 = 0; dc.rs0 = 0; dc.dup = dup;
-        constexpr int kWalk1 = (MODE == MODE_STAGE || MODE == MODE_SP) ? WALK_QUEUE : WALK_TOTALS;
+        constexpr int kWalk1 = (MODE == MODE_STAGE) ? WALK_QUEUE : WALK_TOTALS;
         const WalkOut wo = (!SOA && fast24) ? walk16<kWalk1, SOA, !SOA, kQ>(p, myx, swz, opw, hm, HU, lane, queue, dc)
                                             : walk16<kWalk1, SOA, false, kQ>(p, myx, swz, opw, hm, HU, lane, queue, dc);
 
@@ -685,20 +617,9 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
         const uint32_t in_r = xr + (xf ? gq_r : carry_r);   // lane carry-in
         const uint32_t in_d = xd + (xf ? gq_d : carry_d);
 
-        if (MODE == MODE_STAGE || MODE == MODE_SP) {
+        if (MODE == MODE_STAGE) {
             if (C) {  // wave-uniform
-                if (MODE == MODE_SP) {
-                    const uint32_t need = tile_cnt - stage_base + C;  // this tile's records in the ring after the round
-                    if (sp->p_tile != kNoTile && sp->p_cnt + need > kRing) {  // the previous tile has to leave now
-                        sp_retire(p, lane, stage, *sp, sp_load_pfx(p, sp->p_tile));
-                        wave_lds_sync();
-                    }
-                    if (need > kRing) {  // more than a ring by itself: to the slab
-                        drain(tile_cnt);
-                        spilled = true;
-                        wave_lds_sync();
-                    }
-                } else if (tile_cnt + C - stage_base > (uint32_t)kStage) {  // no room for this round's records
+                if (tile_cnt + C - stage_base > (uint32_t)kStage) {  // no room for this round's records
                     drain(tile_cnt);
                     wave_lds_sync();
                 }
@@ -726,13 +647,7 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
                     uint32_t aln = a_lo + m - 1u;
                     if (dup) aln = find_aln(p.aln_off, p.n_aln, a_lo, g0 + round * kRoundOps + L * kLaneOps + slot);
                     const uint4 rec = make_uint4(aln, ref, rdp, len | (type << 28) | (prec << 29));
-                    if (MODE == MODE_SP) {
-                        if (rank - stage_base < kCap) {
-                            uint32_t pos = ring_lo + (rank - stage_base);
-                            if (pos >= kRing) pos -= kRing;
-                            stage[pos] = rec;
-                        }
-                    } else if (rank - stage_base < (uint32_t)kStage) stage[rank - stage_base] = rec;
+                    if (rank - stage_base < (uint32_t)kStage) stage[rank - stage_base] = rec;
                     else if (kQ > kStage && rank < (uint32_t)kSlab)  // the round's records past the stage buffer
                         p.slab[(uint64_t)tile * kSlab + rank] = rec;
                 }
@@ -787,28 +702,6 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     }
     const uint4 dsc = make_uint4(tile_cnt | (overflow ? kDescForceDense : 0u) | ((seen ? 1u : 0u) << 31), carry_r, carry_d, a_lo);
     if (MODE == MODE_STAGE && lane == 0) p.desc[tile] = dsc;
-    if (MODE == MODE_SP) {
-        const bool dense = tile_cnt > (uint32_t)kSlab || overflow;
-        if (spilled && !dense) {  // the rest of a tile that outgrew the ring
-            drain(tile_cnt - stage_base < kRing ? tile_cnt : stage_base + kRing);
-            ++sp->n_left;
-        }
-        if (lane == 0) {  // published write-through, the epoch in .w: the scanner workgroup polls for it
-            u32x4 w; w.x = dsc.x; w.y = dsc.y; w.z = dsc.z; w.w = p.epoch;
-            __builtin_amdgcn_raw_buffer_store_b128(w, make_rsrc(p.desc, p.n_tiles * 16u), (int)(tile * 16u), 0, 17);
-        }
-        if (sp->p_tile != kNoTile) {  // the previous tile: its prefix has had this tile's time to arrive
-            wave_lds_sync();
-            sp_retire(p, lane, stage, *sp, sp_P_valid ? sp_P : sp_load_pfx(p, sp->p_tile));
-        }
-        if (!spilled && !dense && tile_cnt) {  // this tile's records wait in the ring
-            sp->p_tile = tile;
-            sp->p_cnt = tile_cnt;
-            sp->p_lo = ring_lo;
-            const uint32_t w = ring_lo + tile_cnt;
-            sp->w_lo = w >= kRing ? w - kRing : w;
-        }
-    }
     return dsc;  // wave-uniform
 }
 
@@ -841,12 +734,16 @@ __device__ __forceinline__ void fold_group_desc(const CigarArgs& p, uint4* s_agg
 // words are the hand-off flags of the next launch — write-through, like every later store to those lines.)
 __global__ __launch_bounds__(256) void k_tile_alo(const uint64_t* __restrict__ aln_off, uint32_t n_aln,
                                                   uint32_t n_tiles, uint32_t* __restrict__ tile_alo,
-                                                  uint4* __restrict__ sp_desc, uint4* __restrict__ sp_pfx) {
+                                                  uint4* __restrict__ sp_desc, uint4* __restrict__ sp_desc4, uint4* __restrict__ sp_pfx) {
     const uint32_t a = blockIdx.x * 256u + threadIdx.x;
     if (sp_desc && a < n_tiles) {
         u32x4 z; z.x = z.y = z.z = z.w = 0u;
+        const uint32_t n_groups = (n_tiles + kWaves - 1) / kWaves;
         __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_desc, n_tiles * 16u), (int)(a * 16u), 0, 17);
-        __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_pfx, n_tiles * 16u), (int)(a * 16u), 0, 17);
+        if (a < n_groups) {
+            __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_desc4, n_groups * 16u), (int)(a * 16u), 0, 17);
+            __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_pfx, n_groups * 16u), (int)(a * 16u), 0, 17);
+        }
     }
     if (a >= n_aln) return;
     if (a == 0) tile_alo[0] = 0;
@@ -876,6 +773,22 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
         fold_group_desc(p, s_agg, wave, lane, dsc, blockIdx.x);
         return;
     }
+#ifdef SVX_EXP_PERSIST_DYN  // timing experiment: persistent grid, groups of four tiles claimed from eight per-XCD counters
+    __shared__ uint32_t s_t;
+    const uint32_t q = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;
+    for (;;) {
+        if (threadIdx.x == 0) s_t = atomicAdd(p.n_dense + 16 + q, 1u) * 8u + q;
+        __syncthreads();
+        const uint32_t G = s_t;
+        __syncthreads();
+        if (G * kWaves >= p.n_tiles) break;
+        const uint32_t tile = G * kWaves + wave;
+        if (tile < p.n_tiles)
+            (void)process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
+                                                                  reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
+    }
+    return;
+#endif
     for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves)
         (void)process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
                                                                   reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
@@ -883,42 +796,59 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
 
 // ---- single-pass streaming path: k_tiles_sp = the tile waves of A + the scan of B + (for most tiles) the placement
 // of C in ONE launch.  A persistent grid — as many workgroups as the device holds at once, the host asks the runtime —;
-// workgroup 0 is the SCANNER, every wave of the others walks the tiles w, w + W, w + 2W, ... (W tile waves: static
-// striding, so a tile's predecessors are being walked at the same time or have been).  A tile wave publishes its
-// descriptor {count | flags, ref_tail, read_tail, epoch} write-through, keeps the tile's records in its LDS ring and
-// walks its next tile; the scanner polls the descriptors in tile order (2048 per step, never across a generation of W
-// tiles), runs the segmented exclusive scan of k_desc_scan on them and publishes per tile {output base, carry_ref,
-// carry_read, epoch}, write-through as well, plus the list of dense tiles and the batch's signature count.  One tile
-// time later the wave looks at its previous tile's prefix ONCE: there → records straight from the ring to the final
-// SoA (no slab round trip, nothing for the finish launch); not there → to the slab, as on the five-launch path, and
-// the finish launch places them with the scanner's prefix.  The scanner is the only one that ever waits, and only for
-// waves that never wait: no residency or dispatch-order assumption is needed for correctness — a grid that does not
-// fit, a scanner that starts late only move tiles from the first kind to the second.
-constexpr int kSpPer = 8;                          // descriptors per scanner lane and step
-constexpr uint32_t kSpWaveStep = 64u * kSpPer;     // ... per scanner wave: 512 consecutive tiles, lane-interleaved (coalesced 1 KiB loads)
-constexpr uint32_t kSpStep = kWaves * kSpWaveStep; // 2048 tiles per step
-#ifndef SVX_SP_FINAL_POLLS
-#define SVX_SP_FINAL_POLLS 8
-#endif
+// workgroup 0 is the SCANNER, workgroup w of the others walks the four tiles 4w .. 4w+3 (a GROUP) of every generation
+// of W tiles (static striding: a tile's predecessors are being walked at the same time or have been), a wave each.
+//   * A tile wave stages its records into the tile's slab exactly as on the five-launch path, publishes the tile's
+//     descriptor {count | flags, ref_tail, read_tail, epoch} write-through and arrives at its group's LDS counter; the
+//     last of the four folds the four descriptors into the GROUP descriptor (one segmented sum, as fold_group_desc
+//     does on the two-launch path) and publishes that, write-through as well.  Then the wave walks on.
+//   * The scanner polls the group descriptors in order — one generation per step, 1530 groups on MI355X —, runs the
+//     segmented exclusive scan of k_desc_scan on them and publishes per group {output base, carry_ref, carry_read,
+//     epoch}, write-through, plus the list of dense tiles and the batch's signature count.
+//   * TWO tiles later (≈ 30 us: a hand-off through HBM costs ≈ 4 us each way while 6 000 waves stream, the scanner's step
+//     another 4-8) the wave looks ONCE at the prefix of the tile's group and at the descriptors of the tiles in front
+//     of it inside the group: all there → it reads its own slab records back (its XCD's L2 has them), adds carry-in
+//     and ref_start and writes the final SoA at the output base, and marks the descriptor PLACED; not there → nothing:
+//     the finish launch places that tile from the slab with the scanner's prefix, as on the five-launch path.
+// The scanner is the only one that ever waits for data of another workgroup, and only for waves that never do (inside a
+// workgroup a wave waits for a group slot only if a sibling is four generations behind, and the slowest of four waits for
+// nobody): no residency or dispatch-order assumption is needed for correctness — a grid that does not fit, a scanner that
+// starts late only move tiles from the first kind to the second.
+constexpr int kSpPer = 6;                          // group descriptors per scanner lane and step: 1536 groups = 6144 tiles
+constexpr uint32_t kSpStep = 256u * kSpPer;
+constexpr uint32_t kDescPlaced = 1u << 29;         // tile descriptor flag (single-pass path): the tile wave has placed the records
+constexpr uint32_t kDescCntSp = 0x1FFFFFFFu;       // ... and the count below the flags
+constexpr uint32_t kNoTile = 0xFFFFFFFFu;
 #ifndef SVX_SP_LOAD_AUX
 #define SVX_SP_LOAD_AUX 17
 #endif
+
+__device__ __forceinline__ u32x4 sp_load16(const void* base, const uint32_t n, const uint32_t idx) {
+    // sc0 sc1: served from memory, never from a line this XCD's L2 may still hold (the other side stores write-through)
+    return __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, n * 16u), (int)(idx * 16u), 0, SVX_SP_LOAD_AUX);
+}
+__device__ __forceinline__ void sp_store16(void* base, const uint32_t n, const uint32_t idx, const uint32_t x, const uint32_t y,
+                                           const uint32_t z, const uint32_t w_) {
+    u32x4 w; w.x = x; w.y = y; w.z = z; w.w = w_;
+    __builtin_amdgcn_raw_buffer_store_b128(w, make_rsrc(base, n * 16u), (int)(idx * 16u), 0, 17);
+}
 
 __device__ __forceinline__ void sp_scanner(const CigarArgs& p, uint64_t* __restrict__ n_out, uint32_t* s_u32) {
     uint32_t* s_f = s_u32, *s_r = s_u32 + 4, *s_d = s_u32 + 8, *s_c = s_u32 + 12, *s_nd = s_u32 + 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(p.desc, p.n_tiles * 16u), rs_p = make_rsrc(p.pfx, p.n_tiles * 16u);
+    const uint32_t n_groups = (p.n_tiles + kWaves - 1) / kWaves, per_gen = p.sp_waves / kWaves;
     uint32_t run_r = 0, run_d = 0, run_c = 0, run_dense = 0;
     uint32_t n_steps = 0, n_missed = 0;
-    uint32_t ph_poll = 0, ph_scan = 0, ph_store = 0;  // phase sums in 100 MHz ticks
+    uint32_t ph_poll = 0, ph_scan = 0;  // phase sums in 100 MHz ticks
     const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_setprio(3);
-    for (uint32_t gen = 0; gen < p.n_tiles; gen += p.sp_waves) {
-        const uint32_t gen_end = gen + p.sp_waves < p.n_tiles ? gen + p.sp_waves : p.n_tiles;
+    for (uint32_t gen = 0; gen < n_groups; gen += per_gen) {
+        const uint32_t gen_end = gen + per_gen < n_groups ? gen + per_gen : n_groups;
         for (uint32_t base = gen; base < gen_end; base += kSpStep) {
-            // this wave's 512 tiles of the step, item i of lane l = tile t0 + 64 i + l
-            const uint32_t t0 = base + (uint32_t)wave * kSpWaveStep + (uint32_t)lane;
+            // this wave's 384 groups of the step, lane-interleaved (1 KiB per load and store instruction: a write-through
+            // 16-byte store is a fabric write of its own unless its neighbours complete the line — 17 us per step with six
+            // consecutive groups per lane): item i of lane l = group g0 + 64 i
+            const uint32_t g0 = base + (uint32_t)wave * (64u * kSpPer) + (uint32_t)lane;
             uint4 d[kSpPer];
             if (tid == 0) *s_nd = 0;
             const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
@@ -927,26 +857,26 @@ __device__ __forceinline__ void sp_scanner(const CigarArgs& p, uint64_t* __restr
 #pragma unroll
                 for (int i = 0; i < kSpPer; ++i) {
                     d[i] = make_uint4(0, 0, 0, 0);
-                    if (t0 + 64u * i < gen_end) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)((t0 + 64u * i) * 16u), 0, SVX_SP_LOAD_AUX);
+                    if (g0 + 64u * i < gen_end) {
+                        const u32x4 v = sp_load16(p.desc4, n_groups, g0 + 64u * i);
                         d[i] = make_uint4(v.x, v.y, v.z, v.w);
                         ok = ok && v.w == p.epoch;
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;  // the wave stays together
                 ++n_missed;
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(16);
             }
             ++n_steps;
             const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
             ph_poll += (uint32_t)(t_b - t_a);
-            // segmented exclusive scan in tile order: eight wave scans, the fold of the items before carried along (scalars)
-            uint32_t ef = 0, er[kSpPer], ed[kSpPer], ec[kSpPer], dx[kSpPer];
+            // segmented exclusive scan in group order: six wave scans, the fold of the items before carried along (scalars);
+            // group descriptor .x: count in the low 24 bits, the group's dense tiles in bits 24..27
+            uint32_t ef = 0, er[kSpPer], ed[kSpPer], ec[kSpPer];
             uint32_t wf = 0, wr = 0, wd = 0, wc = 0;
 #pragma unroll
             for (int i = 0; i < kSpPer; ++i) {
-                dx[i] = d[i].x;
-                uint32_t f = d[i].x >> 31, sr = d[i].y, sd = d[i].z, sc = d[i].x & 0x3FFFFFFFu;
+                uint32_t f = d[i].x >> 31, sr = d[i].y, sd = d[i].z, sc = d[i].x & 0xFFFFFFu;
                 SVX_SEG_SCAN()
                 const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
                                xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
@@ -969,26 +899,21 @@ __device__ __forceinline__ void sp_scanner(const CigarArgs& p, uint64_t* __restr
                 else { ar += s_r[w2]; ad += s_d[w2]; }
                 ac += s_c[w2];
             }
-            const uint64_t t_c = __builtin_amdgcn_s_memrealtime();
-            ph_scan += (uint32_t)(t_c - t_b);
 #pragma unroll
             for (int i = 0; i < kSpPer; ++i) {
-                const uint32_t t = t0 + 64u * i;
-                if (t < gen_end) {
-                    const bool own = (ef >> i) & 1u;  // an alignment start among this wave's earlier tiles of the step
-                    u32x4 w; w.x = pc + ec[i]; w.y = own ? er[i] : pr_ + er[i]; w.z = own ? ed[i] : pd_ + ed[i]; w.w = p.epoch;
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rs_p, (int)(t * 16u), 0, 17);
-                    if ((dx[i] & 0x3FFFFFFFu) > (uint32_t)kSlab || (dx[i] & kDescForceDense)) p.dense_list[run_dense + atomicAdd(s_nd, 1u)] = t;
+                const uint32_t G = g0 + 64u * i;
+                if (G < gen_end) {
+                    const bool own = (ef >> i) & 1u;  // an alignment start among this wave's earlier groups of the step
+                    sp_store16(p.pfx, n_groups, G, pc + ec[i], own ? er[i] : pr_ + er[i], own ? ed[i] : pd_ + ed[i], p.epoch);
+                    for (uint32_t m = (d[i].x >> 24) & 0xFu; m; m &= m - 1u)  // the group's dense tiles (rare)
+                        p.dense_list[run_dense + atomicAdd(s_nd, 1u)] = G * kWaves + ((uint32_t)__ffs((int)m) - 1u);
                 }
             }
-#ifdef SVX_SP_EXP_STOREWAIT
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             __syncthreads();
             run_r = ar; run_d = ad; run_c = ac;
             run_dense += *s_nd;
             __syncthreads();
-            ph_store += (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_c);
+            ph_scan += (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_b);
         }
     }
     if (tid == 0) {
@@ -996,44 +921,149 @@ __device__ __forceinline__ void sp_scanner(const CigarArgs& p, uint64_t* __restr
         p.n_dense[2] = run_dense;
         p.sp_stat[p.sp_waves] = make_uint4(n_steps, n_missed, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin),
                                           __builtin_amdgcn_s_getreg((31 << 11) | 4));
-        p.sp_stat[p.sp_waves + 1] = make_uint4(ph_poll, ph_scan, ph_store, 0);
+        p.sp_stat[p.sp_waves + 1] = make_uint4(ph_poll, ph_scan, (uint32_t)t_begin, (uint32_t)__builtin_amdgcn_s_memrealtime());
     }
 }
+
+// prefix of tile 4G + k from its group's prefix P and the descriptors md[j] of the tiles j < k of the group (lane j of
+// `md` holds tile 4G + j's); false if one of them does not carry the epoch yet
+__device__ __forceinline__ bool sp_tile_prefix(const CigarArgs& p, const u32x4 P, const u32x4 md, const uint32_t k, uint32_t* ob,
+                                               uint32_t* cr, uint32_t* cd) {
+    bool ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.w) == p.epoch;
+    uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.x), r = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.y),
+             d = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.z);
+#pragma unroll
+    for (int j = 0; j < kWaves - 1; ++j) {
+        const uint32_t vx = __builtin_amdgcn_readlane(md.x, j), vy = __builtin_amdgcn_readlane(md.y, j),
+                       vz = __builtin_amdgcn_readlane(md.z, j), vw = __builtin_amdgcn_readlane(md.w, j);
+        if ((uint32_t)j < k) {
+            ok = ok && vw == p.epoch;
+            if (vx >> 31) { r = vy; d = vz; }
+            else { r += vy; d += vz; }
+            o += vx & kDescCntSp;
+        }
+    }
+    *ob = o; *cr = r; *cd = d;
+    return ok;
+}
+
+struct SpPrefetch {  // what the hook requests at the top of a tile's last round
+    u32x4 P, md;
+    bool valid;
+};
 
 template <bool SOA>
 __global__ __launch_bounds__(64 * kWaves, 6) void k_tiles_sp(CigarArgs p, uint64_t* __restrict__ n_out) {
     __shared__ uint4 s_xpose[kWaves][kXposeU4];
     __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];  // start mask, then the queue
-    __shared__ uint4 s_ring[kWaves][kRing];
+    __shared__ uint4 s_stage[kWaves][kStage];
+    __shared__ uint4 s_gd[4][kWaves];      // group slots (generation & 3): the four tile descriptors ...
+    __shared__ uint32_t s_gstate[4];       // ... and generation << 3 | arrivals
     if (blockIdx.x == 0) {  // workgroup-uniform
         sp_scanner(p, n_out, s_head[0]);
         return;
     }
     // The scanner's CU stays otherwise empty (its polls and write-through stores then do not queue behind a CU's worth
-    // of streaming loads: 11 us per step of 2048 tiles beside five tile workgroups): workgroups b, b + n_cu, b + 2 n_cu,
-    // ... have been observed to share a CU (block b on XCD b % 8, CUs of an XCD in turn), so the multiples of
-    // p.sp_skip leave at once.  A device that places differently only has a slower scanner — see above.
+    // of streaming loads): workgroups b, b + n_cu, b + 2 n_cu, ... have been observed to share a CU (block b on XCD
+    // b % 8, the CUs of an XCD in turn), so the multiples of p.sp_skip leave at once.  A device that places differently
+    // only has a slower scanner — see above.
     if (p.sp_skip && blockIdx.x % p.sp_skip == 0) return;
     const uint32_t wg = blockIdx.x - 1u - (p.sp_skip ? blockIdx.x / p.sp_skip : 0u);  // dense index of this tile workgroup
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    SpWave sp;
-    sp.p_tile = kNoTile; sp.p_cnt = 0; sp.p_lo = 0; sp.w_lo = 0; sp.n_direct = 0; sp.n_left = 0;
-    for (uint32_t tile = wg * kWaves + wave; tile < p.n_tiles; tile += p.sp_waves)
-        (void)process_tile<MODE_SP, SOA, kTileOps, ALO_TABLE>(p, tile, lane, s_xpose[wave], s_head[wave],
-                                                               reinterpret_cast<uint4*>(s_head[wave]), s_ring[wave], TileIn(), &sp);
-    if (sp.p_tile != kNoTile) {  // the wave's last tile: nothing left to walk meanwhile — a few polls, then the slab
-        u32x4 P = sp_load_pfx(p, sp.p_tile);
-        for (int i = 0; i < SVX_SP_FINAL_POLLS && (uint32_t)__builtin_amdgcn_readfirstlane((int)P.w) != p.epoch; ++i) {
-            __builtin_amdgcn_s_sleep(32);
-            P = sp_load_pfx(p, sp.p_tile);
+    if (threadIdx.x < 4) s_gstate[threadIdx.x] = threadIdx.x << 3;
+    __syncthreads();
+    const uint32_t n_groups = (p.n_tiles + kWaves - 1) / kWaves;
+    const uint64_t t_wave_begin = __builtin_amdgcn_s_memrealtime();
+    // the tiles whose records wait in their slabs for this wave to place them: e0 the older
+    uint32_t e0_tile = kNoTile, e0_cnt = 0, e1_tile = kNoTile, e1_cnt = 0;
+    uint32_t n_direct = 0, n_left = 0;
+    SpPrefetch pf;
+    pf.valid = false;
+    auto place = [&](const uint32_t t, const uint32_t cnt, const u32x4 P, const u32x4 md) {
+        uint32_t ob, cr, cd;
+#ifdef SVX_SP_EXP_NOPLACE
+        ++n_left; return;
+#endif
+        if (!sp_tile_prefix(p, P, md, t & (kWaves - 1), &ob, &cr, &cd)) { ++n_left; return; }  // the finish launch's
+        for (uint32_t r = (uint32_t)lane; r < cnt; r += 64u) {
+            const uint4 rec = p.slab[(uint64_t)t * kSlab + r];  // this wave's own burst of two tiles ago
+            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
+            store_final(p, (uint64_t)ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
         }
-        wave_lds_sync();
-        sp_retire(p, lane, s_ring[wave], sp, P);
+        // marked PLACED for the finish launch; count, flag and tails stay: the tiles behind it in the group fold them into
+        // their prefix.  (Lane k of `md` holds this tile's own descriptor; were it not there, the finish launch would place
+        // the tile a second time — the same bytes.)
+        if ((uint32_t)lane == (t & (kWaves - 1)) && md.w == p.epoch) sp_store16(p.desc, p.n_tiles, t, md.x | kDescPlaced, md.y, md.z, p.epoch);
+        ++n_direct;
+    };
+    for (uint32_t g = 0;; ++g) {
+        const uint32_t first = g * p.sp_waves + wg * kWaves;  // the group's first tile
+        if (first >= p.n_tiles) break;  // workgroup-uniform
+        const uint32_t tile = first + (uint32_t)wave;
+        uint4 dsc = make_uint4(0, 0, 0, 0);
+        pf.valid = false;
+        if (tile < p.n_tiles) {
+            auto hook = [&]() {
+                if (e1_tile != kNoTile) {  // two tiles wait: the older one will be looked at behind this tile
+                    pf.P = sp_load16(p.pfx, n_groups, e0_tile / kWaves);
+                    pf.md = sp_load16(p.desc, p.n_tiles, (e0_tile & ~(uint32_t)(kWaves - 1)) + ((uint32_t)lane & (kWaves - 1)));
+                    pf.valid = true;
+                }
+            };
+            dsc = process_tile<MODE_STAGE, SOA, kTileOps, ALO_TABLE>(p, tile, lane, s_xpose[wave], s_head[wave],
+                                                                    reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn(), hook);
+        }
+        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
+        const bool dense = cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense);
+        // ---- publish: the tile's descriptor (write-through, the epoch in .w), then the arrival at the group's slot
+        const uint32_t slot = g & 3u;
+        uint32_t old = 0;
+        if (lane == 0) {
+            if (tile < p.n_tiles) sp_store16(p.desc, p.n_tiles, tile, dsc.x, dsc.y, dsc.z, p.epoch);
+            while ((__hip_atomic_load(&s_gstate[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 3) != g)
+                __builtin_amdgcn_s_sleep(1);  // (a sibling four generations behind has yet to fold this slot's last use)
+            s_gd[slot][wave] = make_uint4(dsc.x, dsc.y, dsc.z, dense ? 1u : 0u);
+            old = __hip_atomic_fetch_add(&s_gstate[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old & 7u) == (uint32_t)kWaves - 1u) {  // the last of the four: fold (fold_group_desc) and publish the group
+                uint32_t f = 0, r = 0, d = 0, c = 0, dm = 0;
+#pragma unroll
+                for (int k = 0; k < kWaves; ++k) {
+                    const uint4 v = s_gd[slot][k];
+                    if (v.x >> 31) { f = 1; r = v.y; d = v.z; }
+                    else { r += v.y; d += v.z; }
+                    c += v.x & 0x3FFFFFFFu;
+                    dm |= v.w << k;
+                }
+                sp_store16(p.desc4, n_groups, first / kWaves, c | (dm << 24) | (f << 31), r, d, p.epoch);
+                __hip_atomic_store(&s_gstate[slot], (g + 4u) << 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        // ---- place the older waiting tile (requested at the top of the last round), then queue this one
+        if (pf.valid) {
+            place(e0_tile, e0_cnt, pf.P, pf.md);
+            e0_tile = e1_tile; e0_cnt = e1_cnt;
+            e1_tile = kNoTile;
+        }
+        if (cnt && !dense) {
+            if (e0_tile == kNoTile) { e0_tile = tile; e0_cnt = cnt; }
+            else if (e1_tile == kNoTile) { e1_tile = tile; e1_cnt = cnt; }
+            else {  // (both taken and nothing requested: a tile of a single round) the oldest is the finish launch's
+                ++n_left;
+                e0_tile = e1_tile; e0_cnt = e1_cnt;
+                e1_tile = tile; e1_cnt = cnt;
+            }
+        }
     }
+    // the wave's last tiles: one look at the older one (it has had a tile's time), the rest is the finish launch's
+    if (e0_tile != kNoTile) {
+        const u32x4 P = sp_load16(p.pfx, n_groups, e0_tile / kWaves);
+        const u32x4 md = sp_load16(p.desc, p.n_tiles, (e0_tile & ~(uint32_t)(kWaves - 1)) + ((uint32_t)lane & (kWaves - 1)));
+        place(e0_tile, e0_cnt, P, md);
+    }
+    if (e1_tile != kNoTile) ++n_left;
     if (lane == 0 && wg * kWaves + (uint32_t)wave < p.sp_waves)
-        p.sp_stat[wg * kWaves + wave] = make_uint4(sp.n_direct, sp.n_left, __builtin_amdgcn_s_getreg((31 << 11) | 4),
-                                                                  __builtin_amdgcn_s_getreg((31 << 11) | 20));
+        p.sp_stat[wg * kWaves + wave] = make_uint4(n_direct, n_left, (uint32_t)t_wave_begin, (uint32_t)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---- B: segmented exclusive scan over tile descriptors ----
@@ -1146,8 +1176,24 @@ constexpr int kFinLanes = 16;
 #define SVX_FINSPEC 3
 #endif
 constexpr int kFinSpec = SVX_FINSPEC;  // records per lane requested together with the descriptor (48 per tile)
-// Single-pass path (SP): only the tiles whose prefix had not arrived in time are left (their descriptors still carry a
-// count); the descriptor is looked at first, the records are requested behind it, the prefix is the scanner's.
+// Single-pass path, behind the launch boundary: a tile's carry-in and output base from the scanner's prefix of its group
+// and the descriptors of the tiles in front of it inside the group.
+__device__ __forceinline__ TileIn sp_tile_in(const CigarArgs& p, const uint32_t tile) {
+    const uint4 P = p.pfx[tile / kWaves];
+    TileIn in;
+    in.a_lo = 0;
+    in.obase = P.x; in.carry_r = P.y; in.carry_d = P.z;
+    for (uint32_t t = tile & ~(uint32_t)(kWaves - 1); t < tile; ++t) {
+        const uint4 v = p.desc[t];
+        if (v.x >> 31) { in.carry_r = v.y; in.carry_d = v.z; }
+        else { in.carry_r += v.y; in.carry_d += v.z; }
+        in.obase += v.x & kDescCntSp;
+    }
+    return in;
+}
+
+// Single-pass path (SP): only the tiles the tile waves did not place themselves are left (no PLACED flag in the
+// descriptor); the descriptor is looked at first, the records are requested behind it.
 template <bool SP>
 __device__ __forceinline__ void cigar_finish_block(const CigarArgs& p, const uint32_t block) {
     const uint32_t tile = block * (256u / kFinLanes) + threadIdx.x / kFinLanes;
@@ -1155,13 +1201,13 @@ __device__ __forceinline__ void cigar_finish_block(const CigarArgs& p, const uin
     if (tile >= p.n_tiles) return;
     if (SP) {
         const uint4 dsc = p.desc[tile];
-        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
-        if (cnt == 0 || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) return;
-        const uint4 P = p.pfx[tile];
+        const uint32_t cnt = dsc.x & kDescCntSp;
+        if (cnt == 0 || (dsc.x & kDescPlaced) || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) return;
+        const TileIn in = sp_tile_in(p, tile);
         for (uint32_t r = l; r < cnt; r += kFinLanes) {
             const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
             const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
-            store_final(p, (uint64_t)P.x + r, rec.x, rec.y + (prec ? P.y : 0u), rec.z + (prec ? P.z : 0u), len, type);
+            store_final(p, (uint64_t)in.obase + r, rec.x, rec.y + (prec ? in.carry_r : 0u), rec.z + (prec ? in.carry_d : 0u), len, type);
         }
         return;
     }
@@ -1785,11 +1831,9 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_dense(CigarArgs p, A3Args
         const uint32_t tile = p.dense_list[work];
         TileIn in;
         in.a_lo = p.tile_alo[tile];
-        if (SP) {  // the scanner's prefix
-            const uint4 P = p.pfx[tile];
-            in.carry_r = P.y;
-            in.carry_d = P.z;
-            in.obase = P.x;
+        if (SP) {  // the scanner's prefix of the group + the tiles in front of this one inside the group
+            in = sp_tile_in(p, tile);
+            in.a_lo = p.tile_alo[tile];
         } else {
             const uint4 bp = p.blk_prefix[tile / kScanBlock];
             const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
@@ -2223,7 +2267,7 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
         a.epoch = ctx->sp_epoch;
         const uint32_t alo_threads = n_aln > n_tiles ? n_aln : n_tiles;
         hipLaunchKernelGGL(k_tile_alo, dim3((alo_threads + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
-                           a.tile_alo, a.desc, a.pfx);
+                           a.tile_alo, a.desc, a.desc4, a.pfx);
         rc = svx_timing_mark(ctx, 1);
         if (rc != SVX_OK) return rc;
         hipLaunchKernelGGL((k_tiles_sp<SOA>), dim3(grid), dim3(64 * kWaves), 0, ctx->stream, a, d_n_out);
@@ -2246,10 +2290,17 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
         return svx_timing_end(ctx);
     }
     hipLaunchKernelGGL(k_tile_alo, dim3((n_aln + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
-                       a.tile_alo, (uint4*)nullptr, (uint4*)nullptr);
+                       a.tile_alo, (uint4*)nullptr, (uint4*)nullptr, (uint4*)nullptr);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
+#ifdef SVX_EXP_PERSIST  // timing experiment: the five-launch tile kernel on a persistent grid (its loop strides by the grid)
+#ifdef SVX_EXP_PERSIST_DYN
+    SVX_HIP(ctx, hipMemsetAsync(a.n_dense + 16, 0, 32, ctx->stream));
+#endif
+    hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3((uint32_t)ctx->n_cu * SVX_EXP_PERSIST), dim3(64 * kWaves), 0, ctx->stream, a);
+#else
     hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
+#endif
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)

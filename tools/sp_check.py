@@ -77,17 +77,24 @@ def main():
     ctx.lib.svx_debug_sp_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     if ctx.lib.svx_debug_sp_raw(ctx.h, raw.ctypes.data, len(raw)) > 0:
         raw = raw.reshape(-1, 4)
-        stats["scanner_phase_us(poll,scan,store)"] = (raw[-1, :3] / 100.0).tolist()
-        raw = raw[:-1]
-        hw, xcc = raw[:-1:4, 2], raw[:-1:4, 3] & 15  # one per workgroup
-        # HW_ID (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
-        cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
-        shw = int(raw[-1, 3])
-        scu = ((shw >> 8) & 15) | (((shw >> 12) & 1) << 4) | (((shw >> 13) & 7) << 5)
-        stats["wg_xcc_first16"] = xcc[:16].tolist()
-        stats["distinct_cus"] = int(len(np.unique(cu)))
-        stats["wgs_on_scanner_cu(xcc0)"] = (np.nonzero(cu == scu)[0] + 1).tolist()
-        stats["per_cu_wgs_minmax"] = [int(np.bincount(np.unique(cu, return_inverse=True)[1]).min()), int(np.bincount(np.unique(cu, return_inverse=True)[1]).max())]
+        stats["scanner_phase_us(poll,rest)"] = (raw[-1, :2] / 100.0).tolist()
+        t0 = int(raw[-1, 2])
+        w = raw[:-2]
+        beg = ((w[:, 2].astype(np.int64) - t0) & 0xFFFFFFFF) / 100.0
+        end = ((w[:, 3].astype(np.int64) - t0) & 0xFFFFFFFF) / 100.0
+        beg = np.where(beg > 1e6, beg - 2**32 / 100.0, beg)
+        stats["scanner_end_us"] = ((int(raw[-1, 3]) - t0) & 0xFFFFFFFF) / 100.0
+        stats["tile_wave_begin_us(min,med,max)"] = [float(beg.min()), float(np.median(beg)), float(beg.max())]
+        stats["tile_wave_end_us(min,med,max)"] = [float(end.min()), float(np.median(end)), float(end.max())]
+        # by XCD (workgroup b runs on XCD b % 8; dense index wg -> b = wg + 1 + skipped) and by the order of dispatch
+        nw = len(end) // 4
+        wg = np.arange(nw)
+        b = wg + 1 + wg // 255
+        e_wg = end.reshape(-1, 4).max(axis=1)
+        stats["wg_end_by_xcd_med"] = [round(float(np.median(e_wg[b % 8 == x])), 1) for x in range(8)]
+        stats["wg_end_by_layer_med"] = [round(float(np.median(e_wg[b // 256 == l])), 1) for l in range(6)]
+        stats["wave_end_by_wave_in_wg_med"] = [round(float(np.median(end.reshape(-1, 4)[:, k])), 1) for k in range(4)]
+        stats["wg_end_percentiles(5,25,50,75,95)"] = [round(float(x), 1) for x in np.percentile(e_wg, [5, 25, 50, 75, 95])]
     # interleaved timing
     t = {True: [], False: []}
     ctx.set_timing(True)
