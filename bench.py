@@ -64,8 +64,6 @@ def parse():
                     "first collective) before a rank gives up with exit status 3")
     ap.add_argument("--settle-ms", type=float, default=300.0, help="host idle time in front of the warm-up steps (lets the "
                     "cgroup's CPU quota period roll over: see the comment at the timed region); 0 = none")
-    ap.add_argument("--five-launch", action="store_true", help="A/B: the streaming CIGAR path in its five-launch form "
-                    "(svx_ctx_set_cigar_single_pass(0)) instead of the single-pass default")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip latency_case / roofline_pair / roofline_editdist (N=1) and e2e / e2e_sharded (any N) — "
                          "rank 0 only, all outside the timed region of `value`")
@@ -794,8 +792,6 @@ def main():
     # one context, kernels of consecutive steps run back to back.
     ctxs = [_lib.Context(local_rank), _lib.Context(local_rank)] if args.pipeline else [_lib.Context(local_rank)]
     ctx = ctxs[0]
-    for c_ in ctxs:
-        c_.set_cigar_single_pass(not args.five_launch)
     cig_np = batch["cigar"]
     cap = max(1024, n_ops // 16)
     import ctypes as C

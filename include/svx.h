@@ -68,18 +68,6 @@ int svx_device_count(void);
  * streaming path (tiles of 4096 ops, five launches).  Default and upper limit 2^23 ops; 0 disables the
  * small-batch path; larger values are clamped to 2^23.  Results are identical on both. */
 int svx_ctx_set_small_batch_ops(svx_ctx* ctx, uint64_t max_ops);
-/* The streaming path of svx_cigar_extract* (batches beyond the small-batch limit above) runs single-pass by default:
- * ONE launch walks the tiles, scans their descriptors (a scanner workgroup inside the same launch) and writes the
- * signatures of every tile whose output base arrives within a tile time straight to the final arrays; the finish
- * launch only places the rest.  The tile waves never wait for anything, so the launch depends on no residency or
- * dispatch order.  on == 0 restores the five-launch form (tiles -> slabs, scan kernel, finish kernel): same results,
- * kept for comparison.  Replaces the running sums of analyze_cigar_indel (SVIM_intra.py:10-29) across tiles. */
-int svx_ctx_set_cigar_single_pass(svx_ctx* ctx, int on);
-/* Diagnostics of the latest single-pass launch on the context (synchronises the stream; valid until the context's
- * next call): out8 = {workgroups of the launch a CU holds at once (the runtime's answer), tile waves of the launch,
- * tiles (with signatures) the tile waves placed themselves, tiles they left to the finish launch, steps of the scanner
- * workgroup, polls of it that found a descriptor not yet published, its run time in microseconds, 0}. */
-int svx_ctx_cigar_single_pass_stats(svx_ctx* ctx, uint32_t* out8);
 /* svx_collect_batch* send the split-segment chain of a submission (segment rows -> decision tree -> post-passes,
  * SVIM_inter.py:62-340) out INSIDE the launches of the CIGAR path: rows and decision tree among the workgroups of the
  * tile launch (two-launch path) or of the finish launch (streaming path), the post-passes among the workgroups of

@@ -127,8 +127,6 @@ SYMBOLS = {
     "svx_bgzf_inflate_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "svx_hbm_read_probe_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
     "svx_ctx_set_split_chain": (C.c_int, [_P, C.c_int]),
-    "svx_ctx_set_cigar_single_pass": (C.c_int, [_P, C.c_int]),
-    "svx_ctx_cigar_single_pass_stats": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "svx_ctx_set_pair_single_launch_max": (C.c_int, [_P, C.c_uint32]),
     "svx_ctx_barrier_timed_out": (C.c_int, [_P]),
     "svx_ctx_set_edit_wavefront_cap": (C.c_int, [_P, C.c_uint32]),
@@ -272,17 +270,6 @@ class Context:
     def set_small_batch_ops(self, max_ops):
         """Largest batch (CIGAR ops) of the small-batch (two-launch) path; 0 forces the streaming path."""
         self._check(self.lib.svx_ctx_set_small_batch_ops(self.h, int(max_ops)))
-
-    def set_cigar_single_pass(self, on=True):
-        """The streaming CIGAR path as one tile + scan + placement launch (default) or in its five-launch form."""
-        self._check(self.lib.svx_ctx_set_cigar_single_pass(self.h, 1 if on else 0))
-
-    def cigar_single_pass_stats(self):
-        """Latest single-pass launch: dict(wg_per_cu, tile_waves, tiles_placed_in_launch, tiles_left_to_finish, scanner_*)."""
-        out = (C.c_uint32 * 8)()
-        self._check(self.lib.svx_ctx_cigar_single_pass_stats(self.h, out))
-        return dict(wg_per_cu=out[0], tile_waves=out[1], tiles_placed_in_launch=out[2], tiles_left_to_finish=out[3],
-                    scanner_steps=out[4], scanner_missed_polls=out[5], scanner_us=out[6])
 
     def set_split_chain(self, on=True):
         """The split-segment chain of collect_batch as three single-purpose launches instead of one fused kernel."""

@@ -86,16 +86,6 @@ struct CigarArgs {
     uint32_t* n_dense;   // [0] dense-tile counter, [1] scan ticket (both left at 0 by the scan), [2] published count
     uint4* blk_agg;      // per scan block: {has_start, ref_tail, read_tail, count}
     uint4* blk_prefix;   // exclusive scan of blk_agg
-    // single-pass streaming path (k_tiles_sp): the scanner workgroup's exclusive prefix per GROUP of four tiles {output
-    // base, carry_ref, carry_read, epoch}; the word it, the tile descriptors and the group descriptors (desc4) carry in
-    // .w once they are valid for THIS call (k_tile_alo zeroes the three arrays first); the number of tile waves (= the
-    // stride of a wave's tiles)
-    uint4* pfx;
-    uint32_t epoch;
-    uint32_t sp_waves;
-    uint32_t sp_skip;    // workgroups whose index is a multiple of this leave at once (0: none): they would share the scanner's CU
-    uint4* sp_stat;      // per tile wave: {tiles placed by the wave itself, tiles left to the finish launch, HW_ID, XCC_ID}; behind them
-                         // the scanner's {steps, polls that found a descriptor missing, its run in 100 MHz ticks, 0} (svx_ctx_cigar_single_pass_stats)
     svx_sig_soa out;
     uint64_t cap;
 };
@@ -416,12 +406,6 @@ __device__ uint32_t g_prof[kProfTiles * 8];  // 5 phase sums (shader clocks), li
 #define SVX_PROF_ADD(i, d)
 #endif
 
-// Called by process_tile at the top of a tile's last round (wave-uniform): the single-pass path requests the prefix of
-// the tile it will place behind this one there, so that the answer travels during the round's walk.
-struct NoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-
 // What a tile needs from outside.  MODE_STAGE: where a_lo (alignments that start before the tile)
 // comes from; MODE_DIRECT: a_lo, the carry-in and the output base, all known to the caller.
 enum { ALO_TABLE = 0, ALO_SEARCH = 1, ALO_GIVEN = 2 };
@@ -431,10 +415,9 @@ struct TileIn {
 
 // One tile (TILE_OPS <= 4096 ops) processed by one wave.  MODE_STAGE: signatures go to the tile's slab
 // with tile-local cursors; MODE_DIRECT: carry-in and output base are known, signatures are final.
-template <int MODE, bool SOA, int TILE_OPS, int ALO, class Hook = NoHook>
+template <int MODE, bool SOA, int TILE_OPS, int ALO>
 __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t tile, const int lane, uint4* xp,
-                                             uint32_t* hmask, uint4* queue, uint4* stage, const TileIn& in,
-                                             const Hook& last_round_hook = Hook()) {
+                                             uint32_t* hmask, uint4* queue, uint4* stage, const TileIn& in) {
     static_assert(TILE_OPS % kRoundOps == 0 && TILE_OPS <= kTileOps, "a tile is 1..kRounds whole rounds");
     uint4* lcarry = xp;  // per-lane carry-ins reuse the transpose buffer once the walk has consumed it
     const uint64_t g0 = (uint64_t)tile * TILE_OPS;
@@ -542,7 +525,6 @@ __device__ __forceinline__ uint4 process_tile(const CigarArgs& p, const uint32_t
     for (int round = 0; round < kRounds; ++round) {
         const uint32_t ro = (uint32_t)round * kRoundOps;
         if (ro >= tile_len) break;  // wave-uniform
-        if (round == kRounds - 1) last_round_hook();
 
         SVX_PROF_T(t_r0);
         // ---- transpose through wave-private LDS.  uint4 #i (= lane's k-th load) belongs to lane
@@ -730,21 +712,9 @@ __device__ __forceinline__ void fold_group_desc(const CigarArgs& p, uint4* s_agg
 // first op in aln_off).  One thread per alignment: alignment a is the last one starting before
 // tile t exactly when aln_off[a] < t*kTileOps <= aln_off[a+1], so every tile t >= 1 has exactly one
 // writer and the streaming kernel's prologue needs no search (four dependent loads per tile). ----
-// (Single-pass path: the same threads clear the tile descriptors and the scanner's prefixes of the call — their .w
-// words are the hand-off flags of the next launch — write-through, like every later store to those lines.)
 __global__ __launch_bounds__(256) void k_tile_alo(const uint64_t* __restrict__ aln_off, uint32_t n_aln,
-                                                  uint32_t n_tiles, uint32_t* __restrict__ tile_alo,
-                                                  uint4* __restrict__ sp_desc, uint4* __restrict__ sp_desc4, uint4* __restrict__ sp_pfx) {
+                                                  uint32_t n_tiles, uint32_t* __restrict__ tile_alo) {
     const uint32_t a = blockIdx.x * 256u + threadIdx.x;
-    if (sp_desc && a < n_tiles) {
-        u32x4 z; z.x = z.y = z.z = z.w = 0u;
-        const uint32_t n_groups = (n_tiles + kWaves - 1) / kWaves;
-        __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_desc, n_tiles * 16u), (int)(a * 16u), 0, 17);
-        if (a < n_groups) {
-            __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_desc4, n_groups * 16u), (int)(a * 16u), 0, 17);
-            __builtin_amdgcn_raw_buffer_store_b128(z, make_rsrc(sp_pfx, n_groups * 16u), (int)(a * 16u), 0, 17);
-        }
-    }
     if (a >= n_aln) return;
     if (a == 0) tile_alo[0] = 0;
     const uint64_t lo = aln_off[a], hi = aln_off[a + 1];
@@ -773,297 +743,9 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_cigar_tiles
         fold_group_desc(p, s_agg, wave, lane, dsc, blockIdx.x);
         return;
     }
-#ifdef SVX_EXP_PERSIST_DYN  // timing experiment: persistent grid, groups of four tiles claimed from eight per-XCD counters
-    __shared__ uint32_t s_t;
-    const uint32_t q = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;
-    for (;;) {
-        if (threadIdx.x == 0) s_t = atomicAdd(p.n_dense + 16 + q, 1u) * 8u + q;
-        __syncthreads();
-        const uint32_t G = s_t;
-        __syncthreads();
-        if (G * kWaves >= p.n_tiles) break;
-        const uint32_t tile = G * kWaves + wave;
-        if (tile < p.n_tiles)
-            (void)process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
-                                                                  reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
-    }
-    return;
-#endif
     for (uint32_t tile = blockIdx.x * kWaves + wave; tile < p.n_tiles; tile += gridDim.x * kWaves)
         (void)process_tile<MODE_STAGE, SOA, TILE_OPS, ALO>(p, tile, lane, s_xpose[wave], s_head[wave],
                                                                   reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn());
-}
-
-// ---- single-pass streaming path: k_tiles_sp = the tile waves of A + the scan of B + (for most tiles) the placement
-// of C in ONE launch.  A persistent grid — as many workgroups as the device holds at once, the host asks the runtime —;
-// workgroup 0 is the SCANNER, workgroup w of the others walks the four tiles 4w .. 4w+3 (a GROUP) of every generation
-// of W tiles (static striding: a tile's predecessors are being walked at the same time or have been), a wave each.
-//   * A tile wave stages its records into the tile's slab exactly as on the five-launch path, publishes the tile's
-//     descriptor {count | flags, ref_tail, read_tail, epoch} write-through and arrives at its group's LDS counter; the
-//     last of the four folds the four descriptors into the GROUP descriptor (one segmented sum, as fold_group_desc
-//     does on the two-launch path) and publishes that, write-through as well.  Then the wave walks on.
-//   * The scanner polls the group descriptors in order — one generation per step, 1530 groups on MI355X —, runs the
-//     segmented exclusive scan of k_desc_scan on them and publishes per group {output base, carry_ref, carry_read,
-//     epoch}, write-through, plus the list of dense tiles and the batch's signature count.
-//   * TWO tiles later (≈ 30 us: a hand-off through HBM costs ≈ 4 us each way while 6 000 waves stream, the scanner's step
-//     another 4-8) the wave looks ONCE at the prefix of the tile's group and at the descriptors of the tiles in front
-//     of it inside the group: all there → it reads its own slab records back (its XCD's L2 has them), adds carry-in
-//     and ref_start and writes the final SoA at the output base, and marks the descriptor PLACED; not there → nothing:
-//     the finish launch places that tile from the slab with the scanner's prefix, as on the five-launch path.
-// The scanner is the only one that ever waits for data of another workgroup, and only for waves that never do (inside a
-// workgroup a wave waits for a group slot only if a sibling is four generations behind, and the slowest of four waits for
-// nobody): no residency or dispatch-order assumption is needed for correctness — a grid that does not fit, a scanner that
-// starts late only move tiles from the first kind to the second.
-constexpr int kSpPer = 6;                          // group descriptors per scanner lane and step: 1536 groups = 6144 tiles
-constexpr uint32_t kSpStep = 256u * kSpPer;
-constexpr uint32_t kDescPlaced = 1u << 29;         // tile descriptor flag (single-pass path): the tile wave has placed the records
-constexpr uint32_t kDescCntSp = 0x1FFFFFFFu;       // ... and the count below the flags
-constexpr uint32_t kNoTile = 0xFFFFFFFFu;
-#ifndef SVX_SP_LOAD_AUX
-#define SVX_SP_LOAD_AUX 17
-#endif
-
-__device__ __forceinline__ u32x4 sp_load16(const void* base, const uint32_t n, const uint32_t idx) {
-    // sc0 sc1: served from memory, never from a line this XCD's L2 may still hold (the other side stores write-through)
-    return __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base, n * 16u), (int)(idx * 16u), 0, SVX_SP_LOAD_AUX);
-}
-__device__ __forceinline__ void sp_store16(void* base, const uint32_t n, const uint32_t idx, const uint32_t x, const uint32_t y,
-                                           const uint32_t z, const uint32_t w_) {
-    u32x4 w; w.x = x; w.y = y; w.z = z; w.w = w_;
-    __builtin_amdgcn_raw_buffer_store_b128(w, make_rsrc(base, n * 16u), (int)(idx * 16u), 0, 17);
-}
-
-__device__ __forceinline__ void sp_scanner(const CigarArgs& p, uint64_t* __restrict__ n_out, uint32_t* s_u32) {
-    uint32_t* s_f = s_u32, *s_r = s_u32 + 4, *s_d = s_u32 + 8, *s_c = s_u32 + 12, *s_nd = s_u32 + 16;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t n_groups = (p.n_tiles + kWaves - 1) / kWaves, per_gen = p.sp_waves / kWaves;
-    uint32_t run_r = 0, run_d = 0, run_c = 0, run_dense = 0;
-    uint32_t n_steps = 0, n_missed = 0;
-    uint32_t ph_poll = 0, ph_scan = 0;  // phase sums in 100 MHz ticks
-    const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
-    for (uint32_t gen = 0; gen < n_groups; gen += per_gen) {
-        const uint32_t gen_end = gen + per_gen < n_groups ? gen + per_gen : n_groups;
-        for (uint32_t base = gen; base < gen_end; base += kSpStep) {
-            // this wave's 384 groups of the step, lane-interleaved (1 KiB per load and store instruction: a write-through
-            // 16-byte store is a fabric write of its own unless its neighbours complete the line — 17 us per step with six
-            // consecutive groups per lane): item i of lane l = group g0 + 64 i
-            const uint32_t g0 = base + (uint32_t)wave * (64u * kSpPer) + (uint32_t)lane;
-            uint4 d[kSpPer];
-            if (tid == 0) *s_nd = 0;
-            const uint64_t t_a = __builtin_amdgcn_s_memrealtime();
-            for (;;) {  // until all of them carry the call's epoch
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < kSpPer; ++i) {
-                    d[i] = make_uint4(0, 0, 0, 0);
-                    if (g0 + 64u * i < gen_end) {
-                        const u32x4 v = sp_load16(p.desc4, n_groups, g0 + 64u * i);
-                        d[i] = make_uint4(v.x, v.y, v.z, v.w);
-                        ok = ok && v.w == p.epoch;
-                    }
-                }
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;  // the wave stays together
-                ++n_missed;
-                __builtin_amdgcn_s_sleep(16);
-            }
-            ++n_steps;
-            const uint64_t t_b = __builtin_amdgcn_s_memrealtime();
-            ph_poll += (uint32_t)(t_b - t_a);
-            // segmented exclusive scan in group order: six wave scans, the fold of the items before carried along (scalars);
-            // group descriptor .x: count in the low 24 bits, the group's dense tiles in bits 24..27
-            uint32_t ef = 0, er[kSpPer], ed[kSpPer], ec[kSpPer];
-            uint32_t wf = 0, wr = 0, wd = 0, wc = 0;
-#pragma unroll
-            for (int i = 0; i < kSpPer; ++i) {
-                uint32_t f = d[i].x >> 31, sr = d[i].y, sd = d[i].z, sc = d[i].x & 0xFFFFFFu;
-                SVX_SEG_SCAN()
-                const uint32_t xf = dpp0<kDppWaveShr1, 0xF>(f), xr = dpp0<kDppWaveShr1, 0xF>(sr),
-                               xd = dpp0<kDppWaveShr1, 0xF>(sd), xc = dpp0<kDppWaveShr1, 0xF>(sc);
-                ef |= (xf | wf) << i;
-                er[i] = xf ? xr : wr + xr;
-                ed[i] = xf ? xd : wd + xd;
-                ec[i] = wc + xc;
-                const uint32_t F = __builtin_amdgcn_readlane(f, 63), R = __builtin_amdgcn_readlane(sr, 63),
-                               D = __builtin_amdgcn_readlane(sd, 63), Cn = __builtin_amdgcn_readlane(sc, 63);
-                if (F) { wf = 1; wr = R; wd = D; }
-                else { wr += R; wd += D; }
-                wc += Cn;
-            }
-            if (lane == 0) { s_f[wave] = wf; s_r[wave] = wr; s_d[wave] = wd; s_c[wave] = wc; }
-            __syncthreads();
-            uint32_t pr_ = 0, pd_ = 0, pc = 0, ar = run_r, ad = run_d, ac = run_c;
-            for (int w2 = 0; w2 < kWaves; ++w2) {
-                if (w2 == wave) { pr_ = ar; pd_ = ad; pc = ac; }
-                if (s_f[w2]) { ar = s_r[w2]; ad = s_d[w2]; }
-                else { ar += s_r[w2]; ad += s_d[w2]; }
-                ac += s_c[w2];
-            }
-#pragma unroll
-            for (int i = 0; i < kSpPer; ++i) {
-                const uint32_t G = g0 + 64u * i;
-                if (G < gen_end) {
-                    const bool own = (ef >> i) & 1u;  // an alignment start among this wave's earlier groups of the step
-                    sp_store16(p.pfx, n_groups, G, pc + ec[i], own ? er[i] : pr_ + er[i], own ? ed[i] : pd_ + ed[i], p.epoch);
-                    for (uint32_t m = (d[i].x >> 24) & 0xFu; m; m &= m - 1u)  // the group's dense tiles (rare)
-                        p.dense_list[run_dense + atomicAdd(s_nd, 1u)] = G * kWaves + ((uint32_t)__ffs((int)m) - 1u);
-                }
-            }
-            __syncthreads();
-            run_r = ar; run_d = ad; run_c = ac;
-            run_dense += *s_nd;
-            __syncthreads();
-            ph_scan += (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_b);
-        }
-    }
-    if (tid == 0) {
-        *n_out = (uint64_t)run_c;
-        p.n_dense[2] = run_dense;
-        p.sp_stat[p.sp_waves] = make_uint4(n_steps, n_missed, (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin),
-                                          __builtin_amdgcn_s_getreg((31 << 11) | 4));
-        p.sp_stat[p.sp_waves + 1] = make_uint4(ph_poll, ph_scan, (uint32_t)t_begin, (uint32_t)__builtin_amdgcn_s_memrealtime());
-    }
-}
-
-// prefix of tile 4G + k from its group's prefix P and the descriptors md[j] of the tiles j < k of the group (lane j of
-// `md` holds tile 4G + j's); false if one of them does not carry the epoch yet
-__device__ __forceinline__ bool sp_tile_prefix(const CigarArgs& p, const u32x4 P, const u32x4 md, const uint32_t k, uint32_t* ob,
-                                               uint32_t* cr, uint32_t* cd) {
-    bool ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.w) == p.epoch;
-    uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.x), r = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.y),
-             d = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.z);
-#pragma unroll
-    for (int j = 0; j < kWaves - 1; ++j) {
-        const uint32_t vx = __builtin_amdgcn_readlane(md.x, j), vy = __builtin_amdgcn_readlane(md.y, j),
-                       vz = __builtin_amdgcn_readlane(md.z, j), vw = __builtin_amdgcn_readlane(md.w, j);
-        if ((uint32_t)j < k) {
-            ok = ok && vw == p.epoch;
-            if (vx >> 31) { r = vy; d = vz; }
-            else { r += vy; d += vz; }
-            o += vx & kDescCntSp;
-        }
-    }
-    *ob = o; *cr = r; *cd = d;
-    return ok;
-}
-
-struct SpPrefetch {  // what the hook requests at the top of a tile's last round
-    u32x4 P, md;
-    bool valid;
-};
-
-template <bool SOA>
-__global__ __launch_bounds__(64 * kWaves, 6) void k_tiles_sp(CigarArgs p, uint64_t* __restrict__ n_out) {
-    __shared__ uint4 s_xpose[kWaves][kXposeU4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWaves][kHeadWords];  // start mask, then the queue
-    __shared__ uint4 s_stage[kWaves][kStage];
-    __shared__ uint4 s_gd[4][kWaves];      // group slots (generation & 3): the four tile descriptors ...
-    __shared__ uint32_t s_gstate[4];       // ... and generation << 3 | arrivals
-    if (blockIdx.x == 0) {  // workgroup-uniform
-        sp_scanner(p, n_out, s_head[0]);
-        return;
-    }
-    // The scanner's CU stays otherwise empty (its polls and write-through stores then do not queue behind a CU's worth
-    // of streaming loads): workgroups b, b + n_cu, b + 2 n_cu, ... have been observed to share a CU (block b on XCD
-    // b % 8, the CUs of an XCD in turn), so the multiples of p.sp_skip leave at once.  A device that places differently
-    // only has a slower scanner — see above.
-    if (p.sp_skip && blockIdx.x % p.sp_skip == 0) return;
-    const uint32_t wg = blockIdx.x - 1u - (p.sp_skip ? blockIdx.x / p.sp_skip : 0u);  // dense index of this tile workgroup
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 4) s_gstate[threadIdx.x] = threadIdx.x << 3;
-    __syncthreads();
-    const uint32_t n_groups = (p.n_tiles + kWaves - 1) / kWaves;
-    const uint64_t t_wave_begin = __builtin_amdgcn_s_memrealtime();
-    // the tiles whose records wait in their slabs for this wave to place them: e0 the older
-    uint32_t e0_tile = kNoTile, e0_cnt = 0, e1_tile = kNoTile, e1_cnt = 0;
-    uint32_t n_direct = 0, n_left = 0;
-    SpPrefetch pf;
-    pf.valid = false;
-    auto place = [&](const uint32_t t, const uint32_t cnt, const u32x4 P, const u32x4 md) {
-        uint32_t ob, cr, cd;
-#ifdef SVX_SP_EXP_NOPLACE
-        ++n_left; return;
-#endif
-        if (!sp_tile_prefix(p, P, md, t & (kWaves - 1), &ob, &cr, &cd)) { ++n_left; return; }  // the finish launch's
-        for (uint32_t r = (uint32_t)lane; r < cnt; r += 64u) {
-            const uint4 rec = p.slab[(uint64_t)t * kSlab + r];  // this wave's own burst of two tiles ago
-            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
-            store_final(p, (uint64_t)ob + r, rec.x, rec.y + (prec ? cr : 0u), rec.z + (prec ? cd : 0u), len, type);
-        }
-        // marked PLACED for the finish launch; count, flag and tails stay: the tiles behind it in the group fold them into
-        // their prefix.  (Lane k of `md` holds this tile's own descriptor; were it not there, the finish launch would place
-        // the tile a second time — the same bytes.)
-        if ((uint32_t)lane == (t & (kWaves - 1)) && md.w == p.epoch) sp_store16(p.desc, p.n_tiles, t, md.x | kDescPlaced, md.y, md.z, p.epoch);
-        ++n_direct;
-    };
-    for (uint32_t g = 0;; ++g) {
-        const uint32_t first = g * p.sp_waves + wg * kWaves;  // the group's first tile
-        if (first >= p.n_tiles) break;  // workgroup-uniform
-        const uint32_t tile = first + (uint32_t)wave;
-        uint4 dsc = make_uint4(0, 0, 0, 0);
-        pf.valid = false;
-        if (tile < p.n_tiles) {
-            auto hook = [&]() {
-                if (e1_tile != kNoTile) {  // two tiles wait: the older one will be looked at behind this tile
-                    pf.P = sp_load16(p.pfx, n_groups, e0_tile / kWaves);
-                    pf.md = sp_load16(p.desc, p.n_tiles, (e0_tile & ~(uint32_t)(kWaves - 1)) + ((uint32_t)lane & (kWaves - 1)));
-                    pf.valid = true;
-                }
-            };
-            dsc = process_tile<MODE_STAGE, SOA, kTileOps, ALO_TABLE>(p, tile, lane, s_xpose[wave], s_head[wave],
-                                                                    reinterpret_cast<uint4*>(s_head[wave]), s_stage[wave], TileIn(), hook);
-        }
-        const uint32_t cnt = dsc.x & 0x3FFFFFFFu;
-        const bool dense = cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense);
-        // ---- publish: the tile's descriptor (write-through, the epoch in .w), then the arrival at the group's slot
-        const uint32_t slot = g & 3u;
-        uint32_t old = 0;
-        if (lane == 0) {
-            if (tile < p.n_tiles) sp_store16(p.desc, p.n_tiles, tile, dsc.x, dsc.y, dsc.z, p.epoch);
-            while ((__hip_atomic_load(&s_gstate[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 3) != g)
-                __builtin_amdgcn_s_sleep(1);  // (a sibling four generations behind has yet to fold this slot's last use)
-            s_gd[slot][wave] = make_uint4(dsc.x, dsc.y, dsc.z, dense ? 1u : 0u);
-            old = __hip_atomic_fetch_add(&s_gstate[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old & 7u) == (uint32_t)kWaves - 1u) {  // the last of the four: fold (fold_group_desc) and publish the group
-                uint32_t f = 0, r = 0, d = 0, c = 0, dm = 0;
-#pragma unroll
-                for (int k = 0; k < kWaves; ++k) {
-                    const uint4 v = s_gd[slot][k];
-                    if (v.x >> 31) { f = 1; r = v.y; d = v.z; }
-                    else { r += v.y; d += v.z; }
-                    c += v.x & 0x3FFFFFFFu;
-                    dm |= v.w << k;
-                }
-                sp_store16(p.desc4, n_groups, first / kWaves, c | (dm << 24) | (f << 31), r, d, p.epoch);
-                __hip_atomic_store(&s_gstate[slot], (g + 4u) << 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        // ---- place the older waiting tile (requested at the top of the last round), then queue this one
-        if (pf.valid) {
-            place(e0_tile, e0_cnt, pf.P, pf.md);
-            e0_tile = e1_tile; e0_cnt = e1_cnt;
-            e1_tile = kNoTile;
-        }
-        if (cnt && !dense) {
-            if (e0_tile == kNoTile) { e0_tile = tile; e0_cnt = cnt; }
-            else if (e1_tile == kNoTile) { e1_tile = tile; e1_cnt = cnt; }
-            else {  // (both taken and nothing requested: a tile of a single round) the oldest is the finish launch's
-                ++n_left;
-                e0_tile = e1_tile; e0_cnt = e1_cnt;
-                e1_tile = tile; e1_cnt = cnt;
-            }
-        }
-    }
-    // the wave's last tiles: one look at the older one (it has had a tile's time), the rest is the finish launch's
-    if (e0_tile != kNoTile) {
-        const u32x4 P = sp_load16(p.pfx, n_groups, e0_tile / kWaves);
-        const u32x4 md = sp_load16(p.desc, p.n_tiles, (e0_tile & ~(uint32_t)(kWaves - 1)) + ((uint32_t)lane & (kWaves - 1)));
-        place(e0_tile, e0_cnt, P, md);
-    }
-    if (e1_tile != kNoTile) ++n_left;
-    if (lane == 0 && wg * kWaves + (uint32_t)wave < p.sp_waves)
-        p.sp_stat[wg * kWaves + wave] = make_uint4(n_direct, n_left, (uint32_t)t_wave_begin, (uint32_t)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---- B: segmented exclusive scan over tile descriptors ----
@@ -1176,41 +858,10 @@ constexpr int kFinLanes = 16;
 #define SVX_FINSPEC 3
 #endif
 constexpr int kFinSpec = SVX_FINSPEC;  // records per lane requested together with the descriptor (48 per tile)
-// Single-pass path, behind the launch boundary: a tile's carry-in and output base from the scanner's prefix of its group
-// and the descriptors of the tiles in front of it inside the group.
-__device__ __forceinline__ TileIn sp_tile_in(const CigarArgs& p, const uint32_t tile) {
-    const uint4 P = p.pfx[tile / kWaves];
-    TileIn in;
-    in.a_lo = 0;
-    in.obase = P.x; in.carry_r = P.y; in.carry_d = P.z;
-    for (uint32_t t = tile & ~(uint32_t)(kWaves - 1); t < tile; ++t) {
-        const uint4 v = p.desc[t];
-        if (v.x >> 31) { in.carry_r = v.y; in.carry_d = v.z; }
-        else { in.carry_r += v.y; in.carry_d += v.z; }
-        in.obase += v.x & kDescCntSp;
-    }
-    return in;
-}
-
-// Single-pass path (SP): only the tiles the tile waves did not place themselves are left (no PLACED flag in the
-// descriptor); the descriptor is looked at first, the records are requested behind it.
-template <bool SP>
 __device__ __forceinline__ void cigar_finish_block(const CigarArgs& p, const uint32_t block) {
     const uint32_t tile = block * (256u / kFinLanes) + threadIdx.x / kFinLanes;
     const uint32_t l = threadIdx.x % kFinLanes;
     if (tile >= p.n_tiles) return;
-    if (SP) {
-        const uint4 dsc = p.desc[tile];
-        const uint32_t cnt = dsc.x & kDescCntSp;
-        if (cnt == 0 || (dsc.x & kDescPlaced) || cnt > (uint32_t)kSlab || (dsc.x & kDescForceDense)) return;
-        const TileIn in = sp_tile_in(p, tile);
-        for (uint32_t r = l; r < cnt; r += kFinLanes) {
-            const uint4 rec = p.slab[(uint64_t)tile * kSlab + r];
-            const uint32_t len = rec.w & 0x0FFFFFFFu, type = (rec.w >> 28) & 1u, prec = (rec.w >> 29) & 1u;
-            store_final(p, (uint64_t)in.obase + r, rec.x, rec.y + (prec ? in.carry_r : 0u), rec.z + (prec ? in.carry_d : 0u), len, type);
-        }
-        return;
-    }
     // speculative: slots past the tile's count hold stale bytes and are never used
     uint4 spec[kFinSpec];
 #pragma unroll
@@ -1250,8 +901,7 @@ __device__ __forceinline__ void cigar_finish_block(const CigarArgs& p, const uin
     }
 }
 
-template <bool SP>
-__global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) { cigar_finish_block<SP>(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_cigar_finish(CigarArgs p) { cigar_finish_block(p, blockIdx.x); }
 
 // ---- D: dense tiles (more than kSlab signatures, or a round that overflowed the queue: SV-dense stretches of
 // an assembly, satellite arrays, a tiny min_len) are re-walked with carry-in and output base known.  Always
@@ -1813,7 +1463,7 @@ __device__ __forceinline__ void a3_chain_block(const A3Args& a, const uint32_t b
 
 // The dense-tile launch of the streaming path (dense_tile_wg above); with WITH_POST its first n_a3_blocks workgroups
 // run the post-passes of the split-segment chain instead — the launch is empty in the common case anyway.
-template <bool SOA, bool WITH_POST, bool SP>
+template <bool SOA, bool WITH_POST>
 __global__ __launch_bounds__(64 * kWaves) void k_cigar_dense(CigarArgs p, A3Args a3, uint32_t n_a3_blocks) {
     if (WITH_POST && blockIdx.x < n_a3_blocks) {  // workgroup-uniform
         a3_chain_block<A3_POST>(a3, blockIdx.x, nullptr);
@@ -1829,19 +1479,14 @@ __global__ __launch_bounds__(64 * kWaves) void k_cigar_dense(CigarArgs p, A3Args
     const uint32_t first = WITH_POST ? n_a3_blocks : 0u;
     for (uint32_t work = blockIdx.x - first; work < n_dense; work += gridDim.x - first) {
         const uint32_t tile = p.dense_list[work];
+        const uint4 bp = p.blk_prefix[tile / kScanBlock];
+        const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
+        const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
         TileIn in;
         in.a_lo = p.tile_alo[tile];
-        if (SP) {  // the scanner's prefix of the group + the tiles in front of this one inside the group
-            in = sp_tile_in(p, tile);
-            in.a_lo = p.tile_alo[tile];
-        } else {
-            const uint4 bp = p.blk_prefix[tile / kScanBlock];
-            const uint32_t lr = p.carry_ref[tile], ld = p.carry_read[tile], lb = p.out_base[tile];
-            const bool local_head = (lb >> 31) != 0;  // a start precedes the tile inside its scan block
-            in.carry_r = local_head ? lr : lr + bp.y;
-            in.carry_d = local_head ? ld : ld + bp.z;
-            in.obase = (lb & 0x7FFFFFFFu) + bp.w;
-        }
+        in.carry_r = local_head ? lr : lr + bp.y;
+        in.carry_d = local_head ? ld : ld + bp.z;
+        in.obase = (lb & 0x7FFFFFFFu) + bp.w;
         dense_tile_wg<SOA>(p, tile, wave, lane, s_xpose[wave], s_mask, &s_dup, s_round, in);
     }
 }
@@ -2070,7 +1715,6 @@ __global__ __launch_bounds__(64 * kWaves, SVX_TILE_MIN_WAVES) void k_tiles_a3(Ci
 #ifndef SVX_FIN_A3_WAVES
 #define SVX_FIN_A3_WAVES 8
 #endif
-template <bool SP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SVX_FIN_A3_WAVES, 8)))
 void k_finish_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks) {
     if (blockIdx.x < n_a3_blocks) {  // workgroup-uniform
@@ -2081,7 +1725,7 @@ void k_finish_a3(CigarArgs p, A3Args a, uint32_t n_a3_blocks) {
         return;
     }
 #ifndef SVX_EXP_A3_ONLY
-    cigar_finish_block<SP>(p, blockIdx.x - n_a3_blocks);
+    cigar_finish_block(p, blockIdx.x - n_a3_blocks);
 #endif
 }
 
@@ -2185,11 +1829,6 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t n_scan_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
     a.blk_agg = svx_ws_take<uint4>(ctx, n_scan_blocks);
     a.blk_prefix = svx_ws_take<uint4>(ctx, n_scan_blocks);
-    a.pfx = svx_ws_take<uint4>(ctx, n_tiles);
-    a.epoch = 0;
-    a.sp_waves = 0;
-    a.sp_skip = 0;
-    a.sp_stat = svx_ws_take<uint4>(ctx, (size_t)ctx->n_cu * 8u * kWaves + 2u);
     a.out = d_out;
     a.cap = cap;
     A3Args c;
@@ -2241,66 +1880,11 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
     const uint32_t dense_blocks = n_tiles < blocks_cap ? n_tiles : blocks_cap;
     rc = svx_timing_begin(ctx);
     if (rc != SVX_OK) return rc;
-    if (ctx->single_pass) {
-        // ---- single-pass path: k_tile_alo (+ the hand-off words cleared), k_tiles_sp (tiles + scan + placement), the
-        // finish launch for the tiles whose prefix came too late (+ the chain's stage A), the dense-tile launch (+ stage B)
-        if (!ctx->sp_wg_per_cu) {  // how many of its workgroups the device holds at once: asked once per context
-            int per_cu = 0;
-            SVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tiles_sp<SOA>, 64 * kWaves, 0));
-            // (the runtime's answer can be one too many where the SGPR count decides, MI355X_MICROARCH.md: a workgroup
-            //  that has to queue costs time here, never the result — see the comment above k_tiles_sp)
-            ctx->sp_wg_per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
-        }
-        // one workgroup is the scanner, the others that would land on its CU stay empty (k_tiles_sp)
-        uint32_t grid = (uint32_t)ctx->n_cu * (uint32_t)ctx->sp_wg_per_cu;
-        a.sp_skip = ctx->sp_wg_per_cu > 1 ? (uint32_t)ctx->n_cu : 0u;
-        uint32_t tile_wgs = grid - 1u - (a.sp_skip ? (grid - 1u) / a.sp_skip : 0u);
-        if (tile_wgs > blocks_all) {  // a batch of fewer tiles than the device holds
-            tile_wgs = blocks_all;
-            grid = tile_wgs + 1u;
-            grid += a.sp_skip ? (grid - 1u) / (a.sp_skip - 1u) : 0u;  // room for the ones that leave
-        }
-        a.sp_waves = tile_wgs * kWaves;
-        ctx->sp_last_waves = a.sp_waves;
-        ctx->sp_last_stat = a.sp_stat;
-        if (++ctx->sp_epoch == 0) ctx->sp_epoch = 1;
-        a.epoch = ctx->sp_epoch;
-        const uint32_t alo_threads = n_aln > n_tiles ? n_aln : n_tiles;
-        hipLaunchKernelGGL(k_tile_alo, dim3((alo_threads + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
-                           a.tile_alo, a.desc, a.desc4, a.pfx);
-        rc = svx_timing_mark(ctx, 1);
-        if (rc != SVX_OK) return rc;
-        hipLaunchKernelGGL((k_tiles_sp<SOA>), dim3(grid), dim3(64 * kWaves), 0, ctx->stream, a, d_n_out);
-        rc = svx_timing_mark(ctx, 2);
-        if (rc != SVX_OK) return rc;
-        if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)
-            if (!ctx->ev_dom) SVX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dom, hipEventDisableTiming));
-            SVX_HIP(ctx, hipEventRecord(ctx->ev_dom, ctx->stream));
-            ctx->ev_dom_recorded = true;
-        }
-        if (a3) {
-            hipLaunchKernelGGL(k_finish_a3<true>, dim3(n_a3_blocks + finish_blocks), dim3(256), 0, ctx->stream, a, c, n_a3_blocks);
-            hipLaunchKernelGGL((k_cigar_dense<SOA, true, true>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream,
-                               a, c, n_post_blocks);
-        } else {
-            hipLaunchKernelGGL(k_cigar_finish<true>, dim3(finish_blocks), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL((k_cigar_dense<SOA, false, true>), dim3(dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c, 0u);
-        }
-        SVX_HIP(ctx, hipGetLastError());
-        return svx_timing_end(ctx);
-    }
     hipLaunchKernelGGL(k_tile_alo, dim3((n_aln + 255) / 256), dim3(256), 0, ctx->stream, d_aln_off, n_aln, n_tiles,
-                       a.tile_alo, (uint4*)nullptr, (uint4*)nullptr, (uint4*)nullptr);
+                       a.tile_alo);
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-#ifdef SVX_EXP_PERSIST  // timing experiment: the five-launch tile kernel on a persistent grid (its loop strides by the grid)
-#ifdef SVX_EXP_PERSIST_DYN
-    SVX_HIP(ctx, hipMemsetAsync(a.n_dense + 16, 0, 32, ctx->stream));
-#endif
-    hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3((uint32_t)ctx->n_cu * SVX_EXP_PERSIST), dim3(64 * kWaves), 0, ctx->stream, a);
-#else
     hipLaunchKernelGGL((k_cigar_tiles<SOA, kTileOps, ALO_TABLE>), dim3(blocks_all), dim3(64 * kWaves), 0, ctx->stream, a);
-#endif
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     if (ctx->want_dom) {  // somebody pipelines against this context (svx_ctx_wait_dominant)
@@ -2312,12 +1896,12 @@ int cigar_extract_dev_impl(svx_ctx* ctx, const uint32_t* d_cigar_or_len, const u
                        a.out_base, a.carry_ref, a.carry_read, a.dense_list, a.n_dense, a.blk_agg,
                        a.blk_prefix, a.n_dense + 1, d_n_out);
     if (a3) {  // the chain's rows and decision tree inside the finish launch, its post-passes inside the dense-tile launch
-        hipLaunchKernelGGL(k_finish_a3<false>, dim3(n_a3_blocks + finish_blocks), dim3(256), 0, ctx->stream, a, c, n_a3_blocks);
-        hipLaunchKernelGGL((k_cigar_dense<SOA, true, false>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c,
+        hipLaunchKernelGGL(k_finish_a3, dim3(n_a3_blocks + finish_blocks), dim3(256), 0, ctx->stream, a, c, n_a3_blocks);
+        hipLaunchKernelGGL((k_cigar_dense<SOA, true>), dim3(n_post_blocks + dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c,
                            n_post_blocks);
     } else {
-        hipLaunchKernelGGL(k_cigar_finish<false>, dim3(finish_blocks), dim3(256), 0, ctx->stream, a);
-        hipLaunchKernelGGL((k_cigar_dense<SOA, false, false>), dim3(dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c, 0u);
+        hipLaunchKernelGGL(k_cigar_finish, dim3(finish_blocks), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_cigar_dense<SOA, false>), dim3(dense_blocks), dim3(64 * kWaves), 0, ctx->stream, a, c, 0u);
     }
     SVX_HIP(ctx, hipGetLastError());
     return svx_timing_end(ctx);
@@ -2399,32 +1983,6 @@ int cigar_extract_host_impl(svx_ctx* ctx, const uint32_t* cigar_or_len, const ui
 }
 
 }  // namespace
-
-extern "C" int svx_ctx_cigar_single_pass_stats(svx_ctx* ctx, uint32_t* out8) {
-    if (!ctx || !out8) return SVX_E_INVALID;
-    memset(out8, 0, 8 * sizeof(uint32_t));
-    out8[0] = (uint32_t)ctx->sp_wg_per_cu;
-    out8[1] = ctx->sp_last_waves;
-    if (!ctx->sp_last_stat || !ctx->sp_last_waves) return SVX_OK;
-    SVX_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<uint4> h((size_t)ctx->sp_last_waves + 2);
-    SVX_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sp_last_stat, h.size() * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
-    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i + 2 < h.size(); ++i) { out8[2] += h[i].x; out8[3] += h[i].y; }
-    const uint4 sc = h[h.size() - 2], ph = h.back();
-    out8[4] = sc.x; out8[5] = sc.y; out8[6] = sc.z / 100u;  // s_memrealtime: 100 MHz
-    out8[7] = ph.x / 100u;  // of which waiting for descriptors
-    return SVX_OK;
-}
-
-// (tools only: the raw per-wave records of the latest single-pass launch, 4 words per tile wave + the scanner's)
-extern "C" int svx_debug_sp_raw(svx_ctx* ctx, uint32_t* out, uint32_t n_words) {
-    if (!ctx || !out || !ctx->sp_last_stat) return -1;
-    const size_t have = ((size_t)ctx->sp_last_waves + 2) * 4;
-    const size_t n = n_words < have ? n_words : have;
-    if (hipMemcpy(out, ctx->sp_last_stat, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)n;
-}
 
 extern "C" int svx_cigar_extract_dev(svx_ctx* ctx, const uint32_t* d_cigar, uint64_t n_ops,
                                      const uint64_t* d_aln_off, uint32_t n_aln,
@@ -2518,8 +2076,7 @@ size_t svx_cigar_extract_ws_need(const svx_ctx* ctx, uint64_t n_ops) {
     const bool small = n_ops <= (uint64_t)kSmallMaxTiles * kSmallTileOps && n_ops <= ctx->small_batch_ops;
     const uint32_t n_tiles = small ? (uint32_t)((n_ops + kSmallTileOps - 1) / kSmallTileOps)
                                    : (uint32_t)((n_ops + kTileOps - 1) / kTileOps);
-    return 2 * svx_take_bytes(n_tiles, sizeof(uint4)) + svx_take_bytes((n_tiles + kWaves - 1) / kWaves, sizeof(uint4)) +
-           svx_take_bytes((size_t)ctx->n_cu * 8u * kWaves + 2u, sizeof(uint4)) +
+    return svx_take_bytes(n_tiles, sizeof(uint4)) + svx_take_bytes((n_tiles + kWaves - 1) / kWaves, sizeof(uint4)) +
            svx_take_bytes((size_t)n_tiles * kSlab, sizeof(uint4)) +
            5 * svx_take_bytes(n_tiles, sizeof(uint32_t)) + svx_take_bytes(4, sizeof(uint32_t)) +
            2 * svx_take_bytes((n_tiles + kScanBlock - 1) / kScanBlock, sizeof(uint4));

@@ -143,12 +143,6 @@ extern "C" int svx_ctx_barrier_timed_out(svx_ctx* ctx) {
     return was ? 1 : 0;
 }
 
-extern "C" int svx_ctx_set_cigar_single_pass(svx_ctx* ctx, int on) {
-    if (!ctx) return SVX_E_INVALID;
-    ctx->single_pass = on != 0;
-    return SVX_OK;
-}
-
 extern "C" int svx_ctx_set_split_chain(svx_ctx* ctx, int on) {
     if (!ctx) return SVX_E_INVALID;
     ctx->split_chain = on != 0;

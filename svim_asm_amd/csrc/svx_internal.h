@@ -43,11 +43,6 @@ struct svx_ctx {
     uint32_t pair_single_max = 131072;  // svx_ctx_set_pair_single_launch_max: largest batch of the one-launch pair sort
     uint64_t small_batch_ops = 1ull << 23;  // svx_ctx_set_small_batch_ops: largest batch of the two-launch CIGAR path
     bool split_chain = false;               // svx_ctx_set_split_chain: the split-segment chain as three launches
-    bool single_pass = false;               // svx_ctx_set_cigar_single_pass: the streaming CIGAR path as one tile + scan + placement launch
-    int sp_wg_per_cu = 0;                   // workgroups of k_tiles_sp a CU holds at once (asked once)
-    uint32_t sp_epoch = 0;                  // calls of the single-pass path so far: the hand-off word of the next one
-    uint32_t sp_last_waves = 0;             // tile waves of the latest single-pass launch and their counters (svx_ctx_cigar_single_pass_stats)
-    const uint4* sp_last_stat = nullptr;
     char err[512] = {0};
 };
 

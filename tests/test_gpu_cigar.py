@@ -12,17 +12,14 @@ pytestmark = pytest.mark.gpu
 KEYS = ("aln", "ref_pos", "read_pos", "len", "type")
 
 
-@pytest.fixture(autouse=True, params=["small_batch", "single_pass", "five_launch"])
+@pytest.fixture(autouse=True, params=["small_batch", "streaming"])
 def cigar_path(request, svx_ctx):
-    """Every test of this module runs on all three kernel paths: batches up to 2^23 ops in two launches
-    (tiles of 1024 ops, k_cigar_finish_small) and the streaming path (tiles of 4096 ops) that larger batches
-    take — forced here with svx_ctx_set_small_batch_ops(0) — in its single-pass form (k_tiles_sp: tiles, scan
-    and placement in one launch; the default) and in its five-launch form (svx_ctx_set_cigar_single_pass(0))."""
-    svx_ctx.set_small_batch_ops(1 << 23 if request.param == "small_batch" else 0)
-    svx_ctx.set_cigar_single_pass(request.param != "five_launch")
+    """Every test of this module runs on both kernel paths: batches up to 2^23 ops in two launches
+    (tiles of 1024 ops, k_cigar_finish_small) and the five-launch streaming path (tiles of 4096 ops) that
+    larger batches take — forced here with svx_ctx_set_small_batch_ops(0)."""
+    svx_ctx.set_small_batch_ops(0 if request.param == "streaming" else 1 << 23)
     yield request.param
     svx_ctx.set_small_batch_ops(1 << 23)
-    svx_ctx.set_cigar_single_pass(True)
 
 
 def pack(tuples):
