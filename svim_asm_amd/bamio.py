@@ -513,10 +513,29 @@ def default_device_inflate_percent():
     of a run whose wall-clock IS its CPU-seconds over the CPUs it may use when those are few (the pool's 16-CPU quota:
     3.6 CPU-s, 0.22-0.26 s).  So: half the call with at most 24 CPUs' worth of time (0.26 → 0.18-0.20 s end to end,
     profiles/r05_device_leg.txt), none above."""
-    env = os.environ.get("SVX_BAM_DEVICE_INFLATE")
-    if env not in (None, ""):
-        return max(0, min(100, int(env)))
+    asked = env_device_inflate_percent()
+    if asked is not None:
+        return asked
     return 50 if host_cpus() <= 24 else 0
+
+
+def env_device_inflate_percent():
+    """SVX_BAM_DEVICE_INFLATE as a percentage 0..100, or None when it is unset, empty or not a number (said once on
+    stderr: a typo in the variable must not take down every entry point that imports this module)."""
+    env = os.environ.get("SVX_BAM_DEVICE_INFLATE")
+    if env in (None, ""):
+        return None
+    try:
+        return max(0, min(100, int(env)))
+    except ValueError:
+        if env not in _ENV_WARNED:
+            _ENV_WARNED.add(env)
+            import warnings
+            warnings.warn("SVX_BAM_DEVICE_INFLATE=%r is not a percentage (0..100): ignored, the default applies" % env)
+        return None
+
+
+_ENV_WARNED = set()
 
 
 class _BamColumns(C.Structure):
@@ -621,8 +640,13 @@ class AlignmentFile(object):
         return span.astype(np.int64)
 
     # share of a sequence-slice call's members that the pinned device inflates and verifies beside the reader's threads
-    # (svx_bam_set_device_inflate; default_device_inflate_percent above)
-    device_inflate_percent = default_device_inflate_percent()
+    # (svx_bam_set_device_inflate); None = default_device_inflate_percent() above, asked when the file is loaded — the
+    # environment and the CPU quota as they are THEN, not as they were when the module was imported
+    device_inflate_percent = None
+
+    def effective_device_inflate_percent(self):
+        pct = self.device_inflate_percent
+        return default_device_inflate_percent() if pct is None else int(pct)
     device_inflate_min_members = 3000  # the share goes to the device only when it holds that many members (svx_bam.h)
 
     @property
@@ -663,7 +687,7 @@ class AlignmentFile(object):
             return self
         if self._h is not None:
             self._lib.svx_bam_set_pinned_device(self._h, -1 if self._pin_device is None else int(self._pin_device))
-            self._lib.svx_bam_set_device_inflate(self._h, 0 if self._pin_device is None else self.device_inflate_percent)
+            self._lib.svx_bam_set_device_inflate(self._h, 0 if self._pin_device is None else self.effective_device_inflate_percent())
             self._lib.svx_bam_set_device_inflate_min(self._h, int(self.device_inflate_min_members))
             if tids is None:
                 rc = self._lib.svx_bam_load(self._h, None, 0)

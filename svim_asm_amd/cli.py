@@ -17,7 +17,7 @@ TYPE_LABELS = (("DEL", "deletion"), ("INV", "inversion"), ("INS", "insertion"), 
                ("DUP_INT", "interspersed duplication"), ("BND", "breakend"))
 
 
-def _open_file(path, options):
+def _open_file(path, options, one_shot=True):
     f = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
                             threads=bamio.ingest_threads(2 if options.sub == "diploid" else 1),
                             verify=False if getattr(options, "no_bgzf_crc", False) else None)
@@ -26,12 +26,13 @@ def _open_file(path, options):
     # command's wall-clock is start-up: measured on the full-size sample, interleaved (profiles/r05_cli_device_leg.txt),
     # 0.68-0.71 s with the share against 0.64-0.69 s without, four rank processes 1.13-1.27 against 1.04-1.06 s.  So the
     # command runs without it unless SVX_BAM_DEVICE_INFLATE asks for it (svim-asm-cohort keeps the readers' default).
-    asked = os.environ.get("SVX_BAM_DEVICE_INFLATE")
-    f.device_inflate_percent = 0 if asked in (None, "") else max(0, min(100, int(asked)))
+    if one_shot:
+        asked = bamio.env_device_inflate_percent()
+        f.device_inflate_percent = 0 if asked is None else asked
     return f
 
 
-def _open_ahead(path, options):
+def _open_ahead(path, options, one_shot=True):
     """Start opening `path` (header, reference dictionary, index) on a thread; returns a function that waits and
     hands back the file — or raises what opening raised — at the point where the caller would have opened it."""
     import threading
@@ -39,7 +40,7 @@ def _open_ahead(path, options):
 
     def run():
         try:
-            box["file"] = _open_file(path, options)
+            box["file"] = _open_file(path, options, one_shot)
         except BaseException as e:  # noqa: BLE001 — re-raised by the caller at its own time
             box["error"] = e
     th = threading.Thread(target=run, daemon=True)

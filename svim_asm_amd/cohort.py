@@ -1,15 +1,20 @@
 """`svim-asm-cohort`: many samples in one process — what the reference does one invocation per sample
-(svim-asm:74-141), with the COLLECT step of ALL samples as one device submission (svx_collect_batch over every BAM
-of the cohort: the batch size at which the CIGAR walk runs at HBM speed, bench.py's headline workload), then PAIR
-and the VCF per sample exactly as `svim-asm haploid|diploid` produces them.
+(svim-asm:74-141) — as a STREAM: the manifest is cut into groups of G samples (default 1); a group is opened, its COLLECT
+goes out as one device submission (svx_collect_batch over every BAM of the group: at G = the whole manifest the batch size
+at which the CIGAR walk runs at HBM speed, bench.py's headline workload), then PAIR and the VCF per sample exactly as
+`svim-asm haploid|diploid` produces them.  K workers (threads, each with a device context and stream of its own) take
+the groups in manifest order, so the ingest of one group — the BAM readers' own threads, the device's share of the
+inflate work on by default here — runs while another group is in PAIR or writing its VCF; at most K groups are in memory
+whatever the manifest's length.  The process pays interpreter start and HIP bring-up once.
 
-    svim-asm-cohort diploid MANIFEST GENOME [the options of svim-asm diploid]
-    svim-asm-cohort haploid MANIFEST GENOME [the options of svim-asm haploid]
+    svim-asm-cohort diploid MANIFEST GENOME [--cohort_workers K] [--cohort_group G] [the options of svim-asm diploid]
+    svim-asm-cohort haploid MANIFEST GENOME [--cohort_workers K] [--cohort_group G] [the options of svim-asm haploid]
 
 MANIFEST: one sample per line, whitespace-separated — working_dir bam (haploid) or working_dir bam1 bam2 (diploid);
 lines starting with # are skipped.  Every sample gets its own working_dir/variants.vcf, byte-identical to the one
-the single-sample command writes.  The reference has no such mode; this is an addition on top of the drop-in
-command, which is unchanged."""
+the single-sample command writes.  K defaults to 3 (2 below 12 CPUs' worth of time), G to 1; `--cohort_group 0` = the whole
+manifest in one submission (the round-5 behaviour).  The reference has no such mode; this is an addition on top of the
+drop-in command, which is unchanged."""
 import logging
 import os
 import sys
@@ -34,6 +39,61 @@ def read_manifest(path, n_bams):
     return samples
 
 
+def _take_option(rest, name, default):
+    """Removes `name VALUE` (or name=VALUE) from the argument list of the reference's parser; returns int(VALUE)."""
+    out, value, k = [], default, 0
+    while k < len(rest):
+        a = rest[k]
+        if a == name and k + 1 < len(rest):
+            value = int(rest[k + 1])
+            k += 2
+            continue
+        if a.startswith(name + "="):
+            value = int(a.split("=", 1)[1])
+            k += 1
+            continue
+        out.append(a)
+        k += 1
+    return out, value
+
+
+def default_workers():
+    from svim_asm_amd import bamio
+    return 3 if bamio.host_cpus() >= 12 else 2
+
+
+def run_group(mode, group, genome, ctx, first_no, n_total):
+    """One group of samples from the BAMs to the VCFs on the calling thread's device context: (opts, working dir, BAM
+    paths) per sample.  Returns 0, or 1 after logging why an input was refused (as the command does)."""
+    from svim_asm_amd.SVIM_COMBINE import pair_tables
+    n_bams = 2 if mode == "diploid" else 1
+    files = []
+    for o, wd, bams in group:
+        os.makedirs(wd, exist_ok=True)
+        # the files of a sample side by side; with the readers' own default for the device's share of the inflate work
+        # (the one-shot command opens its files without one: cli._open_file)
+        opened = [cli._open_ahead(path, o, one_shot=False) for path in bams]
+        for k, path in enumerate(bams):
+            f = cli._open(path, ("first", "second")[k] if n_bams == 2 else "", o, opened=opened[k])
+            if f is None:
+                return 1
+            files.append(f)
+    tables = SVIM_COLLECT.collect_tables(files, group[0][0], ctx=ctx)
+    for k, (o, wd, bams) in enumerate(group):
+        reference = FastaFile(genome)  # (write_final_vcf closes its FastaFile, SVIM_COMBINE.py:466-467: one per sample)
+        mine, mine_files = tables[k * n_bams:(k + 1) * n_bams], files[k * n_bams:(k + 1) * n_bams]
+        candidates = pair_tables(mine[0], mine[1], reference, mine_files[0], o, ctx=ctx) if mode == "diploid" else mine[0]
+        # as cli._run_steps: a damaged BGZF member among the inserted-sequence bytes must fail the run before a VCF is
+        # written, also when nobody reads them (--symbolic_alleles)
+        _ = candidates.seqs, [t.seqs for t in mine]
+        write_vcf_table(candidates, cli.__version__, mine_files[0].references, mine_files[0].lengths,
+                        [entry.strip() for entry in o.types.split(",")], reference, o)
+        logging.info("sample %d of %d: %s/variants.vcf", first_no + k + 1, n_total, wd)
+    for f in files:
+        f.close()
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if len(argv) < 3 or argv[0] not in ("haploid", "diploid"):
@@ -46,36 +106,54 @@ def main(argv=None):
         print("svim-asm-cohort runs as ONE process (WORLD_SIZE=%d): start one cohort per GPU with --device, or shard a "
               "single sample with `svim-asm` under the launcher" % shard.world()[1], file=sys.stderr)
         return 2
+    rest, workers = _take_option(rest, "--cohort_workers", 0)
+    rest, per_group = _take_option(rest, "--cohort_group", 1)
     samples = read_manifest(manifest, n_bams)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)-7.7s]  %(message)s")
     # one options object per sample through the reference's own parser (working dir and BAM paths differ)
     opts = [parse_arguments(cli.__version__, [mode, wd] + bams + [genome] + rest) for wd, bams in samples]
-    cli._warm_device(getattr(opts[0], "device", 0) or 0)
-    files = []
-    for o, (wd, bams) in zip(opts, samples):
-        os.makedirs(wd, exist_ok=True)
-        for k, path in enumerate(bams):
-            f = cli._open(path, ("first", "second")[k] if n_bams == 2 else "", o)
-            if f is None:
-                return 1
-            files.append(f)
-    logging.info("****************** STEP 1: COLLECT (%d samples, %d BAM files, one submission) ******************",
-                 len(samples), len(files))
-    tables = SVIM_COLLECT.collect_tables(files, opts[0])
-    for k, (o, (wd, bams)) in enumerate(zip(opts, samples)):
-        reference = FastaFile(genome)  # (write_final_vcf closes its FastaFile, SVIM_COMBINE.py:466-467: one per sample)
-        mine, mine_files = tables[k * n_bams:(k + 1) * n_bams], files[k * n_bams:(k + 1) * n_bams]
-        if mode == "diploid":
-            candidates = shard.pair_sharded(mine[0], mine[1], reference, mine_files[0], o)
-        else:
-            candidates = mine[0]
-        # as cli._run_steps: a damaged BGZF member among the inserted-sequence bytes must fail the run before a VCF is
-        # written, also when nobody reads them (--symbolic_alleles)
-        _ = candidates.seqs, [t.seqs for t in mine]
-        write_vcf_table(candidates, cli.__version__, mine_files[0].references, mine_files[0].lengths,
-                        [entry.strip() for entry in o.types.split(",")], reference, o)
-        logging.info("sample %d of %d: %s/variants.vcf", k + 1, len(samples), wd)
-    return 0
+    device = getattr(opts[0], "device", 0) or 0
+    cli._warm_device(device)
+    per_group = len(samples) if per_group <= 0 else per_group
+    groups = [[(opts[k], samples[k][0], samples[k][1]) for k in range(g, min(g + per_group, len(samples)))]
+              for g in range(0, len(samples), per_group)]
+    workers = max(1, min(workers or default_workers(), len(groups)))
+    logging.info("****************** %d samples, %d BAM files: %d group(s) of up to %d, %d worker(s) ******************",
+                 len(samples), len(samples) * n_bams, len(groups), per_group, workers)
+    import gc
+    import threading
+    from svim_asm_amd import _lib
+    gc.collect()
+    gc.freeze()   # (the command switches the collector off for its one sample; here: no pause for what exists already)
+    lock, state = threading.Lock(), {"next": 0, "rc": 0, "error": None}
+
+    def work(worker_no):
+        try:
+            # worker 0 on the process's context (the one _warm_device is bringing up), the others on their own
+            ctx = _lib.default_context(device) if worker_no == 0 else _lib.Context(device)
+            while True:
+                with lock:
+                    g = state["next"]
+                    if g >= len(groups) or state["rc"] or state["error"]:
+                        return
+                    state["next"] = g + 1
+                rc = run_group(mode, groups[g], genome, ctx, g * per_group, len(samples))
+                if rc:
+                    with lock:
+                        state["rc"] = rc
+                    return
+        except BaseException as e:  # noqa: BLE001 — re-raised on the main thread
+            with lock:
+                state["error"] = state["error"] or e
+
+    threads = [threading.Thread(target=work, args=(k,), name="cohort-%d" % k) for k in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if state["error"] is not None:
+        raise state["error"]
+    return state["rc"]
 
 
 def entry():

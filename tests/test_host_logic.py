@@ -291,6 +291,15 @@ def test_device_inflate_share_policy(monkeypatch):
     assert bamio.default_device_inflate_percent() == 50
     monkeypatch.setattr(bamio, "host_cpus", lambda: 64.0)
     assert bamio.default_device_inflate_percent() == 0
+    # not a number: a warning and the default, never an exception (the module is imported by every entry point)
+    monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "on")
+    with pytest.warns(UserWarning):
+        bamio._ENV_WARNED.clear()
+        assert bamio.default_device_inflate_percent() == 0
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 8.0)
+    assert bamio.default_device_inflate_percent() == 50
+    # the class default is resolved when a file is loaded, not at import
+    assert bamio.AlignmentFile.device_inflate_percent is None
 
 
 def test_host_cpus_is_the_smaller_of_threads_and_quota():

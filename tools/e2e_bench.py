@@ -235,8 +235,10 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
         res["page_cache_dropped_before_first_run"] = drop_page_cache([fasta, fasta + ".fai"] + list(bams) + [b + ".bai" for b in bams])
         # three more passes behind the opt-out one when the readers' default gives the device a share of the sequence
         # slices' inflate work (bamio.default_device_inflate_percent): the same run with that share at 0
-        n_host_only = 3 if bamio.AlignmentFile.device_inflate_percent > 0 and repeat > 1 else 0
         default_share = bamio.AlignmentFile.device_inflate_percent
+        if default_share is None:
+            default_share = bamio.default_device_inflate_percent()
+        n_host_only = 3 if default_share > 0 and repeat > 1 else 0
         host_only_runs = []
         for rep_no in range(max(1, repeat) + 1 + n_host_only):
             # the last pass: the opt-out (svx_bam_set_verify(0), `--no_bgzf_crc`) — members inflated only as far as
@@ -303,7 +305,7 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
                           "cigar_ops": [int(f1._cols["n_cig"].sum()), int(f2._cols["n_cig"].sum())],
                           # the device leg of the sequence slices (svx_bam_set_device_inflate): its share of each call and
                           # the members the device inflated + verified for the two readers
-                          "device_inflate_percent": f1.device_inflate_percent,
+                          "device_inflate_percent": f1.effective_device_inflate_percent(),
                           "bgzf_members_inflated_on_device": [f1.device_members, f2.device_members]}
             del t1, t2, paired
             f1.close(), f2.close()
@@ -325,7 +327,7 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
                 last_facts = r.pop("facts")
             else:
                 runs.append(r)
-        bamio.AlignmentFile.device_inflate_percent = default_share
+        bamio.AlignmentFile.device_inflate_percent = None
         if host_only_runs:
             res["host_inflate_only_runs_total_s"] = host_only_runs
             res["host_inflate_only_total_s"] = sorted(host_only_runs)[len(host_only_runs) // 2]

@@ -1,0 +1,34 @@
+#!/bin/bash
+# round 6: rocprofv3 kernel-trace stats + a PMC pass for the SHIPPED k_bgzf_inflate (16 members per workgroup, 4 per wave)
+# on the 7 261-member SEQ probe (the members a full-size run's device leg takes).  Run on the GPU box:
+#   bash tools/r06_inflate_evidence.sh     -> gpurun_out/r06_infl/*
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/r06_infl; mkdir -p $out
+d=/tmp/svx_infl_ds; mkdir -p $d
+args="tools/gpu_inflate_probe.py --scale 0.25 --dataset $d --members 7261 --min-payload 8192 --counts 1000,3000,7261"
+python3 $args > $out/probe.json 2> $out/probe.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $args > $out/kt_probe.json 2>> $out/probe.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc1 -o p -- python3 $args > /dev/null 2>> $out/probe.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc2 -o p -- python3 $args > /dev/null 2>> $out/probe.err
+python3 - $out <<'PY'
+import csv, collections, sys, json, glob
+out=sys.argv[1]
+res={}
+for f in glob.glob(out+"/kt/*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if "inflate" in r["Name"] or "gather" in r["Name"]:
+            res.setdefault("kernel_stats", []).append({k: r[k] for k in ("Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs")})
+for p in ("pmc1","pmc2"):
+    agg=collections.defaultdict(list)
+    for f in glob.glob(out+"/"+p+"/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "k_bgzf_inflate" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]), float(r["Counter_Value"])))
+    # the launch with the most members = the longest one
+    for k,v in agg.items():
+        v.sort(); res.setdefault("pmc_longest_launch", {})[k]=v[-1][1]; res.setdefault("pmc_longest_launch_ns", {})[k]=v[-1][0]
+try: res["probe"]=json.load(open(out+"/probe.json"))
+except Exception as e: res["probe_error"]=str(e)
+json.dump(res, open(out+"/summary.json","w"), indent=1)
+print(json.dumps(res)[:3000])
+PY
