@@ -103,6 +103,11 @@ int svx_bam_set_device_inflate(svx_bam* bam, int percent);
 /* The share goes to the device only when it holds at least `members` BGZF members (default 3000: the leg's latency is one
  * member's decode time on the device, 45-55 ms, whatever their number — below that the threads are through sooner). */
 int svx_bam_set_device_inflate_min(svx_bam* bam, uint32_t members);
+/* A device has two inflate lanes (stream + page-locked ring each): a call that finds both taken — a process with more
+ * than two readers decoding at once, svim-asm-cohort's workers — gives its whole call to the threads (default, 0) or
+ * sleeps up to `milliseconds` for the first lane to come free: the better choice where the process's wall-clock is its
+ * CPU-seconds over a CPU quota and the device would otherwise idle. */
+int svx_bam_set_device_inflate_wait(svx_bam* bam, uint32_t milliseconds);
 uint64_t svx_bam_device_members(const svx_bam* bam);
 
 /* Index the records of contigs tids[0..n_tids) (NULL: every record of the file, unplaced ones

@@ -10,6 +10,8 @@ import ctypes
 import os
 import threading
 
+from svim_asm_amd import _timeline
+
 _state = {"thread": None, "device": None, "handle": None, "lib": None}
 
 
@@ -80,8 +82,10 @@ def start(device, lib_path):
             lib.svx_ctx_create.restype = ctypes.c_int
             lib.svx_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
             h = ctypes.c_void_p()
+            _timeline.mark("libsvx loaded")
             if lib.svx_ctx_create(int(device), ctypes.byref(h)) == 0:
                 _state["handle"], _state["lib"] = h, lib
+            _timeline.mark("device context created")
         except Exception:  # noqa: BLE001 — the regular path reports what is wrong
             pass
     _state["device"] = int(device)

@@ -483,8 +483,20 @@ def ingest_threads(n_files=1):
     """Threads one reader gets when `n_files` BAMs are walked / decoded at the same time (both haplotypes of a
     diploid sample): a quarter of the hardware threads in total, at most 64 and at least 8 per file.  The inflate
     work scales to 16-32 threads per file on the GPU hosts (shared nodes: more threads than free cores only
-    oversubscribe — tools/slice_probe.py, profiles/README.md)."""
+    oversubscribe — tools/slice_probe.py, profiles/README.md).
+    Under a CPU quota (cgroup cpu.max below the hardware threads: the GPU pool grants 16 CPUs of 256) the readers
+    together get as many threads as the quota has CPUs: more only spend a period's budget in a fraction of the period,
+    the whole process then stands still for the rest of it — and a process that calls exit() while it is throttled is
+    gone one period later.  Measured on the full-size sample, nine fresh `svim-asm diploid` processes each
+    (profiles/r06_cli_timeline.txt): 32 threads per reader 0.58-0.60 s, one or two periods throttled in every run, 0.10 s
+    from os._exit to gone; 8 per reader 0.49 s, no period throttled, 3 ms to gone."""
+    asked = os.environ.get("SVX_INGEST_THREADS")  # (experiments: tools/cli_timeline.py)
+    if asked and asked.isdigit() and int(asked) > 0:
+        return int(asked)
     hw = os.cpu_count() or 1
+    quota = host_cpus()
+    if quota < hw:
+        return int(max(2, round(quota / float(max(1, n_files)))))
     return int(max(1, min(64, max(8, hw // (4 * max(1, n_files))), hw)))
 
 
@@ -648,6 +660,7 @@ class AlignmentFile(object):
         pct = self.device_inflate_percent
         return default_device_inflate_percent() if pct is None else int(pct)
     device_inflate_min_members = 3000  # the share goes to the device only when it holds that many members (svx_bam.h)
+    device_inflate_wait_ms = 0         # how long a call waits for one of the device's two inflate lanes (svx_bam.h)
 
     @property
     def device_members(self):
@@ -689,6 +702,7 @@ class AlignmentFile(object):
             self._lib.svx_bam_set_pinned_device(self._h, -1 if self._pin_device is None else int(self._pin_device))
             self._lib.svx_bam_set_device_inflate(self._h, 0 if self._pin_device is None else self.effective_device_inflate_percent())
             self._lib.svx_bam_set_device_inflate_min(self._h, int(self.device_inflate_min_members))
+            self._lib.svx_bam_set_device_inflate_wait(self._h, int(self.device_inflate_wait_ms))
             if tids is None:
                 rc = self._lib.svx_bam_load(self._h, None, 0)
             else:

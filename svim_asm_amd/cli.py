@@ -6,7 +6,7 @@ import os
 import sys
 from time import localtime, strftime
 
-from svim_asm_amd import bamio, shard
+from svim_asm_amd import _timeline, bamio, shard
 from svim_asm_amd.fasta import FastaFile
 from svim_asm_amd.SVIM_COMBINE import write_vcf_table
 from svim_asm_amd.table import TYPE_ORDER
@@ -17,9 +17,9 @@ TYPE_LABELS = (("DEL", "deletion"), ("INV", "inversion"), ("INS", "insertion"), 
                ("DUP_INT", "interspersed duplication"), ("BND", "breakend"))
 
 
-def _open_file(path, options, one_shot=True):
+def _open_file(path, options, one_shot=True, reader_threads=None):
     f = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
-                            threads=bamio.ingest_threads(2 if options.sub == "diploid" else 1),
+                            threads=reader_threads or bamio.ingest_threads(2 if options.sub == "diploid" else 1),
                             verify=False if getattr(options, "no_bgzf_crc", False) else None)
     # The device's share of the sequence slices' inflate work (bamio.default_device_inflate_percent) pays where a
     # process's wall-clock is its CPU-seconds over a CPU quota — a process that handles sample after sample.  A one-shot
@@ -32,7 +32,7 @@ def _open_file(path, options, one_shot=True):
     return f
 
 
-def _open_ahead(path, options, one_shot=True):
+def _open_ahead(path, options, one_shot=True, reader_threads=None):
     """Start opening `path` (header, reference dictionary, index) on a thread; returns a function that waits and
     hands back the file — or raises what opening raised — at the point where the caller would have opened it."""
     import threading
@@ -40,7 +40,7 @@ def _open_ahead(path, options, one_shot=True):
 
     def run():
         try:
-            box["file"] = _open_file(path, options, one_shot)
+            box["file"] = _open_file(path, options, one_shot, reader_threads)
         except BaseException as e:  # noqa: BLE001 — re-raised by the caller at its own time
             box["error"] = e
     th = threading.Thread(target=run, daemon=True)
@@ -178,6 +178,7 @@ def _run(options):
 
 
 def _run_steps(options):
+    _timeline.mark("main starts")
     logging.info("****************** Start SVIM-asm, version {0} ******************".format(__version__))
     logging.info("CMD: python3 {0}".format(" ".join(sys.argv)))
     logging.info("WORKING DIR: {0}".format(os.path.abspath(options.working_dir)))
@@ -203,7 +204,11 @@ def _run_steps(options):
         aln_file2 = _open(options.bam_file2, "second", options, opened=second)
         if aln_file2 is None:
             return
+        _timeline.mark("files open")
         sv_candidates1, sv_candidates2 = _collect([aln_file1, aln_file2], options)
+        if _timeline.enabled():
+            from svim_asm_amd import SVIM_COLLECT
+            _timeline.mark("COLLECT done", stages=dict(SVIM_COLLECT.LAST_TIMING))
 
     try:
         reference = FastaFile(options.genome)
@@ -218,7 +223,11 @@ def _run_steps(options):
 
     if options.sub == "diploid":
         logging.info("****************** STEP 2: PAIR ******************")
+        _timeline.mark("PAIR starts")
         sv_candidates = shard.pair_sharded(sv_candidates1, sv_candidates2, reference, aln_file1, options)
+        if _timeline.enabled():
+            from svim_asm_amd import SVIM_COMBINE
+            _timeline.mark("PAIR done", stages={k: v for k, v in SVIM_COMBINE.LAST_TIMING.items() if k.startswith("pair_")})
     counts = sv_candidates.counts_by_type()
 
     logging.info("****************** STEP {0}: OUTPUT ******************".format(2 if options.sub == "haploid" else 3))
@@ -235,6 +244,9 @@ def _run_steps(options):
     types_to_output = [entry.strip() for entry in options.types.split(",")]
     write_vcf_table(sv_candidates, __version__, aln_file1.references, aln_file1.lengths, types_to_output, reference,
                     options, release_reference=False)  # (the process ends here: the kernel takes the mappings back)
+    if _timeline.enabled():
+        from svim_asm_amd import SVIM_COMBINE
+        _timeline.mark("VCF written", stages={k: v for k, v in SVIM_COMBINE.LAST_TIMING.items() if k.startswith("vcf_")})
     logging.info("Done.")
 
 

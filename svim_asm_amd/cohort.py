@@ -7,19 +7,21 @@ the groups in manifest order, so the ingest of one group — the BAM readers' ow
 inflate work on by default here — runs while another group is in PAIR or writing its VCF; at most K groups are in memory
 whatever the manifest's length.  The process pays interpreter start and HIP bring-up once.
 
-    svim-asm-cohort diploid MANIFEST GENOME [--cohort_workers K] [--cohort_group G] [the options of svim-asm diploid]
-    svim-asm-cohort haploid MANIFEST GENOME [--cohort_workers K] [--cohort_group G] [the options of svim-asm haploid]
+    svim-asm-cohort diploid MANIFEST GENOME [--cohort_workers K] [--cohort_group G] [--cohort_threads T] [the options of svim-asm diploid]
+    svim-asm-cohort haploid MANIFEST GENOME [--cohort_workers K] [--cohort_group G] [--cohort_threads T] [the options of svim-asm haploid]
 
 MANIFEST: one sample per line, whitespace-separated — working_dir bam (haploid) or working_dir bam1 bam2 (diploid);
 lines starting with # are skipped.  Every sample gets its own working_dir/variants.vcf, byte-identical to the one
-the single-sample command writes.  K defaults to 3 (2 below 12 CPUs' worth of time), G to 1; `--cohort_group 0` = the whole
-manifest in one submission (the round-5 behaviour).  The reference has no such mode; this is an addition on top of the
+the single-sample command writes.  K defaults to 4 (2 below 12 CPUs' worth of time), G to 1; `--cohort_group 0` = the whole
+manifest in one submission (the round-5 behaviour); T threads per BAM reader (default: the process's CPUs shared out among
+the readers in flight, default_reader_threads).  The reference has no such mode; this is an addition on top of the
 drop-in command, which is unchanged."""
+import gc
 import logging
 import os
 import sys
 
-from svim_asm_amd import SVIM_COLLECT, cli, shard
+from svim_asm_amd import SVIM_COLLECT, _timeline, cli, shard
 from svim_asm_amd.fasta import FastaFile
 from svim_asm_amd.SVIM_COMBINE import write_vcf_table
 from svim_asm_amd.SVIM_input_parsing import parse_arguments
@@ -57,28 +59,54 @@ def _take_option(rest, name, default):
     return out, value
 
 
+COHORT_DEVICE_INFLATE_PERCENT = 100
+COHORT_DEVICE_INFLATE_WAIT_MS = int(os.environ.get("SVX_COHORT_INFLATE_WAIT_MS") or 400)  # (the variable: tools/r06_cohort_ab.py)
+
+
 def default_workers():
     from svim_asm_amd import bamio
-    return 3 if bamio.host_cpus() >= 12 else 2
+    return 4 if bamio.host_cpus() >= 12 else 2
 
 
-def run_group(mode, group, genome, ctx, first_no, n_total):
+def default_reader_threads(workers, n_bams):
+    """Threads per BAM reader: the CPUs' worth of time the process gets (hardware threads or the cgroup's quota) shared out
+    among the readers of the groups in flight.  Under a quota (cpu.max) a process that runs more threads than it has CPUs
+    spends a period's budget in a fraction of the period and then stands still for the rest of it: the single-sample command
+    may do that once (its record walk is 1.3 CPU-seconds: inside one 100-ms budget of 16 CPUs), a process that works
+    continuously must not."""
+    from svim_asm_amd import bamio
+    # (one and a half times the CPUs: a reader's threads also wait — for pages, for the device's share of the inflate work)
+    return max(2, int(round(1.5 * bamio.host_cpus() / float(max(1, workers * n_bams)))))
+
+
+def run_group(mode, group, genome, ctx, first_no, n_total, workers=1, reader_threads=None):
     """One group of samples from the BAMs to the VCFs on the calling thread's device context: (opts, working dir, BAM
     paths) per sample.  Returns 0, or 1 after logging why an input was refused (as the command does)."""
+    from svim_asm_amd import bamio
     from svim_asm_amd.SVIM_COMBINE import pair_tables
     n_bams = 2 if mode == "diploid" else 1
     files = []
+    _timeline.mark("group starts", sample=first_no)
     for o, wd, bams in group:
         os.makedirs(wd, exist_ok=True)
-        # the files of a sample side by side; with the readers' own default for the device's share of the inflate work
-        # (the one-shot command opens its files without one: cli._open_file)
-        opened = [cli._open_ahead(path, o, one_shot=False) for path in bams]
+        # the files of a sample side by side, each reader with its share of the host's threads among the `workers` groups in
+        # flight.  The device's share of the inflate work (the one-shot command opens its files without one: cli._open_file):
+        # here the process's wall-clock is its CPU-seconds over the CPUs it may use and nobody waits for ONE sample, so
+        # the device takes the WHOLE sequence-slice call of every reader (unless SVX_BAM_DEVICE_INFLATE says otherwise) and a
+        # call that finds both of the device's inflate lanes taken sleeps for one instead of spending the CPU seconds
+        opened = [cli._open_ahead(path, o, one_shot=False, reader_threads=reader_threads or default_reader_threads(workers, n_bams))
+                  for path in bams]
         for k, path in enumerate(bams):
             f = cli._open(path, ("first", "second")[k] if n_bams == 2 else "", o, opened=opened[k])
             if f is None:
                 return 1
+            if bamio.env_device_inflate_percent() is None:
+                f.device_inflate_percent = COHORT_DEVICE_INFLATE_PERCENT
+            f.device_inflate_wait_ms = COHORT_DEVICE_INFLATE_WAIT_MS
             files.append(f)
+    _timeline.mark("files open", sample=first_no)
     tables = SVIM_COLLECT.collect_tables(files, group[0][0], ctx=ctx)
+    _timeline.mark("COLLECT done", sample=first_no)
     for k, (o, wd, bams) in enumerate(group):
         reference = FastaFile(genome)  # (write_final_vcf closes its FastaFile, SVIM_COMBINE.py:466-467: one per sample)
         mine, mine_files = tables[k * n_bams:(k + 1) * n_bams], files[k * n_bams:(k + 1) * n_bams]
@@ -86,11 +114,16 @@ def run_group(mode, group, genome, ctx, first_no, n_total):
         # as cli._run_steps: a damaged BGZF member among the inserted-sequence bytes must fail the run before a VCF is
         # written, also when nobody reads them (--symbolic_alleles)
         _ = candidates.seqs, [t.seqs for t in mine]
+        _timeline.mark("PAIR done", sample=first_no + k)
         write_vcf_table(candidates, cli.__version__, mine_files[0].references, mine_files[0].lengths,
                         [entry.strip() for entry in o.types.split(",")], reference, o)
+        _timeline.mark("VCF written", sample=first_no + k)
         logging.info("sample %d of %d: %s/variants.vcf", first_no + k + 1, n_total, wd)
     for f in files:
         f.close()
+    del tables, files
+    _timeline.mark("files closed", sample=first_no)
+    gc.collect()  # (the collector is off while the workers run — the command's 10-15 % —: what a group leaves in cycles goes here)
     return 0
 
 
@@ -108,7 +141,9 @@ def main(argv=None):
         return 2
     rest, workers = _take_option(rest, "--cohort_workers", 0)
     rest, per_group = _take_option(rest, "--cohort_group", 1)
+    rest, reader_threads = _take_option(rest, "--cohort_threads", 0)
     samples = read_manifest(manifest, n_bams)
+    _timeline.mark("cohort main")
     logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(levelname)-7.7s]  %(message)s")
     # one options object per sample through the reference's own parser (working dir and BAM paths differ)
     opts = [parse_arguments(cli.__version__, [mode, wd] + bams + [genome] + rest) for wd, bams in samples]
@@ -120,11 +155,11 @@ def main(argv=None):
     workers = max(1, min(workers or default_workers(), len(groups)))
     logging.info("****************** %d samples, %d BAM files: %d group(s) of up to %d, %d worker(s) ******************",
                  len(samples), len(samples) * n_bams, len(groups), per_group, workers)
-    import gc
     import threading
     from svim_asm_amd import _lib
     gc.collect()
-    gc.freeze()   # (the command switches the collector off for its one sample; here: no pause for what exists already)
+    gc.freeze()
+    gc.disable()  # as the command does for its one sample; every worker collects once per group (run_group)
     lock, state = threading.Lock(), {"next": 0, "rc": 0, "error": None}
 
     def work(worker_no):
@@ -137,7 +172,7 @@ def main(argv=None):
                     if g >= len(groups) or state["rc"] or state["error"]:
                         return
                     state["next"] = g + 1
-                rc = run_group(mode, groups[g], genome, ctx, g * per_group, len(samples))
+                rc = run_group(mode, groups[g], genome, ctx, g * per_group, len(samples), workers, reader_threads or None)
                 if rc:
                     with lock:
                         state["rc"] = rc
@@ -151,6 +186,9 @@ def main(argv=None):
         t.start()
     for t in threads:
         t.join()
+    gc.enable()
+    _timeline.mark("workers done")
+    _timeline.dump()
     if state["error"] is not None:
         raise state["error"]
     return state["rc"]

@@ -714,6 +714,60 @@ struct DeviceLanes {
 constexpr int kMaxLanes = 64;
 static DeviceLanes g_lanes[kMaxLanes];
 
+// ---- buffers kept between handles.  hipFree and hipHostFree wait for the device (every stream of the process) and unpin
+// pages: a process that opens and closes readers all the time (svim-asm-cohort: 30-170 ms per sample inside close(), during
+// which another worker's inflate kernels had to finish first) gives the buffers back here instead and the next handle of the
+// same device takes one that fits.  At most kKeptMax of either kind, each taken only for a need of at least half its size.
+struct KeptBuffer { void* p; size_t bytes; int device; };
+static std::mutex g_kept_mu;
+static std::vector<KeptBuffer> g_kept_dev, g_kept_host;
+constexpr size_t kKeptMax = 12;
+static bool kept_off() {
+    static const bool off = getenv("SVX_BAM_NO_BUFFER_CACHE") != nullptr;
+    return off;
+}
+static void* kept_take(std::vector<KeptBuffer>& v, int device, size_t need, size_t* got) {
+    if (kept_off()) return nullptr;
+    std::lock_guard<std::mutex> lock(g_kept_mu);
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].device == device && v[i].bytes >= need && v[i].bytes / 2 <= need + (4u << 20) && (best == v.size() || v[i].bytes < v[best].bytes))
+            best = i;
+    if (best == v.size()) return nullptr;
+    void* p = v[best].p;
+    *got = v[best].bytes;
+    v.erase(v.begin() + (long)best);
+    return p;
+}
+static bool kept_give(std::vector<KeptBuffer>& v, int device, void* p, size_t bytes) {
+    if (kept_off() || !p || !bytes) return false;
+    std::lock_guard<std::mutex> lock(g_kept_mu);
+    if (v.size() >= kKeptMax) return false;
+    v.push_back(KeptBuffer{p, bytes, device});
+    return true;
+}
+// device memory of at least `need` bytes on the current device (`device`): *got = its size; nullptr: out of memory
+static void* dev_buffer(int device, size_t need, size_t* got) {
+    if (void* p = kept_take(g_kept_dev, device, need, got)) return p;
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *got = need;
+    return p;
+}
+static void dev_buffer_done(int device, void* p, size_t bytes) {
+    if (p && !kept_give(g_kept_dev, device, p, bytes)) (void)hipFree(p);
+}
+static void* host_buffer(int device, size_t need, size_t* got) {
+    if (void* p = kept_take(g_kept_host, device, need, got)) return p;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *got = need;
+    return p;
+}
+static void host_buffer_done(int device, void* p, size_t bytes) {
+    if (p && !kept_give(g_kept_host, device, p, bytes)) (void)hipHostFree(p);
+}
+
 // A new stream and one host-to-device copy of `bytes` through it (page-locked source `src`, or a buffer of its own): the
 // first copy of a stream sets up its DMA path, and the first copy of this SIZE class does so once more (the command's
 // trace: 6-9 ms for the first 512 KiB part of a pool on a stream that had only moved 4 KiB) — done here, beside the walk.
@@ -786,10 +840,26 @@ static void inflate_lanes_bring_up(int device) {
 
 // start the lanes of `device` once per process (returns at once); the inflate lanes only for a reader that has a device
 // share (svx_bam_set_device_inflate): a one-shot command without one does not pay for two more streams and 32 MB of ring
+// The bring-up threads are detached and inside the HIP runtime for 10-50 ms: a process that leaves in order (exit(),
+// not _exit) within that time must not tear the runtime's statics and g_lanes down under them.  An exit handler
+// registered here — behind the runtime's own, so it runs before them — waits for the ones still running.
+static std::atomic<int> g_bring_ups_running{0};
+static void wait_for_bring_ups() {
+    for (int i = 0; i < 4000 && g_bring_ups_running.load() > 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+}
 static void lanes_start(int device, bool with_inflate) {
     if (device < 0 || device >= kMaxLanes) return;
-    std::call_once(g_lanes[device].once, [device] { std::thread(upload_lane_bring_up, device).detach(); });
-    if (with_inflate) std::call_once(g_lanes[device].inflate_once, [device] { std::thread(inflate_lanes_bring_up, device).detach(); });
+    static std::once_flag exit_hook;
+    std::call_once(exit_hook, [] { (void)std::atexit(wait_for_bring_ups); });
+    std::call_once(g_lanes[device].once, [device] {
+        g_bring_ups_running.fetch_add(1);
+        std::thread([device] { upload_lane_bring_up(device); g_bring_ups_running.fetch_sub(1); }).detach();
+    });
+    if (with_inflate)
+        std::call_once(g_lanes[device].inflate_once, [device] {
+            g_bring_ups_running.fetch_add(1);
+            std::thread([device] { inflate_lanes_bring_up(device); g_bring_ups_running.fetch_sub(1); }).detach();
+        });
 }
 
 static hipStream_t upload_stream(int device) {
@@ -821,6 +891,7 @@ struct svx_bam {
     std::vector<int64_t> sa_off;
     uint32_t* cigar = nullptr;
     bool cigar_pinned = false;
+    size_t cigar_pinned_bytes = 0;  // size of the page-locked buffer the pool lies in (>= the pool: it may come from the kept ones)
     std::vector<char> names;
     std::vector<uint8_t> aux;
     uint64_t blocks_inflated = 0, blocks_spanned = 0;
@@ -830,6 +901,7 @@ struct svx_bam {
     int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
     int inflate_pct = 0;  // share of a sequence-slice call whose members the device inflates (svx_bam_set_device_inflate)
     uint32_t inflate_min_members = 3000;  // ... when that share holds at least this many members
+    uint32_t inflate_wait_ms = 0;         // ... and how long a call waits for one of the device's inflate lanes to come free
     uint8_t* d_inflate = nullptr;  // the device leg's buffer, kept between calls
     size_t d_inflate_cap = 0;
     uint64_t device_members = 0;   // members the device has inflated and verified for this handle
@@ -851,16 +923,17 @@ struct svx_bam {
             d_valid = false;
         }
         if (!cigar) return;
-        if (cigar_pinned) (void)hipHostFree(cigar);
+        if (cigar_pinned) host_buffer_done(pin_device, cigar, cigar_pinned_bytes);
         else free(cigar);
         cigar = nullptr;
         cigar_pinned = false;
+        cigar_pinned_bytes = 0;
     }
     void free_device() {
         d_valid = false;
-        if (d_inflate) (void)hipFree(d_inflate);
+        if (d_inflate) dev_buffer_done(pin_device, d_inflate, d_inflate_cap);
         d_inflate = nullptr; d_inflate_cap = 0;
-        if (d_cigar) (void)hipFree(d_cigar);
+        if (d_cigar) dev_buffer_done(d_device, d_cigar, (size_t)d_cap * 4);
         if (up_done) (void)hipEventDestroy(up_done);
         d_cigar = nullptr; up_done = nullptr; up_stream = nullptr;
         d_cap = 0; d_ops = 0; d_device = -1;
@@ -878,12 +951,13 @@ struct svx_bam {
         bool ok = up_stream != nullptr;
         if (ok && !up_done) ok = hipEventCreateWithFlags(&up_done, hipEventDisableTiming) == hipSuccess;
         if (ok && d_cap < n_words) {
-            if (d_cigar) (void)hipFree(d_cigar);
+            if (d_cigar) dev_buffer_done(d_device, d_cigar, (size_t)d_cap * 4);
             d_cigar = nullptr; d_cap = 0;
             const uint64_t want = (n_words + (n_words >> 3) + 0x3FFFFu) & ~0x3FFFFull;  // 1 MiB steps, an eighth of slack
-            void* p = nullptr;
-            ok = hipMalloc(&p, want * 4) == hipSuccess;
-            if (ok) { d_cigar = static_cast<uint32_t*>(p); d_cap = want; }
+            size_t got = 0;
+            void* p = dev_buffer(pin_device, (size_t)want * 4, &got);
+            ok = p != nullptr;
+            if (ok) { d_cigar = static_cast<uint32_t*>(p); d_cap = got / 4; }
         }
         if (!ok) {
             (void)hipGetLastError();
@@ -1093,6 +1167,12 @@ extern "C" int svx_bam_set_device_inflate_min(svx_bam* b, uint32_t members) {
     return SVX_OK;
 }
 
+extern "C" int svx_bam_set_device_inflate_wait(svx_bam* b, uint32_t milliseconds) {
+    if (!b) return SVX_E_INVALID;
+    b->inflate_wait_ms = milliseconds;
+    return SVX_OK;
+}
+
 extern "C" uint64_t svx_bam_device_members(const svx_bam* b) { return b ? b->device_members : 0; }
 
 extern "C" int svx_bam_set_pinned_device(svx_bam* b, int device) {
@@ -1230,8 +1310,11 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     struct Early {
         void* pinned = nullptr;
         uint64_t words = 0;
-        ~Early() { if (pinned) (void)hipHostFree(pinned); }
+        size_t bytes = 0;
+        int device = -1;
+        ~Early() { if (pinned) host_buffer_done(device, pinned, bytes); }
     } early;
+    early.device = b->pin_device;
     std::atomic<uint64_t> cig_done(0), pieces_done(0);
     std::atomic<bool> early_claimed(false);
     const bool early_ok = b->pin_device >= 0 && nt > 1 && !filter_after && !getenv("SVX_BAM_LATE_POOL");
@@ -1251,12 +1334,15 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
             if (done * 4 >= pieces.size() * 3 && words) {
                 const uint64_t est = words * pieces.size() / done;
                 const uint64_t want = est + (est >> 3) + (64u << 10);
-                if (hipSetDevice(b->pin_device) == hipSuccess && hipHostMalloc(&early.pinned, want * 4, hipHostMallocDefault) == hipSuccess) {
-                    early.words = want;
+                if (hipSetDevice(b->pin_device) == hipSuccess && (early.pinned = host_buffer(b->pin_device, (size_t)want * 4, &early.bytes)) != nullptr) {
+                    early.words = early.bytes / 4;
                     if (b->d_valid) (void)hipEventSynchronize(b->up_done);  // (the previous pool's upload, long over)
+                    // from here on the device buffer may be freed, re-allocated or re-filled: it no longer holds the
+                    // previous load's pool, whatever becomes of this load (a failing piece returns with the old columns
+                    // still in place — svx_bam_device_pool must not hand out a buffer that merely has their op count)
+                    b->d_valid = false;
                     (void)b->prepare_device(want);
                 } else {
-                    (void)hipGetLastError();
                     early.pinned = nullptr;
                 }
             }
@@ -1310,9 +1396,10 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     if (early.pinned && early.words >= std::max<uint64_t>(1, n_cig)) {  // allocated beside the walk
         b->cigar = static_cast<uint32_t*>(early.pinned);
         b->cigar_pinned = true;
+        b->cigar_pinned_bytes = early.bytes;
         early.pinned = nullptr;
     } else if (b->pin_device >= 0 && hipSetDevice(b->pin_device) == hipSuccess &&
-        hipHostMalloc(&pinned, cig_bytes, hipHostMallocDefault) == hipSuccess) {
+               (pinned = host_buffer(b->pin_device, cig_bytes, &b->cigar_pinned_bytes)) != nullptr) {
         b->cigar = static_cast<uint32_t*>(pinned);
         b->cigar_pinned = true;
     } else {
@@ -1575,12 +1662,20 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             L.cv.wait_for(lock, std::chrono::milliseconds(30), [&] { return L.inflate_tried; });
         }
         if (leg_wanted && g_lanes[b->pin_device].inflate_up.load()) {
-            for (int k = 0; k < kInflateLanes && !lane; ++k) {
-                std::unique_lock<std::mutex> l(g_lanes[b->pin_device].inflate[k].busy, std::try_to_lock);
-                if (l.owns_lock()) {
-                    lane = &g_lanes[b->pin_device].inflate[k];
-                    lane_lock = std::move(l);
+            // one of the device's lanes; all taken (more calls in flight than lanes: a process that handles several
+            // samples at once): the threads take everything — or, where the caller would rather wait than spend the CPU
+            // seconds (svx_bam_set_device_inflate_wait), a sleeping wait for the first lane that comes free
+            const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(b->inflate_wait_ms);
+            for (;;) {
+                for (int k = 0; k < kInflateLanes && !lane; ++k) {
+                    std::unique_lock<std::mutex> l(g_lanes[b->pin_device].inflate[k].busy, std::try_to_lock);
+                    if (l.owns_lock()) {
+                        lane = &g_lanes[b->pin_device].inflate[k];
+                        lane_lock = std::move(l);
+                    }
                 }
+                if (lane || std::chrono::steady_clock::now() >= give_up) break;
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
             }
             if (lane) n_g = (uint32_t)((uint64_t)n * (uint64_t)b->inflate_pct / 100 / kRun * kRun);
         }
@@ -1650,12 +1745,13 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             const uint64_t need = o_packed + up256(packed_bytes + 8);
             if (ok && g_members && n_pc) {
                 if (b->d_inflate_cap < need) {
-                    if (b->d_inflate) (void)hipFree(b->d_inflate);
+                    if (b->d_inflate) dev_buffer_done(b->pin_device, b->d_inflate, b->d_inflate_cap);
                     b->d_inflate = nullptr;
                     b->d_inflate_cap = 0;
-                    void* pdev = nullptr;
-                    ok = hipMalloc(&pdev, need + (need >> 3)) == hipSuccess;
-                    if (ok) { b->d_inflate = static_cast<uint8_t*>(pdev); b->d_inflate_cap = need + (need >> 3); }
+                    size_t got = 0;
+                    void* pdev = dev_buffer(b->pin_device, need + (need >> 3), &got);
+                    ok = pdev != nullptr;
+                    if (ok) { b->d_inflate = static_cast<uint8_t*>(pdev); b->d_inflate_cap = got; }
                 }
             } else {
                 ok = false;
@@ -1739,6 +1835,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             leg_o_status = o_status;
             leg_o_packed = o_packed;
         }
+        uint32_t pull_hi = n;  // the threads take the slices [next, pull_hi)
         auto pull = [&]() {
             timespec c0;
             clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
@@ -1748,8 +1845,8 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             State st;
             for (;;) {
                 const uint32_t lo = next.fetch_add(kRun);
-                if (lo >= n || failed.load()) break;
-                work_on(c, st, lo, std::min(n, lo + kRun));
+                if (lo >= pull_hi || failed.load()) break;
+                work_on(c, st, lo, std::min(pull_hi, lo + kRun));
             }
             inflated.fetch_add(st.inf[0].n_blocks + st.inf[1].n_blocks);
             if (debug) {  // wall time far above CPU time: the thread was waiting for a core, not working
@@ -1773,12 +1870,20 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             ok = ok && hipMemcpy(g_status.data(), b->d_inflate + leg_o_status, (size_t)g_members * 4, hipMemcpyDeviceToHost) == hipSuccess &&
                  hipMemcpy(g_packed.data(), b->d_inflate + leg_o_packed, g_packed.size() - 8, hipMemcpyDeviceToHost) == hipSuccess;
             if (!ok) {
+                // a device error BEHIND the launch (every failure in front of it falls back to the threads above): the host
+                // decoder takes the leg's slices now — a transient device error must not fail a run the host can finish,
+                // and the results never depend on the share
                 (void)hipGetLastError();
-                return fail(b, SVX_E_HIP, "svx_bam_seq_slices: the device leg failed");
+                (void)hipStreamSynchronize(lane->stream);  // nothing of the failed leg is still reading the ring
+                (void)hipGetLastError();
+                next.store(0);
+                pull_hi = n_g;
+                b->pool.run((int)nt, pull);
+                g_members = 0;
             }
             for (uint32_t m = 0; m < g_members; ++m)
                 if (g_status[m] != 0) failed.store(true);  // malformed stream, wrong length or CRC32: as the host decoder judges
-            if (!failed.load()) {
+            if (ok && !failed.load()) {
                 // unpack: piece k of the leg (plans in order) lies at g_dst_off[k] of the read-back
                 std::vector<uint32_t> first_piece(plans.size() + 1, 0);
                 for (size_t r = 0; r < plans.size(); ++r) first_piece[r + 1] = first_piece[r] + (uint32_t)plans[r].pieces.size();

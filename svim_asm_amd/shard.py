@@ -77,9 +77,20 @@ def _rendezvous_path():
 
 def _job_token():
     """What the ranks of ONE job share and another job of the same user (same MASTER_PORT, no run id: the same socket
-    path) does not: SVX_JOB_TOKEN if set, else the launcher's run id, else the parent process — a launcher starts all
-    ranks of a node from one agent.  Ranks started by hand from different shells set SVX_JOB_TOKEN."""
-    return (os.environ.get("SVX_JOB_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or "ppid-%d" % os.getppid()).encode()
+    path) does not: SVX_JOB_TOKEN if set; else SVX_RENDEZVOUS — the documented way to name a job whose ranks are started
+    by hand, from different shells or through per-rank wrappers —; else the launcher's run id (torchrun's default, the
+    constant "none", names nothing); else the parent process together with the job's address and port — a launcher starts
+    all ranks of a node from one agent."""
+    token = os.environ.get("SVX_JOB_TOKEN")
+    if token:
+        return token.encode()
+    named = os.environ.get("SVX_RENDEZVOUS")
+    if named:
+        return ("rendezvous-" + named).encode()
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID")
+    if run_id and run_id != "none":
+        return ("run-" + run_id).encode()
+    return ("ppid-%d-%s-%s" % (os.getppid(), os.environ.get("MASTER_ADDR", ""), os.environ.get("MASTER_PORT", ""))).encode()
 
 
 def _send_msg(sock, parts):

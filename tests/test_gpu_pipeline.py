@@ -193,20 +193,23 @@ def test_large_alleles_pair_like_the_oracle(svx_ctx):
 
 
 def test_cohort_command_writes_the_single_sample_vcfs(svx_ctx, tmp_path):
-    """svim-asm-cohort: three diploid samples (the config-1 BAMs in both orders) — COLLECT of all six BAMs as ONE
-    device submission — write, per sample, the VCF the real reference wrote for that sample alone; and the same with
-    the submission cut into several by the op-count limit (here lowered to a few thousand ops)."""
+    """svim-asm-cohort: three diploid samples (the config-1 BAMs in both orders) write, per sample, the VCF the real
+    reference wrote for that sample alone — as a stream (a group per sample, the default number of worker threads, each with
+    a device context of its own), with COLLECT of all six BAMs as ONE device submission (--cohort_group 0), the same with
+    that submission cut into several by the op-count limit (here lowered to a few thousand ops), and as groups of two
+    samples over three workers."""
     from svim_asm_amd import SVIM_COLLECT, cohort
     g = os.path.join(GOLD, "config1")
     rows = [("s1", "hap1.bam", "hap2.bam", "diploid_default"), ("s2", "hap2.bam", "hap1.bam", None), ("s3", "hap1.bam", "hap2.bam", "diploid_default")]
     manifest = tmp_path / "cohort.tsv"
     manifest.write_text("# working_dir bam1 bam2\n" + "".join("%s %s %s\n" % (tmp_path / wd, os.path.join(g, a), os.path.join(g, b)) for wd, a, b, _ in rows))
-    for limit in (None, 4000):
+    for limit, extra in ((None, []), (None, ["--cohort_group", "0"]), (4000, ["--cohort_group=0", "--cohort_workers", "1"]),
+                         (None, ["--cohort_workers", "3", "--cohort_group", "2"])):
         old = SVIM_COLLECT.MAX_OPS_PER_SUBMISSION
         if limit:
             SVIM_COLLECT.MAX_OPS_PER_SUBMISSION = limit
         try:
-            assert cohort.main(["diploid", str(manifest), os.path.join(g, "ref.fa")]) == 0
+            assert cohort.main(["diploid", str(manifest), os.path.join(g, "ref.fa")] + extra) == 0
         finally:
             SVIM_COLLECT.MAX_OPS_PER_SUBMISSION = old
         for wd, a, b, golden in rows:

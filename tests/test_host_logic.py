@@ -322,3 +322,25 @@ def test_command_opens_its_bams_without_a_device_share(monkeypatch, tmp_path):
     monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "40")
     assert cli._open_file(bams[0], opts).device_inflate_percent == 40
     assert bamio.AlignmentFile(bams[0], device=0).device_inflate_percent == 50  # (the library's readers keep their default)
+
+
+def test_job_token_names_the_job_not_the_shell(monkeypatch):
+    """shard._job_token: SVX_JOB_TOKEN wins; SVX_RENDEZVOUS alone names a hand-launched job whatever shell or wrapper
+    started each rank; torchrun's default run id "none" names nothing (the parent process + address + port do)."""
+    import os
+    from svim_asm_amd import shard
+    for name in ("SVX_JOB_TOKEN", "SVX_RENDEZVOUS", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    by_parent = shard._job_token()
+    assert str(os.getppid()).encode() in by_parent and b"29511" in by_parent
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    assert shard._job_token() == by_parent
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-7")
+    assert shard._job_token() == b"run-job-7"
+    monkeypatch.setenv("SVX_RENDEZVOUS", "my-hand-launched-job")
+    assert shard._job_token() == b"rendezvous-my-hand-launched-job"
+    monkeypatch.setattr(os, "getppid", lambda: 1)  # another shell: the same token
+    assert shard._job_token() == b"rendezvous-my-hand-launched-job"
+    monkeypatch.setenv("SVX_JOB_TOKEN", "t0k")
+    assert shard._job_token() == b"t0k"

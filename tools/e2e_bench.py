@@ -181,8 +181,66 @@ def run_samples(n_procs, bams, fasta, out, n_devices, check):
     return leg
 
 
+def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1):
+    """`svim-asm-cohort diploid` as ONE fresh process over `n_samples` own copies of the sample's BAMs (the genome FASTA
+    is shared, as it is for a real cohort): samples per second over the wall-clock of the process (interpreter start and
+    HIP bring-up included, paid once), CPU seconds per sample, peak resident set, every VCF against the reference's
+    digest.  The headline's own workload — many samples through one device — from the BAMs to the VCFs."""
+    import resource
+    dirs, copied = [], True
+    for k in range(n_samples):
+        d = os.path.join(out, "cohort_copy_%d" % k)
+        os.makedirs(d, exist_ok=True)
+        for src in list(bams) + [b + ".bai" for b in bams]:
+            dst = os.path.join(d, os.path.basename(src))
+            if not os.path.exists(dst):
+                try:
+                    shutil.copyfile(src, dst)
+                except OSError:  # no room for real copies: links (the readers then share page-cache pages — said in the record)
+                    copied = False
+                    if os.path.exists(dst):
+                        os.unlink(dst)
+                    os.link(src, dst)
+        shutil.rmtree(os.path.join(d, "wd"), ignore_errors=True)
+        dirs.append(d)
+    manifest = os.path.join(out, "cohort_manifest_%d.txt" % n_samples)
+    with open(manifest, "w") as f:
+        for d in dirs:
+            f.write("%s %s %s\n" % (os.path.join(d, "wd"), os.path.join(d, "hap1.bam"), os.path.join(d, "hap2.bam")))
+    env = dict(os.environ)
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(name, None)
+    argv = [sys.executable, os.path.join(ROOT, "bin", "svim-asm-cohort"), "diploid", manifest, fasta, "--device", str(device)]
+    if workers:
+        argv += ["--cohort_workers", str(workers)]
+    if group != 1:
+        argv += ["--cohort_group", str(group)]
+    ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    t0 = time.perf_counter()
+    p = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    wall = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    oks = []
+    for d in dirs:
+        path = os.path.join(d, "wd", "variants.vcf")
+        oks.append(check(masked(path)) if os.path.exists(path) else False)
+    cpu = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
+    leg = {"samples": n_samples, "workers": workers or "default", "group": group, "wall_s": wall, "samples_per_s": n_samples / wall,
+           "rc": p.returncode, "cpu_seconds": cpu, "cpu_seconds_per_sample": cpu / n_samples, "cpu_quota_cpus": cpu_quota(),
+           "peak_rss_mb_of_any_child_so_far": ru1.ru_maxrss / 1024.0,  # (RUSAGE_CHILDREN: the largest child this process has waited for)
+           "own_copies_of_the_bams": copied, "shared_genome_fasta": True, "vcf_matches_real_reference_digest": oks}
+    log = [l for l in p.stdout.split("\n") if " worker(s) " in l]
+    if log:
+        leg["plan"] = log[0].split("******************")[1].strip() if "******************" in log[0] else log[0][-120:]
+    if p.returncode != 0 or any(o is False for o in oks):
+        leg["output_tail"] = p.stdout[-1500:]
+    for d in dirs:
+        shutil.rmtree(d, ignore_errors=True)
+    return leg
+
+
 def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None, threads=0, repeat=1, device=0,
-            ranks=(1, 2, 4), n_devices=1, mean_m=2000, in_process=True, seed=3, min_gap=1500, bam_level=1, samples=()):
+            ranks=(1, 2, 4), n_devices=1, mean_m=2000, in_process=True, seed=3, min_gap=1500, bam_level=1, samples=(), cohort=()):
     """Generate (or reuse) the dataset, run the product pipeline `repeat` times in this process with phase
     clocks (in_process=False: the caller must not touch the GPU — only the child processes run), then the
     command line as fresh processes (1 rank and the sharded runs), then the checker."""
@@ -388,6 +446,8 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
         res["cli_all_wall_s"] = sharded[0]["all_wall_s"]
     if samples:
         res["samples"] = [run_samples(n, bams, fasta, out, n_devices, check) for n in samples]
+    if cohort:
+        res["cohort"] = [run_cohort(n, bams, fasta, out, device, check) for n in cohort]
 
     if with_oracle is None:
         with_oracle = not same_inputs
@@ -416,6 +476,8 @@ def main():
                     "oracle/make_golden.py config5 (10x small-indel density, crowded partitions, > 131072 candidates)")
     ap.add_argument("--samples", default="", help="comma-separated process counts: N independent `svim-asm diploid` processes at "
                     "once, each on its own copy of the sample (the mode that scales across GPUs)")
+    ap.add_argument("--cohort", default="", help="comma-separated sample counts: `svim-asm-cohort diploid` as one process over N own "
+                    "copies of the sample's BAMs (samples per second, CPU seconds per sample, peak RSS)")
     ap.add_argument("--with-oracle", action="store_true", help="run the CPU oracle pipeline even when the real reference's digest is available")
     ap.add_argument("--dataset", default=None, help="directory holding ref.fa / hap1.bam / hap2.bam from an earlier --keep run")
     ap.add_argument("--bam-level", type=int, default=1, help="zlib level of the BGZF members of the generated BAMs (1: the "
@@ -434,7 +496,8 @@ def main():
                              args.threads, args.repeat, ranks=tuple(int(x) for x in args.ranks.split(",") if x),
                              n_devices=args.devices, mean_m=args.mean_m, in_process=not args.no_in_process, seed=seed,
                              min_gap=min_gap, bam_level=args.bam_level,
-                             samples=tuple(int(x) for x in args.samples.split(",") if x))))
+                             samples=tuple(int(x) for x in args.samples.split(",") if x),
+                             cohort=tuple(int(x) for x in args.cohort.split(",") if x))))
 
 
 if __name__ == "__main__":
