@@ -483,21 +483,33 @@ def ingest_threads(n_files=1):
     """Threads one reader gets when `n_files` BAMs are walked / decoded at the same time (both haplotypes of a
     diploid sample): a quarter of the hardware threads in total, at most 64 and at least 8 per file.  The inflate
     work scales to 16-32 threads per file on the GPU hosts (shared nodes: more threads than free cores only
-    oversubscribe — tools/slice_probe.py, profiles/README.md).
-    Under a CPU quota (cgroup cpu.max below the hardware threads: the GPU pool grants 16 CPUs of 256) the readers
-    together get as many threads as the quota has CPUs: more only spend a period's budget in a fraction of the period,
-    the whole process then stands still for the rest of it — and a process that calls exit() while it is throttled is
-    gone one period later.  Measured on the full-size sample, nine fresh `svim-asm diploid` processes each
-    (profiles/r06_cli_timeline.txt): 32 threads per reader 0.58-0.60 s, one or two periods throttled in every run, 0.10 s
-    from os._exit to gone; 8 per reader 0.49 s, no period throttled, 3 ms to gone."""
+    oversubscribe — tools/slice_probe.py, profiles/README.md).  The policy of a long-lived process that handles one
+    sample at a time: under a CPU quota its bursts run on a fresh period's budget (in-process BAM -> VCF of the full-size
+    sample 0.16-0.18 s; with quota_threads below 0.20-0.21).  A fresh command and a process that works continuously
+    size their readers by the quota instead: quota_threads."""
     asked = os.environ.get("SVX_INGEST_THREADS")  # (experiments: tools/cli_timeline.py)
     if asked and asked.isdigit() and int(asked) > 0:
         return int(asked)
     hw = os.cpu_count() or 1
-    quota = host_cpus()
-    if quota < hw:
-        return int(max(2, round(quota / float(max(1, n_files)))))
     return int(max(1, min(64, max(8, hw // (4 * max(1, n_files))), hw)))
+
+
+def quota_threads(n_files=1, processes=1):
+    """Threads per reader for a process whose start-up or steady work shares the CPU-quota periods with its readers
+    (`svim-asm`, the ranks of a sharded run, svim-asm-cohort): under a quota (cgroup cpu.max below the hardware threads:
+    the GPU pool grants 16 CPUs of 256) the readers of all `processes` together get as many threads as the quota has CPUs
+    — more only spend a period's budget in a fraction of the period, the whole process then stands still for the rest
+    of it, and a process that calls exit() while it is throttled is gone one period later.  Measured on the full-size
+    sample, nine fresh `svim-asm diploid` processes each (profiles/r06_cli_timeline.txt): 32 threads per reader
+    0.58-0.60 s, one or two periods throttled in every run, 0.10 s from os._exit to gone; 8 per reader 0.46-0.49 s, no
+    period throttled, 3 ms to gone.  Without a quota: ingest_threads."""
+    asked = os.environ.get("SVX_INGEST_THREADS")
+    if asked and asked.isdigit() and int(asked) > 0:
+        return int(asked)
+    hw, quota = os.cpu_count() or 1, host_cpus()
+    if quota < hw:
+        return int(max(2, round(quota / float(max(1, n_files) * max(1, processes)))))
+    return ingest_threads(n_files)
 
 
 def host_cpus():

@@ -19,16 +19,18 @@ TYPE_LABELS = (("DEL", "deletion"), ("INV", "inversion"), ("INS", "insertion"), 
 
 def _open_file(path, options, one_shot=True, reader_threads=None):
     f = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
-                            threads=reader_threads or bamio.ingest_threads(2 if options.sub == "diploid" else 1),
+                            threads=reader_threads or bamio.quota_threads(2 if options.sub == "diploid" else 1, shard.world()[1]),
                             verify=False if getattr(options, "no_bgzf_crc", False) else None)
-    # The device's share of the sequence slices' inflate work (bamio.default_device_inflate_percent) pays where a
-    # process's wall-clock is its CPU-seconds over a CPU quota — a process that handles sample after sample.  A one-shot
-    # command's wall-clock is start-up: measured on the full-size sample, interleaved (profiles/r05_cli_device_leg.txt),
-    # 0.68-0.71 s with the share against 0.64-0.69 s without, four rank processes 1.13-1.27 against 1.04-1.06 s.  So the
-    # command runs without it unless SVX_BAM_DEVICE_INFLATE asks for it (svim-asm-cohort keeps the readers' default).
+    # The device's share of the sequence slices' inflate work.  Under a CPU quota the command's readers run on as many
+    # threads as the quota has CPUs (bamio.quota_threads) and the device takes the WHOLE call: nine fresh processes on the
+    # full-size sample, interleaved (profiles/r06_cli_timeline*.txt), 0.425 s median and 2.0 CPU-seconds with the share against
+    # 0.495 s and 3.3 without, no quota period throttled either way.  (Round 5, readers on 32 threads each: 0.68-0.71 s with a
+    # share of one half against 0.64-0.69 s without — the start-up and the exit sat in throttled periods whatever the
+    # device took.)  With a core per thread the host decodes the call in 45 ms and the leg's 60-75 ms would be the longer
+    # path: no share.  SVX_BAM_DEVICE_INFLATE overrides; svim-asm-cohort sets its own (cohort.py).
     if one_shot:
         asked = bamio.env_device_inflate_percent()
-        f.device_inflate_percent = 0 if asked is None else asked
+        f.device_inflate_percent = asked if asked is not None else (100 if bamio.host_cpus() <= 24 else 0)
     return f
 
 

@@ -64,8 +64,10 @@ def _worker(rank, world, port, q, transport):
             shard.shutdown()
 
 
-@pytest.mark.parametrize("transport", ["gloo", "socket"])
-def test_sharded_collect_and_pair_equal_single_process(transport):
+@pytest.mark.parametrize("transport,world", [("gloo", 2), ("socket", 2), ("socket", 8)])
+def test_sharded_collect_and_pair_equal_single_process(transport, world):
+    """world 8 on the three contigs of the config-1 sample: five ranks own no contig at all — they still meet the
+    others at both exchanges and end with the same tables (the rendezvous of eight, empty shards, header-order re-assembly)."""
     import torch.multiprocessing as mp
     from oracle import orc, run_oracle, svim_oracle
     from svim_asm_amd import bamio
@@ -73,10 +75,10 @@ def test_sharded_collect_and_pair_equal_single_process(transport):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in procs]
+    results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -92,7 +94,37 @@ def test_sharded_collect_and_pair_equal_single_process(transport):
         assert c1 == exp1, "rank %d collect order differs (hap 1)" % rank
         assert c2 == exp2, "rank %d collect order differs (hap 2)" % rank
         assert paired == exp_pair, "rank %d pair order differs" % rank
-        assert 0 < n1 < total, "rank %d indexed %d of %d records: contig-restricted ingest" % (rank, n1, total)
+        assert n1 < total, "rank %d indexed %d of %d records: contig-restricted ingest" % (rank, n1, total)
+    assert sorted(r[0] for r in results) == list(range(world))
+    with_records = sum(1 for r in results if r[4] > 0)
+    n_contigs = len(bamio.AlignmentFile(os.path.join(GOLD, "hap1.bam")).references)
+    assert with_records == min(world, n_contigs), "every contig owned by exactly one rank, the other ranks empty"
+    assert sum(r[4] for r in results) == total, "the ranks' records add up to the file's: no contig twice, none missing"
+
+
+def test_eight_rank_plan_on_the_full_size_spans():
+    """The rank plan of BASELINE config 4 (8 GPUs) on the full-size diploid sample, from the compressed bytes the two
+    `.bai` indices attribute to each contig (tests/golden/full_bai_spans.json, tools/dump_bai_spans.py): every contig
+    owned exactly once, the heaviest rank within 1.15 of the mean for 2, 4 and 8 ranks, the same plan on every rank
+    (deterministic), and the merged rows back in header order whatever the owners are."""
+    import json
+    import numpy as np
+    from svim_asm_amd.shard import lpt_assign
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "full_bai_spans.json")))
+    w = np.asarray(fx["files"]["hap1.bam"]["contig_spans"], dtype=np.int64) + np.asarray(fx["files"]["hap2.bam"]["contig_spans"], dtype=np.int64)
+    assert len(w) == len(fx["references"]) == 24 and (w > 0).all()  # chr1..22, X, Y
+    for size in (2, 4, 8):
+        owner = lpt_assign(w, size)
+        assert owner == lpt_assign(list(w), size) and len(owner) == len(w) and set(owner) == set(range(size))
+        loads = np.bincount(owner, weights=w, minlength=size)
+        assert loads.sum() == w.sum()
+        assert loads.max() <= 1.15 * w.sum() / size, (size, loads.max() / (w.sum() / size))
+        # re-assembly as collect_sharded does it: every rank's rows carry their contig index; a stable sort by it puts
+        # the concatenation of the ranks' parts (each in header order for its own contigs) back in header order
+        parts = [np.array([c for c in range(len(w)) if owner[c] == r for _ in range(3)]) for r in range(size)]
+        rec_tid = np.concatenate(parts)
+        merged = rec_tid[np.argsort(rec_tid, kind="stable")]
+        assert (merged == np.repeat(np.arange(len(w)), 3)).all()
 
 
 def test_exchange_socket_lives_in_a_private_directory(tmp_path, monkeypatch):
