@@ -426,252 +426,6 @@ __global__ __launch_bounds__(kThreads) SVX_INFL_OCCUPANCY void k_bgzf_inflate(In
     a.status[m] = st;
 }
 
-// ---- the lanes of a wave IN STEP (round 6).  k_bgzf_inflate above lets every lane run its own member's decode loop:
-// the lanes are at different points of their streams (literal / match / refill / block header), every distinct path is
-// issued for the whole wave and ends in its own wait — 157 VALU + 92 SALU instructions per decoded symbol of a wave
-// (profiles/r04_pmc_inflate.json), two of 64 lanes active per VALU instruction on average (r06_inflate_shipped_kernel.json).
-// Here ONE wave holds the sixteen members of a workgroup (same LDS tables per member, same four workgroups per CU) and
-// all its lanes go through one loop body per step — a state per lane, a block of code per state, executed when any lane
-// is in it:
-//   HEADER   block header, code lengths, table construction (the code above, per lane; rare: a few blocks per member)
-//   SYM      ONE literal/length symbol by table look-up; a literal is stored; a length symbol also takes its extra bits,
-//            the distance symbol and its extra bits in the same step and requests the first eight source bytes
-//   COPY     stores the eight bytes requested a step earlier and requests the next eight — the read-back of the member's own
-//            earlier output travels while the other lanes decode; distances below eight go byte by byte (rare)
-//   STORED   up to four bytes of a stored block per step
-// so a step costs its ~150 instructions once for all sixteen members instead of once per member.  CRC-32 as a second
-// pass, the lanes in step as well, sixteen bytes per lane and step.
-enum { LS_HEADER = 0, LS_SYM = 1, LS_COPY = 2, LS_STORED = 3, LS_DONE = 4 };
-
-__global__ __launch_bounds__(64) void k_bgzf_inflate_ls(InfArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    Lds& s = *reinterpret_cast<Lds*>(lds_raw);
-    const int lane = (int)threadIdx.x;
-    for (int i = threadIdx.x; i < 256; i += 64) {
-        uint32_t c = (uint32_t)i;
-        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        s.crc_table4[0][i] = c;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += 64) {
-        uint32_t c = s.crc_table4[0][i];
-        for (int t = 1; t < 4; ++t) {
-            c = s.crc_table4[0][c & 0xFFu] ^ (c >> 8);
-            s.crc_table4[t][i] = c;
-        }
-    }
-    __syncthreads();
-    const uint32_t m = blockIdx.x * kLanes + (uint32_t)lane;
-    const bool mine = lane < kLanes && m < a.n;
-    if (!mine) return;  // (the wave's other lanes: no barrier from here on)
-    const uint8_t* in = a.in + a.in_off[m];
-    const uint32_t in_len = a.in_len[m], isize = a.isize[m];
-    uint8_t* out = a.out + a.out_off[m];
-    Bits b;
-    bits_init(b, in, in_len);
-    uint32_t produced = 0, st = ST_OK;
-    int state = LS_HEADER;
-    if (isize > 65536u) {  // no BGZF member is longer: a wrong trailer must not move the output limit
-        st = ST_SIZE;
-        state = LS_DONE;
-    }
-    bool last = false;
-    Counts c_ll, c_d;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c_ll.w[k] = c_d.w[k] = 0;
-    uint32_t cp_left = 0, cp_dist = 0, cp_dst = 0;  // COPY: bytes still to request, the distance, where the next store goes
-    uint64_t cp_data = 0;
-    bool cp_have = false;
-    uint32_t stored_left = 0;
-    for (;;) {
-        if (state == LS_HEADER) {
-            last = bits_get(b, 1) != 0;
-            const uint32_t type = bits_get(b, 2);
-            if (type == 0) {  // stored: skip to the byte boundary, LEN / NLEN, raw bytes
-                const uint32_t drop = b.cnt & 7u;
-                b.buf >>= drop;
-                b.cnt -= drop;
-                const uint32_t len = bits_get(b, 16), nlen = bits_get(b, 16);
-                if ((len ^ 0xFFFFu) != nlen) { st = ST_BAD_STREAM; state = LS_DONE; }
-                else if (produced + len > isize) { st = ST_SIZE; state = LS_DONE; }
-                else { stored_left = len; state = LS_STORED; }
-            } else if (type == 3) {
-                st = ST_BAD_STREAM; state = LS_DONE;
-            } else {
-                bool good = true;
-                if (type == 1) {  // fixed codes
-                    for (int i = 0; i < 144; ++i) len_set(s, i, lane, 8);
-                    for (int i = 144; i < 256; ++i) len_set(s, i, lane, 9);
-                    for (int i = 256; i < 280; ++i) len_set(s, i, lane, 7);
-                    for (int i = 280; i < kLL; ++i) len_set(s, i, lane, 8);
-                    for (int i = 0; i < kDist; ++i) len_set(s, kLL + i, lane, 5);
-                    huff_construct(s.cnt_ll, s.sym_ll, s, 0, kLL, lane);
-                    huff_construct(s.cnt_d, s.sym_d, s, kLL, kDist, lane);
-                } else {  // dynamic codes (as in k_bgzf_inflate)
-                    const uint32_t nlen = bits_get(b, 5) + 257, ndist = bits_get(b, 5) + 1, ncode = bits_get(b, 4) + 4;
-                    good = nlen <= 286 && ndist <= 30;
-                    if (good) {
-                        for (int i = 0; i < 19; ++i) len_set(s, i, lane, 0);
-                        for (uint32_t i = 0; i < ncode; ++i) len_set(s, kClOrder[i], lane, bits_get(b, 3));
-                        good = huff_construct(s.cnt_d, s.sym_d, s, 0, 19, lane) == 0;  // (zlib: must be complete)
-                    }
-                    if (good) {
-                        const Counts cl_counts = load_counts(s.cnt_d, lane);
-                        uint32_t idx = 0;
-                        while (good && idx < nlen + ndist) {
-                            const int sym = huff_walk(b, cl_counts, s.sym_d, lane);
-                            if (sym < 0) { good = false; }
-                            else if (sym < 16) { len_set(s, (int)idx++, lane, (uint32_t)sym); }
-                            else {
-                                uint32_t prev = 0, rep = 0;
-                                if (sym == 16) {
-                                    if (idx == 0) good = false;
-                                    else { prev = len_get(s, (int)idx - 1, lane); rep = 3 + bits_get(b, 2); }
-                                } else if (sym == 17) {
-                                    rep = 3 + bits_get(b, 3);
-                                } else {
-                                    rep = 11 + bits_get(b, 7);
-                                }
-                                if (good && idx + rep > nlen + ndist) good = false;
-                                while (good && rep--) len_set(s, (int)idx++, lane, prev);
-                            }
-                        }
-                    }
-                    if (good) good = len_get(s, 256, lane) != 0;  // no end-of-block code
-                    if (good) {
-                        for (int i = (int)ndist - 1; i >= 0; --i) len_set(s, kLL + i, lane, len_get(s, (int)nlen + i, lane));
-                        for (uint32_t i = nlen; i < (uint32_t)kLL; ++i) len_set(s, (int)i, lane, 0);
-                        for (uint32_t i = ndist; i < (uint32_t)kDist; ++i) len_set(s, kLL + (int)i, lane, 0);
-                        // incomplete code sets are allowed only when they consist of ONE code of length 1 (zlib inflate_table)
-                        int err = huff_construct(s.cnt_ll, s.sym_ll, s, 0, kLL, lane);
-                        if (err < 0 || (err > 0 && kLL != (int)s.cnt_ll[0][lane] + (int)s.cnt_ll[1][lane])) good = false;
-                        if (good) {
-                            err = huff_construct(s.cnt_d, s.sym_d, s, kLL, kDist, lane);
-                            if (err < 0 || (err > 0 && kDist != (int)s.cnt_d[0][lane] + (int)s.cnt_d[1][lane])) good = false;
-                        }
-                    }
-                }
-                if (good) {
-                    huff_table<kLLBits>(s.tab_ll, s.cnt_ll, s.sym_ll, lane);
-                    huff_table<kDBits>(s.tab_d, s.cnt_d, s.sym_d, lane);
-                    c_ll = load_counts(s.cnt_ll, lane);
-                    c_d = load_counts(s.cnt_d, lane);
-                    state = LS_SYM;
-                } else {
-                    st = ST_BAD_STREAM;
-                    state = LS_DONE;
-                }
-            }
-        }
-        if (__ballot(state != LS_DONE) == 0ull) break;
-        if (state == LS_COPY) {
-            if (cp_dist >= 8) {
-                if (cp_have) {  // (the last word may write up to seven bytes past the match: bytes this lane overwrites with its
-                                //  next symbols, or the padding behind the member's stretch — the caller leaves 8 bytes)
-                    *reinterpret_cast<u64_unaligned*>(out + cp_dst) = cp_data;
-                    cp_dst += 8;
-                    cp_have = false;
-                    if (cp_left == 0) state = LS_SYM;
-                }
-                if (state == LS_COPY) {
-                    cp_data = *reinterpret_cast<const u64_unaligned*>(out + cp_dst - cp_dist);
-                    cp_have = true;
-                    cp_left = cp_left > 8u ? cp_left - 8u : 0u;
-                }
-            } else {  // source and destination overlap within a word: byte by byte
-                for (uint32_t i = 0; i < cp_left; ++i) out[cp_dst + i] = out[cp_dst + i - cp_dist];
-                state = LS_SYM;
-            }
-        }
-        if (state == LS_STORED) {
-            for (int k = 0; k < 4 && stored_left; ++k, --stored_left) out[produced++] = (uint8_t)bits_get(b, 8);
-            if (stored_left == 0) {
-                if (bits_used(b) > (uint64_t)in_len * 8) { st = ST_INPUT_END; state = LS_DONE; }
-                else state = last ? LS_DONE : LS_HEADER;
-            }
-        }
-        if (state == LS_SYM) {
-            const int sym = huff_decode<kLLBits>(b, s.tab_ll, c_ll, s.sym_ll, lane);
-            if (sym < 0) { st = ST_BAD_STREAM; state = LS_DONE; }
-            else if (sym < 256) {
-                if (produced >= isize) { st = ST_SIZE; state = LS_DONE; }
-                else out[produced++] = (uint8_t)sym;
-            } else if (sym == 256) {
-                if (bits_used(b) > (uint64_t)in_len * 8) { st = ST_INPUT_END; state = LS_DONE; }
-                else state = last ? LS_DONE : LS_HEADER;
-            } else {
-                const int li = sym - 257;
-                if (li >= 29) { st = ST_BAD_STREAM; state = LS_DONE; }
-                else {
-                    uint32_t len;
-                    if (li < 8) {
-                        len = 3u + (uint32_t)li;
-                    } else if (li == 28) {
-                        len = 258u;
-                    } else {
-                        const uint32_t e = ((uint32_t)li - 4u) >> 2;
-                        len = 3u + ((4u + ((uint32_t)li & 3u)) << e) + bits_get(b, e);
-                    }
-                    const int ds = huff_decode<kDBits>(b, s.tab_d, c_d, s.sym_d, lane);
-                    if (ds < 0 || ds >= 30) { st = ST_BAD_STREAM; state = LS_DONE; }
-                    else {
-                        uint32_t dist;
-                        if (ds < 4) {
-                            dist = 1u + (uint32_t)ds;
-                        } else {
-                            const uint32_t ex = ((uint32_t)ds - 2u) >> 1;
-                            dist = 1u + ((2u + ((uint32_t)ds & 1u)) << ex);
-                            if (ex > 8) {  // up to 13 extra bits: two reads keep each within the refill guarantee
-                                const uint32_t lo = bits_get(b, 8);
-                                dist += lo | (bits_get(b, ex - 8) << 8);
-                            } else {
-                                dist += bits_get(b, ex);
-                            }
-                        }
-                        if (dist > produced) { st = ST_BAD_STREAM; state = LS_DONE; }
-                        else if (produced + len > isize) { st = ST_SIZE; state = LS_DONE; }
-                        else if (bits_used(b) > (uint64_t)in_len * 8) { st = ST_INPUT_END; state = LS_DONE; }
-                        else {
-                            cp_dst = produced;
-                            cp_dist = dist;
-                            cp_left = len;
-                            produced += len;
-                            state = LS_COPY;
-                            cp_have = false;
-                            if (dist >= 8) {  // the first eight source bytes travel while the other lanes take their step
-                                cp_data = *reinterpret_cast<const u64_unaligned*>(out + cp_dst - cp_dist);
-                                cp_have = true;
-                                cp_left = len > 8u ? len - 8u : 0u;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // ---- CRC-32 of the member's bytes: a second pass over the lane's own output, the lanes in step
-    if (st == ST_OK && produced != isize) st = ST_SIZE;
-    uint32_t crc = 0xFFFFFFFFu;
-    const uint32_t n = st == ST_OK ? isize : 0u;
-    uint32_t i = 0;
-    while (__ballot(i + 16 <= n) != 0ull) {
-        if (i + 16 <= n) {
-            typedef uint32_t u32x4_un __attribute__((ext_vector_type(4), aligned(1)));
-            const u32x4_un v = *reinterpret_cast<const u32x4_un*>(out + i);
-            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t w = ws[k] ^ crc;
-                crc = s.crc_table4[3][w & 0xFFu] ^ s.crc_table4[2][(w >> 8) & 0xFFu] ^ s.crc_table4[1][(w >> 16) & 0xFFu] ^ s.crc_table4[0][w >> 24];
-            }
-            i += 16;
-        }
-    }
-    for (; i < n; ++i) crc = s.crc_table4[0][(crc ^ out[i]) & 0xFFu] ^ (crc >> 8);
-    if (st == ST_OK && (crc ^ 0xFFFFFFFFu) != a.crc[m]) st = ST_CRC;
-    a.status[m] = st;
-}
-
 // pieces of the inflated members → one compact buffer: piece p = src[src_off[p] .. + len[p]) → dst[dst_off[p] ..]; one
 // wave per piece (the packed SEQ bytes of one sequence slice inside one member: tens to thousands of bytes)
 __global__ __launch_bounds__(256) void k_gather_ranges(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
@@ -694,19 +448,10 @@ int svx_bgzf_inflate_on_stream(void* stream, const uint8_t* d_in, const uint64_t
                                const uint64_t* d_out_off, uint32_t* d_status) {
     if (n_members == 0) return 0;
     InfArgs a{d_in, d_in_off, d_in_len, d_isize, d_crc, d_out, d_out_off, d_status, n_members};
-    static const bool lane_kernel = [] { const char* e = getenv("SVX_INFLATE_KERNEL"); return e && e[0] == 'l' && e[1] == 'a'; }();  // "lane": A/B
-    if (lane_kernel) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(Lds));
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_members + kLanes - 1) / kLanes), dim3(kThreads), sizeof(Lds),
-                           static_cast<hipStream_t>(stream), a);
-        return (int)hipGetLastError();
-    }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_inflate_ls), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sizeof(Lds));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_bgzf_inflate_ls, dim3((n_members + kLanes - 1) / kLanes), dim3(64), sizeof(Lds),
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_members + kLanes - 1) / kLanes), dim3(kThreads), sizeof(Lds),
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
