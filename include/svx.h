@@ -60,6 +60,10 @@ const char* svx_last_error(const svx_ctx* ctx);
 const char* svx_version(void);
 /* Number of visible HIP devices (0 when none / no driver). Never fails. */
 int svx_device_count(void);
+/* PCI address of a visible device as "domain:bus:device.function" (hipDeviceGetPCIBusId): what a host process needs to
+ * find the device's NUMA node (/sys/bus/pci/devices/<address>/numa_node) and keep its threads there — one worker
+ * process per GPU of a node (svim-asm-cohort --device k).  `len` >= 16. */
+int svx_device_pci_bus_id(int device, char* out, int len);
 
 /* svx_cigar_extract* run batches of at most `max_ops` CIGAR ops in TWO kernel launches (tiles of 1024
  * ops; every workgroup of the second kernel scans all tile descriptors itself): the operating point of

@@ -63,6 +63,44 @@ COHORT_DEVICE_INFLATE_PERCENT = 100
 COHORT_DEVICE_INFLATE_WAIT_MS = int(os.environ.get("SVX_COHORT_INFLATE_WAIT_MS") or 400)  # (the variable: tools/r06_cohort_ab.py)
 
 
+def device_numa_cpus(device):
+    """(PCI address, NUMA node, CPUs of that node) of a visible HIP device, from svx_device_pci_bus_id and sysfs; node and
+    CPUs are None where the platform does not say (a single-node host, a container without the sysfs entries)."""
+    import ctypes as C
+    from svim_asm_amd import _lib
+    buf = C.create_string_buffer(32)
+    if _lib.load().svx_device_pci_bus_id(int(device), buf, 32) != 0:
+        return None, None, None
+    addr = buf.value.decode().lower()
+    try:
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % addr).read())
+        if node < 0:
+            return addr, None, None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        return addr, node, (sorted(cpus) or None)
+    except (OSError, ValueError):
+        return addr, None, None
+
+
+def bind_to_device_node(device):
+    """Keeps the calling thread — and every thread it starts from now on: a reader's pool, the writers — on the CPUs of
+    the NUMA node the device hangs on: with one cohort process per GPU of a node the processes then neither share cores
+    nor read their page-locked pools across sockets.  Returns what was done, for the log."""
+    addr, node, cpus = device_numa_cpus(device)
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+            return "device %d (%s): NUMA node %d, threads bound to its %d CPUs" % (device, addr, node, len(cpus))
+        except OSError as e:
+            return "device %d (%s): NUMA node %d, binding refused (%s)" % (device, addr, node, e)
+    return "device %d (%s): no NUMA node reported, threads not bound" % (device, addr or "address unknown")
+
+
 def default_workers():
     from svim_asm_amd import bamio
     return 4 if bamio.host_cpus() >= 12 else 2
@@ -166,6 +204,9 @@ def main(argv=None):
         try:
             # worker 0 on the process's context (the one _warm_device is bringing up), the others on their own
             ctx = _lib.default_context(device) if worker_no == 0 else _lib.Context(device)
+            bound = bind_to_device_node(device)  # (behind the context: the device's address needs the runtime up)
+            if worker_no == 0:
+                logging.info("AFFINITY: %s", bound)
             while True:
                 with lock:
                     g = state["next"]

@@ -9,6 +9,16 @@ extern "C" int svx_device_count(void) {
     return n;
 }
 
+extern "C" int svx_device_pci_bus_id(int device, char* out, int len) {
+    if (!out || len < 16) return SVX_E_INVALID;
+    out[0] = 0;
+    if (hipDeviceGetPCIBusId(out, len, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return SVX_E_NODEVICE;
+    }
+    return SVX_OK;
+}
+
 static int ctx_create_common(int device, void* stream, bool own, svx_ctx** out) {
     if (!out) return SVX_E_INVALID;
     *out = nullptr;

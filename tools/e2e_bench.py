@@ -181,11 +181,13 @@ def run_samples(n_procs, bams, fasta, out, n_devices, check):
     return leg
 
 
-def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1):
-    """`svim-asm-cohort diploid` as ONE fresh process over `n_samples` own copies of the sample's BAMs (the genome FASTA
-    is shared, as it is for a real cohort): samples per second over the wall-clock of the process (interpreter start and
-    HIP bring-up included, paid once), CPU seconds per sample, peak resident set, every VCF against the reference's
-    digest.  The headline's own workload — many samples through one device — from the BAMs to the VCFs."""
+def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1, n_devices=1):
+    """`svim-asm-cohort diploid` over `n_samples` own copies of the sample's BAMs (the genome FASTA is shared, as it is
+    for a real cohort) — ONE fresh process per device (`--device k`, the manifest dealt out round-robin; on one device:
+    one process): samples per second over the wall-clock from the first start to the last exit (interpreter start and HIP
+    bring-up included, paid once per process), CPU seconds per sample, peak resident set, where each process bound its
+    threads, every VCF against the reference's digest.  The headline's own workload — many samples through one device —
+    from the BAMs to the VCFs; the unit that scales across the GPUs of a node is this process."""
     import resource
     dirs, copied = [], True
     for k in range(n_samples):
@@ -203,21 +205,27 @@ def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1):
                     os.link(src, dst)
         shutil.rmtree(os.path.join(d, "wd"), ignore_errors=True)
         dirs.append(d)
-    manifest = os.path.join(out, "cohort_manifest_%d.txt" % n_samples)
-    with open(manifest, "w") as f:
-        for d in dirs:
-            f.write("%s %s %s\n" % (os.path.join(d, "wd"), os.path.join(d, "hap1.bam"), os.path.join(d, "hap2.bam")))
+    n_proc = max(1, min(n_devices, n_samples))
     env = dict(os.environ)
     for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(name, None)
-    argv = [sys.executable, os.path.join(ROOT, "bin", "svim-asm-cohort"), "diploid", manifest, fasta, "--device", str(device)]
-    if workers:
-        argv += ["--cohort_workers", str(workers)]
-    if group != 1:
-        argv += ["--cohort_group", str(group)]
+    argvs = []
+    for k in range(n_proc):
+        manifest = os.path.join(out, "cohort_manifest_%d_of_%d_%d.txt" % (k, n_proc, n_samples))
+        with open(manifest, "w") as f:
+            for d in dirs[k::n_proc]:
+                f.write("%s %s %s\n" % (os.path.join(d, "wd"), os.path.join(d, "hap1.bam"), os.path.join(d, "hap2.bam")))
+        argv = [sys.executable, os.path.join(ROOT, "bin", "svim-asm-cohort"), "diploid", manifest, fasta, "--device",
+                str((device + k) % max(1, n_devices) if n_devices > 1 else device)]
+        if workers:
+            argv += ["--cohort_workers", str(workers)]
+        if group != 1:
+            argv += ["--cohort_group", str(group)]
+        argvs.append(argv)
     ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
-    p = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    procs = [subprocess.Popen(a, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for a in argvs]
+    outs = [p.communicate()[0] for p in procs]
     wall = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     oks = []
@@ -225,15 +233,19 @@ def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1):
         path = os.path.join(d, "wd", "variants.vcf")
         oks.append(check(masked(path)) if os.path.exists(path) else False)
     cpu = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
-    leg = {"samples": n_samples, "workers": workers or "default", "group": group, "wall_s": wall, "samples_per_s": n_samples / wall,
-           "rc": p.returncode, "cpu_seconds": cpu, "cpu_seconds_per_sample": cpu / n_samples, "cpu_quota_cpus": cpu_quota(),
+    leg = {"samples": n_samples, "processes": n_proc, "devices": n_proc, "workers": workers or "default", "group": group, "wall_s": wall,
+           "samples_per_s": n_samples / wall, "rc": [p.returncode for p in procs], "cpu_seconds": cpu,
+           "cpu_seconds_per_sample": cpu / n_samples, "cpu_quota_cpus": cpu_quota(),
            "peak_rss_mb_of_any_child_so_far": ru1.ru_maxrss / 1024.0,  # (RUSAGE_CHILDREN: the largest child this process has waited for)
            "own_copies_of_the_bams": copied, "shared_genome_fasta": True, "vcf_matches_real_reference_digest": oks}
-    log = [l for l in p.stdout.split("\n") if " worker(s) " in l]
+    aff = [l.split("AFFINITY: ", 1)[1].strip() for o in outs for l in o.split("\n") if "AFFINITY: " in l]
+    if aff:
+        leg["affinity"] = aff
+    log = [l for l in outs[0].split("\n") if " worker(s) " in l]
     if log:
         leg["plan"] = log[0].split("******************")[1].strip() if "******************" in log[0] else log[0][-120:]
-    if p.returncode != 0 or any(o is False for o in oks):
-        leg["output_tail"] = p.stdout[-1500:]
+    if any(p.returncode != 0 for p in procs) or any(o is False for o in oks):
+        leg["output_tail"] = [o[-1500:] for o in outs]
     for d in dirs:
         shutil.rmtree(d, ignore_errors=True)
     return leg
@@ -447,7 +459,7 @@ def run_e2e(scale=0.1, keep=None, sv_per_mbp=8.0, with_oracle=None, dataset=None
     if samples:
         res["samples"] = [run_samples(n, bams, fasta, out, n_devices, check) for n in samples]
     if cohort:
-        res["cohort"] = [run_cohort(n, bams, fasta, out, device, check) for n in cohort]
+        res["cohort"] = [run_cohort(n, bams, fasta, out, device, check, n_devices=n_devices) for n in cohort]
 
     if with_oracle is None:
         with_oracle = not same_inputs
