@@ -647,6 +647,11 @@ def e2e_leg(scale, local_rank, n_devices=1):
             "wall_s": med["product_total_s"],  # the MEDIAN of the runs below, every one of them with the default ingest:
             # every touched BGZF member inflated whole and its CRC32 checked, as htslib does under the reference
             "wall_s_first_run": runs[0], "wall_s_best": best["product_total_s"], "all_runs_wall_s": runs,
+            # wall_s leaves out the unmapping of the genome FASTA, which the reference does inside write_final_vcf
+            # (SVIM_COMBINE.py:466-467) and the product defers (the command: to the process's exit, inside command_line_wall_s;
+            # a long-lived caller: to a background thread); timed by itself in the same run:
+            "reference_release_s": med.get("reference_release_s"),
+            "wall_s_including_reference_release": med.get("product_total_including_reference_release_s"),
             "first_run_is_cold": r.get("page_cache_dropped_before_first_run"),  # posix_fadvise(DONTNEED) on both BAMs, their
             # indices and the FASTA right before the first run: it reads its inputs from storage (True = the kernel took
             # every request; the files were written by this process a minute earlier, pages still dirty then are synced first)

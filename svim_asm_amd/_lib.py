@@ -689,6 +689,12 @@ _default_ctx = {}
 _default_ctx_lock = threading.Lock()
 
 
+def new_context(device=0):
+    """A context of its own (stream, workspace) on `device` — for a thread that works beside the process-wide one
+    (svim-asm-cohort's workers)."""
+    return Context(device)
+
+
 def default_context(device=0):
     """Process-wide context per device (created on first use; raises without a GPU)."""
     ctx = _default_ctx.get(device)

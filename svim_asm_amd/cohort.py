@@ -203,7 +203,7 @@ def main(argv=None):
     def work(worker_no):
         try:
             # worker 0 on the process's context (the one _warm_device is bringing up), the others on their own
-            ctx = _lib.default_context(device) if worker_no == 0 else _lib.Context(device)
+            ctx = _lib.default_context(device) if worker_no == 0 else _lib.new_context(device)
             bound = bind_to_device_node(device)  # (behind the context: the device's address needs the runtime up)
             if worker_no == 0:
                 logging.info("AFFINITY: %s", bound)

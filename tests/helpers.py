@@ -458,6 +458,7 @@ def oracle_backed_device(monkeypatch):
     """Patch the product so that every kernel call is answered by the oracle (pytest monkeypatch)."""
     ctx = OracleBackedContext()
     monkeypatch.setattr(_svxlib(), "default_context", lambda device=0: ctx)
+    monkeypatch.setattr(_svxlib(), "new_context", lambda device=0: OracleBackedContext())  # (svim-asm-cohort's other workers)
     return ctx
 
 
