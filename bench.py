@@ -720,7 +720,10 @@ def summary_of(res):
         "e2e_vcf_ok": e2e.get("vcf_matches_real_reference_digest"),
         "product_point": [r3(get(res, "product_point", "ms_per_step")), r3(get(res, "product_point", "frac"))],
         "latency_case": [r3(get(res, "latency_case", "ms_per_step")), r3(get(res, "latency_case", "frac"))],
-        "roofline_editdist_frac": r3(get(res, "roofline_editdist", "frac")), "roofline_pair_frac": r3(get(res, "roofline_pair", "frac")),
+        # (first case of each leg: the PAIR-like batch of 20 000 pairs; the 60 000 keys PAIR hands over)
+        "roofline_editdist": [[r3(c.get("frac")), r3(c.get("ms")), r3(c.get("two_stage_plan_ms"))] for c in (get(res, "roofline_editdist", "cases") or [])
+                              if isinstance(c, dict)][:2],
+        "roofline_pair_frac": r3(((get(res, "roofline_pair", "cases") or [{}])[0] or {}).get("frac")),
         "cpu_quota_cpus": res.get("cpu_quota_cpus"), "cpu_seconds_per_sample": r3(res.get("cpu_seconds_per_sample")),
     }
     for key, fields in (("e2e_cohort", ("samples", "samples_per_s", "cpu_seconds_per_sample")),
