@@ -117,9 +117,11 @@ def default_reader_threads(workers, n_bams):
     return max(2, int(round(1.5 * bamio.host_cpus() / float(max(1, workers * n_bams)))))
 
 
-def run_group(mode, group, genome, ctx, first_no, n_total, workers=1, reader_threads=None):
-    """One group of samples from the BAMs to the VCFs on the calling thread's device context: (opts, working dir, BAM
-    paths) per sample.  Returns 0, or 1 after logging why an input was refused (as the command does)."""
+def run_group(mode, group, genome, get_ctx, first_no, n_total, workers=1, reader_threads=None):
+    """One group of samples from the BAMs to the VCFs on the calling thread's device context (`get_ctx()`: asked for
+    behind the record walks, which do not need it — a fresh process's first groups walk their BAMs while the HIP runtime
+    comes up): (opts, working dir, BAM paths) per sample.  Returns 0, or 1 after logging why an input was refused (as the
+    command does)."""
     from svim_asm_amd import bamio
     from svim_asm_amd.SVIM_COMBINE import pair_tables
     n_bams = 2 if mode == "diploid" else 1
@@ -143,6 +145,8 @@ def run_group(mode, group, genome, ctx, first_no, n_total, workers=1, reader_thr
             f.device_inflate_wait_ms = COHORT_DEVICE_INFLATE_WAIT_MS
             files.append(f)
     _timeline.mark("files open", sample=first_no)
+    SVIM_COLLECT._load_together(files)  # (collect_tables would do it: here, in front of the first use of the context)
+    ctx = get_ctx()
     tables = SVIM_COLLECT.collect_tables(files, group[0][0], ctx=ctx)
     _timeline.mark("COLLECT done", sample=first_no)
     for k, (o, wd, bams) in enumerate(group):
@@ -202,18 +206,23 @@ def main(argv=None):
 
     def work(worker_no):
         try:
-            # worker 0 on the process's context (the one _warm_device is bringing up), the others on their own
-            ctx = _lib.default_context(device) if worker_no == 0 else _lib.new_context(device)
-            bound = bind_to_device_node(device)  # (behind the context: the device's address needs the runtime up)
-            if worker_no == 0:
-                logging.info("AFFINITY: %s", bound)
+            box = {}
+
+            def get_ctx():
+                # worker 0 on the process's context (the one _warm_device is bringing up), the others on their own
+                if "ctx" not in box:
+                    box["ctx"] = _lib.default_context(device) if worker_no == 0 else _lib.new_context(device)
+                    bound = bind_to_device_node(device)  # (behind the context: the device's address needs the runtime up)
+                    if worker_no == 0:
+                        logging.info("AFFINITY: %s", bound)
+                return box["ctx"]
             while True:
                 with lock:
                     g = state["next"]
                     if g >= len(groups) or state["rc"] or state["error"]:
                         return
                     state["next"] = g + 1
-                rc = run_group(mode, groups[g], genome, ctx, g * per_group, len(samples), workers, reader_threads or None)
+                rc = run_group(mode, groups[g], genome, get_ctx, g * per_group, len(samples), workers, reader_threads or None)
                 if rc:
                     with lock:
                         state["rc"] = rc

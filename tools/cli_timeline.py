@@ -69,6 +69,11 @@ def main():
         if main_thread:
             prev_t, prev_cpu = t, c
     print("%-26s %10.3f %10.3f" % ("process gone (parent)", med["wall"], med["wall"] - prev_t))
+    print("per run (wall | " + " | ".join(n for n in names if n in ("device context created", "files open", "COLLECT done", "PAIR done", "VCF written", "leaving")) + "):")
+    for r in runs:
+        byname = {m["name"]: m["t"] for m in r["marks"]}
+        print("  %.3f | %s" % (r["wall"], " | ".join("%.3f" % byname.get(n, float("nan")) for n in names
+                                                  if n in ("device context created", "files open", "COLLECT done", "PAIR done", "VCF written", "leaving"))))
     print("cgroup throttling per run (wall s: periods throttled, ms): %s" % "  ".join(
         "%.3f: %s, %s" % (r["wall"], r["throttled_periods"], "-" if r["throttled_ms"] is None else "%.0f" % r["throttled_ms"]) for r in runs))
     tails = sorted(r["wall"] - r["marks"][-1]["t"] for r in runs if r["marks"])
