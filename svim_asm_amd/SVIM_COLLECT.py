@@ -626,12 +626,16 @@ def collect_tables(bams, options, ctx=None):
     """CandidateTable of every bam in `bams` (the two haplotypes of a diploid sample, or the BAMs of a whole cohort
     of samples: svim_asm_amd/cohort.py): one device submission for all of them when their reference dictionaries
     agree, several where one would exceed the 2^32-op limit of svx_collect_batch."""
-    ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
     tl, cl = time.perf_counter(), time.process_time()
     LAST_TIMING.pop("collect_call_s", None)
     _load_together(bams)
     t0, c0 = time.perf_counter(), time.process_time()
     samples = [_prepare(bam, options) for bam in bams]
+    t1 = time.perf_counter()
+    # the device context only now: in a fresh process it is still coming up (150-270 ms) while the record walks and the
+    # host-side preparation above run — asking for it first made the walks wait for it (round 6: 45 ms of the command)
+    ctx = ctx or _lib.default_context(getattr(options, "device", 0) or 0)
+    LAST_TIMING["context_wait_s"] = time.perf_counter() - t1
     t1 = time.perf_counter()
     groups = _submission_groups(samples, _same_header(bams))
     for group in groups:

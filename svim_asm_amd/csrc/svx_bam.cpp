@@ -691,8 +691,14 @@ extern "C" void svx_bam_register_device_kernels(svx_inflate_launch_fn inflate, s
 }
 
 constexpr int kInflateLanes = 2;
-constexpr int kRingSlots = 8;
-constexpr size_t kSlotBytes = 2u << 20;
+#ifndef SVX_RING_SLOTS
+#define SVX_RING_SLOTS 8
+#endif
+#ifndef SVX_SLOT_MB
+#define SVX_SLOT_MB 2
+#endif
+constexpr int kRingSlots = SVX_RING_SLOTS;
+constexpr size_t kSlotBytes = (size_t)SVX_SLOT_MB << 20;
 struct InflateLane {
     hipStream_t stream = nullptr;
     uint8_t* ring = nullptr;          // kRingSlots * kSlotBytes, page-locked
@@ -904,6 +910,21 @@ struct svx_bam {
     uint32_t inflate_wait_ms = 0;         // ... and how long a call waits for one of the device's inflate lanes to come free
     uint8_t* d_inflate = nullptr;  // the device leg's buffer, kept between calls
     size_t d_inflate_cap = 0;
+    // ... asked for ahead of the first sequence-slice call, on a thread beside whatever follows the record walk: a
+    // hipMalloc of 0.7-1.1 GB takes 20-40 ms and holds the runtime's lock — the staging threads of the OTHER reader's leg
+    // stood in hipMemcpyAsync for that long (8 x 25 ms of "enqueueing" in the leg's debug line, one reader of two)
+    std::thread d_inflate_ahead;
+    void* d_inflate_ahead_ptr = nullptr;
+    size_t d_inflate_ahead_cap = 0;
+    void take_inflate_ahead() {  // (the caller's thread, before it looks at d_inflate)
+        if (!d_inflate_ahead.joinable()) return;
+        d_inflate_ahead.join();
+        if (d_inflate_ahead_ptr) {
+            if (!d_inflate) { d_inflate = static_cast<uint8_t*>(d_inflate_ahead_ptr); d_inflate_cap = d_inflate_ahead_cap; }
+            else dev_buffer_done(pin_device, d_inflate_ahead_ptr, d_inflate_ahead_cap);
+        }
+        d_inflate_ahead_ptr = nullptr; d_inflate_ahead_cap = 0;
+    }
     uint64_t device_members = 0;   // members the device has inflated and verified for this handle
     bool verify = true;   // inflate whole members and check their CRC32 (svx_bam_set_verify); the default
     Pool pool;
@@ -930,6 +951,7 @@ struct svx_bam {
         cigar_pinned_bytes = 0;
     }
     void free_device() {
+        take_inflate_ahead();
         d_valid = false;
         if (d_inflate) dev_buffer_done(pin_device, d_inflate, d_inflate_cap);
         d_inflate = nullptr; d_inflate_cap = 0;
@@ -1467,6 +1489,18 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
         (void)hipStreamSynchronize(b->up_stream);
     }
     b->blocks_spanned = spanned;
+    // the device leg's buffer for the sequence-slice call that follows a load of a whole file: its members' payloads are
+    // about half of the file, their output twice that — 1.6 x the share of the file + the tables (a call that needs more
+    // allocates again)
+    if (!tids && b->inflate_pct > 0 && b->pin_device >= 0 && b->pin_device < kMaxLanes && g_inflate_launch && !b->d_inflate &&
+        !b->d_inflate_ahead.joinable() && b->file.fsize > (64u << 20)) {
+        const size_t want = (size_t)((double)b->file.fsize * 1.6 * b->inflate_pct / 100.0) + (32u << 20);
+        svx_bam* h = b;
+        b->d_inflate_ahead = std::thread([h, want] {
+            if (hipSetDevice(h->pin_device) != hipSuccess) { (void)hipGetLastError(); return; }
+            h->d_inflate_ahead_ptr = dev_buffer(h->pin_device, want, &h->d_inflate_ahead_cap);
+        });
+    }
     return SVX_OK;
 }
 
@@ -1744,6 +1778,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             const uint64_t o_status = o_tab + up256(tab_bytes), o_packed = o_status + up256((uint64_t)g_members * 4);
             const uint64_t need = o_packed + up256(packed_bytes + 8);
             if (ok && g_members && n_pc) {
+                b->take_inflate_ahead();
                 if (b->d_inflate_cap < need) {
                     if (b->d_inflate) dev_buffer_done(b->pin_device, b->d_inflate, b->d_inflate_cap);
                     b->d_inflate = nullptr;
@@ -1782,22 +1817,32 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             std::atomic<uint32_t> next_batch(0), slot_gen[kRingSlots];
             for (int q = 0; q < kRingSlots; ++q) slot_gen[q].store(0);
             std::atomic<bool> stage_failed(false);
+            std::atomic<int64_t> st_turn_us(0), st_event_us(0), st_copy_us(0), st_enqueue_us(0);  // (SVX_BAM_DEBUG: where staging goes)
             auto stage = [&]() {
                 if (hipSetDevice(b->pin_device) != hipSuccess) { stage_failed.store(true); return; }
+                auto now_us = [] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
                 for (;;) {
                     const uint32_t i = next_batch.fetch_add(1);
                     if (i + 1 >= cut.size()) break;
                     const uint32_t q = i % kRingSlots, gen = i / kRingSlots;
+                    const int64_t t0 = debug ? now_us() : 0;
                     while (slot_gen[q].load(std::memory_order_acquire) != gen)  // batch i - kRingSlots has enqueued its copy
                         std::this_thread::sleep_for(std::chrono::microseconds(20));
                     if (stage_failed.load()) { slot_gen[q].store(gen + 1, std::memory_order_release); continue; }
+                    const int64_t t1 = debug ? now_us() : 0;
                     bool good = gen == 0 || hipEventSynchronize(lane->slot_done[q]) == hipSuccess;  // ... and the copy has read the slot
+                    const int64_t t2 = debug ? now_us() : 0;
                     uint8_t* slot = lane->ring + (size_t)q * kSlotBytes;
                     const uint64_t b0 = in_off[cut[i]];
                     const uint64_t b1 = cut[i + 1] < g_members ? in_off[cut[i + 1]] : in_bytes;
                     for (uint32_t m = cut[i]; good && m < cut[i + 1]; ++m) memcpy(slot + (in_off[m] - b0), src[m], in_len[m]);
+                    const int64_t t3 = debug ? now_us() : 0;
                     good = good && hipMemcpyAsync(b->d_inflate + o_in + b0, slot, b1 - b0, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
                            hipEventRecord(lane->slot_done[q], lane->stream) == hipSuccess;
+                    if (debug) {
+                        const int64_t t4 = now_us();
+                        st_turn_us.fetch_add(t1 - t0); st_event_us.fetch_add(t2 - t1); st_copy_us.fetch_add(t3 - t2); st_enqueue_us.fetch_add(t4 - t3);
+                    }
                     if (!good) stage_failed.store(true);
                     slot_gen[q].store(gen + 1, std::memory_order_release);
                 }
@@ -1809,6 +1854,10 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 ok = !stage_failed.load();
             }
             t_staged = since_call_ms();
+            if (debug)
+                fprintf(stderr, "svx_bam_seq_slices: staging %zu batches, %.1f MB: thread-ms waiting for the slot's turn %.1f, for its last copy %.1f, "
+                        "copying members in %.1f, enqueueing %.1f\n", cut.size() - 1, in_bytes / 1e6, st_turn_us.load() / 1e3, st_event_us.load() / 1e3,
+                        st_copy_us.load() / 1e3, st_enqueue_us.load() / 1e3);
             // (3) kernels, and the event behind them
             if (ok) {
                 uint8_t* d = b->d_inflate;

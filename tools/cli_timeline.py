@@ -74,6 +74,13 @@ def main():
         byname = {m["name"]: m["t"] for m in r["marks"]}
         print("  %.3f | %s" % (r["wall"], " | ".join("%.3f" % byname.get(n, float("nan")) for n in names
                                                   if n in ("device context created", "files open", "COLLECT done", "PAIR done", "VCF written", "leaving"))))
+    def gap(r, a_, b_):
+        byname = {m["name"]: m["t"] for m in r["marks"]}
+        return byname.get(b_, float("nan")) - byname.get(a_, float("nan"))
+    gaps = sorted(gap(r, "device context created", "COLLECT done") for r in runs)
+    tails = sorted(gap(r, "COLLECT done", "leaving") for r in runs)
+    print("device context -> COLLECT done: median %.3f s (%s); COLLECT done -> leaving: median %.3f s" % (
+        gaps[len(gaps) // 2], " ".join("%.3f" % g for g in gaps), tails[len(tails) // 2]))
     print("cgroup throttling per run (wall s: periods throttled, ms): %s" % "  ".join(
         "%.3f: %s, %s" % (r["wall"], r["throttled_periods"], "-" if r["throttled_ms"] is None else "%.0f" % r["throttled_ms"]) for r in runs))
     tails = sorted(r["wall"] - r["marks"][-1]["t"] for r in runs if r["marks"])
