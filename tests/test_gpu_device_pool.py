@@ -216,3 +216,50 @@ def test_device_leg_flags_a_damaged_member(svx_ctx, dataset, tmp_path):
         except ValueError:
             results.append("error")
     assert results == ["error", "error"]
+
+
+def test_more_readers_than_lanes_wait_for_one(svx_ctx, dataset):
+    """Four readers decode their sequence slices at once on a device with two inflate lanes: a call that finds both taken
+    sleeps for one (svx_bam_set_device_inflate_wait) — or, without the wait, gives its whole call to the threads —; every
+    reader returns the bases the host alone decodes, and readers opened and closed in a row reuse the device and
+    page-locked buffers the earlier ones gave back (svx_bam.cpp: buffers kept between handles)."""
+    import threading
+    import time
+    fa, bams = dataset
+    host = bamio.AlignmentFile(bams[0], device=0)
+    host.device_inflate_percent = 0
+    host.load(None)
+    rec, a, b = random_slices(host, np.random.default_rng(11), 6000)
+    exp, exp_off = host.sequence_slices_raw(rec, a, b)
+    for wait_ms in (400, 0):
+        readers = []
+        for _ in range(4):
+            f = bamio.AlignmentFile(bams[0], device=0, threads=4)
+            f.device_inflate_percent = 100
+            f.device_inflate_min_members = 0
+            f.device_inflate_wait_ms = wait_ms
+            f.load(None)
+            readers.append(f)
+        time.sleep(0.3)  # (the lanes of a first load in this process)
+        out, errors = [None] * 4, []
+
+        def run(k):
+            try:
+                out[k] = readers[k].sequence_slices_raw(rec, a, b)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors
+        for got, got_off in out:
+            assert np.array_equal(got_off, exp_off) and np.array_equal(got, exp)
+        on_device = [f.device_members for f in readers]
+        if wait_ms:
+            assert all(n > 0 for n in on_device), on_device  # everybody got a lane in the end
+        else:
+            assert sum(1 for n in on_device if n > 0) >= 1     # two lanes: at least somebody; the others decoded on their threads
+        for f in readers:
+            f.close()

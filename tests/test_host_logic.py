@@ -348,3 +348,100 @@ def test_job_token_names_the_job_not_the_shell(monkeypatch):
     assert shard._job_token() == b"rendezvous-my-hand-launched-job"
     monkeypatch.setenv("SVX_JOB_TOKEN", "t0k")
     assert shard._job_token() == b"t0k"
+
+
+def test_quota_threads_share_the_quota_among_readers_and_ranks(monkeypatch):
+    """bamio.quota_threads: under a CPU quota the readers of all processes of a run together get the quota's CPUs (at
+    least two each); without a quota the library's policy (ingest_threads); SVX_INGEST_THREADS overrides both."""
+    import os
+    from svim_asm_amd import bamio
+    monkeypatch.delenv("SVX_INGEST_THREADS", raising=False)
+    monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 16.0)
+    assert bamio.quota_threads(2) == 8 and bamio.quota_threads(1) == 16
+    assert bamio.quota_threads(2, processes=2) == 4 and bamio.quota_threads(2, processes=4) == 2 and bamio.quota_threads(2, processes=8) == 2
+    assert bamio.ingest_threads(2) == 32  # the long-lived caller's bursts: a quarter of the hardware threads in total
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 256.0)
+    assert bamio.quota_threads(2) == bamio.ingest_threads(2) == 32
+    monkeypatch.setenv("SVX_INGEST_THREADS", "5")
+    assert bamio.quota_threads(2) == bamio.ingest_threads(2) == 5
+
+
+def test_cohort_options_and_plan(monkeypatch):
+    """svim-asm-cohort's own options are taken out of the argument list before the reference's parser sees it; workers and
+    reader threads follow the CPUs the process may use."""
+    from svim_asm_amd import bamio, cohort
+    rest, k = cohort._take_option(["--min_sv_size", "50", "--cohort_workers", "6", "--types=DEL"], "--cohort_workers", 0)
+    assert rest == ["--min_sv_size", "50", "--types=DEL"] and k == 6
+    rest, g = cohort._take_option(["--cohort_group=0", "--symbolic_alleles"], "--cohort_group", 1)
+    assert rest == ["--symbolic_alleles"] and g == 0
+    assert cohort._take_option(["--symbolic_alleles"], "--cohort_threads", 0) == (["--symbolic_alleles"], 0)
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 16.0)
+    assert cohort.default_workers() == 4 and cohort.default_reader_threads(4, 2) == 3 and cohort.default_reader_threads(3, 2) == 4
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 8.0)
+    assert cohort.default_workers() == 2 and cohort.default_reader_threads(2, 2) == 3
+    monkeypatch.setattr(bamio, "host_cpus", lambda: 2.0)
+    assert cohort.default_reader_threads(2, 2) == 2  # never below two
+
+
+def test_cohort_manifest_errors(tmp_path):
+    from svim_asm_amd import cohort
+    m = tmp_path / "m.txt"
+    m.write_text("# comment\n\nwd1 a.bam b.bam\n")
+    assert cohort.read_manifest(str(m), 2) == [(os.path.abspath("wd1"), ["a.bam", "b.bam"])]
+    with pytest.raises(ValueError):
+        cohort.read_manifest(str(m), 1)  # a diploid line in a haploid cohort
+    m.write_text("# nothing\n")
+    with pytest.raises(ValueError):
+        cohort.read_manifest(str(m), 2)
+
+
+def test_timeline_marks_only_when_asked(tmp_path, monkeypatch):
+    """svim_asm_amd._timeline: one dictionary look-up without SVX_CLI_TIMELINE; with it, JSON lines of wall clock, process
+    CPU seconds and thread per mark."""
+    import importlib
+    import json
+    from svim_asm_amd import _timeline
+    monkeypatch.delenv("SVX_CLI_TIMELINE", raising=False)
+    tl = importlib.reload(_timeline)
+    tl.mark("nothing")
+    tl.dump()
+    assert not tl.enabled() and tl._marks == []
+    path = tmp_path / "tl.jsonl"
+    monkeypatch.setenv("SVX_CLI_TIMELINE", str(path))
+    tl = importlib.reload(_timeline)
+    tl.mark("a")
+    tl.mark("b", stages={"x": 0.5})
+    tl.dump()
+    rows = [json.loads(l) for l in open(path)]
+    assert [r["name"] for r in rows] == ["a", "b"] and rows[1]["stages"] == {"x": 0.5}
+    assert rows[0]["t"] <= rows[1]["t"] and rows[0]["cpu"] <= rows[1]["cpu"] and rows[0]["thread"] == "MainThread"
+    monkeypatch.delenv("SVX_CLI_TIMELINE")
+    importlib.reload(_timeline)
+
+
+def test_device_numa_lookup_reads_sysfs(monkeypatch, tmp_path):
+    """cohort.device_numa_cpus: the device's PCI address (svx_device_pci_bus_id) -> numa_node -> that node's cpulist, cut
+    down to the CPUs the process may run on; (address, None, None) where the platform reports no node."""
+    import builtins
+    import os
+    from svim_asm_amd import _lib, cohort
+
+    class FakeLib:
+        def svx_device_pci_bus_id(self, device, buf, n):
+            buf.value = b"0000:72:00.0"
+            return 0
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib())
+    files = {"/sys/bus/pci/devices/0000:72:00.0/numa_node": "1\n", "/sys/devices/system/node/node1/cpulist": "2-3,6,64-65\n"}
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path in files:
+            import io
+            return io.StringIO(files[path])
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(0, 8)))
+    assert cohort.device_numa_cpus(0) == ("0000:72:00.0", 1, [2, 3, 6])
+    files["/sys/bus/pci/devices/0000:72:00.0/numa_node"] = "-1\n"
+    assert cohort.device_numa_cpus(0) == ("0000:72:00.0", None, None)
