@@ -498,10 +498,17 @@ int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* s
  *                        The two paddings above are the only bytes outside a member's own input and output stretch that
  *                        are ever read (3 behind the input) or written (7 behind the output).
  * Asynchronous on the context's stream.
+ * Two forms with the same bytes and statuses (svx_inflate.hip): one launch, a lane per member that decodes and copies
+ * (k_bgzf_inflate); or two — the bit streams parsed with the lanes of a wave in step and every match written as a token,
+ * then the tokens applied and the CRC-32 taken by a wave per member (k_inflate_parse, k_inflate_resolve; the token lists
+ * come out of the context's workspace: 8 bytes per 3 bytes of output at most).  svx_bgzf_inflate_set_two_pass chooses for
+ * the whole process — this entry and the BAM reader's device leg (svx_bam_set_device_inflate) — and returns the previous
+ * choice; SVX_INFLATE_KERNEL=1 in the environment starts the process on the one-launch form.
  */
 int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                          const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
                          const uint64_t* d_out_off, uint32_t* d_status);
+int svx_bgzf_inflate_set_two_pass(int on);
 
 /* ------------------------------------------------------------ a5 + a6 ------ */
 /*

@@ -18,6 +18,8 @@
 //     one-code distance set zlib allows —, distances beyond the output so far, output beyond ISIZE, input that
 //     ends early) ends the lane with a status, never with an access outside the member's input and output.
 // Integer / byte work, no MFMA.  Bound by the serial decode chain per lane (LDS and HBM latencies), not by bytes.
+#include <atomic>
+
 #include "svx_internal.h"
 
 namespace {
@@ -426,6 +428,886 @@ __global__ __launch_bounds__(kThreads) SVX_INFL_OCCUPANCY void k_bgzf_inflate(In
     a.status[m] = st;
 }
 
+// ==================================================================================================================
+// Two-pass form (round 6).  What bounds k_bgzf_inflate above is a member's own serial chain — ≈ 0.7 us per symbol — and
+// every step of it ends in a wait for global memory: the refill word, the literal store, a match's read-back of the
+// member's own output.  Here the bit stream is PARSED in one launch and the matches are APPLIED in a second one:
+//   k_inflate_parse    one wave per sixteen members, the lanes in step (a state per lane, one block of code per state);
+//                      the compressed input of each member travels through a 128-byte LDS ring that all 64 lanes of the
+//                      wave top up together every eight steps (one 16-byte load per lane: 64 bytes per member), so a step
+//                      reads nothing from global memory; a literal is stored where it belongs; a match is NOT copied —
+//                      {destination, length, distance} goes to the member's token list (8 bytes) and the output position
+//                      moves on.  Decoding never needs the output, so no step waits for it.
+//   k_inflate_resolve  one wave per member: the tokens 64 at a time, a lane each.  A match whose source lies in front of
+//                      the batch's first destination is independent of the others of the batch (most are: distances reach
+//                      32 KiB back) and all of those are copied at once; the others follow in token order.  Then the CRC-32
+//                      of the finished bytes, a lane per 1 KiB piece, folded with the x^(8192 * 2^j) operators of
+//                      crc32_combine (constants from the host), and the member's status.
+// Statuses and bytes are those of k_bgzf_inflate (the tests run both).
+struct TwoPassArgs {
+    InfArgs a;
+    uint2* tok;               // token lists of all members, one behind the other
+    const uint64_t* tok_off;  // per member: first token slot; capacity isize / 3 + 2 (a match yields at least 3 bytes)
+    uint32_t* n_tok;          // per member: tokens written (k_inflate_parse), or 0xFFFFFFFF: the parse ended the member itself
+    uint32_t shift[6][32];    // columns of the operators x^(8192 * 2^j) mod P, j = 0..5 (CRC-32, reflected)
+    uint32_t redo_only;       // k_inflate_parse: only the members k_inflate_wparse has left to it (n_tok == kTokPending)
+};
+constexpr uint32_t kTokFinal = 0xFFFFFFFFu;    // n_tok: the parse has ended the member with its status
+constexpr uint32_t kTokPending = 0xFFFFFFFEu;  // n_tok: k_inflate_wparse hands the member to k_inflate_parse
+
+constexpr int kRingBytes = 128;  // per member: 2 refills of 64 bytes
+struct ParseLds {
+    uint16_t tab_ll[1 << kLLBits][kLanes];
+    uint16_t tab_d[1 << kDBits][kLanes];
+    uint16_t cnt_ll[kMaxBits + 1][kLanes];
+    uint16_t cnt_d[kMaxBits + 1][kLanes];
+    uint16_t sym_ll[kLL][kLanes];
+    uint16_t sym_d[kDist][kLanes];
+    uint8_t lens4[(kLL + kDist + 2) / 2][kLanes];
+    uint32_t ring[kRingBytes / 4][kLanes];   // [word][member]: lanes reading the same word index hit different banks
+    uint32_t in_lo[kLanes], in_hi[kLanes], in_len[kLanes], ring_hi[kLanes], rd_pos[kLanes];  // what the refill lanes need of a member
+};
+// (the helpers above take the table struct as `Lds`: the same member names)
+__device__ __forceinline__ uint32_t len_get(const ParseLds& s, int i, int lane) { return (s.lens4[i >> 1][lane] >> (4 * (i & 1))) & 15u; }
+__device__ __forceinline__ void len_set(ParseLds& s, int i, int lane, uint32_t v) {
+    const uint32_t sh = 4 * (i & 1);
+    s.lens4[i >> 1][lane] = (uint8_t)((s.lens4[i >> 1][lane] & ~(15u << sh)) | ((v & 15u) << sh));
+}
+template <typename CNT, typename SYM>
+__device__ __forceinline__ int huff_construct_p(CNT cnt, SYM sym, const ParseLds& lds, int base, int n, int lane) {
+    for (int l = 0; l <= kMaxBits; ++l) cnt[l][lane] = 0;
+    for (int s = 0; s < n; ++s) cnt[len_get(lds, base + s, lane)][lane] += 1;
+    if (cnt[0][lane] == n) return 0;
+    int left = 1;
+    for (int l = 1; l <= kMaxBits; ++l) {
+        left <<= 1;
+        left -= cnt[l][lane];
+        if (left < 0) return left;
+    }
+    uint16_t offs[kMaxBits + 1];
+    offs[1] = 0;
+    for (int l = 1; l < kMaxBits; ++l) offs[l + 1] = offs[l] + cnt[l][lane];
+    for (int s = 0; s < n; ++s) {
+        const int l = (int)len_get(lds, base + s, lane);
+        if (l) sym[offs[l]++][lane] = (uint16_t)s;
+    }
+    return left;
+}
+
+// The bit buffer of a member, fed from its LDS ring.  pos: input bytes taken into buf / next; the ring holds the input
+// bytes [.., ring_hi), zero behind the member's end.
+struct RBits {
+    uint64_t buf;
+    uint32_t cnt, pos, next, ring_hi, in_len;
+    const uint8_t* in;
+};
+// 64 more bytes into THIS lane's ring by the lane itself (block headers take their bits in long runs; the symbol loop
+// is topped up by the whole wave, parse_top_up)
+// (out of line, like the walk below and the block header: the symbol loop has to stay small enough for the instruction
+//  cache — inlined at every refill site the kernel was 150 KB of code and a step took 1 300 clocks)
+// (arguments by value: a reference would pin the caller's bit reader to scratch memory)
+__device__ __noinline__ void rb_fill_words(const uint8_t* in, uint32_t ring_hi, uint32_t in_len, ParseLds& s, int lane) {
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { uint32_t real; w[k] = load_word(in, ring_hi + 4u * k, in_len, &real); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s.ring[((ring_hi >> 2) + k) & (kRingBytes / 4 - 1)][lane] = w[k];
+}
+__device__ __forceinline__ void rb_fill_self(RBits& b, ParseLds& s, int lane) {
+    rb_fill_words(b.in, b.ring_hi, b.in_len, s, lane);
+    b.ring_hi += 64;
+}
+__device__ __forceinline__ void rb_refill(RBits& b, ParseLds& s, int lane) {
+    if (b.cnt <= 32) {
+        b.buf |= (uint64_t)b.next << b.cnt;
+        b.cnt += 32;
+        b.pos += 4;
+        if (b.pos + 4 > b.ring_hi) rb_fill_self(b, s, lane);
+        b.next = s.ring[(b.pos >> 2) & (kRingBytes / 4 - 1)][lane];
+    }
+}
+__device__ __forceinline__ uint32_t rb_get(RBits& b, ParseLds& s, int lane, uint32_t n) {  // n <= 16
+    rb_refill(b, s, lane);
+    const uint32_t v = (uint32_t)b.buf & ((1u << n) - 1u);
+    b.buf >>= n;
+    b.cnt -= n;
+    return v;
+}
+__device__ __forceinline__ uint64_t rb_used(const RBits& b) { return (uint64_t)b.pos * 8 - b.cnt; }
+
+// puff.c's decode() on the register-resident counts: the code-length code of a dynamic block's header, and the codes
+// the look-up tables do not hold (longer than 9 / 7 bits).  `sym`: the sorted symbols, [index][member].
+// Returns symbol << 8 | bits used, or -1.
+__device__ __noinline__ int rb_walk_cold(uint32_t bitbuf, const Counts c, const uint16_t (*sym)[kLanes], int lane) {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= kMaxBits; ++len) {
+        code |= (int)(bitbuf & 1u);
+        bitbuf >>= 1;
+        const int count = (int)((c.w[len >> 1] >> (16 * (len & 1))) & 0xFFFFu);
+        if (code - count < first) return ((int)sym[index + (code - first)][lane] << 8) | len;
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+template <typename SYM>
+__device__ __forceinline__ int rb_walk(RBits& b, ParseLds& s, const Counts& c, SYM sym, int lane) {
+    rb_refill(b, s, lane);
+    const int r = rb_walk_cold((uint32_t)b.buf, c, sym, lane);
+    if (r < 0) return -1;
+    b.buf >>= (uint32_t)r & 255u;
+    b.cnt -= (uint32_t)r & 255u;
+    return r >> 8;
+}
+template <int BITS, typename TAB, typename SYM>
+__device__ __forceinline__ int rb_decode(RBits& b, ParseLds& s, TAB tab, const Counts& c, SYM sym, int lane) {
+    rb_refill(b, s, lane);
+    const uint32_t e = tab[(uint32_t)b.buf & ((1u << BITS) - 1u)][lane];
+    if (__builtin_expect(e != 0u, 1)) {
+        const uint32_t len = e & 15u;
+        b.buf >>= len;
+        b.cnt -= len;
+        return (int)(e >> 4);
+    }
+    return rb_walk(b, s, c, sym, lane);  // (refills nothing: 32 bits are there)
+}
+
+enum { PS_HEADER = 0, PS_SYM = 1, PS_STORED = 2, PS_DONE = 3 };
+
+// what a member's lane carries through the parse
+struct ParseLane {
+    RBits b;
+    Counts c_ll, c_d;
+    uint32_t isize, produced, st, stored_left;
+    bool last;
+};
+
+// A block header: type, (for dynamic codes) the code lengths, the tables of the block.  Out of line — a few calls per
+// member, thousands of instructions.  Returns the lane's next state.
+__device__ __noinline__ int parse_header(ParseLane& h, ParseLds& s, const int lane) {
+    RBits& b = h.b;
+    h.last = rb_get(b, s, lane, 1) != 0;
+    const uint32_t type = rb_get(b, s, lane, 2);
+    if (type == 0) {  // stored: skip to the byte boundary, LEN / NLEN, raw bytes
+        const uint32_t drop = b.cnt & 7u;
+        b.buf >>= drop;
+        b.cnt -= drop;
+        const uint32_t len = rb_get(b, s, lane, 16), nlen = rb_get(b, s, lane, 16);
+        if ((len ^ 0xFFFFu) != nlen) { h.st = ST_BAD_STREAM; return PS_DONE; }
+        if (h.produced + len > h.isize) { h.st = ST_SIZE; return PS_DONE; }
+        h.stored_left = len;
+        return PS_STORED;
+    }
+    if (type == 3) { h.st = ST_BAD_STREAM; return PS_DONE; }
+    bool good = true;
+    if (type == 1) {  // fixed codes
+        for (int i = 0; i < 144; ++i) len_set(s, i, lane, 8);
+        for (int i = 144; i < 256; ++i) len_set(s, i, lane, 9);
+        for (int i = 256; i < 280; ++i) len_set(s, i, lane, 7);
+        for (int i = 280; i < kLL; ++i) len_set(s, i, lane, 8);
+        for (int i = 0; i < kDist; ++i) len_set(s, kLL + i, lane, 5);
+        huff_construct_p(s.cnt_ll, s.sym_ll, s, 0, kLL, lane);
+        huff_construct_p(s.cnt_d, s.sym_d, s, kLL, kDist, lane);
+    } else {  // dynamic codes (as in k_bgzf_inflate)
+        const uint32_t nlen = rb_get(b, s, lane, 5) + 257, ndist = rb_get(b, s, lane, 5) + 1, ncode = rb_get(b, s, lane, 4) + 4;
+        good = nlen <= 286 && ndist <= 30;
+        if (good) {
+            for (int i = 0; i < 19; ++i) len_set(s, i, lane, 0);
+            for (uint32_t i = 0; i < ncode; ++i) len_set(s, kClOrder[i], lane, rb_get(b, s, lane, 3));
+            good = huff_construct_p(s.cnt_d, s.sym_d, s, 0, 19, lane) == 0;  // (zlib: must be complete)
+        }
+        if (good) {
+            const Counts cl_counts = load_counts(s.cnt_d, lane);
+            uint32_t idx = 0;
+            while (good && idx < nlen + ndist) {
+                const int sym = rb_walk(b, s, cl_counts, s.sym_d, lane);
+                if (sym < 0) { good = false; }
+                else if (sym < 16) { len_set(s, (int)idx++, lane, (uint32_t)sym); }
+                else {
+                    uint32_t prev = 0, rep = 0;
+                    if (sym == 16) {
+                        if (idx == 0) good = false;
+                        else { prev = len_get(s, (int)idx - 1, lane); rep = 3 + rb_get(b, s, lane, 2); }
+                    } else if (sym == 17) {
+                        rep = 3 + rb_get(b, s, lane, 3);
+                    } else {
+                        rep = 11 + rb_get(b, s, lane, 7);
+                    }
+                    if (good && idx + rep > nlen + ndist) good = false;
+                    while (good && rep--) len_set(s, (int)idx++, lane, prev);
+                }
+            }
+        }
+        if (good) good = len_get(s, 256, lane) != 0;  // no end-of-block code
+        if (good) {
+            for (int i = (int)ndist - 1; i >= 0; --i) len_set(s, kLL + i, lane, len_get(s, (int)nlen + i, lane));
+            for (uint32_t i = nlen; i < (uint32_t)kLL; ++i) len_set(s, (int)i, lane, 0);
+            for (uint32_t i = ndist; i < (uint32_t)kDist; ++i) len_set(s, kLL + (int)i, lane, 0);
+            // incomplete code sets are allowed only when they consist of ONE code of length 1 (zlib inflate_table)
+            int err = huff_construct_p(s.cnt_ll, s.sym_ll, s, 0, kLL, lane);
+            if (err < 0 || (err > 0 && kLL != (int)s.cnt_ll[0][lane] + (int)s.cnt_ll[1][lane])) good = false;
+            if (good) {
+                err = huff_construct_p(s.cnt_d, s.sym_d, s, kLL, kDist, lane);
+                if (err < 0 || (err > 0 && kDist != (int)s.cnt_d[0][lane] + (int)s.cnt_d[1][lane])) good = false;
+            }
+        }
+    }
+    if (!good) { h.st = ST_BAD_STREAM; return PS_DONE; }
+    huff_table<kLLBits>(s.tab_ll, s.cnt_ll, s.sym_ll, lane);
+    huff_table<kDBits>(s.tab_d, s.cnt_d, s.sym_d, lane);
+    h.c_ll = load_counts(s.cnt_ll, lane);
+    h.c_d = load_counts(s.cnt_d, lane);
+    return PS_SYM;
+}
+
+__global__ __launch_bounds__(64) void k_inflate_parse(TwoPassArgs t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ParseLds& s = *reinterpret_cast<ParseLds*>(lds_raw);
+    const InfArgs& a = t.a;
+    const int lane = (int)threadIdx.x;
+    const uint32_t m = blockIdx.x * kLanes + (uint32_t)lane;
+    const bool mine = lane < kLanes && m < a.n && (!t.redo_only || t.n_tok[m] == kTokPending);
+    ParseLane h;
+    RBits& b = h.b;
+    b.buf = 0; b.cnt = 0; b.pos = 0; b.next = 0; b.ring_hi = 0; b.in_len = 0; b.in = a.in;
+    h.isize = 0; h.produced = 0; h.st = ST_OK; h.stored_left = 0; h.last = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h.c_ll.w[k] = h.c_d.w[k] = 0;
+    uint32_t n_tok = 0;
+    uint8_t* out = a.out;
+    uint2* tok = t.tok;
+    int state = PS_DONE;
+    if (mine) {
+        b.in = a.in + a.in_off[m];
+        b.in_len = a.in_len[m];
+        h.isize = a.isize[m];
+        out = a.out + a.out_off[m];
+        tok = t.tok + t.tok_off[m];
+        state = PS_HEADER;
+        if (h.isize > 65536u) { h.st = ST_SIZE; state = PS_DONE; }  // no BGZF member is longer
+        s.in_lo[lane] = (uint32_t)(uintptr_t)b.in;
+        s.in_hi[lane] = (uint32_t)((uintptr_t)b.in >> 32);
+        s.in_len[lane] = b.in_len;
+        rb_fill_self(b, s, lane);
+        rb_fill_self(b, s, lane);
+        b.next = s.ring[0][lane];
+    } else if (lane < kLanes) {
+        s.in_len[lane] = 0; s.in_lo[lane] = 0; s.in_hi[lane] = 0;
+    }
+    // the wave-wide top-up: lane l serves member l & 15 with bytes [16 * (l >> 4), + 16) of the member's next 64
+    const int tm = lane & (kLanes - 1), tq = lane >> 4;
+    uint32_t step_no = 0;
+    for (;;) {
+        if (state == PS_HEADER) {  // (through a copy: `h` itself stays in registers)
+            ParseLane at_call = h;
+            state = parse_header(at_call, s, lane);
+            h = at_call;
+        }
+        if (__ballot(state != PS_DONE) == 0ull) break;
+        // ---- every eight steps: all 64 lanes top the sixteen rings up, 64 bytes per member that has room for them
+        if ((++step_no & 7u) == 0u) {
+            if (lane < kLanes) { s.ring_hi[lane] = b.ring_hi; s.rd_pos[lane] = state == PS_DONE ? 0xFFFFFFFFu : b.pos; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t hi = s.ring_hi[tm], rd = s.rd_pos[tm];
+            const bool want = rd != 0xFFFFFFFFu && hi - rd <= 64u && hi < s.in_len[tm] + 8u;
+            if (want) {
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(((uintptr_t)s.in_hi[tm] << 32) | (uintptr_t)s.in_lo[tm]);
+                const uint32_t off = hi + 16u * (uint32_t)tq, len_m = s.in_len[tm];
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { uint32_t real; w[k] = load_word(src, off + 4u * k, len_m, &real); }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s.ring[((off >> 2) + k) & (kRingBytes / 4 - 1)][tm] = w[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < kLanes && state != PS_DONE && b.ring_hi - b.pos <= 64u && b.ring_hi < b.in_len + 8u) b.ring_hi += 64;
+        }
+        if (state == PS_STORED) {
+            for (int k = 0; k < 4 && h.stored_left; ++k, --h.stored_left) out[h.produced++] = (uint8_t)rb_get(b, s, lane, 8);
+            if (h.stored_left == 0) {
+                if (rb_used(b) > (uint64_t)b.in_len * 8) { h.st = ST_INPUT_END; state = PS_DONE; }
+                else state = h.last ? PS_DONE : PS_HEADER;
+            }
+        }
+        if (state == PS_SYM) {
+            const int sym = rb_decode<kLLBits>(b, s, s.tab_ll, h.c_ll, s.sym_ll, lane);
+            if (sym < 256) {
+                if (sym < 0) { h.st = ST_BAD_STREAM; state = PS_DONE; }
+                else if (h.produced >= h.isize) { h.st = ST_SIZE; state = PS_DONE; }
+                else out[h.produced++] = (uint8_t)sym;
+            } else if (sym == 256) {
+                if (rb_used(b) > (uint64_t)b.in_len * 8) { h.st = ST_INPUT_END; state = PS_DONE; }
+                else state = h.last ? PS_DONE : PS_HEADER;
+            } else {
+                const int li = sym - 257;
+                if (li >= 29) { h.st = ST_BAD_STREAM; state = PS_DONE; }
+                else {
+                    uint32_t len;
+                    if (li < 8) {
+                        len = 3u + (uint32_t)li;
+                    } else if (li == 28) {
+                        len = 258u;
+                    } else {
+                        const uint32_t e = ((uint32_t)li - 4u) >> 2;
+                        len = 3u + ((4u + ((uint32_t)li & 3u)) << e) + rb_get(b, s, lane, e);
+                    }
+                    const int ds = rb_decode<kDBits>(b, s, s.tab_d, h.c_d, s.sym_d, lane);
+                    if (ds < 0 || ds >= 30) { h.st = ST_BAD_STREAM; state = PS_DONE; }
+                    else {
+                        uint32_t dist;
+                        if (ds < 4) {
+                            dist = 1u + (uint32_t)ds;
+                        } else {
+                            const uint32_t ex = ((uint32_t)ds - 2u) >> 1;
+                            dist = 1u + ((2u + ((uint32_t)ds & 1u)) << ex);
+                            if (ex > 8) {  // up to 13 extra bits: two reads keep each within the refill guarantee
+                                const uint32_t lo = rb_get(b, s, lane, 8);
+                                dist += lo | (rb_get(b, s, lane, ex - 8) << 8);
+                            } else {
+                                dist += rb_get(b, s, lane, ex);
+                            }
+                        }
+                        if (dist > h.produced) { h.st = ST_BAD_STREAM; state = PS_DONE; }
+                        else if (h.produced + len > h.isize) { h.st = ST_SIZE; state = PS_DONE; }
+                        else if (rb_used(b) > (uint64_t)b.in_len * 8) { h.st = ST_INPUT_END; state = PS_DONE; }
+                        else {
+                            tok[n_tok++] = make_uint2(h.produced | (len << 16), dist);  // (produced <= 65535, len <= 258)
+                            h.produced += len;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (mine) {
+        uint32_t st = h.st;
+        if (st == ST_OK && h.produced != h.isize) st = ST_SIZE;
+        a.status[m] = st;
+        t.n_tok[m] = st == ST_OK ? n_tok : kTokFinal;
+    }
+}
+
+// ==================================================================================================================
+// Wave-parallel parse (round 6).  k_inflate_parse gives a member ONE lane, and the member's symbols are a chain of
+// ~40 000 steps that nothing shortens.  Here a member has a WAVE, and the 64 lanes decode 64 stretches of the member's
+// bit stream at once — which they can, because a Huffman-coded stream resynchronises: a decoder started at a wrong bit
+// falls onto true symbol boundaries within a few symbols.
+//   header   the block's header out of a 1 KiB window staged in LDS; the code-length symbols one after the other (all
+//            lanes the same way), everything else across the lanes: code counts by LDS atomics, the canonical order by
+//            ballots, the look-up tables (10 bits literal/length, 8 bits distance) a symbol per lane; longer codes are
+//            found by comparing the next 15 bits against the left-justified code limit of each length (6 or 7 compares).
+//   window   the bits from the header's end to the (guessed) end of the block, cut into up to 64 stretches of >= 256 bits.
+//     pass 1   lane i decodes from the first bit of stretch i — a guess — to the first symbol that starts behind the
+//              stretch, counting the bytes and the matches it would produce;
+//     pass 2+  lane i starts again at the bit where lane i - 1 has ended, if that is not where it had started; until every
+//              lane up to the first one that met the end-of-block code starts where its predecessor ended.  Lane 0 starts
+//              at the true position, so by induction all of these are the member's true symbols (two passes when every
+//              lane's guess resynchronised inside its stretch: the rule, at 600 symbols per stretch);
+//     write    prefix sums of the byte and match counts give every lane its place in the output and in the token list;
+//              the lanes decode their stretches once more, storing literals and tokens as k_inflate_parse does.
+//   The first window of a block is the rest of the member (nothing is known), later ones 1.125 x the block before; a
+//   block that outlasts its window goes on in the next window with the same tables.
+// Anything unusual — a stored block, a code set that is not complete, an invalid code or distance on the true chain, a
+// size that does not match — is NOT judged here: the member is marked kTokPending and k_inflate_parse (launched behind
+// this kernel for exactly these members) decodes it from the start and gives it its status.
+constexpr int kWLL = 10, kWD = 8;
+constexpr uint32_t kMinStretchBits = 256;
+constexpr int kMaxSyncPasses = 24;
+struct WaveLds {
+    uint16_t tab_ll[1 << kWLL];  // next bits -> symbol << 4 | code length (0: a longer code, or none)
+    uint16_t tab_d[1 << kWD];
+    uint16_t tab_cl[128];
+    uint16_t sym_ll[kLL];        // symbols sorted by (code length, symbol)
+    uint16_t sym_d[32];
+    uint32_t lim_ll[16], lim_d[16], lim_cl[16];  // per length: left-justified code limit << 16 | (first index - first code + 32768)
+    uint32_t cnt[16], base[16];
+    uint8_t lens[kLL + 32 + 8];
+    uint32_t hw[258];            // the header window: 1 KiB of the member's input from the word the header starts in
+};
+
+__device__ __forceinline__ void wave_sync() {  // LDS written by one lane, read by another of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t wave_scan_excl(uint32_t v, int lane, uint32_t* total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if (lane >= d) x += y;
+    }
+    *total = (uint32_t)__shfl((int)x, 63);
+    return x - v;
+}
+
+// The canonical code of `n` lengths (lens[0..n)), all lanes together: the primary table of PB bits, the sorted symbols and
+// the per-length limits.  0: built; 1: over-subscribed, or incomplete in a way zlib does not allow (`any_incomplete`: the
+// fixed codes, which leave two distance codes unused).
+template <int PB>
+__device__ __forceinline__ int wave_build_code(WaveLds& s, const uint8_t* lens, int n, int chunks, uint16_t* tab, uint16_t* sorted,
+                                               uint32_t* lim, bool must_be_complete, bool any_incomplete, int lane) {
+    if (lane < 16) s.cnt[lane] = 0;
+    for (int i = lane; i < (1 << PB); i += 64) tab[i] = 0;
+    wave_sync();
+    for (int c = 0; c < chunks; ++c) {
+        const int si = c * 64 + lane;
+        const uint32_t l = si < n ? lens[si] : 0u;
+        if (l) atomicAdd(&s.cnt[l], 1u);
+    }
+    wave_sync();
+    uint32_t code = 0, index = 0, kraft = 0;
+    for (int l = 1; l <= kMaxBits; ++l) {  // (every lane the same)
+        const uint32_t c = s.cnt[l];
+        kraft += c << (kMaxBits - l);
+        if (lane == 0) {
+            lim[l] = (((code + c) << (kMaxBits - l)) << 16) | ((index - code + 32768u) & 0xFFFFu);
+            s.base[l] = index;
+        }
+        code = (code + c) << 1;
+        index += c;
+    }
+    if (kraft > (1u << kMaxBits)) return 1;
+    if (kraft < (1u << kMaxBits) && !any_incomplete) {
+        if (must_be_complete) return 1;
+        if (!(index == 0u || (index == 1u && s.cnt[1] == 1u))) return 1;
+    }
+    wave_sync();
+    for (int c = 0; c < chunks; ++c) {
+        const int si = c * 64 + lane;
+        const uint32_t l = si < n ? lens[si] : 0u;
+        uint32_t rank = 0;
+        uint64_t todo = __ballot(l != 0u);
+        while (todo) {  // one round per distinct length among the chunk's symbols
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t l0 = (uint32_t)__shfl((int)l, leader);
+            const uint64_t same = __ballot(l == l0);
+            const uint32_t b0 = s.base[l0];
+            if (l == l0) rank = b0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (lane == leader) s.base[l0] = b0 + (uint32_t)__popcll(same);
+            todo &= ~same;
+        }
+        if (l) {
+            sorted[rank] = (uint16_t)si;
+            if (l <= (uint32_t)PB) {
+                const uint32_t cd = rank + 32768u - (lim[l] & 0xFFFFu);  // rank - (first index - first code)
+                const uint32_t rev = __brev(cd) >> (32 - l);
+                const uint16_t e = (uint16_t)(((uint32_t)si << 4) | l);
+                for (uint32_t i = rev; i < (1u << PB); i += 1u << l) tab[i] = e;
+            }
+        }
+        wave_sync();
+    }
+    return 0;
+}
+
+// bits [bit, bit + n) of the header window, n <= 16
+__device__ __forceinline__ uint32_t hw_peek(const WaveLds& s, uint32_t bit, uint32_t n) {
+    const uint32_t i = bit >> 5;
+    const uint64_t w = (uint64_t)s.hw[i] | ((uint64_t)s.hw[i + 1] << 32);
+    return (uint32_t)(w >> (bit & 31u)) & ((1u << n) - 1u);
+}
+
+// The block header at bit `pos` of the member: 0 and the tables of the block, `pos` behind the header, `last`; or 1: not
+// for this kernel.
+__device__ __forceinline__ int wave_header(WaveLds& s, const uint8_t* in, uint32_t in_len, uint32_t* pos_io, uint32_t* last_out, int lane) {
+    const uint32_t pos = *pos_io;
+    const uint32_t byte0 = (pos >> 5) << 2;
+    for (int i = lane; i < 258; i += 64) {
+        uint32_t real;
+        s.hw[i] = load_word(in, byte0 + 4u * (uint32_t)i, in_len, &real);
+    }
+    wave_sync();
+    uint32_t hb = pos & 31u;
+    *last_out = hw_peek(s, hb, 1);
+    const uint32_t type = hw_peek(s, hb + 1, 2);
+    hb += 3;
+    if (type == 0u || type == 3u) return 1;
+    uint32_t nlen, ndist;
+    if (type == 1u) {
+        nlen = 288; ndist = 30;
+        for (int i = lane; i < 288; i += 64) s.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+        if (lane < 30) s.lens[288 + lane] = 5;
+        wave_sync();
+    } else {
+        nlen = hw_peek(s, hb, 5) + 257u;
+        ndist = hw_peek(s, hb + 5, 5) + 1u;
+        const uint32_t ncode = hw_peek(s, hb + 10, 4) + 4u;
+        hb += 14;
+        if (nlen > 286u || ndist > 30u) return 1;
+        if (lane < 19) s.lens[kClOrder[lane]] = (uint8_t)((uint32_t)lane < ncode ? hw_peek(s, hb + 3u * (uint32_t)lane, 3) : 0u);
+        hb += 3u * ncode;
+        wave_sync();
+        if (wave_build_code<7>(s, s.lens, 19, 1, s.tab_cl, s.sym_d, s.lim_cl, true, false, lane)) return 1;
+        // the code lengths, one symbol after the other
+        const uint32_t total = nlen + ndist;
+        uint32_t idx = 0, prev = 0;
+        while (idx < total) {
+            const uint32_t e = s.tab_cl[hw_peek(s, hb, 7)];
+            if (e == 0u) return 1;
+            hb += e & 15u;
+            const uint32_t sym = e >> 4;
+            if (sym < 16u) {
+                if (lane == 0) s.lens[idx] = (uint8_t)sym;
+                ++idx;
+                prev = sym;
+            } else {
+                uint32_t rep, v = 0;
+                if (sym == 16u) {
+                    if (idx == 0u) return 1;
+                    rep = 3u + hw_peek(s, hb, 2); hb += 2; v = prev;
+                } else if (sym == 17u) {
+                    rep = 3u + hw_peek(s, hb, 3); hb += 3;
+                } else {
+                    rep = 11u + hw_peek(s, hb, 7); hb += 7;
+                }
+                if (idx + rep > total) return 1;
+                for (uint32_t j = (uint32_t)lane; j < rep; j += 64u) s.lens[idx + j] = (uint8_t)v;
+                idx += rep;
+                prev = v;
+            }
+        }
+        wave_sync();
+        if (s.lens[256] == 0u) return 1;  // no end-of-block code
+    }
+    const uint32_t after = byte0 * 8u + hb;
+    if (after > in_len * 8u) return 1;
+    *pos_io = after;
+    const bool fixed = type == 1u;
+    if (wave_build_code<kWLL>(s, s.lens, (int)nlen, 5, s.tab_ll, s.sym_ll, s.lim_ll, false, fixed, lane)) return 1;
+    if (wave_build_code<kWD>(s, s.lens + nlen, (int)ndist, 1, s.tab_d, s.sym_d, s.lim_d, false, fixed, lane)) return 1;
+    return 0;
+}
+
+// A lane's bit reader on the member's input in global memory: the next word is requested one refill ahead.
+struct WBits {
+    uint64_t buf;
+    uint32_t cnt, pos, next;  // pos: input bytes taken into buf
+};
+__device__ __forceinline__ void wb_init(WBits& b, const uint8_t* in, uint32_t in_len, uint32_t bit) {
+    const uint32_t byte0 = (bit >> 5) << 2, sh = bit & 31u;
+    uint32_t real;
+    b.buf = (uint64_t)(load_word(in, byte0, in_len, &real) >> sh);
+    b.cnt = 32u - sh;
+    b.pos = byte0 + 4u;
+    b.next = load_word(in, b.pos, in_len, &real);
+}
+__device__ __forceinline__ void wb_refill(WBits& b, const uint8_t* in, uint32_t in_len) {  // >= 33 bits afterwards
+    if (b.cnt <= 32u) {
+        b.buf |= (uint64_t)b.next << b.cnt;
+        b.cnt += 32u;
+        b.pos += 4u;
+        uint32_t real;
+        b.next = load_word(in, b.pos, in_len, &real);
+    }
+}
+__device__ __forceinline__ uint32_t wb_at(const WBits& b) { return b.pos * 8u - b.cnt; }
+
+template <int PB, int NSYM>
+__device__ __forceinline__ int wave_symbol(WBits& b, const uint16_t* tab, const uint16_t* sorted, const uint32_t (&lim)[kMaxBits - PB]) {
+    const uint32_t bits = (uint32_t)b.buf;
+    uint32_t e = tab[bits & ((1u << PB) - 1u)];
+    if (__builtin_expect(e == 0u, 0)) {
+        const uint32_t code15 = __brev(bits) >> 17;  // the next 15 bits, first bit on top
+        uint32_t len = 0, packed = 0;
+#pragma unroll
+        for (int l = kMaxBits; l > PB; --l) {  // the shortest length whose limit lies above the bits
+            const uint32_t p = lim[l - PB - 1];
+            if (code15 < (p >> 16)) { len = (uint32_t)l; packed = p; }
+        }
+        if (len == 0u) return -1;
+        const uint32_t idx = (code15 >> (kMaxBits - len)) + (packed & 0xFFFFu) - 32768u;
+        if (idx >= (uint32_t)NSYM) return -1;
+        e = ((uint32_t)sorted[idx] << 4) | len;
+    }
+    const uint32_t l = e & 15u;
+    b.buf >>= l;
+    b.cnt -= l;
+    return (int)(e >> 4);
+}
+
+enum { WF_NONE = 0, WF_EOB = 1, WF_BAD = 2 };
+
+// One lane's stretch: the symbols that start in [start, limit).  WRITE: literals to out[o..], matches to tok[..].
+template <bool WRITE>
+__device__ __forceinline__ void wave_decode(const uint8_t* in, uint32_t in_len, const WaveLds& s, const uint32_t (&lim_ll)[kMaxBits - kWLL],
+                                            const uint32_t (&lim_d)[kMaxBits - kWD], bool active, uint32_t start, uint32_t limit,
+                                            uint32_t& end, uint32_t& flag, uint32_t& n_bytes, uint32_t& n_toks, uint8_t* out, uint32_t o,
+                                            uint2* tok) {
+    if (!active) return;
+    WBits b;
+    wb_init(b, in, in_len, start);
+    uint32_t bytes = 0, toks = 0, fl = WF_NONE, at = start;
+    for (;;) {
+        at = wb_at(b);
+        if (at >= limit) break;
+        wb_refill(b, in, in_len);
+        const int sym = wave_symbol<kWLL, kLL>(b, s.tab_ll, s.sym_ll, lim_ll);
+        if (sym < 256) {
+            if (sym < 0) { fl = WF_BAD; break; }
+            if (WRITE) out[o] = (uint8_t)sym;
+            ++o;
+            ++bytes;
+            continue;
+        }
+        if (sym == 256) { fl = WF_EOB; at = wb_at(b); break; }
+        const int li = sym - 257;
+        if (li >= 29) { fl = WF_BAD; break; }
+        uint32_t len;
+        if (li < 8) {
+            len = 3u + (uint32_t)li;
+        } else if (li == 28) {
+            len = 258u;
+        } else {
+            const uint32_t e = ((uint32_t)li - 4u) >> 2;
+            len = 3u + ((4u + ((uint32_t)li & 3u)) << e) + ((uint32_t)b.buf & ((1u << e) - 1u));
+            b.buf >>= e;
+            b.cnt -= e;
+        }
+        wb_refill(b, in, in_len);
+        const int ds = wave_symbol<kWD, 32>(b, s.tab_d, s.sym_d, lim_d);
+        if (ds < 0 || ds >= 30) { fl = WF_BAD; break; }
+        uint32_t dist;
+        if (ds < 4) {
+            dist = 1u + (uint32_t)ds;
+        } else {
+            const uint32_t ex = ((uint32_t)ds - 2u) >> 1;  // <= 13: there after a 15-bit code (33 bits behind a refill)
+            dist = 1u + ((2u + ((uint32_t)ds & 1u)) << ex) + ((uint32_t)b.buf & ((1u << ex) - 1u));
+            b.buf >>= ex;
+            b.cnt -= ex;
+        }
+        if (WRITE) {
+            if (dist > o) { fl = WF_BAD; break; }
+            tok[toks] = make_uint2(o | (len << 16), dist);
+        }
+        o += len;
+        bytes += len;
+        ++toks;
+    }
+    end = at;
+    flag = fl;
+    n_bytes = bytes;
+    n_toks = toks;
+}
+
+__global__ __launch_bounds__(64) void k_inflate_wparse(TwoPassArgs t) {
+    __shared__ WaveLds s;
+    const InfArgs& a = t.a;
+    const int lane = (int)threadIdx.x;
+    const uint32_t m = blockIdx.x;
+    if (m >= a.n) return;
+    const uint8_t* in = a.in + a.in_off[m];
+    const uint32_t in_len = a.in_len[m], isize = a.isize[m], nbits = in_len * 8u;
+    uint8_t* out = a.out + a.out_off[m];
+    uint2* tok = t.tok + t.tok_off[m];
+    if (isize > 65536u || in_len > 65536u) {  // (no BGZF member is longer; the serial parse says what it is)
+        if (lane == 0) t.n_tok[m] = kTokPending;
+        return;
+    }
+    uint32_t pos = 0, produced = 0, n_tok = 0, last = 0, guess = nbits, block_start = 0;
+    bool need_header = true, give_up = false;
+    uint32_t lim_ll[kMaxBits - kWLL], lim_d[kMaxBits - kWD];
+    for (;;) {
+        if (pos >= nbits) { give_up = true; break; }
+        if (need_header) {
+            if (wave_header(s, in, in_len, &pos, &last, lane)) { give_up = true; break; }
+#pragma unroll
+            for (int l = kWLL + 1; l <= kMaxBits; ++l) lim_ll[l - kWLL - 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.lim_ll[l]);
+#pragma unroll
+            for (int l = kWD + 1; l <= kMaxBits; ++l) lim_d[l - kWD - 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.lim_d[l]);
+            block_start = pos;
+            need_header = false;
+            if (pos >= nbits) { give_up = true; break; }
+        }
+        // ---- the window and its stretches
+        const uint32_t span = min(nbits - pos, guess), w_end = pos + span;
+        const uint32_t stretch = max((span + 63u) / 64u, kMinStretchBits);
+        const uint32_t n_lanes = (span + stretch - 1u) / stretch;  // 1..64
+        const bool active = (uint32_t)lane < n_lanes;
+        uint32_t start = pos + (uint32_t)lane * stretch;
+        const uint32_t limit = (uint32_t)lane + 1u == n_lanes ? w_end : min(start + stretch, w_end);
+        uint32_t end = w_end, flag = WF_NONE, nb = 0, nt = 0;
+        bool decode = active;
+        int passes = 0, k = 0;
+        for (;;) {
+            wave_decode<false>(in, in_len, s, lim_ll, lim_d, decode, start, limit, end, flag, nb, nt, nullptr, 0u, nullptr);
+            const uint64_t flagged = __ballot(active && flag != WF_NONE);
+            k = flagged ? __ffsll((unsigned long long)flagged) - 1 : (int)n_lanes - 1;  // the chain runs to lane k
+            const uint32_t before = (uint32_t)__shfl_up((int)end, 1);
+            const uint32_t true_start = lane == 0 ? pos : before;
+            decode = active && lane <= k && true_start != start;
+            if (__ballot(decode) == 0ull) break;
+            if (++passes > kMaxSyncPasses) { give_up = true; break; }
+            if (decode) start = true_start;
+        }
+        if (give_up) break;
+        const uint32_t flag_k = (uint32_t)__shfl((int)flag, k), end_k = (uint32_t)__shfl((int)end, k);
+        if (flag_k == WF_BAD) { give_up = true; break; }
+        const bool in_chain = active && lane <= k;
+        uint32_t sum_b, sum_t;
+        const uint32_t off_b = wave_scan_excl(in_chain ? nb : 0u, lane, &sum_b);
+        const uint32_t off_t = wave_scan_excl(in_chain ? nt : 0u, lane, &sum_t);
+        if (produced + sum_b > isize) { give_up = true; break; }
+        uint32_t end_w = 0, flag_w = WF_NONE, nb_w = 0, nt_w = 0;
+        wave_decode<true>(in, in_len, s, lim_ll, lim_d, in_chain, start, limit, end_w, flag_w, nb_w, nt_w, out, produced + off_b,
+                          tok + n_tok + off_t);
+        if (__ballot(in_chain && (flag_w == WF_BAD || end_w != end)) != 0ull) { give_up = true; break; }
+        produced += sum_b;
+        n_tok += sum_t;
+        pos = end_k;
+        if (flag_k == WF_EOB) {
+            if (last) break;
+            const uint32_t block_bits = pos - block_start;
+            guess = max(block_bits + block_bits / 8u, 64u * kMinStretchBits);
+            need_header = true;
+        } else if (w_end >= nbits) {  // the input ends inside a block
+            give_up = true;
+            break;
+        }
+    }
+    if (!give_up && (pos > nbits || produced != isize)) give_up = true;
+    if (lane == 0) {
+        if (give_up) {
+            t.n_tok[m] = kTokPending;
+        } else {
+            a.status[m] = ST_OK;
+            t.n_tok[m] = n_tok;
+        }
+    }
+}
+
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+
+// x -> x * z^(8 * bytes) in the CRC's field, as the 32 columns of the operator: out = XOR of col[i] over the set bits i of x
+__device__ __forceinline__ uint32_t crc_apply(const uint32_t (&col)[32], uint32_t x) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r ^= (0u - ((x >> i) & 1u)) & col[i];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_inflate_resolve(TwoPassArgs t) {
+    __shared__ uint32_t s_crc[4][256];  // slicing-by-4 tables of CRC-32 (reflected 0xEDB88320)
+    __shared__ uint32_t s_shift[6][32];
+    const InfArgs& a = t.a;
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        s_crc[0][i] = c;
+    }
+    if (threadIdx.x < 192) s_shift[threadIdx.x >> 5][threadIdx.x & 31] = t.shift[threadIdx.x >> 5][threadIdx.x & 31];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        uint32_t c = s_crc[0][i];
+        for (int k = 1; k < 4; ++k) {
+            c = s_crc[0][c & 0xFFu] ^ (c >> 8);
+            s_crc[k][i] = c;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (m >= a.n) return;
+    const uint32_t n_tok = t.n_tok[m];
+    if (n_tok == kTokFinal) return;  // the parse has written the member's status
+    uint8_t* out = a.out + a.out_off[m];
+    const uint32_t isize = a.isize[m];
+    const uint2* tok = t.tok + t.tok_off[m];
+    // ---- the matches, 64 at a time
+    auto copy_one = [&](uint32_t dst, uint32_t len, uint32_t dist) {
+        const uint8_t* src = out + dst - dist;
+        uint8_t* d = out + dst;
+        if (dist >= 8) {
+            uint32_t i = 0;
+            for (; i + 8 <= len; i += 8) {
+                const uint64_t v = __builtin_nontemporal_load(reinterpret_cast<const u64_unaligned*>(src + i));
+                *reinterpret_cast<u64_unaligned*>(d + i) = v;
+            }
+            if (i < len) {  // the last 1..7 bytes: exactly (the bytes behind a match are literals the parse has stored)
+                uint64_t v = __builtin_nontemporal_load(reinterpret_cast<const u64_unaligned*>(src + i));
+                const uint32_t rem = len - i;
+                if (rem & 4u) { *reinterpret_cast<u32_unaligned*>(d + i) = (uint32_t)v; v >>= 32; i += 4; }
+                if (rem & 2u) { *reinterpret_cast<u16_unaligned*>(d + i) = (uint16_t)v; v >>= 16; i += 2; }
+                if (rem & 1u) d[i] = (uint8_t)v;
+            }
+        } else {  // the source repeats with period `dist`: every byte of it lies in front of the destination
+            uint64_t pat = 0;
+            for (uint32_t i = 0; i < dist; ++i) pat |= (uint64_t)__builtin_nontemporal_load(src + i) << (8 * i);
+            for (uint32_t i = 0; i < len; ++i) d[i] = (uint8_t)(pat >> (8 * (i % dist)));
+        }
+    };
+    for (uint32_t base = 0; base < n_tok; base += 64) {
+        const bool valid = base + (uint32_t)lane < n_tok;
+        uint2 tk = make_uint2(0, 1);
+        if (valid) tk = tok[base + lane];
+        const uint32_t dst = tk.x & 0xFFFFu, len = tk.x >> 16, dist = tk.y;
+        const uint32_t dst_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);
+        // (the batch's destinations ascend; a source that ends at or in front of the first of them depends on none of them)
+        const uint32_t src_end = dst - dist + (len < dist ? len : dist);
+        const bool dep = valid && lane > 0 && src_end > dst_first;
+        if (valid && !dep) copy_one(dst, len, dist);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t todo = __ballot(dep);
+        while (todo) {  // in token order; each one's bytes are in the XCD's L2 (write-through L1) before the next one reads
+            const int l = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            if (lane == l) copy_one(dst, len, dist);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    // ---- CRC-32: the member's bytes in pieces of 1 KiB, the LAST piece on lane 63 and the odd-sized one first, so that
+    // every fold has a right-hand side of 2^j whole pieces; lanes in front of the first piece hold 0 (the field's zero)
+    const uint32_t n_pc = (isize + 1023u) / 1024u;   // <= 64
+    uint32_t state_crc = 0;
+    if (n_pc) {
+        const uint32_t first_lane = 64u - n_pc, r = isize - (n_pc - 1u) * 1024u;  // 1..1024 bytes in the first piece
+        if ((uint32_t)lane >= first_lane) {
+            const uint32_t k = (uint32_t)lane - first_lane;
+            const uint32_t lo = k == 0 ? 0u : r + (k - 1u) * 1024u, hi = k == 0 ? r : lo + 1024u;
+            uint32_t crc = k == 0 ? 0xFFFFFFFFu : 0u;
+            uint32_t i = lo;
+            for (; i + 16 <= hi; i += 16) {
+                const u32x4_a1 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a1*>(out + i));
+                const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t w = ws[q] ^ crc;
+                    crc = s_crc[3][w & 0xFFu] ^ s_crc[2][(w >> 8) & 0xFFu] ^ s_crc[1][(w >> 16) & 0xFFu] ^ s_crc[0][w >> 24];
+                }
+            }
+            for (; i < hi; ++i) crc = s_crc[0][(crc ^ __builtin_nontemporal_load(out + i)) & 0xFFu] ^ (crc >> 8);
+            state_crc = crc;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {  // lane l (a multiple of 2^(j+1)) takes in the 2^j pieces to its right
+            uint32_t col[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) col[i] = s_shift[j][i];
+            const uint32_t right = (uint32_t)__shfl_down((int)state_crc, 1 << j);
+            const uint32_t folded = crc_apply(col, state_crc) ^ right;
+            if ((lane & ((2 << j) - 1)) == 0) state_crc = folded;
+        }
+    } else {
+        state_crc = 0xFFFFFFFFu;
+    }
+    if (lane == 0) {
+        uint32_t st = a.status[m];
+        if (st == ST_OK && ((uint32_t)__builtin_amdgcn_readfirstlane((int)state_crc) ^ 0xFFFFFFFFu) != a.crc[m]) st = ST_CRC;
+        a.status[m] = st;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tok_offsets(uint32_t n, uint64_t slots_each, uint64_t* __restrict__ tok_off) {
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m < n) tok_off[m] = (uint64_t)m * slots_each;
+}
+
 // pieces of the inflated members → one compact buffer: piece p = src[src_off[p] .. + len[p]) → dst[dst_off[p] ..]; one
 // wave per piece (the packed SEQ bytes of one sequence slice inside one member: tens to thousands of bytes)
 __global__ __launch_bounds__(256) void k_gather_ranges(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
@@ -443,11 +1325,75 @@ __global__ __launch_bounds__(256) void k_gather_ranges(const uint8_t* __restrict
 
 // The two launches the BAM reader's device leg needs (svx_bam_seq_slices with svx_bam_set_device_inflate), on a stream of
 // the caller's: hipError_t as int.
+// the columns of x -> x * z^(8 * 1024 * 2^j) for the CRC-32 state (reflected polynomial 0xEDB88320): column i = the
+// state after 1024 * 2^j zero bytes from the state 1 << i; j = 0 by running the bytes, j + 1 by applying j to itself
+static const uint32_t (*crc_shift_columns())[32] {
+    static uint32_t cols[6][32];
+    static const bool made = [] {
+        uint32_t table[256];
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        for (int i = 0; i < 32; ++i) {
+            uint32_t x = 1u << i;
+            for (int b = 0; b < 1024; ++b) x = table[x & 0xFFu] ^ (x >> 8);
+            cols[0][i] = x;
+        }
+        for (int j = 1; j < 6; ++j)
+            for (int i = 0; i < 32; ++i) {
+                const uint32_t x = cols[j - 1][i];
+                uint32_t r = 0;
+                for (int q = 0; q < 32; ++q)
+                    if ((x >> q) & 1u) r ^= cols[j - 1][q];
+                cols[j][i] = r;
+            }
+        return true;
+    }();
+    (void)made;
+    return cols;
+}
+
+// which form svx_bgzf_inflate_dev and the BAM reader's device leg launch (process-wide; SVX_INFLATE_KERNEL=1 in the
+// environment: the one-pass kernel from the start)
+// 1: the one-launch kernel; 2: two passes, a lane per member in the parse; 3: two passes, a wave per member in the parse
+static std::atomic<int> g_form{[] {
+    const char* e = getenv("SVX_INFLATE_KERNEL");
+    return e && e[0] >= '1' && e[0] <= '3' && !e[1] ? e[0] - '0' : 3;
+}()};
+extern "C" int svx_bgzf_inflate_set_two_pass(int on) {
+    const int was = g_form.exchange(on == 0 ? 1 : on == 2 ? 2 : 3);
+    return was == 1 ? 0 : was == 2 ? 2 : 1;
+}
+
+// The two launches of the two-pass form: d_tok_off[m] = first slot of member m's token list in d_tok (prefix sums of
+// isize / 3 + 2, filled in by the caller), d_n_tok one word per member.
+static int inflate_two_pass(hipStream_t stream, int form, const InfArgs& a, const uint64_t* d_tok_off, uint32_t* d_n_tok, void* d_tok) {
+    TwoPassArgs t;
+    t.a = a;
+    t.tok_off = d_tok_off;
+    t.n_tok = d_n_tok;
+    t.tok = static_cast<uint2*>(d_tok);
+    memcpy(t.shift, crc_shift_columns(), sizeof(t.shift));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_parse), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(ParseLds));
+    if (e != hipSuccess) return (int)e;
+    t.redo_only = form == 3 ? 1u : 0u;
+    if (form == 3) hipLaunchKernelGGL(k_inflate_wparse, dim3(a.n), dim3(64), 0, stream, t);
+    hipLaunchKernelGGL(k_inflate_parse, dim3((a.n + kLanes - 1) / kLanes), dim3(64), sizeof(ParseLds), stream, t);
+    hipLaunchKernelGGL(k_inflate_resolve, dim3((a.n + 3) / 4), dim3(256), 0, stream, t);
+    return (int)hipGetLastError();
+}
+
 int svx_bgzf_inflate_on_stream(void* stream, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
-                               const uint64_t* d_out_off, uint32_t* d_status) {
+                               const uint64_t* d_out_off, uint32_t* d_status, const uint64_t* d_tok_off, uint32_t* d_n_tok,
+                               void* d_tok) {
     if (n_members == 0) return 0;
     InfArgs a{d_in, d_in_off, d_in_len, d_isize, d_crc, d_out, d_out_off, d_status, n_members};
+    const int form = g_form.load();
+    if (d_tok_off && d_n_tok && d_tok && form != 1) return inflate_two_pass(static_cast<hipStream_t>(stream), form, a, d_tok_off, d_n_tok, d_tok);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sizeof(Lds));
     if (e != hipSuccess) return (int)e;
@@ -467,7 +1413,7 @@ int svx_gather_ranges_on_stream(void* stream, const uint8_t* d_src, const uint64
 // svx_bam.cpp reaches the two launches through pointers (it also builds alone, without this file, for the CPU sanitizer tests)
 extern "C" void svx_bam_register_device_kernels(
     int (*)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint8_t*,
-            const uint64_t*, uint32_t*),
+            const uint64_t*, uint32_t*, const uint64_t*, uint32_t*, void*),
     int (*)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, uint8_t*));
 static const int svx_device_kernels_registered =
     (svx_bam_register_device_kernels(&svx_bgzf_inflate_on_stream, &svx_gather_ranges_on_stream), 0);
@@ -483,8 +1429,21 @@ extern "C" int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uin
     if (rc != SVX_OK) return rc;
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
+    // the two-pass form's token lists: the sizes are on the device, so room for the longest possible lists (a member is
+    // at most 65 536 bytes, a match at least 3) and the offsets by a small launch
+    constexpr uint64_t kMaxSlots = 65536 / 3 + 2;
+    const size_t need = svx_take_bytes(n_members, 8) + svx_take_bytes(n_members, 4) + svx_take_bytes((size_t)n_members * kMaxSlots, 8);
+    uint64_t* d_tok_off = nullptr;
+    uint32_t* d_n_tok = nullptr;
+    void* d_tok = nullptr;
+    if (svx_ws_reserve(ctx, need) == SVX_OK) {
+        d_tok_off = svx_ws_take<uint64_t>(ctx, n_members);
+        d_n_tok = svx_ws_take<uint32_t>(ctx, n_members);
+        d_tok = svx_ws_take<uint2>(ctx, (size_t)n_members * kMaxSlots);
+        hipLaunchKernelGGL(k_tok_offsets, dim3((n_members + 255) / 256), dim3(256), 0, ctx->stream, n_members, kMaxSlots, d_tok_off);
+    }  // (no room: the one-pass kernel)
     SVX_HIP(ctx, (hipError_t)svx_bgzf_inflate_on_stream(ctx->stream, d_in, d_in_off, d_in_len, d_isize, d_crc, n_members, d_out, d_out_off,
-                                                        d_status));
+                                                        d_status, d_tok_off, d_n_tok, d_tok));
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     return svx_timing_end(ctx);

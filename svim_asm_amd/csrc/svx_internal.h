@@ -128,7 +128,7 @@ static inline size_t svx_take_bytes(size_t count, size_t elem) {
 // svx_inflate.hip, for the BAM reader's device leg (svx_bam.cpp): hipError_t as int
 int svx_bgzf_inflate_on_stream(void* stream, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
-                               const uint64_t* d_out_off, uint32_t* d_status);
+                               const uint64_t* d_out_off, uint32_t* d_status, const uint64_t* d_tok_off, uint32_t* d_n_tok, void* d_tok);
 int svx_gather_ranges_on_stream(void* stream, const uint8_t* d_src, const uint64_t* d_src_off, const uint32_t* d_len,
                                 const uint64_t* d_dst_off, uint32_t n, uint8_t* d_dst);
 int svx_wait_blocking(svx_ctx* ctx);

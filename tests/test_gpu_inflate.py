@@ -11,6 +11,21 @@ import pytest
 from svim_asm_amd import bamio
 
 pytestmark = pytest.mark.gpu
+
+
+FORMS = {"wave_parse": 1, "lane_parse": 2, "one_pass": 0}
+
+
+@pytest.fixture(autouse=True, params=list(FORMS))
+def inflate_form(request, svx_ctx):
+    """Every test of this module runs on the three forms of the device decoder (svx_bgzf_inflate_set_two_pass): the bit
+    streams parsed by a wave per member (64 stretches at once, resynchronised) or by a lane per member, matches as tokens,
+    then applied and CRC-checked by a wave per member; and the one-launch lane-per-member kernel."""
+    was = svx_ctx.lib.svx_bgzf_inflate_set_two_pass(FORMS[request.param])
+    yield request.param
+    svx_ctx.lib.svx_bgzf_inflate_set_two_pass(was)
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "config1")
 

@@ -1,9 +1,10 @@
 #!/bin/bash
-# round 6: rocprofv3 kernel-trace stats + a PMC pass for the SHIPPED k_bgzf_inflate (16 members per workgroup, 4 per wave)
-# on the 7 261-member SEQ probe (the members a full-size run's device leg takes).  Run on the GPU box:
-#   bash tools/r06_inflate_evidence.sh     -> gpurun_out/r06_infl/*
+# round 6: rocprofv3 kernel-trace stats + PMC passes of the device inflate kernels on the 7 261-member SEQ probe (the members a
+# full-size run's device leg takes): the two-pass form (k_inflate_parse, k_inflate_resolve; default) and, with "1" as $1, the
+# one-launch kernel (k_bgzf_inflate).  Run on the GPU box: bash tools/r06_inflate_evidence.sh [1]  -> gpurun_out/r06_infl[_1]/*
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r06_infl; mkdir -p $out
+k=${1:-2}; export SVX_INFLATE_KERNEL=$k
+out=gpurun_out/r06_infl; [ "$k" = 1 ] && out=gpurun_out/r06_infl_1; mkdir -p $out
 d=/tmp/svx_infl_ds; mkdir -p $d
 args="tools/gpu_inflate_probe.py --scale 0.25 --dataset $d --members 7261 --min-payload 8192 --counts 1000,3000,7261"
 python3 $args > $out/probe.json 2> $out/probe.err
@@ -19,16 +20,18 @@ for f in glob.glob(out+"/kt/*kernel_stats.csv"):
         if "inflate" in r["Name"] or "gather" in r["Name"]:
             res.setdefault("kernel_stats", []).append({k: r[k] for k in ("Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs")})
 for p in ("pmc1","pmc2"):
-    agg=collections.defaultdict(list)
+    agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out+"/"+p+"/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "k_bgzf_inflate" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]), float(r["Counter_Value"])))
+            for name in ("k_bgzf_inflate", "k_inflate_parse", "k_inflate_resolve"):
+                if name in r["Kernel_Name"]:
+                    agg[name][r["Counter_Name"]].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]), float(r["Counter_Value"])))
     # the launch with the most members = the longest one
-    for k,v in agg.items():
-        v.sort(); res.setdefault("pmc_longest_launch", {})[k]=v[-1][1]; res.setdefault("pmc_longest_launch_ns", {})[k]=v[-1][0]
+    for name, cs in agg.items():
+        for k,v in cs.items():
+            v.sort(); res.setdefault("pmc_longest_launch", {}).setdefault(name, {})[k]=v[-1][1]; res.setdefault("pmc_longest_launch_ns", {}).setdefault(name, {})[k]=v[-1][0]
 try: res["probe"]=json.load(open(out+"/probe.json"))
 except Exception as e: res["probe_error"]=str(e)
 json.dump(res, open(out+"/summary.json","w"), indent=1)
-print(json.dumps(res)[:3000])
+print(json.dumps(res)[:4000])
 PY
