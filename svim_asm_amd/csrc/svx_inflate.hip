@@ -819,6 +819,10 @@ __global__ __launch_bounds__(64) void k_inflate_parse(TwoPassArgs t) {
 constexpr int kWLL = 10, kWD = 8;
 constexpr uint32_t kMinStretchBits = 256;
 constexpr int kMaxSyncPasses = 24;
+#ifndef SVX_JOIN_BITS
+#define SVX_JOIN_BITS 512
+#endif
+constexpr uint32_t kJoinBits = SVX_JOIN_BITS;        // how far into its stretch a lane looks for the place where it joins its earlier pass
 struct WaveLds {
     uint16_t tab_ll[1 << kWLL];  // next bits -> symbol << 4 | code length (0: a longer code, or none)
     uint16_t tab_d[1 << kWD];
@@ -985,26 +989,50 @@ __device__ __forceinline__ int wave_header(WaveLds& s, const uint8_t* in, uint32
     return 0;
 }
 
-// A lane's bit reader on the member's input in global memory: the next word is requested one refill ahead.
+// A lane's bit reader on the member's input in global memory.  The input comes 16 bytes at a time and the 16 bytes behind
+// the ones in use are requested when those are taken up: a load has ~14 symbols to arrive (the lanes of a wave read 64
+// different places and the waves of a CU more lines than its L1 holds: most loads come from the L2 or from further away).
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 struct WBits {
     uint64_t buf;
-    uint32_t cnt, pos, next;  // pos: input bytes taken into buf
+    uint32_t cnt, pos;   // pos: input bytes taken into buf
+    uint32_t q0, q1, q2, q3, left;  // the next `left` words of the input, q0 first
+    u32x4_a1 ahead;      // the 16 bytes behind q's
 };
+__device__ __forceinline__ u32x4_a1 wb_load16(const uint8_t* in, uint32_t at, uint32_t in_len) {
+    u32x4_a1 v;
+    if (__builtin_expect(at + 16u <= in_len, 1)) {
+        v = *reinterpret_cast<const u32x4_a1*>(in + at);
+    } else {  // the member's last bytes: zero behind them
+        uint32_t real;
+        v.x = load_word(in, at, in_len, &real);
+        v.y = load_word(in, at + 4u, in_len, &real);
+        v.z = load_word(in, at + 8u, in_len, &real);
+        v.w = load_word(in, at + 12u, in_len, &real);
+    }
+    return v;
+}
 __device__ __forceinline__ void wb_init(WBits& b, const uint8_t* in, uint32_t in_len, uint32_t bit) {
     const uint32_t byte0 = (bit >> 5) << 2, sh = bit & 31u;
-    uint32_t real;
-    b.buf = (uint64_t)(load_word(in, byte0, in_len, &real) >> sh);
+    const u32x4_a1 first = wb_load16(in, byte0, in_len);
+    b.ahead = wb_load16(in, byte0 + 16u, in_len);
+    b.buf = (uint64_t)(first.x >> sh);
     b.cnt = 32u - sh;
     b.pos = byte0 + 4u;
-    b.next = load_word(in, b.pos, in_len, &real);
+    b.q0 = first.y; b.q1 = first.z; b.q2 = first.w; b.q3 = 0;
+    b.left = 3;
 }
 __device__ __forceinline__ void wb_refill(WBits& b, const uint8_t* in, uint32_t in_len) {  // >= 33 bits afterwards
     if (b.cnt <= 32u) {
-        b.buf |= (uint64_t)b.next << b.cnt;
+        b.buf |= (uint64_t)b.q0 << b.cnt;
         b.cnt += 32u;
         b.pos += 4u;
-        uint32_t real;
-        b.next = load_word(in, b.pos, in_len, &real);
+        b.q0 = b.q1; b.q1 = b.q2; b.q2 = b.q3;
+        if (--b.left == 0u) {
+            b.q0 = b.ahead.x; b.q1 = b.ahead.y; b.q2 = b.ahead.z; b.q3 = b.ahead.w;
+            b.left = 4;
+            b.ahead = wb_load16(in, b.pos + 16u, in_len);
+        }
     }
 }
 __device__ __forceinline__ uint32_t wb_at(const WBits& b) { return b.pos * 8u - b.cnt; }
@@ -1034,19 +1062,42 @@ __device__ __forceinline__ int wave_symbol(WBits& b, const uint16_t* tab, const 
 
 enum { WF_NONE = 0, WF_EOB = 1, WF_BAD = 2 };
 
+// What a lane keeps of its last pass over its stretch.  `chk_at`: the first symbol start at or behind `chk_limit` (a little
+// way into the stretch), with the bytes and matches counted in front of it: a later pass from another start that arrives
+// at exactly this bit has joined the old pass — everything behind it is the same, and it stops there.
+struct Stretch {
+    uint32_t start, limit, chk_limit;
+    uint32_t end, flag, n_bytes, n_toks;
+    uint32_t chk_at, chk_bytes, chk_toks;
+};
+constexpr uint32_t kNoCheckpoint = 0xFFFFFFFFu;
+
 // One lane's stretch: the symbols that start in [start, limit).  WRITE: literals to out[o..], matches to tok[..].
 template <bool WRITE>
 __device__ __forceinline__ void wave_decode(const uint8_t* in, uint32_t in_len, const WaveLds& s, const uint32_t (&lim_ll)[kMaxBits - kWLL],
-                                            const uint32_t (&lim_d)[kMaxBits - kWD], bool active, uint32_t start, uint32_t limit,
-                                            uint32_t& end, uint32_t& flag, uint32_t& n_bytes, uint32_t& n_toks, uint8_t* out, uint32_t o,
+                                            const uint32_t (&lim_d)[kMaxBits - kWD], bool active, Stretch& st, uint8_t* out, uint32_t o,
                                             uint2* tok) {
     if (!active) return;
     WBits b;
-    wb_init(b, in, in_len, start);
-    uint32_t bytes = 0, toks = 0, fl = WF_NONE, at = start;
+    wb_init(b, in, in_len, st.start);
+    uint32_t bytes = 0, toks = 0, fl = WF_NONE, at = st.start;
+    bool before_chk = !WRITE;
     for (;;) {
         at = wb_at(b);
-        if (at >= limit) break;
+        if (at >= st.limit) break;
+        if (!WRITE && before_chk && at >= st.chk_limit) {
+            before_chk = false;
+            if (at == st.chk_at) {  // joined the pass before: its end, its counts from here on
+                st.n_bytes = bytes + (st.n_bytes - st.chk_bytes);
+                st.n_toks = toks + (st.n_toks - st.chk_toks);
+                st.chk_bytes = bytes;
+                st.chk_toks = toks;
+                return;
+            }
+            st.chk_at = at;
+            st.chk_bytes = bytes;
+            st.chk_toks = toks;
+        }
         wb_refill(b, in, in_len);
         const int sym = wave_symbol<kWLL, kLL>(b, s.tab_ll, s.sym_ll, lim_ll);
         if (sym < 256) {
@@ -1090,13 +1141,27 @@ __device__ __forceinline__ void wave_decode(const uint8_t* in, uint32_t in_len, 
         bytes += len;
         ++toks;
     }
-    end = at;
-    flag = fl;
-    n_bytes = bytes;
-    n_toks = toks;
+    if (!WRITE && before_chk) st.chk_at = kNoCheckpoint;  // this pass ended in front of the checkpoint's place
+    st.end = at;
+    st.flag = fl;
+    st.n_bytes = bytes;
+    st.n_toks = toks;
 }
 
-__global__ __launch_bounds__(64) void k_inflate_wparse(TwoPassArgs t) {
+#ifdef SVX_WPARSE_STATS  // experiments: where a member's wave spends its clocks (tools/r06_wave_stats.sh)
+__device__ unsigned long long g_wstats[16];
+#define WSTAT_CLOCK() __builtin_readcyclecounter()
+#define WSTAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_wstats[i], (unsigned long long)(v)); } while (0)
+#else
+#define WSTAT_CLOCK() 0ull
+#define WSTAT_ADD(i, v) do { } while (0)
+#endif
+#ifdef SVX_WPARSE_WAVES  // waves per SIMD the register allocator leaves room for (experiments)
+#define SVX_WPARSE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SVX_WPARSE_WAVES, SVX_WPARSE_WAVES)))
+#else
+#define SVX_WPARSE_OCCUPANCY
+#endif
+__global__ __launch_bounds__(64) SVX_WPARSE_OCCUPANCY void k_inflate_wparse(TwoPassArgs t) {
     __shared__ WaveLds s;
     const InfArgs& a = t.a;
     const int lane = (int)threadIdx.x;
@@ -1110,13 +1175,17 @@ __global__ __launch_bounds__(64) void k_inflate_wparse(TwoPassArgs t) {
         if (lane == 0) t.n_tok[m] = kTokPending;
         return;
     }
+    [[maybe_unused]] const unsigned long long c_begin = WSTAT_CLOCK();
     uint32_t pos = 0, produced = 0, n_tok = 0, last = 0, guess = nbits, block_start = 0;
     bool need_header = true, give_up = false;
     uint32_t lim_ll[kMaxBits - kWLL], lim_d[kMaxBits - kWD];
     for (;;) {
         if (pos >= nbits) { give_up = true; break; }
         if (need_header) {
+            [[maybe_unused]] const unsigned long long c0 = WSTAT_CLOCK();
             if (wave_header(s, in, in_len, &pos, &last, lane)) { give_up = true; break; }
+            WSTAT_ADD(0, WSTAT_CLOCK() - c0);
+            WSTAT_ADD(1, 1);
 #pragma unroll
             for (int l = kWLL + 1; l <= kMaxBits; ++l) lim_ll[l - kWLL - 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.lim_ll[l]);
 #pragma unroll
@@ -1130,34 +1199,47 @@ __global__ __launch_bounds__(64) void k_inflate_wparse(TwoPassArgs t) {
         const uint32_t stretch = max((span + 63u) / 64u, kMinStretchBits);
         const uint32_t n_lanes = (span + stretch - 1u) / stretch;  // 1..64
         const bool active = (uint32_t)lane < n_lanes;
-        uint32_t start = pos + (uint32_t)lane * stretch;
-        const uint32_t limit = (uint32_t)lane + 1u == n_lanes ? w_end : min(start + stretch, w_end);
-        uint32_t end = w_end, flag = WF_NONE, nb = 0, nt = 0;
+        Stretch st;
+        st.start = pos + (uint32_t)lane * stretch;
+        st.limit = (uint32_t)lane + 1u == n_lanes ? w_end : min(st.start + stretch, w_end);
+        st.chk_limit = st.start + min(stretch / 2u, kJoinBits);
+        st.end = w_end; st.flag = WF_NONE; st.n_bytes = 0; st.n_toks = 0;
+        st.chk_at = kNoCheckpoint; st.chk_bytes = 0; st.chk_toks = 0;
         bool decode = active;
         int passes = 0, k = 0;
+        WSTAT_ADD(2, 1);
+        WSTAT_ADD(9, span);
         for (;;) {
-            wave_decode<false>(in, in_len, s, lim_ll, lim_d, decode, start, limit, end, flag, nb, nt, nullptr, 0u, nullptr);
-            const uint64_t flagged = __ballot(active && flag != WF_NONE);
+            [[maybe_unused]] const unsigned long long c1 = WSTAT_CLOCK();
+            wave_decode<false>(in, in_len, s, lim_ll, lim_d, decode, st, nullptr, 0u, nullptr);
+            WSTAT_ADD(passes == 0 ? 3 : 4, WSTAT_CLOCK() - c1);
+            WSTAT_ADD(5, 1);
+            const uint64_t flagged = __ballot(active && st.flag != WF_NONE);
             k = flagged ? __ffsll((unsigned long long)flagged) - 1 : (int)n_lanes - 1;  // the chain runs to lane k
-            const uint32_t before = (uint32_t)__shfl_up((int)end, 1);
+            const uint32_t before = (uint32_t)__shfl_up((int)st.end, 1);
             const uint32_t true_start = lane == 0 ? pos : before;
-            decode = active && lane <= k && true_start != start;
+            decode = active && lane <= k && true_start != st.start;
             if (__ballot(decode) == 0ull) break;
             if (++passes > kMaxSyncPasses) { give_up = true; break; }
-            if (decode) start = true_start;
+            if (decode) st.start = true_start;
         }
         if (give_up) break;
-        const uint32_t flag_k = (uint32_t)__shfl((int)flag, k), end_k = (uint32_t)__shfl((int)end, k);
+        const uint32_t flag_k = (uint32_t)__shfl((int)st.flag, k), end_k = (uint32_t)__shfl((int)st.end, k);
         if (flag_k == WF_BAD) { give_up = true; break; }
         const bool in_chain = active && lane <= k;
         uint32_t sum_b, sum_t;
-        const uint32_t off_b = wave_scan_excl(in_chain ? nb : 0u, lane, &sum_b);
-        const uint32_t off_t = wave_scan_excl(in_chain ? nt : 0u, lane, &sum_t);
+        const uint32_t off_b = wave_scan_excl(in_chain ? st.n_bytes : 0u, lane, &sum_b);
+        const uint32_t off_t = wave_scan_excl(in_chain ? st.n_toks : 0u, lane, &sum_t);
         if (produced + sum_b > isize) { give_up = true; break; }
-        uint32_t end_w = 0, flag_w = WF_NONE, nb_w = 0, nt_w = 0;
-        wave_decode<true>(in, in_len, s, lim_ll, lim_d, in_chain, start, limit, end_w, flag_w, nb_w, nt_w, out, produced + off_b,
-                          tok + n_tok + off_t);
-        if (__ballot(in_chain && (flag_w == WF_BAD || end_w != end)) != 0ull) { give_up = true; break; }
+        Stretch wr = st;
+        [[maybe_unused]] const unsigned long long c2 = WSTAT_CLOCK();
+        wave_decode<true>(in, in_len, s, lim_ll, lim_d, in_chain, wr, out, produced + off_b, tok + n_tok + off_t);
+        WSTAT_ADD(6, WSTAT_CLOCK() - c2);
+        WSTAT_ADD(10, end_k - pos);
+        if (__ballot(in_chain && (wr.flag != st.flag || wr.end != st.end || wr.n_bytes != st.n_bytes || wr.n_toks != st.n_toks)) != 0ull) {
+            give_up = true;
+            break;
+        }
         produced += sum_b;
         n_tok += sum_t;
         pos = end_k;
@@ -1172,6 +1254,10 @@ __global__ __launch_bounds__(64) void k_inflate_wparse(TwoPassArgs t) {
         }
     }
     if (!give_up && (pos > nbits || produced != isize)) give_up = true;
+    WSTAT_ADD(7, WSTAT_CLOCK() - c_begin);
+    WSTAT_ADD(8, give_up ? 1 : 0);
+    WSTAT_ADD(11, n_tok);
+    WSTAT_ADD(12, 1);
     if (lane == 0) {
         if (give_up) {
             t.n_tok[m] = kTokPending;
@@ -1181,8 +1267,6 @@ __global__ __launch_bounds__(64) void k_inflate_wparse(TwoPassArgs t) {
         }
     }
 }
-
-typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 
 // x -> x * z^(8 * bytes) in the CRC's field, as the 32 columns of the operator: out = XOR of col[i] over the set bits i of x
 __device__ __forceinline__ uint32_t crc_apply(const uint32_t (&col)[32], uint32_t x) {
@@ -1195,6 +1279,7 @@ __device__ __forceinline__ uint32_t crc_apply(const uint32_t (&col)[32], uint32_
 __global__ __launch_bounds__(256) void k_inflate_resolve(TwoPassArgs t) {
     __shared__ uint32_t s_crc[4][256];  // slicing-by-4 tables of CRC-32 (reflected 0xEDB88320)
     __shared__ uint32_t s_shift[6][32];
+    __shared__ uint32_t s_dst[4][2][64];  // per wave: where the tokens of the batch in hand start and end
     const InfArgs& a = t.a;
     for (int i = threadIdx.x; i < 256; i += 256) {
         uint32_t c = (uint32_t)i;
@@ -1242,23 +1327,40 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(TwoPassArgs t) {
             for (uint32_t i = 0; i < len; ++i) d[i] = (uint8_t)(pat >> (8 * (i % dist)));
         }
     };
+    // A token depends on the tokens of its batch whose destination its source touches — destinations ascend, so these are
+    // a run of the batch, found by two binary searches over the batch's destinations in LDS.  A round copies every token
+    // whose run is done; the number of rounds is the depth of the batch's dependences, not their number (matches a few
+    // bytes back — the rule in packed sequence at the fast deflate levels — chain two or three deep, not twenty).
+    uint32_t* d_lo = s_dst[threadIdx.x >> 6][0];
+    uint32_t* d_hi = s_dst[threadIdx.x >> 6][1];
     for (uint32_t base = 0; base < n_tok; base += 64) {
         const bool valid = base + (uint32_t)lane < n_tok;
-        uint2 tk = make_uint2(0, 1);
+        uint2 tk = make_uint2(0xFFFFu, 1);  // (behind the last token: destinations that nothing reaches)
         if (valid) tk = tok[base + lane];
         const uint32_t dst = tk.x & 0xFFFFu, len = tk.x >> 16, dist = tk.y;
-        const uint32_t dst_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);
-        // (the batch's destinations ascend; a source that ends at or in front of the first of them depends on none of them)
-        const uint32_t src_end = dst - dist + (len < dist ? len : dist);
-        const bool dep = valid && lane > 0 && src_end > dst_first;
-        if (valid && !dep) copy_one(dst, len, dist);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint64_t todo = __ballot(dep);
-        while (todo) {  // in token order; each one's bytes are in the XCD's L2 (write-through L1) before the next one reads
-            const int l = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            if (lane == l) copy_one(dst, len, dist);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        d_lo[lane] = dst;
+        d_hi[lane] = dst + len;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t src = dst - dist, src_end = src + (len < dist ? len : dist);
+        uint32_t first = 0, behind = 0;  // first token whose destination ends behind src; first one that starts at or behind src_end
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            if (d_hi[first + step - 1] <= src) first += step;
+            if (d_lo[behind + step - 1] < src_end) behind += step;
+        }
+        // (both searches stop at 63 when every entry qualifies; the token's own entry never does: its destination lies behind its source's start)
+        if (behind > (uint32_t)lane) behind = (uint32_t)lane;
+        uint64_t needs = first < behind ? (((behind - first >= 64u) ? ~0ull : ((1ull << (behind - first)) - 1ull)) << first) : 0ull;
+        uint64_t done = ~__ballot(valid);
+        bool mine_done = !valid;
+        while (~done) {
+            const bool ready = !mine_done && (needs & ~done) == 0ull;
+            if (ready) copy_one(dst, len, dist);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the copies' bytes are in the XCD's L2 (write-through L1) before the next round reads
+            done |= __ballot(ready);
+            mine_done |= ready;
         }
     }
     // ---- CRC-32: the member's bytes in pieces of 1 KiB, the LAST piece on lane 63 and the odd-sized one first, so that
@@ -1355,6 +1457,16 @@ static const uint32_t (*crc_shift_columns())[32] {
     return cols;
 }
 
+#ifdef SVX_WPARSE_STATS
+extern "C" int svx_debug_wparse_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wstats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 // which form svx_bgzf_inflate_dev and the BAM reader's device leg launch (process-wide; SVX_INFLATE_KERNEL=1 in the
 // environment: the one-pass kernel from the start)
 // 1: the one-launch kernel; 2: two passes, a lane per member in the parse; 3: two passes, a wave per member in the parse

@@ -1,10 +1,11 @@
 #!/bin/bash
 # round 6: rocprofv3 kernel-trace stats + PMC passes of the device inflate kernels on the 7 261-member SEQ probe (the members a
-# full-size run's device leg takes): the two-pass form (k_inflate_parse, k_inflate_resolve; default) and, with "1" as $1, the
-# one-launch kernel (k_bgzf_inflate).  Run on the GPU box: bash tools/r06_inflate_evidence.sh [1]  -> gpurun_out/r06_infl[_1]/*
+# full-size run's device leg takes): the shipped form (3: k_inflate_wparse, k_inflate_parse for what the wave parse leaves,
+# k_inflate_resolve), the lane-per-member parse (2) and the one-launch kernel (1: k_bgzf_inflate).
+# Run on the GPU box: bash tools/r06_inflate_evidence.sh [3|2|1]  -> gpurun_out/r06_infl[_2|_1]/*
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-k=${1:-2}; export SVX_INFLATE_KERNEL=$k
-out=gpurun_out/r06_infl; [ "$k" = 1 ] && out=gpurun_out/r06_infl_1; mkdir -p $out
+k=${1:-3}; export SVX_INFLATE_KERNEL=$k
+out=gpurun_out/r06_infl; [ "$k" != 3 ] && out=gpurun_out/r06_infl_$k; mkdir -p $out
 d=/tmp/svx_infl_ds; mkdir -p $d
 args="tools/gpu_inflate_probe.py --scale 0.25 --dataset $d --members 7261 --min-payload 8192 --counts 1000,3000,7261"
 python3 $args > $out/probe.json 2> $out/probe.err
@@ -23,7 +24,7 @@ for p in ("pmc1","pmc2"):
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(out+"/"+p+"/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            for name in ("k_bgzf_inflate", "k_inflate_parse", "k_inflate_resolve"):
+            for name in ("k_bgzf_inflate", "k_inflate_wparse", "k_inflate_parse", "k_inflate_resolve"):
                 if name in r["Kernel_Name"]:
                     agg[name][r["Counter_Name"]].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]), float(r["Counter_Value"])))
     # the launch with the most members = the longest one
