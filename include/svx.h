@@ -485,7 +485,7 @@ int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* s
 /*
  * BGZF members inflated and checked on the device: what htslib's bgzf_read_block does under every record the
  * reference reads (pysam bam.fetch, SVIM_COLLECT.py:65-68) — inflate the member's raw DEFLATE payload, compare
- * the CRC32 and the length with the member's trailer.  One lane per member, all members of a call in one launch.
+ * the CRC32 and the length with the member's trailer.  All members of a call at once, a wave per member.
  *   d_in                 compressed payloads (the bytes between a member's header and its 8-byte trailer), anywhere
  *                        in one buffer: member m is d_in[d_in_off[m] .. + d_in_len[m]); the buffer must be readable 3 bytes
  *                        past the end of any member (input words are fetched whole)
@@ -498,12 +498,17 @@ int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* s
  *                        The two paddings above are the only bytes outside a member's own input and output stretch that
  *                        are ever read (3 behind the input) or written (7 behind the output).
  * Asynchronous on the context's stream.
- * Two forms with the same bytes and statuses (svx_inflate.hip): one launch, a lane per member that decodes and copies
- * (k_bgzf_inflate); or two — the bit streams parsed with the lanes of a wave in step and every match written as a token,
- * then the tokens applied and the CRC-32 taken by a wave per member (k_inflate_parse, k_inflate_resolve; the token lists
- * come out of the context's workspace: 8 bytes per 3 bytes of output at most).  svx_bgzf_inflate_set_two_pass chooses for
- * the whole process — this entry and the BAM reader's device leg (svx_bam_set_device_inflate) — and returns the previous
- * choice; SVX_INFLATE_KERNEL=1 in the environment starts the process on the one-launch form.
+ * Three forms with the same bytes and statuses (svx_inflate.hip).  Shipped: three launches — a WAVE per member parses the bit
+ * stream (64 stretches of it decoded at once and resynchronised), storing the literals and writing every match as a token
+ * (k_inflate_wparse); a lane per member does the same for whatever the wave parse has left alone — anything but plain
+ * fixed / dynamic blocks, every malformed stream — and is the judge of those (k_inflate_parse); a wave per member applies the
+ * tokens and takes the CRC-32 (k_inflate_resolve).  The token lists come out of the context's workspace, 175 KB a member,
+ * for up to 16 384 members at a time (more members: one set of launches behind the other).  The other two: the lane-per-
+ * member parse for every member; and ONE launch, a lane per member that decodes and copies (k_bgzf_inflate, rounds 4-5).
+ * svx_bgzf_inflate_set_two_pass chooses for the whole process — this entry and the BAM reader's device leg
+ * (svx_bam_set_device_inflate): 0 the one-launch kernel, 2 the lane-per-member parse, any other value the shipped form; it
+ * returns the previous choice in the same terms (0 / 2 / 1).  SVX_INFLATE_KERNEL=1|2|3 in the environment starts the process
+ * on the one-launch / lane-parse / shipped form.
  */
 int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                          const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,

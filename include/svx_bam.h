@@ -100,8 +100,9 @@ int svx_bam_device_pool_wait(svx_bam* bam, double* waited_us);
  * once — so the share is what the threads would need that long for; results never depend on it.  0 (default): host only.
  * svx_bam_device_members: members the device has inflated for this handle so far. */
 int svx_bam_set_device_inflate(svx_bam* bam, int percent);
-/* The share goes to the device only when it holds at least `members` BGZF members (default 3000: the leg's latency is one
- * member's decode time on the device, 45-55 ms, whatever their number — below that the threads are through sooner). */
+/* The share goes to the device only when it holds at least `members` BGZF members (default 500: a launch costs one member's
+ * latency on the device, 3-4 ms, and the leg its staging — below that the threads are through sooner.  BASELINE config 5's
+ * 1 200-member calls: the same wall-clock on the device, 0.6 instead of 1.0 CPU-seconds: profiles/r06_wave_min_members.txt). */
 int svx_bam_set_device_inflate_min(svx_bam* bam, uint32_t members);
 /* A device has two inflate lanes (stream + page-locked ring each): a call that finds both taken — a process with more
  * than two readers decoding at once, svim-asm-cohort's workers — gives its whole call to the threads (default, 0) or

@@ -532,15 +532,17 @@ def host_cpus():
 
 def default_device_inflate_percent():
     """Share of a sequence-slice call the device inflates (svx_bam_set_device_inflate) unless SVX_BAM_DEVICE_INFLATE says
-    otherwise.  The device decodes any number of members up to 16 k in 55-60 ms (one lane per member) plus ~10 ms of
-    staging — a full-size sample's call takes the host's threads 45 ms when every thread has a core, but 1.4 CPU-seconds
-    of a run whose wall-clock IS its CPU-seconds over the CPUs it may use when those are few (the pool's 16-CPU quota:
-    3.6 CPU-s, 0.22-0.26 s).  So: half the call with at most 24 CPUs' worth of time (0.26 → 0.18-0.20 s end to end,
-    profiles/r05_device_leg.txt), none above."""
+    otherwise.  The device decodes a full-size sample's 14 k sequence members in ~17 ms (a wave per member,
+    csrc/svx_inflate.hip) behind their staging; the host's threads take 45 ms for them when every thread has a core, but
+    1.4 CPU-seconds of a run whose wall-clock IS its CPU-seconds over the CPUs it may use when those are few (the pool's
+    16-CPU quota).  Measured there on the full-size sample (profiles/r06_wave_e2e.txt, r06_wave_cli_shares.txt): in one
+    process 0.135-0.146 s at a share of 50 %, 0.132 at 60, 0.137 at 100 with 2.7 / 2.5 / 1.9 CPU-seconds (0.20-0.24 s and
+    3.3 without the device); as a fresh command the same wall-clock at every share with 3.4 / 2.6 / 2.0 CPU-seconds at
+    0 / 50 / 100.  So: the whole call with at most 24 CPUs' worth of time, none above (unmeasured there: no such host)."""
     asked = env_device_inflate_percent()
     if asked is not None:
         return asked
-    return 50 if host_cpus() <= 24 else 0
+    return 100 if host_cpus() <= 24 else 0
 
 
 def env_device_inflate_percent():
@@ -671,7 +673,8 @@ class AlignmentFile(object):
     def effective_device_inflate_percent(self):
         pct = self.device_inflate_percent
         return default_device_inflate_percent() if pct is None else int(pct)
-    device_inflate_min_members = 3000  # the share goes to the device only when it holds that many members (svx_bam.h)
+    # the share goes to the device only when it holds that many members (svx_bam.h; SVX_BAM_DEVICE_INFLATE_MIN for experiments)
+    device_inflate_min_members = int(os.environ.get("SVX_BAM_DEVICE_INFLATE_MIN") or 500)
     device_inflate_wait_ms = 0         # how long a call waits for one of the device's two inflate lanes (svx_bam.h)
 
     @property

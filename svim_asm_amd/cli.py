@@ -21,16 +21,11 @@ def _open_file(path, options, one_shot=True, reader_threads=None):
     f = bamio.AlignmentFile(path, device=getattr(options, "device", 0) or 0,
                             threads=reader_threads or bamio.quota_threads(2 if options.sub == "diploid" else 1, shard.world()[1]),
                             verify=False if getattr(options, "no_bgzf_crc", False) else None)
-    # The device's share of the sequence slices' inflate work.  Under a CPU quota the command's readers run on as many
-    # threads as the quota has CPUs (bamio.quota_threads) and the device takes HALF of each call — the readers' own default:
-    # nine fresh processes per setting on the full-size sample (profiles/r06_cli_timeline*.txt, r06_cli_share_sweep.txt), from
-    # the moment the device context exists to the end of COLLECT 0.173 s at 50 %, 0.178-0.192 at 60, 0.213 at 70, 0.219 at 100
-    # (2.4 / 2.3 / 2.2 / 2.0 CPU-seconds; 0.245 and 3.3 with no share): at 100 % the two readers' 22 600 members are two
-    # rounds of the inflate kernel behind 75 ms of staging, at 50 % one round behind 9 ms while the threads decode the rest.
-    # (Round 5, readers on 32 threads each: 0.68-0.71 s with a share of one half against 0.64-0.69 s without — the start-up and
-    # the exit sat in throttled periods whatever the device took.)  With a core per thread the host decodes the call in 45 ms
-    # and the leg's 60-75 ms would be the longer path: no share.  SVX_BAM_DEVICE_INFLATE overrides; svim-asm-cohort sets its
-    # own (cohort.py: the whole call — there CPU-seconds count, not one sample's latency).
+    # The device's share of the sequence slices' inflate work: the readers' own default (bamio.default_device_inflate_percent:
+    # under a CPU quota the whole call — a fresh command's wall-clock is the same at every share, its CPU-seconds are 3.4 / 2.6 /
+    # 2.0 at 0 / 50 / 100 %, profiles/r06_wave_cli_shares.txt; with a core per thread none).  The command's readers run on as
+    # many threads as the quota has CPUs (bamio.quota_threads).  SVX_BAM_DEVICE_INFLATE overrides; svim-asm-cohort sets its own
+    # (cohort.py: the whole call and a wait for a free inflate lane — there CPU-seconds count, not one sample's latency).
     if one_shot:
         asked = bamio.env_device_inflate_percent()
         f.device_inflate_percent = asked if asked is not None else bamio.default_device_inflate_percent()

@@ -39,6 +39,7 @@
 
 #include "svx.h"
 #include "svx_inflate.h"
+#include "svx_inflate_dev.h"
 
 namespace {
 
@@ -680,9 +681,6 @@ class Pool {
 //   upload    the copy stream of the CIGAR pools' device copies (svx_bam_device_pool)
 //   inflate   kInflateLanes streams, each with a ring of page-locked staging slots, for svx_bam_seq_slices' device leg
 //             (svx_bam_set_device_inflate): one per call in flight — both haplotype BAMs decode at the same time
-typedef int (*svx_inflate_launch_fn)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint32_t*,
-                                     uint32_t, uint8_t*, const uint64_t*, uint32_t*, const uint64_t*, uint32_t*, void*);
-typedef int (*svx_gather_launch_fn)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, uint8_t*);
 static svx_inflate_launch_fn g_inflate_launch = nullptr;  // svx_inflate.hip registers its launches when the library loads
 static svx_gather_launch_fn g_gather_launch = nullptr;    // (a build of this file alone — the sanitizer tests — has none)
 extern "C" void svx_bam_register_device_kernels(svx_inflate_launch_fn inflate, svx_gather_launch_fn gather) {
@@ -906,7 +904,7 @@ struct svx_bam {
                                              // SEQ bytes holds its head and CIGAR) needs only its prefix, not a second check
     int pin_device = -1;  // HIP device whose context page-locks the CIGAR pool; -1: pageable memory
     int inflate_pct = 0;  // share of a sequence-slice call whose members the device inflates (svx_bam_set_device_inflate)
-    uint32_t inflate_min_members = 3000;  // ... when that share holds at least this many members
+    uint32_t inflate_min_members = 500;   // ... when that share holds at least this many members
     uint32_t inflate_wait_ms = 0;         // ... and how long a call waits for one of the device's inflate lanes to come free
     uint8_t* d_inflate = nullptr;  // the device leg's buffer, kept between calls
     size_t d_inflate_cap = 0;
@@ -1490,11 +1488,14 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     }
     b->blocks_spanned = spanned;
     // the device leg's buffer for the sequence-slice call that follows a load of a whole file: its members' payloads are
-    // about two fifths of the file, their output twice that, the two-pass kernels' token lists (8 bytes per 3 of output at
-    // most) once more — 2.3 x the share of the file + the tables (a call that needs more allocates again)
+    // about half of the file, their output twice that (1.6 x the share of the file), the token arena of the two-pass
+    // kernels (a list per member, a member per 32 KiB of the file at most, SVX_INFLATE_ARENA_MEMBERS at most) and the
+    // tables (a call that needs more allocates again)
     if (!tids && b->inflate_pct > 0 && b->pin_device >= 0 && b->pin_device < kMaxLanes && g_inflate_launch && !b->d_inflate &&
         !b->d_inflate_ahead.joinable() && b->file.fsize > (64u << 20)) {
-        const size_t want = (size_t)((double)b->file.fsize * 2.3 * b->inflate_pct / 100.0) + (32u << 20);
+        const double share_bytes = (double)b->file.fsize * b->inflate_pct / 100.0;
+        const size_t lists = std::min<size_t>((size_t)(share_bytes / 32768.0) + 512, SVX_INFLATE_ARENA_MEMBERS);
+        const size_t want = (size_t)(share_bytes * 1.6) + lists * SVX_INFLATE_TOK_STRIDE * 8 + (32u << 20);
         svx_bam* h = b;
         b->d_inflate_ahead = std::thread([h, want] {
             if (hipSetDevice(h->pin_device) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -1742,8 +1743,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             t_located = since_call_ms();
             ok = ok && !failed.load();
             // member and piece tables; device memory
-            std::vector<uint64_t> in_off, out_off_m, tok_off_m;  // (tok_off_m: the two-pass kernels' token lists, a slot per 3 bytes of a member + 2)
-            uint64_t tok_slots = 0;
+            std::vector<uint64_t> in_off, out_off_m;
             std::vector<uint32_t> in_len, isz, crc;
             std::vector<const uint8_t*> src;
             uint64_t in_bytes = 0, out_bytes = 0, packed_bytes = 0;
@@ -1755,8 +1755,6 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                     isz.push_back(jb.blk.isize);
                     crc.push_back(jb.blk.crc);
                     out_off_m.push_back(out_bytes);
-                    tok_off_m.push_back(tok_slots);
-                    tok_slots += (uint64_t)jb.blk.isize / 3u + 2u;
                     src.push_back(b->file.map + jb.coff + jb.blk.payload_off);
                     in_bytes += ((uint64_t)jb.blk.payload_len + 3) & ~3ull;
                     out_bytes += ((uint64_t)jb.blk.isize + 8 + 15) & ~15ull;
@@ -1777,10 +1775,12 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             const uint32_t n_pc = (uint32_t)g_len.size();
             auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
             const uint64_t o_in = 0, o_out = up256(in_bytes + 8), o_tab = o_out + up256(out_bytes + 16);
-            const uint64_t tab_bytes = (uint64_t)g_members * 36 + (uint64_t)n_pc * 20 + 256;
+            const uint64_t tab_bytes = (uint64_t)g_members * 28 + (uint64_t)n_pc * 20 + 256;
+            // the two-pass kernels' token lists: an arena for SVX_INFLATE_ARENA_MEMBERS members at a time (svx_inflate_dev.h)
+            const uint32_t arena_members = std::min<uint32_t>(g_members, SVX_INFLATE_ARENA_MEMBERS);
             const uint64_t o_status = o_tab + up256(tab_bytes), o_packed = o_status + up256((uint64_t)g_members * 4);
             const uint64_t o_ntok = o_packed + up256(packed_bytes + 8), o_tok = o_ntok + up256((uint64_t)g_members * 4);
-            const uint64_t need = o_tok + up256(tok_slots * 8);
+            const uint64_t need = o_tok + up256((uint64_t)arena_members * SVX_INFLATE_TOK_STRIDE * 8);
             if (ok && g_members && n_pc) {
                 b->take_inflate_ahead();
                 if (b->d_inflate_cap < need) {
@@ -1797,12 +1797,11 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             }
             // the tables as one blob: in_off | out_off | src_off | dst_off (u64) | in_len | isize | crc | len (u32)
             std::vector<uint8_t> blob;
-            uint64_t t_in_off = 0, t_out_off = 0, t_src_off = 0, t_dst_off = 0, t_in_len = 0, t_isz = 0, t_crc = 0, t_len = 0, t_tok_off = 0;
+            uint64_t t_in_off = 0, t_out_off = 0, t_src_off = 0, t_dst_off = 0, t_in_len = 0, t_isz = 0, t_crc = 0, t_len = 0;
             if (ok) {
                 auto put = [&](const void* ptr, size_t bytes) { const uint64_t at = blob.size(); blob.insert(blob.end(), (const uint8_t*)ptr, (const uint8_t*)ptr + bytes); return at; };
                 t_in_off = put(in_off.data(), (size_t)g_members * 8);
                 t_out_off = put(out_off_m.data(), (size_t)g_members * 8);
-                t_tok_off = put(tok_off_m.data(), (size_t)g_members * 8);
                 t_src_off = put(g_src_off.data(), (size_t)n_pc * 8);
                 t_dst_off = put(g_dst_off.data(), (size_t)n_pc * 8);
                 t_in_len = put(in_len.data(), (size_t)g_members * 4);
@@ -1869,8 +1868,8 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 const uint8_t* tab = d + o_tab;
                 ok = g_inflate_launch(lane->stream, d + o_in, (const uint64_t*)(tab + t_in_off), (const uint32_t*)(tab + t_in_len),
                                       (const uint32_t*)(tab + t_isz), (const uint32_t*)(tab + t_crc), g_members, d + o_out,
-                                      (const uint64_t*)(tab + t_out_off), (uint32_t*)(d + o_status), (const uint64_t*)(tab + t_tok_off),
-                                      (uint32_t*)(d + o_ntok), d + o_tok) == 0 &&
+                                      (const uint64_t*)(tab + t_out_off), (uint32_t*)(d + o_status), (uint32_t*)(d + o_ntok), d + o_tok,
+                                      arena_members) == 0 &&
                      g_gather_launch(lane->stream, d + o_out, (const uint64_t*)(tab + t_src_off), (const uint32_t*)(tab + t_len),
                                      (const uint64_t*)(tab + t_dst_off), n_pc, d + o_packed) == 0 &&
                      hipEventRecord(lane->done, lane->stream) == hipSuccess;

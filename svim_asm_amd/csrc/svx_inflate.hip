@@ -2,24 +2,29 @@
 // inflate").  What it stands in for: htslib's bgzf_read_block under every record the reference reads
 // (pysam bam.fetch, SVIM_COLLECT.py:65-68; the inserted sequences of SVIM_intra.py:42) — inflate a member, check
 // its CRC32 and ISIZE.  In the product path it is the kernel of the BAM reader's device leg (svx_bam.cpp,
-// svx_bam_set_device_inflate): a share of the members under a call's sequence slices, beside the reader's threads.
+// svx_bam_set_device_inflate): the members under a call's sequence slices, beside the reader's threads.
 //
-// DEFLATE (RFC 1951) is a serial bit stream per member, so the parallelism is ACROSS members: one LANE per member,
-// kActive members per wave (4: below), all members of a call (thousands) in one launch.  Per lane:
-//   * bit buffer of 64 bits, refilled 32 bits at a time from the member's compressed bytes in HBM; the next word
-//     is requested one refill ahead, so a refill never waits for memory;
-//   * canonical Huffman decoding by code length (count / first / index walk, one bit per step — the scheme of
-//     zlib's puff.c): no lookup tables to build per block, the per-length counts and the symbols sorted by code
-//     sit in LDS, element-major ([entry][lane]) so that lanes reading the same entry hit different banks;
-//   * literals and match copies go to the member's own stretch of the output buffer in HBM (a lane reads back
-//     its own earlier output for a match: program order per lane), every output byte passes through the running
-//     CRC32 (one 256-entry table per workgroup in LDS);
-//   * stored, fixed and dynamic blocks; anything malformed (over-subscribed or incomplete code sets — except the
-//     one-code distance set zlib allows —, distances beyond the output so far, output beyond ISIZE, input that
-//     ends early) ends the lane with a status, never with an access outside the member's input and output.
-// Integer / byte work, no MFMA.  Bound by the serial decode chain per lane (LDS and HBM latencies), not by bytes.
+// Three forms, the same bytes and statuses (tests/test_gpu_inflate.py runs all of them; svx_bgzf_inflate_set_two_pass):
+//   3 (shipped)  k_inflate_wparse + k_inflate_parse + k_inflate_resolve.  A WAVE per member parses the bit stream — its
+//                64 lanes decode 64 stretches of it at once and resynchronise (a Huffman-coded stream does: see the kernel)
+//                —, stores the literals and writes every match as a token; whatever it does not recognise as plain it
+//                leaves to the lane-per-member parse behind it, which is also the judge of every malformed stream; a wave
+//                per member then applies the tokens in rounds by dependence depth and takes the CRC-32 (1 KiB a lane,
+//                folded with crc32_combine's operators).  7 261 sequence members: 8.1 ms; 28 000: 26 ms.
+//   2            the same with the lane-per-member parse for every member (16 members a wave, the lanes in step): 36.7 ms.
+//   1            k_bgzf_inflate: one launch, a lane per member that decodes, copies its matches from its own earlier
+//                output and takes the CRC (rounds 4-5): 49 ms.  DEFLATE (RFC 1951) is a serial bit stream per member; with
+//                a lane per member the parallelism is ACROSS members only and a member's ~45 000 symbols are one chain.
+// Common to all: canonical Huffman decoding from LDS tables built per block from the code lengths (one look-up for the
+// short codes, the long ones by comparison against per-length code limits or puff.c's walk); stored, fixed and dynamic
+// blocks; anything malformed (over-subscribed or incomplete code sets — except the one-code set zlib allows —, distances
+// beyond the output so far, output beyond ISIZE, input that ends early) ends the member with a status, never with an access
+// outside the member's input and output (and their documented padding: include/svx.h).
+// Integer / byte work, no MFMA.  Form 3 is bound by instruction issue (~70 VALU per symbol and pass, two passes and a write
+// pass per window), forms 1-2 by a member's serial chain.
 #include <atomic>
 
+#include "svx_inflate_dev.h"
 #include "svx_internal.h"
 
 namespace {
@@ -447,11 +452,13 @@ __global__ __launch_bounds__(kThreads) SVX_INFL_OCCUPANCY void k_bgzf_inflate(In
 struct TwoPassArgs {
     InfArgs a;
     uint2* tok;               // token lists of all members, one behind the other
-    const uint64_t* tok_off;  // per member: first token slot; capacity isize / 3 + 2 (a match yields at least 3 bytes)
+    uint32_t first, count;    // the members of this launch: [first, first + count) — member m's token list is slice
+                              // m - first of `tok`, kTokStride slots each (a member is 65 536 bytes at most, a match 3 at least)
     uint32_t* n_tok;          // per member: tokens written (k_inflate_parse), or 0xFFFFFFFF: the parse ended the member itself
     uint32_t shift[6][32];    // columns of the operators x^(8192 * 2^j) mod P, j = 0..5 (CRC-32, reflected)
     uint32_t redo_only;       // k_inflate_parse: only the members k_inflate_wparse has left to it (n_tok == kTokPending)
 };
+constexpr uint32_t kTokStride = SVX_INFLATE_TOK_STRIDE;
 constexpr uint32_t kTokFinal = 0xFFFFFFFFu;    // n_tok: the parse has ended the member with its status
 constexpr uint32_t kTokPending = 0xFFFFFFFEu;  // n_tok: k_inflate_wparse hands the member to k_inflate_parse
 
@@ -667,8 +674,8 @@ __global__ __launch_bounds__(64) void k_inflate_parse(TwoPassArgs t) {
     ParseLds& s = *reinterpret_cast<ParseLds*>(lds_raw);
     const InfArgs& a = t.a;
     const int lane = (int)threadIdx.x;
-    const uint32_t m = blockIdx.x * kLanes + (uint32_t)lane;
-    const bool mine = lane < kLanes && m < a.n && (!t.redo_only || t.n_tok[m] == kTokPending);
+    const uint32_t m = t.first + blockIdx.x * kLanes + (uint32_t)lane;
+    const bool mine = lane < kLanes && m < t.first + t.count && (!t.redo_only || t.n_tok[m] == kTokPending);
     ParseLane h;
     RBits& b = h.b;
     b.buf = 0; b.cnt = 0; b.pos = 0; b.next = 0; b.ring_hi = 0; b.in_len = 0; b.in = a.in;
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(64) void k_inflate_parse(TwoPassArgs t) {
         b.in_len = a.in_len[m];
         h.isize = a.isize[m];
         out = a.out + a.out_off[m];
-        tok = t.tok + t.tok_off[m];
+        tok = t.tok + (uint64_t)(m - t.first) * kTokStride;
         state = PS_HEADER;
         if (h.isize > 65536u) { h.st = ST_SIZE; state = PS_DONE; }  // no BGZF member is longer
         s.in_lo[lane] = (uint32_t)(uintptr_t)b.in;
@@ -1165,12 +1172,12 @@ __global__ __launch_bounds__(64) SVX_WPARSE_OCCUPANCY void k_inflate_wparse(TwoP
     __shared__ WaveLds s;
     const InfArgs& a = t.a;
     const int lane = (int)threadIdx.x;
-    const uint32_t m = blockIdx.x;
-    if (m >= a.n) return;
+    if (blockIdx.x >= t.count) return;
+    const uint32_t m = t.first + blockIdx.x;
     const uint8_t* in = a.in + a.in_off[m];
     const uint32_t in_len = a.in_len[m], isize = a.isize[m], nbits = in_len * 8u;
     uint8_t* out = a.out + a.out_off[m];
-    uint2* tok = t.tok + t.tok_off[m];
+    uint2* tok = t.tok + (uint64_t)blockIdx.x * kTokStride;
     if (isize > 65536u || in_len > 65536u) {  // (no BGZF member is longer; the serial parse says what it is)
         if (lane == 0) t.n_tok[m] = kTokPending;
         return;
@@ -1297,13 +1304,14 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(TwoPassArgs t) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (m >= a.n) return;
+    const uint32_t in_slice = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (in_slice >= t.count) return;
+    const uint32_t m = t.first + in_slice;
     const uint32_t n_tok = t.n_tok[m];
     if (n_tok == kTokFinal) return;  // the parse has written the member's status
     uint8_t* out = a.out + a.out_off[m];
     const uint32_t isize = a.isize[m];
-    const uint2* tok = t.tok + t.tok_off[m];
+    const uint2* tok = t.tok + (uint64_t)in_slice * kTokStride;
     // ---- the matches, 64 at a time
     auto copy_one = [&](uint32_t dst, uint32_t len, uint32_t dist) {
         const uint8_t* src = out + dst - dist;
@@ -1405,11 +1413,6 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(TwoPassArgs t) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_tok_offsets(uint32_t n, uint64_t slots_each, uint64_t* __restrict__ tok_off) {
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
-    if (m < n) tok_off[m] = (uint64_t)m * slots_each;
-}
-
 // pieces of the inflated members → one compact buffer: piece p = src[src_off[p] .. + len[p]) → dst[dst_off[p] ..]; one
 // wave per piece (the packed SEQ bytes of one sequence slice inside one member: tens to thousands of bytes)
 __global__ __launch_bounds__(256) void k_gather_ranges(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
@@ -1479,12 +1482,11 @@ extern "C" int svx_bgzf_inflate_set_two_pass(int on) {
     return was == 1 ? 0 : was == 2 ? 2 : 1;
 }
 
-// The two launches of the two-pass form: d_tok_off[m] = first slot of member m's token list in d_tok (prefix sums of
-// isize / 3 + 2, filled in by the caller), d_n_tok one word per member.
-static int inflate_two_pass(hipStream_t stream, int form, const InfArgs& a, const uint64_t* d_tok_off, uint32_t* d_n_tok, void* d_tok) {
+// The launches of the two-pass forms: the token lists live in an arena of `tok_members` slices (kTokStride slots of 8 bytes
+// each), so the members go out `tok_members` at a time, one slice of launches behind the other on the stream.
+static int inflate_two_pass(hipStream_t stream, int form, const InfArgs& a, uint32_t* d_n_tok, void* d_tok, uint32_t tok_members) {
     TwoPassArgs t;
     t.a = a;
-    t.tok_off = d_tok_off;
     t.n_tok = d_n_tok;
     t.tok = static_cast<uint2*>(d_tok);
     memcpy(t.shift, crc_shift_columns(), sizeof(t.shift));
@@ -1492,20 +1494,23 @@ static int inflate_two_pass(hipStream_t stream, int form, const InfArgs& a, cons
                                        (int)sizeof(ParseLds));
     if (e != hipSuccess) return (int)e;
     t.redo_only = form == 3 ? 1u : 0u;
-    if (form == 3) hipLaunchKernelGGL(k_inflate_wparse, dim3(a.n), dim3(64), 0, stream, t);
-    hipLaunchKernelGGL(k_inflate_parse, dim3((a.n + kLanes - 1) / kLanes), dim3(64), sizeof(ParseLds), stream, t);
-    hipLaunchKernelGGL(k_inflate_resolve, dim3((a.n + 3) / 4), dim3(256), 0, stream, t);
+    for (uint32_t first = 0; first < a.n; first += tok_members) {
+        t.first = first;
+        t.count = a.n - first < tok_members ? a.n - first : tok_members;
+        if (form == 3) hipLaunchKernelGGL(k_inflate_wparse, dim3(t.count), dim3(64), 0, stream, t);
+        hipLaunchKernelGGL(k_inflate_parse, dim3((t.count + kLanes - 1) / kLanes), dim3(64), sizeof(ParseLds), stream, t);
+        hipLaunchKernelGGL(k_inflate_resolve, dim3((t.count + 3) / 4), dim3(256), 0, stream, t);
+    }
     return (int)hipGetLastError();
 }
 
 int svx_bgzf_inflate_on_stream(void* stream, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
-                               const uint64_t* d_out_off, uint32_t* d_status, const uint64_t* d_tok_off, uint32_t* d_n_tok,
-                               void* d_tok) {
+                               const uint64_t* d_out_off, uint32_t* d_status, uint32_t* d_n_tok, void* d_tok, uint32_t tok_members) {
     if (n_members == 0) return 0;
     InfArgs a{d_in, d_in_off, d_in_len, d_isize, d_crc, d_out, d_out_off, d_status, n_members};
     const int form = g_form.load();
-    if (d_tok_off && d_n_tok && d_tok && form != 1) return inflate_two_pass(static_cast<hipStream_t>(stream), form, a, d_tok_off, d_n_tok, d_tok);
+    if (d_n_tok && d_tok && tok_members && form != 1) return inflate_two_pass(static_cast<hipStream_t>(stream), form, a, d_n_tok, d_tok, tok_members);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sizeof(Lds));
     if (e != hipSuccess) return (int)e;
@@ -1523,10 +1528,7 @@ int svx_gather_ranges_on_stream(void* stream, const uint8_t* d_src, const uint64
 }
 
 // svx_bam.cpp reaches the two launches through pointers (it also builds alone, without this file, for the CPU sanitizer tests)
-extern "C" void svx_bam_register_device_kernels(
-    int (*)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint8_t*,
-            const uint64_t*, uint32_t*, const uint64_t*, uint32_t*, void*),
-    int (*)(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, uint8_t*));
+extern "C" void svx_bam_register_device_kernels(svx_inflate_launch_fn, svx_gather_launch_fn);
 static const int svx_device_kernels_registered =
     (svx_bam_register_device_kernels(&svx_bgzf_inflate_on_stream, &svx_gather_ranges_on_stream), 0);
 
@@ -1541,21 +1543,20 @@ extern "C" int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uin
     if (rc != SVX_OK) return rc;
     rc = svx_timing_mark(ctx, 1);
     if (rc != SVX_OK) return rc;
-    // the two-pass form's token lists: the sizes are on the device, so room for the longest possible lists (a member is
-    // at most 65 536 bytes, a match at least 3) and the offsets by a small launch
-    constexpr uint64_t kMaxSlots = 65536 / 3 + 2;
-    const size_t need = svx_take_bytes(n_members, 8) + svx_take_bytes(n_members, 4) + svx_take_bytes((size_t)n_members * kMaxSlots, 8);
-    uint64_t* d_tok_off = nullptr;
+    // the two-pass forms' token lists: an arena for up to kArenaMembers members at a time out of the context's workspace
+    // (175 KB a member: 8 bytes per 3 bytes of output at most); a smaller one when the device has no room for it
+    constexpr uint32_t kArenaMembers = SVX_INFLATE_ARENA_MEMBERS;
+    uint32_t arena = n_members < kArenaMembers ? n_members : kArenaMembers;
     uint32_t* d_n_tok = nullptr;
     void* d_tok = nullptr;
-    if (svx_ws_reserve(ctx, need) == SVX_OK) {
-        d_tok_off = svx_ws_take<uint64_t>(ctx, n_members);
+    for (; arena; arena = arena > 512u ? arena / 2u : 0u) {
+        if (svx_ws_reserve(ctx, svx_take_bytes(n_members, 4) + svx_take_bytes((size_t)arena * kTokStride, 8)) != SVX_OK) continue;
         d_n_tok = svx_ws_take<uint32_t>(ctx, n_members);
-        d_tok = svx_ws_take<uint2>(ctx, (size_t)n_members * kMaxSlots);
-        hipLaunchKernelGGL(k_tok_offsets, dim3((n_members + 255) / 256), dim3(256), 0, ctx->stream, n_members, kMaxSlots, d_tok_off);
-    }  // (no room: the one-pass kernel)
+        d_tok = svx_ws_take<uint2>(ctx, (size_t)arena * kTokStride);
+        break;
+    }  // (no room at all: the one-launch kernel)
     SVX_HIP(ctx, (hipError_t)svx_bgzf_inflate_on_stream(ctx->stream, d_in, d_in_off, d_in_len, d_isize, d_crc, n_members, d_out, d_out_off,
-                                                        d_status, d_tok_off, d_n_tok, d_tok));
+                                                        d_status, d_n_tok, d_tok, d_tok ? arena : 0u));
     rc = svx_timing_mark(ctx, 2);
     if (rc != SVX_OK) return rc;
     return svx_timing_end(ctx);

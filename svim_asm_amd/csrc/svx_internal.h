@@ -126,9 +126,11 @@ static inline size_t svx_take_bytes(size_t count, size_t elem) {
 // puts the thread to sleep until the device signals (hipStreamSynchronize burns a CPU for the whole wait: under a
 // CPU quota, milliseconds of kernel time then cost the host's other threads their share).
 // svx_inflate.hip, for the BAM reader's device leg (svx_bam.cpp): hipError_t as int
+// (d_tok: room for the token lists of `tok_members` members, SVX_INFLATE_TOK_STRIDE slots of 8 bytes each — the members go
+//  out that many at a time; d_n_tok: a word per member; both null: the one-launch kernel)
 int svx_bgzf_inflate_on_stream(void* stream, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
-                               const uint64_t* d_out_off, uint32_t* d_status, const uint64_t* d_tok_off, uint32_t* d_n_tok, void* d_tok);
+                               const uint64_t* d_out_off, uint32_t* d_status, uint32_t* d_n_tok, void* d_tok, uint32_t tok_members);
 int svx_gather_ranges_on_stream(void* stream, const uint8_t* d_src, const uint64_t* d_src_off, const uint32_t* d_len,
                                 const uint64_t* d_dst_off, uint32_t n, uint8_t* d_dst);
 int svx_wait_blocking(svx_ctx* ctx);

@@ -279,8 +279,8 @@ def test_native_recipes_equal_the_array_form(seed):
 
 
 def test_device_inflate_share_policy(monkeypatch):
-    """bamio.default_device_inflate_percent: the environment wins; otherwise half a call with at most 24 CPUs' worth of
-    time (hardware threads or cgroup quota), none above; the one-shot command runs without a share unless asked."""
+    """bamio.default_device_inflate_percent: the environment wins; otherwise the whole call with at most 24 CPUs' worth of
+    time (hardware threads or cgroup quota), none above."""
     from svim_asm_amd import bamio
     monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "35")
     assert bamio.default_device_inflate_percent() == 35
@@ -288,7 +288,7 @@ def test_device_inflate_share_policy(monkeypatch):
     assert bamio.default_device_inflate_percent() == 100
     monkeypatch.delenv("SVX_BAM_DEVICE_INFLATE")
     monkeypatch.setattr(bamio, "host_cpus", lambda: 16.0)
-    assert bamio.default_device_inflate_percent() == 50
+    assert bamio.default_device_inflate_percent() == 100
     monkeypatch.setattr(bamio, "host_cpus", lambda: 64.0)
     assert bamio.default_device_inflate_percent() == 0
     # not a number: a warning and the default, never an exception (the module is imported by every entry point)
@@ -297,7 +297,7 @@ def test_device_inflate_share_policy(monkeypatch):
         bamio._ENV_WARNED.clear()
         assert bamio.default_device_inflate_percent() == 0
     monkeypatch.setattr(bamio, "host_cpus", lambda: 8.0)
-    assert bamio.default_device_inflate_percent() == 50
+    assert bamio.default_device_inflate_percent() == 100
     # the class default is resolved when a file is loaded, not at import
     assert bamio.AlignmentFile.device_inflate_percent is None
 
@@ -310,8 +310,8 @@ def test_host_cpus_is_the_smaller_of_threads_and_quota():
 
 
 def test_command_device_share_policy(monkeypatch, tmp_path):
-    """cli._open_file: under a CPU quota half of each sequence-slice call goes to the device (the readers' default), with
-    a core per thread none of it; SVX_BAM_DEVICE_INFLATE overrides either."""
+    """cli._open_file: under a CPU quota each sequence-slice call goes to the device (the readers' default), with a core
+    per thread none of it; SVX_BAM_DEVICE_INFLATE overrides either."""
     import types
     from svim_asm_amd import bamio, cli, synth_bam
     fa, bams = synth_bam.write_dataset(str(tmp_path), seed=3, contigs=(("chrA", 80000), ("chrB", 60000)), n_shared=3, n_private=1,
@@ -322,7 +322,7 @@ def test_command_device_share_policy(monkeypatch, tmp_path):
     monkeypatch.setattr(bamio, "host_cpus", lambda: 64.0)
     assert cli._open_file(bams[0], opts).device_inflate_percent == 0
     monkeypatch.setattr(bamio, "host_cpus", lambda: 16.0)
-    assert cli._open_file(bams[0], opts).device_inflate_percent == 50
+    assert cli._open_file(bams[0], opts).device_inflate_percent == 100
     monkeypatch.setenv("SVX_BAM_DEVICE_INFLATE", "40")
     assert cli._open_file(bams[0], opts).device_inflate_percent == 40
     assert bamio.AlignmentFile(bams[0], device=0).device_inflate_percent == 50  # (the library's readers keep their default)

@@ -32,12 +32,13 @@ def main():
     ap.add_argument("--min-payload", type=int, default=0, help="only members whose compressed payload has at least this many "
                     "bytes (8192: the SEQ members — what sequence slices touch —, not the all-0xFF QUAL members)")
     ap.add_argument("--check-all", action="store_true", help="compare EVERY member's device output with zlib's (not only the first 2000)")
+    ap.add_argument("--hap", type=int, default=1, help="1 or 2: hap1.bam or hap2.bam of the sample")
     ap.add_argument("--counts", default="", help="comma-separated member counts: kernel time of the first n selected members each")
     args = ap.parse_args()
     from svim_asm_amd import _lib, bamio, synth_bam
     from tools import e2e_bench
     d = args.dataset or tempfile.mkdtemp(prefix="svx_infl_")
-    bam = os.path.join(d, "hap1.bam")
+    bam = os.path.join(d, "hap%d.bam" % args.hap)
     if not os.path.exists(bam):
         synth_bam.write_dataset(d, **e2e_bench.dataset_args(args.scale))
     raw = open(bam, "rb").read()
@@ -67,7 +68,7 @@ def main():
         by_count[c] = [round(ctx.bgzf_inflate(payloads[:c], isize[:c], crc[:c], keep_output=False)[2], 2) for _ in range(2)]
     n = len(payloads)
     out_bytes, in_bytes = int(sum(isize)), int(sum(len(p) for p in payloads))
-    print(json.dumps({"members": n, "members_compared_with_zlib": checked, "min_payload": args.min_payload, "kernel_ms_by_member_count": by_count, "compressed_bytes": in_bytes, "inflated_bytes": out_bytes,
+    print(json.dumps({"bam": os.path.basename(bam), "inflate_form": os.environ.get("SVX_INFLATE_KERNEL", "3 (default)"), "members": n, "members_compared_with_zlib": checked, "min_payload": args.min_payload, "kernel_ms_by_member_count": by_count, "compressed_bytes": in_bytes, "inflated_bytes": out_bytes,
                       "device_kernel_ms": ms, "device_inflated_GBps": out_bytes / (ms * 1e-3) / 1e9,
                       "device_us_per_member_amortised": ms * 1e3 / n, "binding_call_s_including_pageable_upload_and_download": call_s,
                       "zlib_us_per_member_one_thread": zlib_us, "zlib_members_per_s_16_threads": 16e6 / zlib_us,
