@@ -181,7 +181,7 @@ def run_samples(n_procs, bams, fasta, out, n_devices, check):
     return leg
 
 
-def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1, n_devices=1):
+def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1, n_devices=1, procs_per_device=1):
     """`svim-asm-cohort diploid` over `n_samples` own copies of the sample's BAMs (the genome FASTA is shared, as it is
     for a real cohort) — ONE fresh process per device (`--device k`, the manifest dealt out round-robin; on one device:
     one process): samples per second over the wall-clock from the first start to the last exit (interpreter start and HIP
@@ -205,7 +205,7 @@ def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1, n
                     os.link(src, dst)
         shutil.rmtree(os.path.join(d, "wd"), ignore_errors=True)
         dirs.append(d)
-    n_proc = max(1, min(n_devices, n_samples))
+    n_proc = max(1, min(n_devices * max(1, procs_per_device), n_samples))  # (procs_per_device > 1: experiments)
     env = dict(os.environ)
     for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(name, None)
@@ -216,7 +216,7 @@ def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1, n
             for d in dirs[k::n_proc]:
                 f.write("%s %s %s\n" % (os.path.join(d, "wd"), os.path.join(d, "hap1.bam"), os.path.join(d, "hap2.bam")))
         argv = [sys.executable, os.path.join(ROOT, "bin", "svim-asm-cohort"), "diploid", manifest, fasta, "--device",
-                str((device + k) % max(1, n_devices) if n_devices > 1 else device)]
+                str((device + k // max(1, procs_per_device)) % max(1, n_devices) if n_devices > 1 else device)]
         if workers:
             argv += ["--cohort_workers", str(workers)]
         if group != 1:
@@ -233,7 +233,7 @@ def run_cohort(n_samples, bams, fasta, out, device, check, workers=0, group=1, n
         path = os.path.join(d, "wd", "variants.vcf")
         oks.append(check(masked(path)) if os.path.exists(path) else False)
     cpu = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
-    leg = {"samples": n_samples, "processes": n_proc, "devices": n_proc, "workers": workers or "default", "group": group, "wall_s": wall,
+    leg = {"samples": n_samples, "processes": n_proc, "devices": max(1, min(n_devices, n_proc)), "workers": workers or "default", "group": group, "wall_s": wall,
            "samples_per_s": n_samples / wall, "rc": [p.returncode for p in procs], "cpu_seconds": cpu,
            "cpu_seconds_per_sample": cpu / n_samples, "cpu_quota_cpus": cpu_quota(),
            "peak_rss_mb_of_any_child_so_far": ru1.ru_maxrss / 1024.0,  # (RUSAGE_CHILDREN: the largest child this process has waited for)

@@ -28,17 +28,18 @@ def main():
 
     def check(text):
         return None if meta is None else hashlib.sha256(text.encode()).hexdigest() == meta["vcf_sha256"]
-    settings = [  # (workers, share %, wait ms, group)
+    settings = [  # (workers, share %, wait ms, group[, processes on the device])
         (3, 100, 400, 1), (3, 50, 0, 1), (3, 100, 0, 1), (2, 100, 400, 1), (4, 100, 400, 1), (6, 100, 400, 1), (3, 0, 0, 1),
         (4, 100, 400, 2), (3, 100, 400, 1)]
     if a.settings:
         settings = [tuple(int(x) for x in s.split(":")) for s in a.settings.split(",")]
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
-        for workers, share, wait, group in settings:
+        for workers, share, wait, group, *more in settings:
+            procs = more[0] if more else 1
             os.environ["SVX_BAM_DEVICE_INFLATE"] = str(share)
             os.environ["SVX_COHORT_INFLATE_WAIT_MS"] = str(wait)
-            leg = e2e_bench.run_cohort(a.n, bams, fasta, d, 0, check, workers=workers, group=group)
+            leg = e2e_bench.run_cohort(a.n, bams, fasta, d, 0, check, workers=workers, group=group, procs_per_device=procs)
             leg.update(device_inflate_percent=share, lane_wait_ms=wait)
             leg.pop("output_tail", None)
             line = json.dumps(leg)
