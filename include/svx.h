@@ -514,6 +514,10 @@ int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in
                          const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
                          const uint64_t* d_out_off, uint32_t* d_status);
 int svx_bgzf_inflate_set_two_pass(int on);
+/* Members whose token lists svx_bgzf_inflate_dev keeps at once (default 16 384, 175 KB each; 0: back to the default): a call
+ * with more members goes out in slices of that many.  Returns the previous value.  A memory / latency trade-off — a slice
+ * costs at least one member's decode latency — and what the tests use to run many slices over few members. */
+uint32_t svx_bgzf_inflate_set_arena(uint32_t members);
 
 /* ------------------------------------------------------------ a5 + a6 ------ */
 /*

@@ -128,6 +128,7 @@ SYMBOLS = {
     "svx_hbm_read_probe_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
     "svx_ctx_set_split_chain": (C.c_int, [_P, C.c_int]),
     "svx_bgzf_inflate_set_two_pass": (C.c_int, [C.c_int]),
+    "svx_bgzf_inflate_set_arena": (C.c_uint32, [C.c_uint32]),
     "svx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "svx_ctx_set_pair_single_launch_max": (C.c_int, [_P, C.c_uint32]),
     "svx_ctx_barrier_timed_out": (C.c_int, [_P]),

@@ -1482,6 +1482,12 @@ extern "C" int svx_bgzf_inflate_set_two_pass(int on) {
     return was == 1 ? 0 : was == 2 ? 2 : 1;
 }
 
+// members per slice of launches in svx_bgzf_inflate_dev (tests: many slices over few members)
+static std::atomic<uint32_t> g_arena_members{SVX_INFLATE_ARENA_MEMBERS};
+extern "C" uint32_t svx_bgzf_inflate_set_arena(uint32_t members) {
+    return g_arena_members.exchange(members ? members : SVX_INFLATE_ARENA_MEMBERS);
+}
+
 // The launches of the two-pass forms: the token lists live in an arena of `tok_members` slices (kTokStride slots of 8 bytes
 // each), so the members go out `tok_members` at a time, one slice of launches behind the other on the stream.
 static int inflate_two_pass(hipStream_t stream, int form, const InfArgs& a, uint32_t* d_n_tok, void* d_tok, uint32_t tok_members) {
@@ -1545,8 +1551,8 @@ extern "C" int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uin
     if (rc != SVX_OK) return rc;
     // the two-pass forms' token lists: an arena for up to kArenaMembers members at a time out of the context's workspace
     // (175 KB a member: 8 bytes per 3 bytes of output at most); a smaller one when the device has no room for it
-    constexpr uint32_t kArenaMembers = SVX_INFLATE_ARENA_MEMBERS;
-    uint32_t arena = n_members < kArenaMembers ? n_members : kArenaMembers;
+    const uint32_t arena_max = g_arena_members.load();
+    uint32_t arena = n_members < arena_max ? n_members : arena_max;
     uint32_t* d_n_tok = nullptr;
     void* d_tok = nullptr;
     for (; arena; arena = arena > 512u ? arena / 2u : 0u) {

@@ -108,3 +108,39 @@ def test_damaged_members_are_flagged(svx_ctx):
         assert (st == 0) == ok, (k, st, ok)
         if ok:
             assert outs[k] == expect[k]
+
+
+def test_members_in_slices_and_blocks_that_outlast_their_window(svx_ctx):
+    """More members than the token arena holds go out in slices (svx_bgzf_inflate_set_arena: 37 at a time here), members of
+    one block each (Z_HUFFMAN_ONLY / Z_RLE at memLevel 9: 64 KiB of symbols in a single block) and of many (memLevel 1:
+    a block every 127 symbols' worth of buffer), empty and one-byte members in between."""
+    rng = np.random.default_rng(5)
+    payloads, expect = [], []
+    for k in range(300):
+        kind = k % 6
+        if kind == 0:
+            data = rng.choice(np.frombuffer(b"\x11\x12\x14\x18\x21\x22\x24\x28\x41\x42\x44\x48\x81\x82\x84\x88", np.uint8),
+                              size=int(rng.integers(1, 65281))).tobytes()
+        elif kind == 1:
+            data = bytes(rng.integers(0, 4, int(rng.integers(1, 65281)), dtype=np.uint8) + 65)
+        elif kind == 2:
+            data = b"" if k % 12 == 2 else b"N"
+        elif kind == 3:
+            data = (b"ACGT" * 20000)[:int(rng.integers(1000, 65281))]
+        elif kind == 4:
+            data = rng.integers(0, 256, int(rng.integers(1, 20000)), dtype=np.uint8).tobytes()
+        else:
+            data = bytes(65280)
+        level, strategy, mem = [(1, zlib.Z_DEFAULT_STRATEGY, 8), (6, zlib.Z_DEFAULT_STRATEGY, 8), (9, zlib.Z_HUFFMAN_ONLY, 9),
+                                (6, zlib.Z_RLE, 9), (4, zlib.Z_FILTERED, 1), (6, zlib.Z_FIXED, 8)][(k // 6) % 6]
+        payloads.append(deflate(data, level, strategy, mem))
+        expect.append(data)
+    isize = [len(d) for d in expect]
+    crc = [zlib.crc32(d) & 0xFFFFFFFF for d in expect]
+    was = svx_ctx.lib.svx_bgzf_inflate_set_arena(37)
+    try:
+        status, outs, _ = svx_ctx.bgzf_inflate(payloads, isize, crc)
+    finally:
+        svx_ctx.lib.svx_bgzf_inflate_set_arena(was)
+    assert status.tolist() == [0] * len(payloads)
+    assert all(o == e for o, e in zip(outs, expect))
