@@ -697,10 +697,21 @@ constexpr int kInflateLanes = 2;
 #endif
 constexpr int kRingSlots = SVX_RING_SLOTS;
 constexpr size_t kSlotBytes = (size_t)SVX_SLOT_MB << 20;
+constexpr int kLegPhasesMax = 8;
+// SVX_BAM_LEG_PHASES=N: the device leg stages and decodes its members in N phases, a phase's kernels (on a second stream)
+// beside the next phase's copies.  Measured on the full-size sample with both readers' calls at once (tools/r06_leg_probe.py,
+// profiles/r06_leg_phases.txt): 1 phase 55-81 ms, 2 phases 51-79, 3 phases 67-100, 4 phases 70-83 — both readers' copies
+// already share the host link, and every set of launches costs a member's latency; so ONE phase, and this stays a switch.
+static uint32_t leg_phases_asked() {
+    static const uint32_t n = [] { const char* e = getenv("SVX_BAM_LEG_PHASES"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
+    return n;
+}
 struct InflateLane {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // the copies of the payloads
+    hipStream_t kstream = nullptr;    // the kernels: a phase's members are decoded while the next phase's payloads travel
     uint8_t* ring = nullptr;          // kRingSlots * kSlotBytes, page-locked
     hipEvent_t slot_done[kRingSlots] = {};
+    hipEvent_t staged[kLegPhasesMax] = {};  // behind the last copy of a phase
     hipEvent_t done = nullptr;
     std::mutex busy;                  // held by the call that uses the lane
 };
@@ -825,6 +836,10 @@ static void inflate_lanes_bring_up(int device) {
             if (ok) memset(ring, 0, kSlotBytes);
             I.ring = static_cast<uint8_t*>(ring);
             ok = ok && warm_stream(&I.stream, kSlotBytes, ring);
+            if (leg_phases_asked() > 1) {  // (experiments: the leg's decode pipelined with its staging)
+                ok = ok && hipStreamCreateWithFlags(&I.kstream, hipStreamNonBlocking) == hipSuccess;
+                for (int q = 0; q < kLegPhasesMax && ok; ++q) ok = hipEventCreateWithFlags(&I.staged[q], hipEventDisableTiming) == hipSuccess;
+            }
             // (blocking events: a thread that waits for a slot or for the leg sleeps — under a CPU quota a spinning wait
             //  spends the very seconds the leg is there to save)
             for (int q = 0; q < kRingSlots && ok; ++q)
@@ -1818,7 +1833,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 if (end_m - in_off[cut.back()] > kSlotBytes) cut.push_back(m);
             }
             cut.push_back(g_members);
-            std::atomic<uint32_t> next_batch(0), slot_gen[kRingSlots];
+            std::atomic<uint32_t> next_batch(0), phase_end(0), slot_gen[kRingSlots];
             for (int q = 0; q < kRingSlots; ++q) slot_gen[q].store(0);
             std::atomic<bool> stage_failed(false);
             std::atomic<int64_t> st_turn_us(0), st_event_us(0), st_copy_us(0), st_enqueue_us(0);  // (SVX_BAM_DEBUG: where staging goes)
@@ -1827,7 +1842,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 auto now_us = [] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
                 for (;;) {
                     const uint32_t i = next_batch.fetch_add(1);
-                    if (i + 1 >= cut.size()) break;
+                    if (i >= phase_end.load()) break;
                     const uint32_t q = i % kRingSlots, gen = i / kRingSlots;
                     const int64_t t0 = debug ? now_us() : 0;
                     while (slot_gen[q].load(std::memory_order_acquire) != gen)  // batch i - kRingSlots has enqueued its copy
@@ -1851,28 +1866,39 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                     slot_gen[q].store(gen + 1, std::memory_order_release);
                 }
             };
-            if (ok) {
+            // (2 + 3) the payloads through the ring, then the kernels, the gather and the event behind it — in one phase, or
+            // (leg_phases_asked) in several with a phase's kernels on the lane's second stream beside the next phase's copies
+            const uint32_t n_batches = (uint32_t)cut.size() - 1;
+            const uint32_t n_phases = lane && lane->kstream ? std::max(1u, std::min(std::min<uint32_t>(leg_phases_asked(), kLegPhasesMax), n_batches)) : 1u;
+            const hipStream_t ks = lane ? (n_phases > 1 ? lane->kstream : lane->stream) : nullptr;
+            uint8_t* const d = b->d_inflate;
+            const uint8_t* const tab = d + o_tab;
+            for (uint32_t ph = 0; ok && ph < n_phases; ++ph) {
+                const uint32_t b0 = (uint32_t)((uint64_t)n_batches * ph / n_phases), b1 = (uint32_t)((uint64_t)n_batches * (ph + 1) / n_phases);
+                next_batch.store(b0);
+                phase_end.store(b1);
                 // as many threads as the ring has slots: each batch finds its slot free or about to be — more threads would
                 // only wait for their turn (spinning through the CPU quota: measured, 3.4 instead of 2.9 CPU-seconds per run)
-                b->pool.run((int)std::min<uint32_t>(std::min<uint32_t>(nt, (uint32_t)kRingSlots), (uint32_t)cut.size() - 1), stage);
+                b->pool.run((int)std::min<uint32_t>(std::min<uint32_t>(nt, (uint32_t)kRingSlots), b1 - b0), stage);
                 ok = !stage_failed.load();
+                const uint32_t m0 = cut[b0], m1 = cut[b1];
+                if (n_phases > 1)
+                    ok = ok && hipEventRecord(lane->staged[ph], lane->stream) == hipSuccess && hipStreamWaitEvent(ks, lane->staged[ph], 0) == hipSuccess;
+                ok = ok &&
+                     g_inflate_launch(ks, d + o_in, (const uint64_t*)(tab + t_in_off) + m0, (const uint32_t*)(tab + t_in_len) + m0,
+                                      (const uint32_t*)(tab + t_isz) + m0, (const uint32_t*)(tab + t_crc) + m0, m1 - m0, d + o_out,
+                                      (const uint64_t*)(tab + t_out_off) + m0, (uint32_t*)(d + o_status) + m0, (uint32_t*)(d + o_ntok) + m0,
+                                      d + o_tok, arena_members) == 0;
+                if (ph == 0) t_staged = since_call_ms();  // (the first phase's: what the kernels wait for at least)
             }
-            t_staged = since_call_ms();
             if (debug)
-                fprintf(stderr, "svx_bam_seq_slices: staging %zu batches, %.1f MB: thread-ms waiting for the slot's turn %.1f, for its last copy %.1f, "
-                        "copying members in %.1f, enqueueing %.1f\n", cut.size() - 1, in_bytes / 1e6, st_turn_us.load() / 1e3, st_event_us.load() / 1e3,
+                fprintf(stderr, "svx_bam_seq_slices: staging %zu batches in %u phase(s), %.1f MB: thread-ms waiting for the slot's turn %.1f, for its last copy %.1f, "
+                        "copying members in %.1f, enqueueing %.1f\n", cut.size() - 1, n_phases, in_bytes / 1e6, st_turn_us.load() / 1e3, st_event_us.load() / 1e3,
                         st_copy_us.load() / 1e3, st_enqueue_us.load() / 1e3);
-            // (3) kernels, and the event behind them
             if (ok) {
-                uint8_t* d = b->d_inflate;
-                const uint8_t* tab = d + o_tab;
-                ok = g_inflate_launch(lane->stream, d + o_in, (const uint64_t*)(tab + t_in_off), (const uint32_t*)(tab + t_in_len),
-                                      (const uint32_t*)(tab + t_isz), (const uint32_t*)(tab + t_crc), g_members, d + o_out,
-                                      (const uint64_t*)(tab + t_out_off), (uint32_t*)(d + o_status), (uint32_t*)(d + o_ntok), d + o_tok,
-                                      arena_members) == 0 &&
-                     g_gather_launch(lane->stream, d + o_out, (const uint64_t*)(tab + t_src_off), (const uint32_t*)(tab + t_len),
+                ok = g_gather_launch(ks, d + o_out, (const uint64_t*)(tab + t_src_off), (const uint32_t*)(tab + t_len),
                                      (const uint64_t*)(tab + t_dst_off), n_pc, d + o_packed) == 0 &&
-                     hipEventRecord(lane->done, lane->stream) == hipSuccess;
+                     hipEventRecord(lane->done, ks) == hipSuccess;
             }
             t_launched = since_call_ms();
             if (ok) {
@@ -1882,7 +1908,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 next.store(n_g);  // the threads take the slices behind the leg's
             } else {
                 (void)hipGetLastError();
-                if (lane) (void)hipStreamSynchronize(lane->stream);  // nothing of a failed leg is still reading the ring
+                if (lane) { (void)hipStreamSynchronize(lane->stream); if (lane->kstream) (void)hipStreamSynchronize(lane->kstream); }  // nothing of a failed leg is still at work
                 n_g = 0;      // the threads take everything
                 g_members = 0;
             }
@@ -1929,6 +1955,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 // and the results never depend on the share
                 (void)hipGetLastError();
                 (void)hipStreamSynchronize(lane->stream);  // nothing of the failed leg is still reading the ring
+                if (lane->kstream) (void)hipStreamSynchronize(lane->kstream);
                 (void)hipGetLastError();
                 next.store(0);
                 pull_hi = n_g;
