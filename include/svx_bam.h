@@ -104,6 +104,17 @@ int svx_bam_set_device_inflate(svx_bam* bam, int percent);
  * latency on the device, 3-4 ms, and the leg its staging — below that the threads are through sooner.  BASELINE config 5's
  * 1 200-member calls: the same wall-clock on the device, 0.6 instead of 1.0 CPU-seconds: profiles/r06_wave_min_members.txt). */
 int svx_bam_set_device_inflate_min(svx_bam* bam, uint32_t members);
+/* The record walks' share of the default check, deferred to the device.  With `on` (and a device share, a pinned device and
+ * the check itself on) svx_bam_load's walks inflate a member only as far as the bytes they need — as they do with the check
+ * off: a third of the CPU time — and note every member they took bytes from; the next svx_bam_seq_slices call hands those
+ * members to its device leg, which inflates them whole and checks CRC32 and ISIZE beside its own members (no leg in that
+ * call: the handle's threads do it before the call returns).  A caller that sets this MUST call svx_bam_verify_pending
+ * before it trusts the records when no svx_bam_seq_slices call follows the load: it checks what is still pending on the
+ * threads (SVX_E_INVALID for a damaged member, like the load itself would have said).  svx_bam_pending_members: how many
+ * members wait for their check.  Off by default: every load returns with its members checked. */
+int svx_bam_set_defer_verify(svx_bam* bam, int on);
+int svx_bam_verify_pending(svx_bam* bam);
+uint64_t svx_bam_pending_members(const svx_bam* bam);
 /* A device has two inflate lanes (stream + page-locked ring each): a call that finds both taken — a process with more
  * than two readers decoding at once, svim-asm-cohort's workers — gives its whole call to the threads (default, 0) or
  * sleeps up to `milliseconds` for the first lane to come free: the better choice where the process's wall-clock is its

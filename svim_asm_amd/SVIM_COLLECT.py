@@ -493,12 +493,23 @@ def _pending_sequences(s):
             LAST_TIMING["sequences_wait_s"] = LAST_TIMING.get("sequences_wait_s", 0.0) + time.perf_counter() - t0
             if "error" in box:
                 raise box["error"]
+            _verify_pending(s)  # (nothing left when the call's device leg took the walks' members along)
             pool, got_off = box["out"]
             if not np.array_equal(got_off, off):
                 raise ValueError("the reader returned other slice lengths than were asked for")
             return pool
         t.seqs = PendingBytes(int(off[-1]), resolve)
+    else:
+        _verify_pending(s)  # (no sequence-slice call for this reader: its threads check what the walks left)
     return t
+
+
+def _verify_pending(s):
+    """bamio.AlignmentFile.defer_verify: the members this sample's record walks took bytes from without checking them, if no
+    device leg has checked them meanwhile (only ever called when no sequence-slice call of the reader is in flight)."""
+    base = getattr(getattr(s, "rec", None), "base", None)
+    if isinstance(base, AlignmentFile):
+        base.verify_pending()
 
 
 _WHAT = {T_DEL: "Deletion", T_INV: "Inversion", T_DUP_TAN: "Tandem duplication"}

@@ -676,6 +676,10 @@ class AlignmentFile(object):
     # the share goes to the device only when it holds that many members (svx_bam.h; SVX_BAM_DEVICE_INFLATE_MIN for experiments)
     device_inflate_min_members = int(os.environ.get("SVX_BAM_DEVICE_INFLATE_MIN") or 500)
     device_inflate_wait_ms = 0         # how long a call waits for one of the device's two inflate lanes (svx_bam.h)
+    # svx_bam_set_defer_verify: the record walks leave the check of the members they touch to the device leg of the next
+    # sequence-slice call (a third of the walks' CPU time instead of all of it).  Whoever sets this calls verify_pending()
+    # before trusting the records when no sequence_slices_raw call follows (SVIM_COLLECT.collect_tables does).
+    defer_verify = False
 
     @property
     def device_members(self):
@@ -718,6 +722,7 @@ class AlignmentFile(object):
             self._lib.svx_bam_set_device_inflate(self._h, 0 if self._pin_device is None else self.effective_device_inflate_percent())
             self._lib.svx_bam_set_device_inflate_min(self._h, int(self.device_inflate_min_members))
             self._lib.svx_bam_set_device_inflate_wait(self._h, int(self.device_inflate_wait_ms))
+            self._lib.svx_bam_set_defer_verify(self._h, 1 if self.defer_verify else 0)
             if tids is None:
                 rc = self._lib.svx_bam_load(self._h, None, 0)
             else:
@@ -730,6 +735,16 @@ class AlignmentFile(object):
             self._index_records_python(None if tids is None else set(tids))
         self._loaded = want
         return self
+
+    def verify_pending(self):
+        """Check (on the reader's threads) the members the record walks took bytes from and no device leg has checked yet
+        (defer_verify); ValueError for a damaged one, as load() itself raises without the deferral.  No-op otherwise."""
+        if self._h is not None and self._lib.svx_bam_verify_pending(self._h) != 0:
+            raise ValueError("%s: %s" % (self.filename, self._lib.svx_bam_last_error(self._h).decode(errors="replace")))
+
+    @property
+    def pending_members(self):
+        return int(self._lib.svx_bam_pending_members(self._h)) if self._h is not None else 0
 
     def _ensure(self):
         if self._loaded is None:

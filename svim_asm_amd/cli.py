@@ -26,6 +26,9 @@ def _open_file(path, options, one_shot=True, reader_threads=None):
     # 2.0 at 0 / 50 / 100 %, profiles/r06_wave_cli_shares.txt; with a core per thread none).  The command's readers run on as
     # many threads as the quota has CPUs (bamio.quota_threads).  SVX_BAM_DEVICE_INFLATE overrides; svim-asm-cohort sets its own
     # (cohort.py: the whole call and a wait for a free inflate lane — there CPU-seconds count, not one sample's latency).
+    # the walks leave the check of the members they touch to the device leg of the sequence slices (bamio: defer_verify; only
+    # where a leg can take it, and COLLECT checks on the threads what no leg has taken): a third of the walks' CPU seconds
+    f.defer_verify = not os.environ.get("SVX_BAM_NO_DEFER_VERIFY")
     if one_shot:
         asked = bamio.env_device_inflate_percent()
         f.device_inflate_percent = asked if asked is not None else bamio.default_device_inflate_percent()

@@ -237,6 +237,7 @@ struct Cursor {
     bool whole = false;         // the member in `buf` has been inflated to its end and its CRC32 checked
     uint64_t n_hopped = 0;      // members passed (inflated or not)
     std::vector<uint64_t>* verified = nullptr;  // (walks) file offsets of the members inflated whole with their CRC32 checked
+    std::vector<uint64_t>* touched = nullptr;   // (walks with the check deferred) file offsets of every member bytes were taken from
     std::vector<uint8_t> buf;
 
     Cursor(const File* file, Inflater* i) : f(file), inf(i) {}
@@ -266,6 +267,7 @@ struct Cursor {
             if (!inf->begin(f->map + coff + blk.payload_off, blk.payload_len)) { bad = true; return false; }
             buf_valid = 0;
             whole = false;
+            if (touched) touched->push_back(coff);
         } else if (buf_valid >= upto && (prefix_mode || whole)) {
             return true;
         }
@@ -319,6 +321,7 @@ struct Chunk {
     std::vector<uint8_t> aux;
     uint64_t blocks_spanned = 0;
     std::vector<uint64_t> verified;  // members this walk inflated whole and CRC-checked (verifying ingest)
+    std::vector<uint64_t> touched;   // members this walk took bytes from without checking them (svx_bam_set_defer_verify)
     std::string err;
 };
 
@@ -355,12 +358,14 @@ size_t aux_value_size(const uint8_t* p, const uint8_t* end) {
 const uint32_t kRefMask = 0x18D;  // M D N = X consume the reference (htslib bam_cigar2rlen)
 
 // Walk records from `start` to `stop` (exclusive; canonical position) or to the end of the file.
-bool walk_records(const File* f, VPos start, bool have_stop, VPos stop, Inflater* inf, Chunk* out, bool whole_members) {
+bool walk_records(const File* f, VPos start, bool have_stop, VPos stop, Inflater* inf, Chunk* out, bool whole_members,
+                  bool note_touched = false) {
     Cursor c(f, inf);
     // a record's head, name and CIGAR are followed by its SEQ bytes — the expensive kind to inflate (svx_inflate.h) —
     // which the walk hops over: stopping right behind the CIGAR is a third of the CPU time of inflating the member
     c.prefix_mode = !whole_members;
     if (whole_members) c.verified = &out->verified;
+    else if (note_touched) c.touched = &out->touched;
     char msg[256];
     if (!c.seek(start)) { out->err = "malformed BGZF member at a walk start"; return false; }
     std::vector<uint8_t> body;
@@ -921,6 +926,11 @@ struct svx_bam {
     int inflate_pct = 0;  // share of a sequence-slice call whose members the device inflates (svx_bam_set_device_inflate)
     uint32_t inflate_min_members = 500;   // ... when that share holds at least this many members
     uint32_t inflate_wait_ms = 0;         // ... and how long a call waits for one of the device's inflate lanes to come free
+    // svx_bam_set_defer_verify: the record walks take only the bytes they need of a member (as with the check off) and note
+    // the member here; the next sequence-slice call's device leg checks these members whole beside its own, or the threads do
+    // (at the end of that call, or in svx_bam_verify_pending).  Sorted, unique.
+    bool defer_verify = false;
+    std::vector<uint64_t> pending_members;
     uint8_t* d_inflate = nullptr;  // the device leg's buffer, kept between calls
     size_t d_inflate_cap = 0;
     // ... asked for ahead of the first sequence-slice call, on a thread beside whatever follows the record walk: a
@@ -1202,6 +1212,56 @@ extern "C" int svx_bam_set_device_inflate_min(svx_bam* b, uint32_t members) {
     return SVX_OK;
 }
 
+extern "C" int svx_bam_set_defer_verify(svx_bam* b, int on) {
+    if (!b) return SVX_E_INVALID;
+    b->defer_verify = on != 0;
+    return SVX_OK;
+}
+
+// the members in `coffs` inflated whole and checked (CRC32, ISIZE) by the handle's threads; true: all good (they then count
+// as verified)
+static bool verify_members_on_host(svx_bam* b, const std::vector<uint64_t>& coffs) {
+    if (coffs.empty()) return true;
+    std::atomic<size_t> next(0);
+    std::atomic<bool> bad(false);
+    std::atomic<uint64_t> n_inflated(0);
+    auto check = [&]() {
+        Inflater inf;
+        std::vector<uint8_t> buf(65536);
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= coffs.size() || bad.load()) break;
+            Blk blk;
+            if (parse_block(b->file.map, b->file.fsize, coffs[i], &blk) != 0 ||
+                !inf.run(b->file.map + coffs[i] + blk.payload_off, blk.payload_len, buf.data(), blk.isize, blk.crc))
+                bad.store(true);
+        }
+        n_inflated.fetch_add(inf.n_blocks);
+    };
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)b->n_threads, coffs.size() / 16 + 1));
+    if (nt <= 1) check();
+    else b->pool.run(nt, check);
+    b->blocks_inflated += n_inflated.load();
+    if (bad.load()) return false;
+    std::vector<uint64_t> all;
+    all.reserve(b->verified_members.size() + coffs.size());
+    std::merge(b->verified_members.begin(), b->verified_members.end(), coffs.begin(), coffs.end(), std::back_inserter(all));
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    b->verified_members.swap(all);
+    return true;
+}
+
+extern "C" int svx_bam_verify_pending(svx_bam* b) {
+    if (!b) return SVX_E_INVALID;
+    if (b->pending_members.empty()) return SVX_OK;
+    std::vector<uint64_t> todo;
+    todo.swap(b->pending_members);
+    if (!verify_members_on_host(b, todo)) return fail(b, SVX_E_INVALID, "svx_bam_verify_pending: a BGZF member a record walk took bytes from is malformed or fails its CRC32");
+    return SVX_OK;
+}
+
+extern "C" uint64_t svx_bam_pending_members(const svx_bam* b) { return b ? (uint64_t)b->pending_members.size() : 0; }
+
 extern "C" int svx_bam_set_device_inflate_wait(svx_bam* b, uint32_t milliseconds) {
     if (!b) return SVX_E_INVALID;
     b->inflate_wait_ms = milliseconds;
@@ -1353,12 +1413,16 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
     std::atomic<uint64_t> cig_done(0), pieces_done(0);
     std::atomic<bool> early_claimed(false);
     const bool early_ok = b->pin_device >= 0 && nt > 1 && !filter_after && !getenv("SVX_BAM_LATE_POOL");
+    // the check of the members these walks touch, deferred to the device (svx_bam_set_defer_verify): only where a device leg
+    // can take it — otherwise the walks check as they go, as ever
+    const bool deferred = b->verify && b->defer_verify && b->inflate_pct > 0 && b->pin_device >= 0 && b->pin_device < kMaxLanes &&
+                          g_inflate_launch && g_gather_launch;
     auto worker = [&]() {
         Inflater inf;
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= pieces.size() || failed.load()) break;
-            if (!walk_records(&b->file, pieces[i].start, pieces[i].have_stop, pieces[i].stop, &inf, &chunks[i], b->verify))
+            if (!walk_records(&b->file, pieces[i].start, pieces[i].have_stop, pieces[i].stop, &inf, &chunks[i], b->verify && !deferred, deferred))
                 failed.store(true);
             cig_done.fetch_add(chunks[i].cigar.size());
             pieces_done.fetch_add(1);
@@ -1413,6 +1477,18 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
             for (const Chunk& ch : chunks) b->verified_members.insert(b->verified_members.end(), ch.verified.begin(), ch.verified.end());
             std::sort(b->verified_members.begin(), b->verified_members.end());
             b->verified_members.erase(std::unique(b->verified_members.begin(), b->verified_members.end()), b->verified_members.end());
+        }
+        add = 0;
+        for (const Chunk& ch : chunks) add += ch.touched.size();
+        if (add) {
+            std::vector<uint64_t>& pm = b->pending_members;
+            pm.reserve(pm.size() + add);
+            for (const Chunk& ch : chunks) pm.insert(pm.end(), ch.touched.begin(), ch.touched.end());
+            std::sort(pm.begin(), pm.end());
+            pm.erase(std::unique(pm.begin(), pm.end()), pm.end());
+            if (!b->verified_members.empty())
+                pm.erase(std::remove_if(pm.begin(), pm.end(), [&](uint64_t c) {
+                             return std::binary_search(b->verified_members.begin(), b->verified_members.end(), c); }), pm.end());
         }
     }
     for (const Chunk& ch : chunks) {
@@ -1675,6 +1751,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
         inflated.fetch_add(st.inf[0].n_blocks + st.inf[1].n_blocks);
     };
     const uint32_t nt = (uint32_t)std::max(1, std::min<int>(b->n_threads, (int)(n / 16 + 1)));
+    bool pending_on_leg = false;  // the device leg has checked the members the record walks left unchecked (svx_bam_set_defer_verify)
     if (nt <= 1) {
         work(0, n);
     } else {
@@ -1734,7 +1811,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
         std::vector<uint32_t> g_len;
         std::vector<uint32_t> g_status;
         std::vector<uint8_t> g_packed;
-        uint32_t g_members = 0;
+        uint32_t g_members = 0, g_extra = 0;  // (g_extra: members of the deferred check among them, svx_bam_set_defer_verify)
         bool leg_running = false;
         uint64_t leg_o_status = 0, leg_o_packed = 0;  // where the leg's statuses and packed bytes lie in d_inflate
         double t_located = 0, t_staged = 0, t_launched = 0;
@@ -1779,6 +1856,29 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                     g_len.push_back(pc.n);
                     g_dst_off.push_back(packed_bytes);
                     packed_bytes += pc.n;
+                }
+            }
+            // the members the record walks took bytes from without checking them (svx_bam_set_defer_verify) ride along: whole
+            // members with no piece to gather — those that are not among the leg's own already
+            if (!b->pending_members.empty()) {
+                std::vector<uint64_t> own;
+                own.reserve(in_off.size());
+                for (const RunPlan& pl : plans)
+                    for (const Job& jb : pl.jobs) own.push_back(jb.coff);
+                std::sort(own.begin(), own.end());
+                for (const uint64_t coff : b->pending_members) {
+                    if (std::binary_search(own.begin(), own.end(), coff)) continue;
+                    Blk blk;
+                    if (parse_block(b->file.map, b->file.fsize, coff, &blk) != 0) { failed.store(true); ok = false; break; }
+                    in_off.push_back(in_bytes);
+                    in_len.push_back(blk.payload_len);
+                    isz.push_back(blk.isize);
+                    crc.push_back(blk.crc);
+                    out_off_m.push_back(out_bytes);
+                    src.push_back(b->file.map + coff + blk.payload_off);
+                    in_bytes += ((uint64_t)blk.payload_len + 3) & ~3ull;
+                    out_bytes += ((uint64_t)blk.isize + 8 + 15) & ~15ull;
+                    ++g_extra;
                 }
             }
             g_members = (uint32_t)in_off.size();
@@ -1903,6 +2003,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             t_launched = since_call_ms();
             if (ok) {
                 leg_running = true;
+                pending_on_leg = true;  // (taken back below if the leg fails behind its launch)
                 g_status.resize(g_members);
                 g_packed.resize(packed_bytes + 8);
                 next.store(n_g);  // the threads take the slices behind the leg's
@@ -1961,6 +2062,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 pull_hi = n_g;
                 b->pool.run((int)nt, pull);
                 g_members = 0;
+                pending_on_leg = false;
             }
             for (uint32_t m = 0; m < g_members; ++m)
                 if (g_status[m] != 0) failed.store(true);  // malformed stream, wrong length or CRC32: as the host decoder judges
@@ -1982,8 +2084,8 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             inflated.fetch_add(g_members);
             b->device_members += g_members;
             if (debug)
-                fprintf(stderr, "svx_bam_seq_slices: device leg: %u of %u slices, %u members, %.1f MB packed; located +%.1f ms, staged +%.1f, "
-                        "launched +%.1f, threads done +%.1f, device done +%.1f, all +%.1f\n", n_g, n, g_members, g_packed.size() / 1e6,
+                fprintf(stderr, "svx_bam_seq_slices: device leg: %u of %u slices, %u members (%u of them for the record walks' check), %.1f MB packed; located +%.1f ms, staged +%.1f, "
+                        "launched +%.1f, threads done +%.1f, device done +%.1f, all +%.1f\n", n_g, n, g_members, g_extra, g_packed.size() / 1e6,
                         t_located, t_staged, t_launched, t_cpu_done, t_dev_done, since_call_ms());
         }
         if (debug)
@@ -1993,6 +2095,19 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                     start_max.load() / 1e3, wall_max.load() / 1e3, cpu_max.load() / 1e3, cpu_sum.load() / 1e3);
     }
     b->blocks_inflated += inflated.load();
+    if (!failed.load() && !b->pending_members.empty()) {
+        std::vector<uint64_t> todo;
+        todo.swap(b->pending_members);
+        if (pending_on_leg) {  // every status of the leg was 0: they count as verified
+            std::vector<uint64_t> all;
+            all.reserve(b->verified_members.size() + todo.size());
+            std::merge(b->verified_members.begin(), b->verified_members.end(), todo.begin(), todo.end(), std::back_inserter(all));
+            all.erase(std::unique(all.begin(), all.end()), all.end());
+            b->verified_members.swap(all);
+        } else if (!verify_members_on_host(b, todo)) {
+            failed.store(true);
+        }
+    }
     if (getenv("SVX_BAM_DEBUG"))
         fprintf(stderr, "svx_bam_seq_slices: %llu member inflations, %llu of them of members a record walk had verified (prefix only); "
                 "%zu members verified by walks\n", (unsigned long long)n_jobs.load(), (unsigned long long)n_known.load(),

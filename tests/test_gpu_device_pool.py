@@ -263,3 +263,95 @@ def test_more_readers_than_lanes_wait_for_one(svx_ctx, dataset):
             assert sum(1 for n in on_device if n > 0) >= 1     # two lanes: at least somebody; the others decoded on their threads
         for f in readers:
             f.close()
+
+
+def test_the_walks_check_rides_on_the_device_leg(svx_ctx, dataset, tmp_path):
+    """bamio.AlignmentFile.defer_verify (svx_bam_set_defer_verify): the record walks take only the bytes they need and leave
+    the members they touched pending; the next sequence-slice call's device leg checks them beside its own members (the same
+    records, the same bases, nothing pending afterwards); a member damaged BEHIND the bytes a walk needs lets the load pass
+    and fails the sequence call — or verify_pending() — instead."""
+    import shutil
+    import time
+    fa, bams = dataset
+    plain = bamio.AlignmentFile(bams[0], device=0)
+    plain.device_inflate_percent = 0
+    plain.load(None)
+    rec, a, b = random_slices(plain, np.random.default_rng(9), 6000)
+    exp, exp_off = plain.sequence_slices_raw(rec, a, b)
+    for attempt in range(200):
+        f = bamio.AlignmentFile(bams[0], device=0)
+        f.device_inflate_percent = 100
+        f.device_inflate_min_members = 0
+        f.defer_verify = True
+        f.load(None)
+        assert f.pending_members > 0
+        for name in ("tid", "pos", "l_seq", "flag"):
+            assert np.array_equal(f._cols[name], plain._cols[name])
+        assert np.array_equal(f._cigar, plain._cigar)
+        got, got_off = f.sequence_slices_raw(rec, a, b)
+        assert np.array_equal(got_off, exp_off) and np.array_equal(got, exp)
+        assert f.pending_members == 0
+        if f.device_members:
+            break
+        time.sleep(0.05)  # (the lanes come up beside the first load of the process; until then the threads do the check)
+    assert f.device_members > 0
+    # without a sequence call: verify_pending() on the threads
+    g = bamio.AlignmentFile(bams[0], device=0)
+    g.device_inflate_percent = 100
+    g.defer_verify = True
+    g.load(None)
+    assert g.pending_members > 0
+    g.verify_pending()
+    assert g.pending_members == 0
+    # ---- a member damaged behind the bytes the walks need: the checking load notices, the deferring load does not — the
+    # sequence call (device leg) or verify_pending() (threads) does
+    bad = str(tmp_path / "bad.bam")
+    shutil.copy(bams[0] + ".bai", bad + ".bai")
+    clean = open(bams[0], "rb").read()
+    import zlib
+
+    def opened(defer):
+        r = bamio.AlignmentFile(bad, device=0)
+        r.device_inflate_percent = 100 if defer else 0
+        r.device_inflate_min_members = 0
+        r.defer_verify = defer
+        return r
+    found = False
+    for st, ln, isz, *_ in bamio._bgzf_block_spans(clean):
+        if not isz or ln < 2000 or found:
+            continue
+        good = zlib.decompress(clean[st:st + ln], -15)
+        for back in range(3, 400):
+            trial = bytearray(clean[st:st + ln])
+            trial[ln - back] ^= 4
+            try:
+                out = zlib.decompress(bytes(trial), -15)
+            except zlib.error:
+                continue
+            if len(out) != len(good) or out == good or out[:len(good) * 3 // 4] != good[:len(good) * 3 // 4]:
+                continue
+            raw = bytearray(clean)
+            raw[st + ln - back] ^= 4
+            open(bad, "wb").write(bytes(raw))
+            try:
+                opened(False).load(None)
+                break  # no walk touches this member: the next one
+            except ValueError:
+                pass
+            try:
+                opened(True).load(None)
+            except ValueError:
+                break  # the damage lies in bytes a walk needs
+            found = True
+            break
+    if not found:
+        pytest.skip("no damage found that only a whole-member check notices")
+    h = opened(True)
+    h.load(None)
+    assert h.pending_members > 0
+    with pytest.raises(ValueError):
+        h.sequence_slices_raw(rec, a, b)
+    k = opened(True)
+    k.load(None)
+    with pytest.raises(ValueError):
+        k.verify_pending()

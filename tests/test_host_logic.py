@@ -445,3 +445,40 @@ def test_device_numa_lookup_reads_sysfs(monkeypatch, tmp_path):
     assert cohort.device_numa_cpus(0) == ("0000:72:00.0", 1, [2, 3, 6])
     files["/sys/bus/pci/devices/0000:72:00.0/numa_node"] = "-1\n"
     assert cohort.device_numa_cpus(0) == ("0000:72:00.0", None, None)
+
+
+def test_deferred_check_falls_back_to_the_threads(tmp_path):
+    """bamio.AlignmentFile.defer_verify without a usable device: whatever the walks leave pending is checked by the
+    reader's threads — at the end of the next sequence-slice call or in verify_pending() — and nothing stays pending; a
+    reader without a device share or a pinned device does not defer at all."""
+    import numpy as np
+    from svim_asm_amd import bamio, synth_bam
+    fa, bams = synth_bam.write_dataset(str(tmp_path), seed=5, contigs=(("chrA", 300000), ("chrB", 200000)), n_shared=6, n_private=2,
+                                       median_aln=60000)
+    plain = bamio.AlignmentFile(bams[0])
+    plain.defer_verify = True
+    plain.load(None)
+    assert plain.pending_members == 0  # (no pinned device: the walks check as they go)
+    f = bamio.AlignmentFile(bams[0], device=0)
+    f.device_inflate_percent = 100
+    f.defer_verify = True
+    f.load(None)
+    if f.pending_members == 0:
+        pytest.skip("this build has no device kernels registered: nothing is deferred")
+    for name in ("tid", "pos", "l_seq", "flag"):
+        assert np.array_equal(f._cols[name], plain._cols[name])
+    l_seq = f._cols["l_seq"]
+    rec = np.arange(len(l_seq), dtype=np.uint32)
+    a = np.zeros(len(rec), np.int64)
+    b = np.minimum(l_seq, 50).astype(np.int64)
+    got = f.sequence_slices_raw(rec, a, b)
+    exp = plain.sequence_slices_raw(rec, a, b)
+    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
+    assert f.pending_members == 0
+    g = bamio.AlignmentFile(bams[0], device=0)
+    g.device_inflate_percent = 100
+    g.defer_verify = True
+    g.load(None)
+    assert g.pending_members > 0
+    g.verify_pending()
+    assert g.pending_members == 0
