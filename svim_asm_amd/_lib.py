@@ -187,6 +187,7 @@ SYMBOLS = {
     "svx_bam_set_device_inflate_min": (C.c_int, [_P, C.c_uint32]),
     "svx_bam_set_device_inflate_wait": (C.c_int, [_P, C.c_uint32]),
     "svx_bam_set_defer_verify": (C.c_int, [_P, C.c_int]),
+    "svx_bam_set_inflate_lanes": (C.c_int, [C.c_int]),
     "svx_bam_verify_pending": (C.c_int, [_P]),
     "svx_bam_pending_members": (C.c_uint64, [_P]),
     "svx_bam_device_members": (C.c_uint64, [_P]),

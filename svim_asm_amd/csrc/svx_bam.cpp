@@ -693,7 +693,17 @@ extern "C" void svx_bam_register_device_kernels(svx_inflate_launch_fn inflate, s
     g_gather_launch = gather;
 }
 
-constexpr int kInflateLanes = 2;
+constexpr int kInflateLanes = 8;  // at most; a device gets g_inflate_lanes of them when they are brought up
+// How many a device's readers get (svx_bam_set_inflate_lanes, before the first load with a device share).  Two serve a
+// diploid sample's two readers; a process that decodes many samples at once (svim-asm-cohort) keeps more calls in flight —
+// a call holds its lane for 40-60 ms, staging included, and with the walks' check on the leg the lanes, not the CPUs, were
+// what its workers waited for (N = 24: 9.5 samples/s on two lanes in one process, 11.5 as two processes with two each).
+static std::atomic<int> g_inflate_lanes{2};
+extern "C" int svx_bam_set_inflate_lanes(int lanes) {
+    if (lanes < 1 || lanes > kInflateLanes) return SVX_E_INVALID;
+    g_inflate_lanes.store(lanes);
+    return SVX_OK;
+}
 #ifndef SVX_RING_SLOTS
 #define SVX_RING_SLOTS 8
 #endif
@@ -728,6 +738,7 @@ struct DeviceLanes {
     hipStream_t upload = nullptr;
     std::atomic<bool> upload_up{false};
     InflateLane inflate[kInflateLanes];
+    int n_inflate = 0;                    // lanes brought up (g_inflate_lanes at that time)
     std::atomic<bool> inflate_up{false};  // all inflate lanes are usable
     bool inflate_tried = false;
 };
@@ -833,7 +844,8 @@ static void inflate_lanes_bring_up(int device) {
     std::vector<std::thread> th;
     std::atomic<int> good(0);
     const bool want_inflate = g_inflate_launch && !getenv("SVX_BAM_NO_INFLATE_LANES");
-    for (int k = 0; want_inflate && k < kInflateLanes; ++k)
+    const int n_lanes = g_inflate_lanes.load();
+    for (int k = 0; want_inflate && k < n_lanes; ++k)
         th.emplace_back([&L, &good, device, k] {
             InflateLane& I = L.inflate[k];
             void* ring = nullptr;
@@ -856,7 +868,8 @@ static void inflate_lanes_bring_up(int device) {
     for (std::thread& t : th) t.join();
     {
         std::lock_guard<std::mutex> lock(L.mu);
-        L.inflate_up.store(want_inflate && good.load() == kInflateLanes);
+        L.n_inflate = n_lanes;
+        L.inflate_up.store(want_inflate && good.load() == n_lanes);
         L.inflate_tried = true;
     }
     L.cv.notify_all();
@@ -1794,7 +1807,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
             // seconds (svx_bam_set_device_inflate_wait), a sleeping wait for the first lane that comes free
             const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(b->inflate_wait_ms);
             for (;;) {
-                for (int k = 0; k < kInflateLanes && !lane; ++k) {
+                for (int k = 0; k < g_lanes[b->pin_device].n_inflate && !lane; ++k) {
                     std::unique_lock<std::mutex> l(g_lanes[b->pin_device].inflate[k].busy, std::try_to_lock);
                     if (l.owns_lock()) {
                         lane = &g_lanes[b->pin_device].inflate[k];
