@@ -503,7 +503,7 @@ int svx_chain_deal(const uint32_t* read_off, uint32_t n_reads, const uint32_t* s
  * (k_inflate_wparse); a lane per member does the same for whatever the wave parse has left alone — anything but plain
  * fixed / dynamic blocks, every malformed stream — and is the judge of those (k_inflate_parse); a wave per member applies the
  * tokens and takes the CRC-32 (k_inflate_resolve).  The token lists come out of the context's workspace, 175 KB a member,
- * for up to 16 384 members at a time (more members: one set of launches behind the other).  The other two: the lane-per-
+ * for up to 20 480 members at a time (more members: one set of launches behind the other).  The other two: the lane-per-
  * member parse for every member; and ONE launch, a lane per member that decodes and copies (k_bgzf_inflate, rounds 4-5).
  * svx_bgzf_inflate_set_two_pass chooses for the whole process — this entry and the BAM reader's device leg
  * (svx_bam_set_device_inflate): 0 the one-launch kernel, 2 the lane-per-member parse, any other value the shipped form; it
@@ -514,7 +514,7 @@ int svx_bgzf_inflate_dev(svx_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in
                          const uint32_t* d_isize, const uint32_t* d_crc, uint32_t n_members, uint8_t* d_out,
                          const uint64_t* d_out_off, uint32_t* d_status);
 int svx_bgzf_inflate_set_two_pass(int on);
-/* Members whose token lists svx_bgzf_inflate_dev keeps at once (default 16 384, 175 KB each; 0: back to the default): a call
+/* Members whose token lists svx_bgzf_inflate_dev keeps at once (default 20 480, 175 KB each; 0: back to the default): a call
  * with more members goes out in slices of that many.  Returns the previous value.  A memory / latency trade-off — a slice
  * costs at least one member's decode latency — and what the tests use to run many slices over few members. */
 uint32_t svx_bgzf_inflate_set_arena(uint32_t members);

@@ -1599,7 +1599,8 @@ extern "C" int svx_bam_load(svx_bam* b, const int32_t* tids, int32_t n_tids) {
         !b->d_inflate_ahead.joinable() && b->file.fsize > (64u << 20)) {
         const double share_bytes = (double)b->file.fsize * b->inflate_pct / 100.0;
         const size_t lists = std::min<size_t>((size_t)(share_bytes / 32768.0) + 512, SVX_INFLATE_ARENA_MEMBERS);
-        const size_t want = (size_t)(share_bytes * 1.6) + lists * SVX_INFLATE_TOK_STRIDE * 8 + (32u << 20);
+        // (with the walks' check deferred to the leg, svx_bam_set_defer_verify: + the members the walks touched — 2.0 x)
+        const size_t want = (size_t)(share_bytes * (b->defer_verify ? 2.0 : 1.6)) + lists * SVX_INFLATE_TOK_STRIDE * 8 + (32u << 20);
         svx_bam* h = b;
         b->d_inflate_ahead = std::thread([h, want] {
             if (hipSetDevice(h->pin_device) != hipSuccess) { (void)hipGetLastError(); return; }

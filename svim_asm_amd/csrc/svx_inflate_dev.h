@@ -5,12 +5,13 @@
 // slots (8 bytes: destination | length << 16, distance) of a member's token list in the two-pass forms: a BGZF member is
 // 65 536 bytes at most and a match yields 3 at least
 #define SVX_INFLATE_TOK_STRIDE (65536u / 3u + 2u)
-// members whose token lists the arena holds at once (175 KB each: 2.9 GB at most); a call's members go out that many at a
+// members whose token lists the arena holds at once (175 KB each: 3.6 GB at most); a call's members go out that many at a
 // time, one slice of launches behind the other.  A slice costs at least one member's latency (3.6 ms), so the arena is as
-// large as a full-size sample's call (14.5 k members a reader): 7 261 members 8.1 ms in one slice, 11.2 in slices of 6 144;
-// 28 000 members 27 ms in slices of 16 384, 34.5 in slices of 6 144 (profiles/README.md, round 6)
+// large as a full-size sample's call (11 k members a reader under its sequence slices + 6.5 k the record walks touched):
+// 7 261 members 8.1 ms in one slice, 11.2 in slices of 6 144; 28 000 members 27 ms in slices of 16 384, 34.5 in slices of
+// 6 144 (profiles/README.md, round 6)
 #ifndef SVX_INFLATE_ARENA_MEMBERS
-#define SVX_INFLATE_ARENA_MEMBERS 16384u
+#define SVX_INFLATE_ARENA_MEMBERS 20480u
 #endif
 
 // svx_bgzf_inflate_on_stream / svx_gather_ranges_on_stream (svx_inflate.hip), reached through pointers: svx_bam.cpp also
