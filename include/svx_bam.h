@@ -120,7 +120,7 @@ uint64_t svx_bam_pending_members(const svx_bam* bam);
  * sleeps up to `milliseconds` for the first lane to come free: the better choice where the process's wall-clock is its
  * CPU-seconds over a CPU quota and the device would otherwise idle. */
 int svx_bam_set_device_inflate_wait(svx_bam* bam, uint32_t milliseconds);
-/* Inflate lanes per device of this process, 1..8 (default 2: a diploid sample's two readers), effective for devices whose
+/* Inflate lanes per device of this process, 1..16 (default 2: a diploid sample's two readers), effective for devices whose
  * lanes have not been brought up yet (the first load with a device share does that): a process that keeps many readers
  * decoding at once asks for more before its first load (svim-asm-cohort: one per reader its workers keep in flight).  Each
  * lane is a stream and 16 MiB of page-locked ring. */

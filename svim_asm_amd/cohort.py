@@ -109,8 +109,8 @@ def default_workers():
 def default_lanes(workers, n_bams):
     """Inflate lanes for `workers` workers of `n_bams` readers each: one per reader (N = 24 full-size samples, 4 workers, one
     box: 6.2 samples/s on the library's two lanes, 9.2 on four, 10.0 on eight — a call that finds no lane within its wait
-    decodes on the threads), at least the library's two, at most its eight."""
-    return max(2, min(8, workers * n_bams))
+    decodes on the threads), at least the library's two, at most its sixteen."""
+    return max(2, min(16, workers * n_bams))
 
 
 def default_reader_threads(workers, n_bams):
@@ -209,7 +209,7 @@ def main(argv=None):
     from svim_asm_amd import _lib
     # inflate lanes of the device (svx_bam_set_inflate_lanes, before the first load): one per reader the workers keep in
     # flight — with the walks' check on the device leg the workers waited for the default's two lanes, not for CPUs
-    lanes = max(1, min(8, lanes or int(os.environ.get("SVX_COHORT_LANES") or 0) or default_lanes(workers, n_bams)))
+    lanes = max(1, min(16, lanes or int(os.environ.get("SVX_COHORT_LANES") or 0) or default_lanes(workers, n_bams)))
     _lib.load().svx_bam_set_inflate_lanes(lanes)
     gc.collect()
     gc.freeze()

@@ -693,7 +693,7 @@ extern "C" void svx_bam_register_device_kernels(svx_inflate_launch_fn inflate, s
     g_gather_launch = gather;
 }
 
-constexpr int kInflateLanes = 8;  // at most; a device gets g_inflate_lanes of them when they are brought up
+constexpr int kInflateLanes = 16;  // at most; a device gets g_inflate_lanes of them when they are brought up
 // How many a device's readers get (svx_bam_set_inflate_lanes, before the first load with a device share).  Two serve a
 // diploid sample's two readers; a process that decodes many samples at once (svim-asm-cohort) keeps more calls in flight —
 // a call holds its lane for 40-60 ms, staging included, and with the walks' check on the leg the lanes, not the CPUs, were
