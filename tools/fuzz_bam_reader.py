@@ -3,7 +3,7 @@
 haplotype BAM is re-blocked at random BGZF payload sizes (1 KiB … 64 KiB: slices and records then span many members)
 and re-compressed at random zlib levels / strategies (stored blocks, fixed-code blocks, Huffman-only, RLE), indexed,
 and read by both readers — records, CIGARs, tags, and random base slices; with and without whole-member verification;
-with the build's decoder and with zlib.
+with the build's decoder and with zlib; with the walks' check deferred (bamio defer_verify).
     python tools/fuzz_bam_reader.py [--seconds 120] [--seed 1]"""
 import argparse
 import os
@@ -79,7 +79,13 @@ sys.path.insert(0, %r)
 sys.path.insert(0, %r)
 from svim_asm_amd import bamio
 import fuzz_bam_reader as F
-f = bamio.AlignmentFile(sys.argv[1], reader=sys.argv[2], verify=(sys.argv[3] == "1") if sys.argv[2] == "native" else None)
+defer = len(sys.argv) > 5 and sys.argv[5] == "defer"
+f = bamio.AlignmentFile(sys.argv[1], reader=sys.argv[2], verify=(sys.argv[3] == "1") if sys.argv[2] == "native" else None,
+                        device=0 if defer else None)
+if defer:  # the walks' check left to the next sequence call (its device leg where there is one, the threads otherwise)
+    f.device_inflate_percent = 100
+    f.device_inflate_min_members = 0
+    f.defer_verify = True
 f.load()
 print(F.columns_digest(f, int(sys.argv[4])))
 """ % (ROOT, os.path.join(ROOT, "tools"))
@@ -104,8 +110,8 @@ def main():
             dst = os.path.join(tmp, "re.bam")
             reblock(bams[0], dst, rng)
             want = columns_digest(bamio.AlignmentFile(dst, reader="python").load(), seed)
-            for env, verify in (({}, "0"), ({}, "1"), ({"SVX_BAM_ZLIB": "1"}, "0"), ({"SVX_BAM_ZLIB": "1"}, "1")):
-                got = subprocess.run([sys.executable, "-c", CHILD, dst, "native", verify, str(seed)], env=dict(os.environ, **env),
+            for env, verify, *more in (({}, "0"), ({}, "1"), ({"SVX_BAM_ZLIB": "1"}, "0"), ({"SVX_BAM_ZLIB": "1"}, "1"), ({}, "1", "defer")):
+                got = subprocess.run([sys.executable, "-c", CHILD, dst, "native", verify, str(seed)] + list(more), env=dict(os.environ, **env),
                                      check=True, capture_output=True, text=True).stdout.strip()
                 if got != want:
                     keep = os.path.join(ROOT, "gpurun_out", "fuzz_bam_reader_seed%d.bam" % seed)
@@ -115,7 +121,7 @@ def main():
                     return 1
             cases += 1
             seed += 1
-        print("fuzz_bam_reader ok: %d files x 4 reader modes, seeds %d..%d" % (cases, args.seed, seed - 1))
+        print("fuzz_bam_reader ok: %d files x 5 reader modes, seeds %d..%d" % (cases, args.seed, seed - 1))
         return 0
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
