@@ -1083,7 +1083,7 @@ constexpr uint32_t kNoCheckpoint = 0xFFFFFFFFu;
 template <bool WRITE>
 __device__ __forceinline__ void wave_decode(const uint8_t* in, uint32_t in_len, const WaveLds& s, const uint32_t (&lim_ll)[kMaxBits - kWLL],
                                             const uint32_t (&lim_d)[kMaxBits - kWD], bool active, Stretch& st, uint8_t* out, uint32_t o,
-                                            uint2* tok) {
+                                            uint2* tok, uint32_t o_end = 0) {  // (o_end: the member's ISIZE — the write pass never stores behind it)
     if (!active) return;
     WBits b;
     wb_init(b, in, in_len, st.start);
@@ -1109,7 +1109,10 @@ __device__ __forceinline__ void wave_decode(const uint8_t* in, uint32_t in_len, 
         const int sym = wave_symbol<kWLL, kLL>(b, s.tab_ll, s.sym_ll, lim_ll);
         if (sym < 256) {
             if (sym < 0) { fl = WF_BAD; break; }
-            if (WRITE) out[o] = (uint8_t)sym;
+            if (WRITE) {
+                if (o >= o_end) { fl = WF_BAD; break; }
+                out[o] = (uint8_t)sym;
+            }
             ++o;
             ++bytes;
             continue;
@@ -1141,7 +1144,7 @@ __device__ __forceinline__ void wave_decode(const uint8_t* in, uint32_t in_len, 
             b.cnt -= ex;
         }
         if (WRITE) {
-            if (dist > o) { fl = WF_BAD; break; }
+            if (dist > o || o + len > o_end) { fl = WF_BAD; break; }
             tok[toks] = make_uint2(o | (len << 16), dist);
         }
         o += len;
@@ -1240,7 +1243,7 @@ __global__ __launch_bounds__(64) SVX_WPARSE_OCCUPANCY void k_inflate_wparse(TwoP
         if (produced + sum_b > isize) { give_up = true; break; }
         Stretch wr = st;
         [[maybe_unused]] const unsigned long long c2 = WSTAT_CLOCK();
-        wave_decode<true>(in, in_len, s, lim_ll, lim_d, in_chain, wr, out, produced + off_b, tok + n_tok + off_t);
+        wave_decode<true>(in, in_len, s, lim_ll, lim_d, in_chain, wr, out, produced + off_b, tok + n_tok + off_t, isize);
         WSTAT_ADD(6, WSTAT_CLOCK() - c2);
         WSTAT_ADD(10, end_k - pos);
         if (__ballot(in_chain && (wr.flag != st.flag || wr.end != st.end || wr.n_bytes != st.n_bytes || wr.n_toks != st.n_toks)) != 0ull) {
