@@ -144,3 +144,49 @@ def test_members_in_slices_and_blocks_that_outlast_their_window(svx_ctx):
         svx_ctx.lib.svx_bgzf_inflate_set_arena(was)
     assert status.tolist() == [0] * len(payloads)
     assert all(o == e for o, e in zip(outs, expect))
+
+
+def test_members_written_by_libdeflate(svx_ctx):
+    """htslib is usually built with libdeflate, whose compressor splits blocks and builds codes differently from zlib's
+    (optimal parsing at the high levels, its own choice of stored / fixed / dynamic blocks, blocks of any length): members of
+    every kind of data at its levels 0 / 1 / 6 / 9 / 12 through the three forms of the device decoder, zlib's inflate being
+    the referee."""
+    import ctypes as C
+    try:
+        L = C.CDLL("libdeflate.so.0")
+    except OSError:
+        pytest.skip("libdeflate is not installed here")
+    L.libdeflate_alloc_compressor.restype = C.c_void_p
+    L.libdeflate_alloc_compressor.argtypes = [C.c_int]
+    L.libdeflate_deflate_compress.restype = C.c_size_t
+    L.libdeflate_deflate_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.libdeflate_deflate_compress_bound.restype = C.c_size_t
+    L.libdeflate_deflate_compress_bound.argtypes = [C.c_void_p, C.c_size_t]
+    L.libdeflate_free_compressor.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(12)
+    payloads, expect = [], []
+    for level in (0, 1, 6, 9, 12):
+        comp = L.libdeflate_alloc_compressor(level)
+        assert comp
+        try:
+            for rep in range(3):
+                for name, data in kinds(rng).items():
+                    data = data[:65280]
+                    bound = L.libdeflate_deflate_compress_bound(comp, len(data))
+                    buf = C.create_string_buffer(bound + 16)
+                    n = L.libdeflate_deflate_compress(comp, data, len(data), buf, bound + 16)
+                    assert n > 0
+                    stream = buf.raw[:n]
+                    if len(stream) > 65000:  # (no BGZF member holds that; libdeflate's stored form of random bytes)
+                        continue
+                    assert zlib.decompress(stream, -15) == data
+                    payloads.append(stream)
+                    expect.append(data)
+        finally:
+            L.libdeflate_free_compressor(comp)
+    assert len(payloads) > 60
+    isize = [len(d) for d in expect]
+    crc = [zlib.crc32(d) & 0xFFFFFFFF for d in expect]
+    status, outs, _ = svx_ctx.bgzf_inflate(payloads, isize, crc)
+    assert status.tolist() == [0] * len(payloads)
+    assert all(o == e for o, e in zip(outs, expect))
