@@ -831,7 +831,9 @@ constexpr int kMaxSyncPasses = 24;
 #endif
 constexpr uint32_t kJoinBits = SVX_JOIN_BITS;        // how far into its stretch a lane looks for the place where it joins its earlier pass
 struct WaveLds {
-    uint16_t tab_ll[1 << kWLL];  // next bits -> symbol << 4 | code length (0: a longer code, or none)
+    // next bits -> symbol << 4 | code length (0: a longer code, or none); where the bits hold TWO whole literals:
+    // literal 1 << 4 | both lengths, and in the upper half 0x1000 | length 1 << 8 | literal 2 (wave_pair_literals)
+    uint32_t tab_ll[1 << kWLL];
     uint16_t tab_d[1 << kWD];
     uint16_t tab_cl[128];
     uint16_t sym_ll[kLL];        // symbols sorted by (code length, symbol)
@@ -861,8 +863,8 @@ __device__ __forceinline__ uint32_t wave_scan_excl(uint32_t v, int lane, uint32_
 // The canonical code of `n` lengths (lens[0..n)), all lanes together: the primary table of PB bits, the sorted symbols and
 // the per-length limits.  0: built; 1: over-subscribed, or incomplete in a way zlib does not allow (`any_incomplete`: the
 // fixed codes, which leave two distance codes unused).
-template <int PB>
-__device__ __forceinline__ int wave_build_code(WaveLds& s, const uint8_t* lens, int n, int chunks, uint16_t* tab, uint16_t* sorted,
+template <int PB, typename ENTRY>
+__device__ __forceinline__ int wave_build_code(WaveLds& s, const uint8_t* lens, int n, int chunks, ENTRY* tab, uint16_t* sorted,
                                                uint32_t* lim, bool must_be_complete, bool any_incomplete, int lane) {
     if (lane < 16) s.cnt[lane] = 0;
     for (int i = lane; i < (1 << PB); i += 64) tab[i] = 0;
@@ -909,13 +911,38 @@ __device__ __forceinline__ int wave_build_code(WaveLds& s, const uint8_t* lens, 
             if (l <= (uint32_t)PB) {
                 const uint32_t cd = rank + 32768u - (lim[l] & 0xFFFFu);  // rank - (first index - first code)
                 const uint32_t rev = __brev(cd) >> (32 - l);
-                const uint16_t e = (uint16_t)(((uint32_t)si << 4) | l);
+                const ENTRY e = (ENTRY)(((uint32_t)si << 4) | l);
                 for (uint32_t i = rev; i < (1u << PB); i += 1u << l) tab[i] = e;
             }
         }
         wave_sync();
     }
     return 0;
+}
+
+// Two literals per look-up: where the kWLL bits of an index hold a literal AND the whole code of a second one, the entry says
+// so (packed sequence is literals of 4-5 bits for the most part: libdeflate writes hardly anything else into a SEQ member).
+// Every lane takes 16 entries: the new values from the single-symbol table first, all of them, then the stores.
+__device__ __forceinline__ void wave_pair_literals(uint32_t* tab, int lane) {
+    constexpr int kPer = (1 << kWLL) / 64;
+    uint32_t made[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const uint32_t i = (uint32_t)lane + 64u * (uint32_t)q;
+        const uint32_t e1 = tab[i];
+        uint32_t v = e1;
+        const uint32_t l1 = e1 & 15u, s1 = e1 >> 4;
+        if (e1 && s1 < 256u && l1 < (uint32_t)kWLL) {
+            const uint32_t e2 = tab[i >> l1];  // (the index's upper bits are zeros here, not stream bits: only a code that
+            const uint32_t l2 = e2 & 15u, s2 = e2 >> 4;                       //  ends inside the real ones counts)
+            if (e2 && s2 < 256u && l1 + l2 <= (uint32_t)kWLL) v = (s1 << 4) | (l1 + l2) | ((0x1000u | (l1 << 8) | s2) << 16);
+        }
+        made[q] = v;
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) tab[(uint32_t)lane + 64u * (uint32_t)q] = made[q];
+    wave_sync();
 }
 
 // bits [bit, bit + n) of the header window, n <= 16
@@ -992,6 +1019,7 @@ __device__ __forceinline__ int wave_header(WaveLds& s, const uint8_t* in, uint32
     *pos_io = after;
     const bool fixed = type == 1u;
     if (wave_build_code<kWLL>(s, s.lens, (int)nlen, 5, s.tab_ll, s.sym_ll, s.lim_ll, false, fixed, lane)) return 1;
+    wave_pair_literals(s.tab_ll, lane);
     if (wave_build_code<kWD>(s, s.lens + nlen, (int)ndist, 1, s.tab_d, s.sym_d, s.lim_d, false, fixed, lane)) return 1;
     return 0;
 }
@@ -1043,6 +1071,22 @@ __device__ __forceinline__ void wb_refill(WBits& b, const uint8_t* in, uint32_t 
     }
 }
 __device__ __forceinline__ uint32_t wb_at(const WBits& b) { return b.pos * 8u - b.cnt; }
+
+// the code at the head of the bits that no table entry resolves: symbol << 4 | length, or 0
+template <int PB, int NSYM>
+__device__ __forceinline__ uint32_t wave_long_code(uint32_t bits, const uint16_t* sorted, const uint32_t (&lim)[kMaxBits - PB]) {
+    const uint32_t code15 = __brev(bits) >> 17;  // the next 15 bits, first bit on top
+    uint32_t len = 0, packed = 0;
+#pragma unroll
+    for (int l = kMaxBits; l > PB; --l) {  // the shortest length whose limit lies above the bits
+        const uint32_t p = lim[l - PB - 1];
+        if (code15 < (p >> 16)) { len = (uint32_t)l; packed = p; }
+    }
+    if (len == 0u) return 0u;
+    const uint32_t idx = (code15 >> (kMaxBits - len)) + (packed & 0xFFFFu) - 32768u;
+    if (idx >= (uint32_t)NSYM) return 0u;
+    return ((uint32_t)sorted[idx] << 4) | len;
+}
 
 template <int PB, int NSYM>
 __device__ __forceinline__ int wave_symbol(WBits& b, const uint16_t* tab, const uint16_t* sorted, const uint32_t (&lim)[kMaxBits - PB]) {
@@ -1106,9 +1150,38 @@ __device__ __forceinline__ void wave_decode(const uint8_t* in, uint32_t in_len, 
             st.chk_toks = toks;
         }
         wb_refill(b, in, in_len);
-        const int sym = wave_symbol<kWLL, kLL>(b, s.tab_ll, s.sym_ll, lim_ll);
+        int sym;
+        {
+            const uint32_t bits = (uint32_t)b.buf;
+            uint32_t e = s.tab_ll[bits & ((1u << kWLL) - 1u)];
+            if (__builtin_expect(e == 0u, 0)) {
+                e = wave_long_code<kWLL, kLL>(bits, s.sym_ll, lim_ll);
+                if (e == 0u) { fl = WF_BAD; break; }
+            }
+            uint32_t l = e & 15u;
+            const uint32_t up = e >> 16;
+            if (up) {  // two literals — if the second one still starts inside this stretch (and in front of the checkpoint's place)
+                const uint32_t l1 = (up >> 8) & 15u;
+                const uint32_t bound = (!WRITE && before_chk) ? st.chk_limit : st.limit;
+                if (at + l1 < bound) {
+                    if (WRITE) {
+                        if (o + 2u > o_end) { fl = WF_BAD; break; }
+                        out[o] = (uint8_t)(e >> 4);
+                        out[o + 1] = (uint8_t)up;
+                    }
+                    b.buf >>= l;
+                    b.cnt -= l;
+                    o += 2;
+                    bytes += 2;
+                    continue;
+                }
+                l = l1;
+            }
+            b.buf >>= l;
+            b.cnt -= l;
+            sym = (int)((e >> 4) & 0xFFFu);
+        }
         if (sym < 256) {
-            if (sym < 0) { fl = WF_BAD; break; }
             if (WRITE) {
                 if (o >= o_end) { fl = WF_BAD; break; }
                 out[o] = (uint8_t)sym;
