@@ -96,8 +96,9 @@ int svx_bam_device_pool_wait(svx_bam* bam, double* waited_us);
  * and a call of at least 2048 slices): the BGZF members under the first `percent` % of a call's slices are inflated and
  * checked (CRC32, ISIZE: the same judgement as the host decoder's, svx_bgzf_inflate_dev's kernel) on the pinned device
  * while the handle's threads decode the members of the other slices; the slices' packed bases come back, nothing else.
- * DEFLATE on the device is one lane per member — 55-60 ms for any number of members up to the 16 k the chip holds at
- * once — so the share is what the threads would need that long for; results never depend on it.  0 (default): host only.
+ * DEFLATE on the device is a wave per member (svx_inflate.hip): 4 ms for a thousand members, 13 for a full-size call's
+ * 14 000 — the whole call where CPU-seconds are what a run is short of; results never depend on the share.  0 (default):
+ * host only.
  * svx_bam_device_members: members the device has inflated for this handle so far. */
 int svx_bam_set_device_inflate(svx_bam* bam, int percent);
 /* The share goes to the device only when it holds at least `members` BGZF members (default 500: a launch costs one member's
@@ -115,7 +116,7 @@ int svx_bam_set_device_inflate_min(svx_bam* bam, uint32_t members);
 int svx_bam_set_defer_verify(svx_bam* bam, int on);
 int svx_bam_verify_pending(svx_bam* bam);
 uint64_t svx_bam_pending_members(const svx_bam* bam);
-/* A device has two inflate lanes (stream + page-locked ring each): a call that finds both taken — a process with more
+/* A device has two inflate lanes by default (stream + page-locked ring each; svx_bam_set_inflate_lanes): a call that finds them all taken — a process with more
  * than two readers decoding at once, svim-asm-cohort's workers — gives its whole call to the threads (default, 0) or
  * sleeps up to `milliseconds` for the first lane to come free: the better choice where the process's wall-clock is its
  * CPU-seconds over a CPU quota and the device would otherwise idle. */

@@ -675,7 +675,7 @@ class AlignmentFile(object):
         return default_device_inflate_percent() if pct is None else int(pct)
     # the share goes to the device only when it holds that many members (svx_bam.h; SVX_BAM_DEVICE_INFLATE_MIN for experiments)
     device_inflate_min_members = int(os.environ.get("SVX_BAM_DEVICE_INFLATE_MIN") or 500)
-    device_inflate_wait_ms = 0         # how long a call waits for one of the device's two inflate lanes (svx_bam.h)
+    device_inflate_wait_ms = 0         # how long a call waits for one of the device's inflate lanes (svx_bam.h)
     # svx_bam_set_defer_verify: the record walks leave the check of the members they touch to the device leg of the next
     # sequence-slice call (a third of the walks' CPU time instead of all of it).  Whoever sets this calls verify_pending()
     # before trusting the records when no sequence_slices_raw call follows (SVIM_COLLECT.collect_tables does).

@@ -1779,10 +1779,9 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
         auto since_call_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
 
         // ---- the device leg (svx_bam_set_device_inflate): the members of the first n_g slices are inflated and verified
-        // by svx_inflate.hip's kernel while the handle's threads take the other slices.  DEFLATE on the device is one
-        // lane per member — 55-60 ms for ANY number of members up to the 16 k the chip holds at once — so the leg is
-        // worth what the threads get done in that time: it takes its share in one launch and is collected when the
-        // threads are through.  In order: (1) the threads locate the leg's runs (member headers only), (2) the payloads
+        // by svx_inflate.hip's kernels (a wave per member: 13 ms for a full-size call's 14 k members) while the handle's
+        // threads take the other slices; the members the record walks left unchecked ride along (svx_bam_set_defer_verify).
+        // The leg takes its share in one set of launches and is collected when the threads are through.  In order: (1) the threads locate the leg's runs (member headers only), (2) the payloads
         // travel through a ring of page-locked slots (the threads fill, the lane's stream copies), (3) inflate kernel,
         // a gather of the slices' packed bytes, (4) the threads' own share, (5) read-back, statuses, unpacking.
         struct RunPlan {
@@ -1896,10 +1895,9 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                 }
             }
             g_members = (uint32_t)in_off.size();
-            // The leg's latency is that of ONE member on the device (45-55 ms) whatever their number: it pays when the
-            // members it takes would keep the threads busy about that long — 3 000 members are 0.2 CPU-seconds, 25 ms of
-            // eight cores (two readers share the pool's sixteen).  A small sample's call (config 5: 1 200 members, 6 ms on
-            // the host) stays on the host.
+            // A set of launches costs one member's latency on the device (3-4 ms) and the leg its staging: below a few
+            // hundred members the threads are through sooner (svx_bam_set_device_inflate_min, default 500; config 5's
+            // 1 200-member calls: the same wall-clock on the device for 0.6 of 1.0 CPU-seconds).
             if (g_members < b->inflate_min_members) ok = false;
             const uint32_t n_pc = (uint32_t)g_len.size();
             auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
