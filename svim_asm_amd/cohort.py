@@ -14,7 +14,7 @@ MANIFEST: one sample per line, whitespace-separated — working_dir bam (haploid
 lines starting with # are skipped.  Every sample gets its own working_dir/variants.vcf, byte-identical to the one
 the single-sample command writes.  K defaults to 4 (2 below 12 CPUs' worth of time), G to 1; `--cohort_group 0` = the whole
 manifest in one submission (the round-5 behaviour); T threads per BAM reader (default: the process's CPUs shared out among
-the readers in flight, default_reader_threads); L inflate lanes on the device (default_lanes: one per reader in flight).  The reference has no such mode; this is an addition on top of the
+the readers in flight, default_reader_threads); L inflate lanes on the device (default_lanes: one per three readers in flight).  The reference has no such mode; this is an addition on top of the
 drop-in command, which is unchanged."""
 import gc
 import logging
@@ -60,7 +60,7 @@ def _take_option(rest, name, default):
 
 
 COHORT_DEVICE_INFLATE_PERCENT = 100
-COHORT_DEVICE_INFLATE_WAIT_MS = int(os.environ.get("SVX_COHORT_INFLATE_WAIT_MS") or 400)  # (the variable: tools/r06_cohort_ab.py)
+COHORT_DEVICE_INFLATE_WAIT_MS = int(os.environ.get("SVX_COHORT_INFLATE_WAIT_MS") or 3000)  # (the variable: tools/r06_cohort_ab.py)
 
 
 def device_numa_cpus(device):
@@ -107,10 +107,14 @@ def default_workers():
 
 
 def default_lanes(workers, n_bams):
-    """Inflate lanes for `workers` workers of `n_bams` readers each: one per reader (N = 24 full-size samples, 4 workers, one
-    box: 6.2 samples/s on the library's two lanes, 9.2 on four, 10.0 on eight — a call that finds no lane within its wait
-    decodes on the threads), at least the library's two, at most its sixteen."""
-    return max(2, min(16, workers * n_bams))
+    """Inflate lanes for `workers` workers of `n_bams` readers each: one per three readers in flight, at least the library's
+    two.  A lane is held for a call's 50-70 ms and the workers are elsewhere most of the time, so a few lanes serve them;
+    every further lane that is busy at the same time shares the same host link and costs CPU-seconds (N = 16 full-size
+    samples, 4 workers, one box, twice: 2 lanes 8.4-8.9 samples/s at 0.79 CPU-seconds per sample, 3 lanes 8.6-9.0 at 0.85,
+    8 lanes 7.7-8.6 at 1.0; another box at N = 24 with a 400 ms wait: 6.2 on 2 lanes — calls that found no lane in time
+    decoded on the threads —, 9.2 on 4, 10.0 on 8: profiles/r06_cohort_lanes.txt).  What a call must not do is give up on the
+    lane: COHORT_DEVICE_INFLATE_WAIT_MS."""
+    return max(2, min(16, (workers * n_bams + 1) // 3))
 
 
 def default_reader_threads(workers, n_bams):

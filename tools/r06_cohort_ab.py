@@ -18,11 +18,16 @@ def main():
     ap.add_argument("--n", type=int, default=8)
     ap.add_argument("--out", default="gpurun_out/r06_cohort_ab.jsonl")
     ap.add_argument("--settings", default="")
+    ap.add_argument("--dataset", default="", help="directory with the sample (made there when it has none); kept.  Without: a fresh one, removed at the end")
     a = ap.parse_args()
     from svim_asm_amd import synth_bam
     from tools import e2e_bench
-    d = tempfile.mkdtemp(prefix="svx_cohort_")
-    fasta, bams = synth_bam.write_dataset(d, **e2e_bench.dataset_args(a.scale))
+    d = a.dataset or tempfile.mkdtemp(prefix="svx_cohort_")
+    os.makedirs(d, exist_ok=True)
+    if os.path.exists(os.path.join(d, "hap1.bam")):
+        fasta, bams = os.path.join(d, "ref.fa"), [os.path.join(d, "hap1.bam"), os.path.join(d, "hap2.bam")]
+    else:
+        fasta, bams = synth_bam.write_dataset(d, **e2e_bench.dataset_args(a.scale))
     meta_name, meta = e2e_bench.reference_meta(a.scale, 8.0, 2000)
     import hashlib
 
@@ -46,6 +51,9 @@ def main():
             print(line, flush=True)
             f.write(line + "\n")
     print("DATASET", d)
+    if not a.dataset and not os.environ.get("SVX_KEEP_DATASET"):
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 # round 6, one dataset generation: svim-asm-cohort settings A/B (tools/r06_cohort_ab.py), then the per-phase timeline of the
 # one-shot command on the same files (tools/cli_timeline.py)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-python3 tools/r06_cohort_ab.py --n 8 --out gpurun_out/r06_cohort_ab.jsonl "$@" > gpurun_out/r06_cohort_ab.log 2> gpurun_out/r06_cohort_ab.err
+SVX_KEEP_DATASET=1 python3 tools/r06_cohort_ab.py --n 8 --out gpurun_out/r06_cohort_ab.jsonl "$@" > gpurun_out/r06_cohort_ab.log 2> gpurun_out/r06_cohort_ab.err
 d=$(grep DATASET gpurun_out/r06_cohort_ab.log | awk '{print $2}')
 python3 - <<'PY'
 import json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: svim-asm-cohort as P processes on one device (each with its own workers) against one process, N=16 samples
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-python3 tools/r06_cohort_ab.py --n ${N:-16} --out gpurun_out/r06_cohort_procs.jsonl --settings "${SETTINGS:-4:100:400:1:1,3:100:400:1:2,2:100:400:1:2,2:100:400:1:4,6:100:400:1:1,4:100:400:1:2,4:100:400:1:1}" > gpurun_out/r06_cohort_procs.log 2> gpurun_out/r06_cohort_procs.err
+python3 tools/r06_cohort_ab.py --dataset /tmp/svx_cohort_ds --n ${N:-16} --out gpurun_out/r06_cohort_procs.jsonl --settings "${SETTINGS:-4:100:400:1:1,3:100:400:1:2,2:100:400:1:2,2:100:400:1:4,6:100:400:1:1,4:100:400:1:2,4:100:400:1:1}" > gpurun_out/r06_cohort_procs.log 2> gpurun_out/r06_cohort_procs.err
 python3 - <<'PY'
 import json
 for l in open("gpurun_out/r06_cohort_procs.jsonl"):

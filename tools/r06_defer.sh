@@ -15,7 +15,7 @@ for rep in 1 2; do for off in "" 1; do
 done; done
 } | tee gpurun_out/r06_defer.txt
 for off in "" 1 "" 1; do
-  SVX_BAM_NO_DEFER_VERIFY=$off python3 tools/r06_cohort_ab.py --n 16 --out gpurun_out/r06_defer_cohort_$off.jsonl --settings "4:100:400:1" > /dev/null 2>> gpurun_out/r06_defer.err
+  SVX_BAM_NO_DEFER_VERIFY=$off python3 tools/r06_cohort_ab.py --dataset /tmp/svx_cohort_ds --n 16 --out gpurun_out/r06_defer_cohort_$off.jsonl --settings "4:100:400:1" > /dev/null 2>> gpurun_out/r06_defer.err
   python3 -c "
 import json
 for l in open('gpurun_out/r06_defer_cohort_$off.jsonl'):

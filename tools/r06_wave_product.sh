@@ -3,7 +3,7 @@
 # settings and the one-shot command's timeline at device shares 50 / 100 / 0 (and the former kernel at 50 for the difference)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 timeout 900 python3 -m pytest tests/test_gpu_device_pool.py tests/test_gpu_pipeline.py -x -q 2>&1 | tail -4
-python3 tools/r06_cohort_ab.py --n 8 --out gpurun_out/r06_wave_cohort.jsonl --settings "${SETTINGS:-4:100:400:1,4:100:0:1,4:50:0:1,3:100:400:1,6:100:400:1}" > gpurun_out/r06_wave_cohort.log 2> gpurun_out/r06_wave_cohort.err
+SVX_KEEP_DATASET=1 python3 tools/r06_cohort_ab.py --n 8 --out gpurun_out/r06_wave_cohort.jsonl --settings "${SETTINGS:-4:100:400:1,4:100:0:1,4:50:0:1,3:100:400:1,6:100:400:1}" > gpurun_out/r06_wave_cohort.log 2> gpurun_out/r06_wave_cohort.err
 d=$(grep DATASET gpurun_out/r06_wave_cohort.log | awk '{print $2}')
 python3 - <<'PY'
 import json
