@@ -704,6 +704,9 @@ extern "C" int svx_bam_set_inflate_lanes(int lanes) {
     g_inflate_lanes.store(lanes);
     return SVX_OK;
 }
+#ifndef SVX_STAGE_POLL_US
+#define SVX_STAGE_POLL_US 20  // how long a staging thread sleeps between looks at its slot's turn
+#endif
 #ifndef SVX_RING_SLOTS
 #define SVX_RING_SLOTS 8
 #endif
@@ -1958,7 +1961,7 @@ extern "C" int svx_bam_seq_slices(svx_bam* b, const uint32_t* rec, const uint32_
                     const uint32_t q = i % kRingSlots, gen = i / kRingSlots;
                     const int64_t t0 = debug ? now_us() : 0;
                     while (slot_gen[q].load(std::memory_order_acquire) != gen)  // batch i - kRingSlots has enqueued its copy
-                        std::this_thread::sleep_for(std::chrono::microseconds(20));
+                        std::this_thread::sleep_for(std::chrono::microseconds(SVX_STAGE_POLL_US));
                     if (stage_failed.load()) { slot_gen[q].store(gen + 1, std::memory_order_release); continue; }
                     const int64_t t1 = debug ? now_us() : 0;
                     bool good = gen == 0 || hipEventSynchronize(lane->slot_done[q]) == hipSuccess;  // ... and the copy has read the slot
