@@ -204,7 +204,7 @@ def test_cohort_command_writes_the_single_sample_vcfs(svx_ctx, tmp_path):
     manifest = tmp_path / "cohort.tsv"
     manifest.write_text("# working_dir bam1 bam2\n" + "".join("%s %s %s\n" % (tmp_path / wd, os.path.join(g, a), os.path.join(g, b)) for wd, a, b, _ in rows))
     for limit, extra in ((None, []), (None, ["--cohort_group", "0"]), (4000, ["--cohort_group=0", "--cohort_workers", "1"]),
-                         (None, ["--cohort_workers", "3", "--cohort_group", "2"])):
+                         (None, ["--cohort_workers", "3", "--cohort_group", "2", "--cohort_lanes", "2"])):
         old = SVIM_COLLECT.MAX_OPS_PER_SUBMISSION
         if limit:
             SVIM_COLLECT.MAX_OPS_PER_SUBMISSION = limit

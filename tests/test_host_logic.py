@@ -382,6 +382,14 @@ def test_cohort_options_and_plan(monkeypatch):
     assert cohort.default_workers() == 2 and cohort.default_reader_threads(2, 2) == 3
     monkeypatch.setattr(bamio, "host_cpus", lambda: 2.0)
     assert cohort.default_reader_threads(2, 2) == 2  # never below two
+    # inflate lanes: one per three readers in flight, the library's two at least; the library takes 1..16
+    assert [cohort.default_lanes(w, 2) for w in (1, 2, 4, 6, 8, 32)] == [2, 2, 3, 4, 5, 16] and cohort.default_lanes(4, 1) == 2
+    assert cohort._take_option(["--cohort_lanes", "5"], "--cohort_lanes", 0) == ([], 5)
+    assert cohort.COHORT_DEVICE_INFLATE_WAIT_MS >= 1000  # (a call must not give up on its lane: cohort.default_lanes)
+    from svim_asm_amd import _lib
+    lib = _lib.load()
+    assert lib.svx_bam_set_inflate_lanes(0) != 0 and lib.svx_bam_set_inflate_lanes(17) != 0
+    assert lib.svx_bam_set_inflate_lanes(4) == 0 and lib.svx_bam_set_inflate_lanes(2) == 0
 
 
 def test_cohort_manifest_errors(tmp_path):
