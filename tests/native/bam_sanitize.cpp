@@ -13,6 +13,15 @@
 #include <vector>
 
 #include "svx_bam.h"
+#include "svx_inflate_dev.h"
+
+// Stand-ins for the device launches (svx_inflate.hip is not in this build): they fail like everything else that needs a
+// device here, but with them registered the reader takes the paths of a build that has kernels — the record walks defer
+// their check (svx_bam_set_defer_verify) and the threads have to catch up on it.
+static int no_inflate(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint8_t*,
+                      const uint64_t*, uint32_t*, uint32_t*, void*, uint32_t) { return 1; }
+static int no_gather(void*, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, uint8_t*) { return 1; }
+extern "C" void svx_bam_register_device_kernels(svx_inflate_launch_fn, svx_gather_launch_fn);
 
 static uint64_t g_sum = 0;  // keeps the reads of every column alive
 
@@ -29,6 +38,9 @@ static int walk(const char* path, int threads, bool per_contig) {
         (void)svx_bam_set_pinned_device(b, 0);
         (void)svx_bam_set_device_inflate(b, 50);
         (void)svx_bam_set_device_inflate_min(b, 0);
+        static const bool registered = (svx_bam_register_device_kernels(&no_inflate, &no_gather), true);
+        (void)registered;
+        (void)svx_bam_set_defer_verify(b, (int)((turn / 3) & 1));  // every other one of them leaves the walks' check pending
     }
     const char* text = nullptr;
     uint64_t l_text = 0;
@@ -76,8 +88,11 @@ static int walk(const char* path, int threads, bool per_contig) {
             }
         }
         std::vector<uint8_t> out(off.back() + 1);
+        g_sum += svx_bam_pending_members(b);
+        if (pass == 0 && (turn & 2)) g_sum += (uint64_t)svx_bam_verify_pending(b);  // (sometimes before, sometimes inside the slices' call)
         if (!rec.empty() && svx_bam_seq_slices(b, rec.data(), begin.data(), end.data(), (uint32_t)rec.size(), off.data(), out.data()) == 0)
             for (uint8_t v : out) g_sum += v;
+        g_sum += (uint64_t)svx_bam_verify_pending(b) + svx_bam_pending_members(b);
     }
     svx_bam_close(b);
     return 0;
