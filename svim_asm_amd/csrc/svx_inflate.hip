@@ -826,6 +826,10 @@ __global__ __launch_bounds__(64) void k_inflate_parse(TwoPassArgs t) {
 constexpr int kWLL = 10, kWD = 8;
 constexpr uint32_t kMinStretchBits = 256;
 constexpr int kMaxSyncPasses = 24;
+#ifndef SVX_NEXT_WINDOW_16THS
+#define SVX_NEXT_WINDOW_16THS 2
+#endif
+constexpr uint32_t kNextWindowSixteenths = SVX_NEXT_WINDOW_16THS;  // a block's first window: the block before + this many sixteenths of it
 #ifndef SVX_FIRST_WINDOW_PCT
 #define SVX_FIRST_WINDOW_PCT 50
 #endif
@@ -1336,7 +1340,7 @@ __global__ __launch_bounds__(64) SVX_WPARSE_OCCUPANCY void k_inflate_wparse(TwoP
         if (flag_k == WF_EOB) {
             if (last) break;
             const uint32_t block_bits = pos - block_start;
-            guess = max(block_bits + block_bits / 8u, 64u * kMinStretchBits);
+            guess = max(block_bits + block_bits * kNextWindowSixteenths / 16u, 64u * kMinStretchBits);
             need_header = true;
         } else if (w_end >= nbits) {  // the input ends inside a block
             give_up = true;
