@@ -10,7 +10,7 @@
 //                —, stores the literals and writes every match as a token; whatever it does not recognise as plain it
 //                leaves to the lane-per-member parse behind it, which is also the judge of every malformed stream; a wave
 //                per member then applies the tokens in rounds by dependence depth and takes the CRC-32 (1 KiB a lane,
-//                folded with crc32_combine's operators).  7 261 sequence members: 8.1 ms; 28 000: 26 ms.
+//                folded with crc32_combine's operators).  7 261 sequence members: 6.9 ms; 28 000: 23 ms.
 //   2            the same with the lane-per-member parse for every member (16 members a wave, the lanes in step): 36.7 ms.
 //   1            k_bgzf_inflate: one launch, a lane per member that decodes, copies its matches from its own earlier
 //                output and takes the CRC (rounds 4-5): 49 ms.  DEFLATE (RFC 1951) is a serial bit stream per member; with
